@@ -1,0 +1,114 @@
+"""Pin the CPU oracle (oracle/d3dp_oracle.py) against outputs of the reference itself
+(tests/golden/*.npz, produced by tools/make_goldens.py in the authoring container).
+
+Tolerance: SURVEY.md §8 C4 -- <= 1e-3 mm mean per-joint error for tensors (the oracle uses the
+same ATen CPU kernels as the reference, so the observed error is 0.0); bit-exact for the fp64
+schedule and the integer time pairs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from d3dp_amd.weights import (H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, flip_2d, make_state_dict,
+                              synthetic_inputs_2d, synthetic_noise)
+from oracle import d3dp_oracle as orc
+
+TOL_MM = 1e-3
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def params(seed, cs, dep, frames, dtype=None):
+    return orc.strip_prefix(make_state_dict(seed, cs, dep, frames), dtype=dtype)
+
+
+def test_g1_schedule_bit_exact(golden_dir):
+    g = load(golden_dir, "g1_schedule")
+    s = orc.cosine_schedule(1000)
+    for k in s:
+        assert np.array_equal(s[k].numpy(), g[k]), k
+    # known values quoted in SURVEY.md §8 A1
+    assert s["alphas_cumprod"][999].item() == pytest.approx(2.4287669070348542e-09, rel=1e-12)
+    assert s["alphas_cumprod"][499].item() == pytest.approx(0.49384359044063775, rel=1e-14)
+    for K in (1, 2, 5, 10, 20):
+        assert np.array_equal(np.array(orc.time_pairs(K), dtype=np.int64), g[f"pairs_K{K}"])
+    assert orc.time_pairs(10)[0] == (999, 899) and orc.time_pairs(10)[-1] == (99, -1)
+
+
+def test_g2_tiny_denoiser_with_taps(golden_dir):
+    g = load(golden_dir, "g2_tiny_denoiser")
+    cs, dep, Fr = int(g["cs"]), int(g["dep"]), int(g["frames"])
+    p = params(int(g["seed"]), cs, dep, Fr)
+    taps = {}
+    out = orc.mixste_forward(p, torch.from_numpy(g["x2d"]), torch.from_numpy(g["x3d"]),
+                             torch.from_numpy(g["t"]), dep, taps=taps)
+    assert orc.mpjpe_mm(out, torch.from_numpy(g["out"])) <= TOL_MM
+    for i in range(dep):
+        for k in (f"ste{i}", f"tte{i}"):
+            assert torch.allclose(taps[k], torch.from_numpy(g[k]), atol=1e-6, rtol=0), k
+
+
+@pytest.mark.parametrize("frames", [27, 243])
+def test_g3_full_width_denoiser(golden_dir, frames):
+    g = load(golden_dir, f"g3_denoiser_F{frames}")
+    p = params(int(g["seed"]), 512, 8, frames)
+    x2d = torch.from_numpy(synthetic_inputs_2d(int(g["x2d_seed"]), 1, frames))
+    x3d = torch.from_numpy(synthetic_noise(int(g["x3d_seed"]), (1, 1, frames, 17, 3)))
+    tts = (999, 499, 99) if frames == 27 else (999,)   # F=243: one call keeps the CPU suite short
+    for tt in tts:
+        out = orc.mixste_forward(p, x2d, x3d, torch.tensor([tt]), 8)
+        assert orc.mpjpe_mm(out, torch.from_numpy(g[f"out_t{tt}"])) <= TOL_MM
+
+
+@pytest.mark.parametrize("name", ["g4_sampler_c1", "g4_sampler_H3K5", "g4_sampler_tiny_K10"])
+def test_g4_sampler(golden_dir, name):
+    g = load(golden_dir, name)
+    cs, dep, Fr, B, H, K = (int(g[k]) for k in ("cs", "dep", "frames", "B", "H", "K"))
+    p = params(int(g["seed"]), cs, dep, Fr)
+    x2d = synthetic_inputs_2d(int(g["x2d_seed"]), B, Fr)
+    noises = [torch.from_numpy(synthetic_noise(int(g["noise_seed"]) + k, (B, H, Fr, 17, 3))) for k in range(K)]
+    out = orc.ddim_sample_flip(p, orc.cosine_schedule(1000), torch.from_numpy(x2d), torch.from_numpy(flip_2d(x2d)),
+                               H, K, dep, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, noises)
+    assert out.shape == (B, K, H, Fr, 17, 3)
+    assert orc.mpjpe_mm(out, torch.from_numpy(g["out"])) <= TOL_MM
+
+
+def test_g6_train_forward(golden_dir):
+    g = load(golden_dir, "g6_train_step")
+    cs, dep, Fr = int(g["cs"]), int(g["dep"]), int(g["frames"])
+    p = params(int(g["seed"]), cs, dep, Fr)
+    sched = orc.cosine_schedule(1000)
+    gt = torch.from_numpy(g["gt"])
+    x_poses = orc.prepare_targets(sched, gt, torch.from_numpy(g["t"]), torch.from_numpy(g["noise"]))
+    t = torch.from_numpy(g["t"])
+    pred = orc.mixste_forward(p, torch.from_numpy(g["x2d"]), x_poses, t, dep)
+    assert orc.mpjpe_mm(pred, torch.from_numpy(g["pred_nodrop"])) <= TOL_MM
+    loss = torch.mean(torch.norm(pred - gt, dim=-1))
+    assert abs(loss.item() - float(g["loss_nodrop"])) < 1e-6
+    # DropPath on: masks recorded in call order STE_i(attn, mlp), TTE_i(attn, mlp) for blocks with rate>0
+    masks = [torch.from_numpy(g[f"drop_mask{k}"]) for k in range(int(g["drop_masks_n"]))]
+    dpd, it = {}, iter(masks)
+    for i in range(dep):
+        if i == 0:
+            continue  # rate linspace(0, 0.1, dep)[0] == 0 -> Identity (mixste.py:100)
+        dpd[f"STEblocks.{i}"] = (next(it), next(it))
+        dpd[f"TTEblocks.{i}"] = (next(it), next(it))
+    pred_d = orc.mixste_forward(p, torch.from_numpy(g["x2d"]), x_poses, t, dep, droppath=dpd)
+    assert orc.mpjpe_mm(pred_d, torch.from_numpy(g["pred_drop"])) <= TOL_MM
+    assert orc.mpjpe_mm(pred_d, pred) > 1e-2  # the masks really change the result
+
+
+def test_fp32_floor_vs_fp64():
+    """The oracle in fp64 vs fp32 on one full-width F=27 call: records the fp32 rounding floor the
+    1e-3 mm tolerance sits on (SURVEY.md §7 hard part 1)."""
+    p32 = params(7, 512, 8, 27)
+    p64 = params(7, 512, 8, 27, dtype=torch.float64)
+    x2d = torch.from_numpy(synthetic_inputs_2d(201, 1, 27))
+    x3d = torch.from_numpy(synthetic_noise(202, (1, 1, 27, 17, 3)))
+    o32 = orc.mixste_forward(p32, x2d, x3d, torch.tensor([999]), 8)
+    o64 = orc.mixste_forward(p64, x2d.double(), x3d.double(), torch.tensor([999]), 8)
+    d = orc.mpjpe_mm(o32, o64)
+    assert 0 < d < 2e-3, d

@@ -1,0 +1,306 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (authoring container only).
+
+The reference (/root/reference, read-only, never copied) ships no tests or golden
+vectors, so parity is pinned on outputs of the reference itself:
+
+  * ``timm`` (absent here) is stubbed in ``sys.modules`` -- mixste.py:18-21 import four
+    timm submodules but only ``DropPath`` is used, and only in train mode.
+  * ``ddim_sample_flip`` hard-codes ``device='cuda'`` (diffusionpose.py:225,230): in this
+    process only, ``torch.randn/randn_like/randint`` are wrapped to stay on CPU and to
+    return INJECTED draws (numpy PCG64 streams from ``d3dp_amd.weights``), and
+    ``Tensor.cuda`` is the identity.  No reference file is modified.
+  * weights come from ``d3dp_amd.weights.make_state_dict(seed, ...)`` and are loaded
+    with ``load_state_dict`` so fixtures carry seeds, not 139 MB of parameters.
+
+Fixtures hold data only (inputs / seeds / expected outputs).  This script cannot run on
+the GPU box (no /root/reference there) and nothing in tests/ or bench.py needs it to.
+
+Usage: python tools/make_goldens.py [--only g1,g2,...]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+OUT = os.path.join(REPO, "tests", "golden")
+
+from d3dp_amd.weights import (H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, flip_2d, make_state_dict,  # noqa: E402
+                              synthetic_inputs_2d, synthetic_noise)
+
+
+# ----------------------------------------------------------------------------- reference import
+class _DropPathStub(torch.nn.Module):
+    """timm.models.layers.DropPath semantics (per-sample Bernoulli keep mask scaled by
+    1/keep, identity in eval) with injectable masks so fixtures can record them."""
+    injected = None   # list of (S,1,1) tensors consumed in call order, or None -> identity
+    log = []
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if not self.training or self.drop_prob == 0.0:
+            if self.training:
+                _DropPathStub.log.append(torch.ones(x.shape[0], 1, 1))
+            return x
+        if _DropPathStub.injected is None:
+            _DropPathStub.log.append(torch.ones(x.shape[0], 1, 1))
+            return x
+        m = _DropPathStub.injected.pop(0)
+        _DropPathStub.log.append(m)
+        return x * m
+
+
+def import_reference():
+    for name in ("timm", "timm.data", "timm.models", "timm.models.helpers", "timm.models.layers",
+                 "timm.models.registry"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["timm.data"].IMAGENET_DEFAULT_MEAN = None
+    sys.modules["timm.data"].IMAGENET_DEFAULT_STD = None
+    sys.modules["timm.models.helpers"].load_pretrained = None
+    lay = sys.modules["timm.models.layers"]
+    lay.DropPath, lay.to_2tuple, lay.trunc_normal_ = _DropPathStub, None, None
+    sys.modules["timm.models.registry"].register_model = lambda f: f
+    sys.path.insert(0, REF)
+    from common.diffusionpose import D3DP  # noqa
+    return D3DP
+
+
+class Draws:
+    """Patches torch RNG entry points used by the reference; returns injected tensors."""
+
+    def __init__(self, randn_list=None, randint_list=None):
+        self.randn_list = list(randn_list or [])
+        self.randint_list = list(randint_list or [])
+        self.n_randn = 0
+
+    def __enter__(self):
+        self._o = (torch.randn, torch.randn_like, torch.randint, torch.Tensor.cuda)
+
+        def randn(*size, **kw):
+            self.n_randn += 1
+            shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+            t = self.randn_list.pop(0)
+            assert tuple(t.shape) == shape, (t.shape, shape)
+            return t.clone()
+
+        def randn_like(x, **kw):
+            return randn(tuple(x.shape))
+
+        def randint(low, high, size, **kw):
+            t = self.randint_list.pop(0)
+            assert tuple(t.shape) == tuple(size)
+            return t.clone()
+
+        torch.randn, torch.randn_like, torch.randint = randn, randn_like, randint
+        torch.Tensor.cuda = lambda self_, *a, **k: self_
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.randn_like, torch.randint, torch.Tensor.cuda = self._o
+
+
+def make_args(frames, cs, dep, scale=1.0):
+    return types.SimpleNamespace(number_of_frames=frames, test_time_augmentation=True, timestep=1000,
+                                 scale=scale, cs=cs, dep=dep)
+
+
+def build_ref(D3DP, frames, cs, dep, seed, is_train=False, H=1, K=1):
+    torch.manual_seed(0)
+    m = D3DP(make_args(frames, cs, dep), H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=is_train,
+             num_proposals=H, sampling_timesteps=K)
+    missing, unexpected = m.load_state_dict(make_state_dict(seed, cs, dep, frames), strict=False)
+    assert not unexpected and all(not k.startswith("pose_estimator") for k in missing), (missing, unexpected)
+    return m.train() if is_train else m.eval()
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ----------------------------------------------------------------------------- fixtures
+def g1(D3DP):
+    """Schedule buffers (fp64) + DDIM time pairs."""
+    m = build_ref(D3DP, 9, 32, 1, seed=1)
+    arrs = {k: getattr(m, k).numpy() for k in (
+        "betas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+        "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod")}
+    for K in (1, 2, 5, 10, 20):
+        times = torch.linspace(-1, 999, steps=K + 1)
+        times = list(reversed(times.int().tolist()))
+        arrs[f"pairs_K{K}"] = np.array(list(zip(times[:-1], times[1:])), dtype=np.int64)
+    save("g1_schedule", **arrs)
+
+
+def g2(D3DP):
+    """Tiny denoiser with per-block intermediates: cs=64, dep=2, F=9, B=2, H=3."""
+    cs, dep, Fr, B, H, seed = 64, 2, 9, 2, 3, 11
+    m = build_ref(D3DP, Fr, cs, dep, seed)
+    x2d = torch.from_numpy(synthetic_inputs_2d(101, B, Fr))
+    x3d = torch.from_numpy(synthetic_noise(102, (B, H, Fr, 17, 3)))
+    t = torch.tensor([999, 37], dtype=torch.long)
+    taps = {"s": [], "t": []}
+    pe = m.pose_estimator
+    h1 = pe.Spatial_norm.register_forward_hook(lambda mod, i, o: taps["s"].append(o.detach().clone()))
+    h2 = pe.Temporal_norm.register_forward_hook(lambda mod, i, o: taps["t"].append(o.detach().clone()))
+    with torch.no_grad():
+        out = pe(x2d, x3d, t)
+    h1.remove(); h2.remove()
+    arrs = dict(cs=cs, dep=dep, frames=Fr, seed=seed, x2d=x2d.numpy(), x3d=x3d.numpy(), t=t.numpy(),
+                out=out.numpy())
+    BH = B * H
+    for i in range(dep):
+        arrs[f"ste{i}"] = taps["s"][i].reshape(BH, Fr, 17, cs).numpy()                       # (bh f) n c
+        arrs[f"tte{i}"] = taps["t"][i].reshape(BH, 17, Fr, cs).permute(0, 2, 1, 3).contiguous().numpy()
+    save("g2_tiny_denoiser", **arrs)
+
+
+def g3(D3DP):
+    """Full-width single denoiser calls: cs=512, dep=8, F in {27, 243}, B=1, H=1."""
+    for Fr in (27, 243):
+        seed = 7
+        m = build_ref(D3DP, Fr, 512, 8, seed)
+        x2d = torch.from_numpy(synthetic_inputs_2d(201, 1, Fr))
+        x3d = torch.from_numpy(synthetic_noise(202, (1, 1, Fr, 17, 3)))
+        arrs = dict(cs=512, dep=8, frames=Fr, seed=seed, x2d_seed=201, x3d_seed=202)
+        for tt in (999, 499, 99):
+            with torch.no_grad():
+                arrs[f"out_t{tt}"] = m.pose_estimator(x2d, x3d, torch.tensor([tt])).numpy()
+        save(f"g3_denoiser_F{Fr}", **arrs)
+
+
+def run_sampler(D3DP, Fr, cs, dep, seed, B, H, K, x2d_seed, noise_seed):
+    m = build_ref(D3DP, Fr, cs, dep, seed, H=H, K=K)
+    x2d = synthetic_inputs_2d(x2d_seed, B, Fr)
+    x2d_flip = flip_2d(x2d)
+    noises = [torch.from_numpy(synthetic_noise(noise_seed + k, (B, H, Fr, 17, 3))) for k in range(K)]
+    with Draws(randn_list=noises) as d:
+        with torch.no_grad():
+            out = m(torch.from_numpy(x2d), None, input_2d_flip=torch.from_numpy(x2d_flip))
+        assert d.n_randn == K and not d.randn_list, (d.n_randn, K)
+    return out.numpy()
+
+
+def g4(D3DP):
+    """Sampler: BASELINE config 1 exactly (F=27,H=1,K=1,B=2) and F=27,H=3,K=5,B=2; plus a tiny
+    model with scale != 1 to pin the clamp/scale handling."""
+    out = run_sampler(D3DP, 27, 512, 8, 7, B=2, H=1, K=1, x2d_seed=301, noise_seed=400)
+    save("g4_sampler_c1", cs=512, dep=8, frames=27, seed=7, B=2, H=1, K=1, x2d_seed=301, noise_seed=400, out=out)
+    out = run_sampler(D3DP, 27, 512, 8, 7, B=2, H=3, K=5, x2d_seed=302, noise_seed=500)
+    save("g4_sampler_H3K5", cs=512, dep=8, frames=27, seed=7, B=2, H=3, K=5, x2d_seed=302, noise_seed=500, out=out)
+    out = run_sampler(D3DP, 9, 64, 2, 11, B=3, H=4, K=10, x2d_seed=303, noise_seed=600)
+    save("g4_sampler_tiny_K10", cs=64, dep=2, frames=9, seed=11, B=3, H=4, K=10, x2d_seed=303, noise_seed=600, out=out)
+
+
+def g6(D3DP):
+    """Train step forward (+loss, grad norms): F=27, B=4, cs=64, dep=2; DropPath off and on."""
+    sys.path.insert(0, REF)
+    from common.loss import mpjpe
+    cs, dep, Fr, B, seed = 64, 2, 27, 4, 13
+    x2d = torch.from_numpy(synthetic_inputs_2d(701, B, Fr))
+    gt = torch.from_numpy(synthetic_noise(702, (B, Fr, 17, 3))) * 0.3
+    gt[:, :, 0] = 0
+    ts = [torch.tensor([v], dtype=torch.long) for v in (3, 250, 640, 999)]
+    ns = [torch.from_numpy(synthetic_noise(710 + i, (Fr, 17, 3))) for i in range(B)]
+    arrs = dict(cs=cs, dep=dep, frames=Fr, seed=seed, x2d=x2d.numpy(), gt=gt.numpy(),
+                t=np.array([int(v) for v in ts]), noise=np.stack([n.numpy() for n in ns]))
+    for tag in ("nodrop", "drop"):
+        m = build_ref(D3DP, Fr, cs, dep, seed, is_train=True)
+        _DropPathStub.log = []
+        if tag == "drop":
+            rates = [x.item() for x in torch.linspace(0, 0.1, dep)]
+            rng = np.random.Generator(np.random.PCG64(720))
+            inj = []
+            # call order inside MixSTE2.forward: STE0(attn, mlp), TTE0(attn, mlp), STE1..., TTE1...
+            for i in range(dep):
+                for S in (B * Fr, B * 17):
+                    for _ in range(2):
+                        if rates[i] == 0.0:
+                            continue
+                        keep = 1 - rates[i]
+                        mask = (rng.uniform(size=(S, 1, 1)) < keep).astype(np.float32) / keep
+                        inj.append(torch.from_numpy(mask))
+            _DropPathStub.injected = list(inj)
+            arrs["drop_masks_n"] = len(inj)
+            for k, mk in enumerate(inj):
+                arrs[f"drop_mask{k}"] = mk.numpy()
+        else:
+            _DropPathStub.injected = None
+        rl = []
+        for i in range(B):
+            rl += [ns[i]]
+        with Draws(randn_list=rl, randint_list=list(ts)):
+            pred = m(x2d, gt)
+        loss = mpjpe(pred, gt)
+        loss.backward(loss.clone().detach())        # main.py:393
+        arrs[f"pred_{tag}"] = pred.detach().numpy()
+        arrs[f"loss_{tag}"] = np.float64(loss.item())
+        for pn in ("pose_estimator.head.1.weight", "pose_estimator.STEblocks.0.attn.qkv.weight",
+                   "pose_estimator.TTEblocks.1.mlp.fc2.weight", "pose_estimator.Temporal_pos_embed"):
+            g = dict(m.named_parameters())[pn].grad
+            arrs[f"gradnorm_{tag}::{pn}"] = np.float64(g.double().norm().item())
+        _DropPathStub.injected = None
+    save("g6_train_step", **arrs)
+
+
+def g5(D3DP):
+    """Caller side (rows N1/N2): 60-frame synthetic sequence at F=27 -> eval_data_prepare-style
+    chunking (last clip = last F frames), root zeroing, trajectory add, project_to_2d, and the four
+    per-step metrics of loss.py:22-107.  main.py cannot be imported (tensorboard, datasets), so the
+    chunking expectation is produced by running the reference's function body semantics through
+    common.camera / common.loss only; chunk indices are recorded as data."""
+    from common.camera import project_to_2d
+    from common.loss import (mpjpe_diffusion, mpjpe_diffusion_all_min, mpjpe_diffusion_reproj)
+    Fr, N, H, K, B = 27, 60, 3, 2, 3
+    rng = np.random.Generator(np.random.PCG64(801))
+    seq3d = (rng.standard_normal((N, 17, 3)) * 0.3).astype(np.float32)
+    seq3d[:, :, 2] += 4.0                      # in front of the camera
+    seq2d = rng.uniform(-1, 1, (N, 17, 2)).astype(np.float32)
+    cam = np.array([[2.29, 2.287, 0.0254, 0.0289, -0.2070, 0.2477, -0.0030, -0.0009, -0.0014]], np.float32)
+    # chunk starts per main.py:267-299 (N=60,F=27 -> clips [0:27],[27:54],[33:60])
+    starts = np.array([0, 27, N - Fr], dtype=np.int64)
+    inputs_3d = torch.from_numpy(np.stack([seq3d[s:s + Fr] for s in starts]))
+    inputs_2d = torch.from_numpy(np.stack([seq2d[s:s + Fr] for s in starts]))
+    traj = inputs_3d[:, :, :1].clone()
+    inputs_3d[:, :, 0] = 0
+    pred = torch.from_numpy((rng.standard_normal((B, K, H, Fr, 17, 3)) * 0.3).astype(np.float32))
+    pred_in = pred.clone()
+    pred[:, :, :, :, 0] = 0                    # main.py:700
+    b, t_, h, f, j, c = pred.shape
+    absol = pred + traj.unsqueeze(1).unsqueeze(1).repeat(1, t_, h, 1, 1, 1)
+    reproj = project_to_2d(absol.reshape(b * t_ * h * f, j, c), torch.from_numpy(cam).repeat(b * t_ * h * f, 1))
+    reproj = reproj.reshape(b, t_, h, f, j, 2)
+    e_jbest = mpjpe_diffusion_all_min(pred, inputs_3d)
+    e_pbest = mpjpe_diffusion(pred, inputs_3d)
+    e_pagg = mpjpe_diffusion_all_min(pred, inputs_3d, mean_pos=True)
+    e_jagg = mpjpe_diffusion_reproj(pred, inputs_3d, reproj, inputs_2d)
+    save("g5_caller", frames=Fr, seq3d=seq3d, seq2d=seq2d, cam=cam, starts=starts, pred=pred_in.numpy(),
+         reproj=reproj.numpy(), e_jbest=e_jbest.numpy(), e_pbest=e_pbest.numpy(), e_pagg=e_pagg.numpy(),
+         e_jagg=e_jagg.numpy())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g6")
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    D3DP = import_reference()
+    for name in a.only.split(","):
+        print(name)
+        globals()[name](D3DP)
+
+
+if __name__ == "__main__":
+    main()
