@@ -1,0 +1,332 @@
+// Multi-head attention of the MixSTE2 blocks: softmax(q k^T * hd^-0.5) v per (sequence, head)
+// (reference common/mixste.py:63-79; spatial sequences = 17 joints of one frame, temporal sequences =
+// F frames of one joint).  Sequences are addressed through SeqMap strides in the ONE physical token
+// layout (bh, f, n, c): the reference's physical transposes (mixste.py:244, 270, 274) never happen.
+//
+//   attn_rows_kernel          : fp32 VALU, one thread per query row, K/V of the (sequence, head) problem
+//                               broadcast from LDS.  Used for EXACT mode (fp32 activations, both axes)
+//                               and for the spatial axis in FAST mode (bf16 activations; 0.4 % of FLOPs
+//                               and HBM-bound, so matrix cores would buy nothing).
+//   attn_temporal_bf16_kernel : FAST mode temporal axis on v_mfma_f32_16x16x32_bf16.  One workgroup per
+//                               (sequence, head); all of K (swizzled, row-major) and V^T live in LDS; each
+//                               wave owns 16-query tiles and keeps a whole score row-block in registers
+//                               (keys <= 256), so softmax is a plain two-pass fp32 softmax with wavefront
+//                               shuffles -- no online rescaling.  S^T = K Q^T is computed transposed so the
+//                               probabilities land directly in the A/B fragment layout of the P.V MFMA.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ int seq_base(const SeqMap& m, int s) {
+  return (s / m.inner) * m.outer_stride + (s % m.inner) * m.inner_stride;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic fp32-VALU attention: thread per query row
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Vec16;   // 16-byte vector of T
+template <> struct Vec16<float> { static constexpr int N = 4; };
+template <> struct Vec16<bf16> { static constexpr int N = 8; };
+
+template <typename T, int N>
+__device__ __forceinline__ void ld_vec(const T* p, float* v) {
+  if constexpr (N == 4) {
+    float4 a = *reinterpret_cast<const float4*>(p);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  } else {
+    load8(reinterpret_cast<const bf16*>(p), v);
+  }
+}
+
+template <typename T, int HD, int TPP>
+__global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n_prob,
+                                                        SeqMap map, int C, int heads) {
+  constexpr int PPB = 256 / TPP;
+  constexpr int VN = Vec16<T>::N;                 // elements per 16-byte vector
+  constexpr int LDR = HD + VN;                    // padded LDS row (elements)
+  constexpr int CH = (HD >= VN) ? HD / VN : 1;    // 16-byte chunks per row
+  static_assert(HD % VN == 0, "head dim must be a multiple of the 16-byte vector");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+
+  const int n = map.n_tok;
+  const int tid = threadIdx.x;
+  const int lp = tid / TPP, row = tid % TPP;
+  const int pid = blockIdx.x * PPB + lp;
+  const bool live = pid < n_prob;
+  const int seq = live ? pid / heads : 0, head = live ? pid % heads : 0;
+  const int base = seq_base(map, seq);
+  T* Ks = smem + (size_t)lp * 2 * n * LDR;
+  T* Vs = Ks + (size_t)n * LDR;
+
+  if (live) {
+    for (int u = row; u < n * CH; u += TPP) {
+      const int j = u / CH, c = u % CH;
+      const T* src = qkv + (size_t)(base + j * map.tok_stride) * 3 * C + C + head * HD + c * VN;
+      *reinterpret_cast<float4*>(Ks + j * LDR + c * VN) = *reinterpret_cast<const float4*>(src);
+      *reinterpret_cast<float4*>(Vs + j * LDR + c * VN) = *reinterpret_cast<const float4*>(src + C);
+    }
+  }
+  __syncthreads();
+  if (!live || row >= n) return;
+
+  const size_t tok = (size_t)(base + row * map.tok_stride);
+  float q[HD], o[HD];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) ld_vec<T, VN>(qkv + tok * 3 * C + head * HD + c * VN, q + c * VN);
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+  const float scale = 1.0f / sqrtf((float)HD);
+  float m = -INFINITY, l = 0.f;
+  for (int j = 0; j < n; ++j) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      float kv[VN];
+      ld_vec<T, VN>(Ks + j * LDR + c * VN, kv);
+#pragma unroll
+      for (int e = 0; e < VN; e += 2) {
+        s0 = fmaf(q[c * VN + e], kv[e], s0);
+        s1 = fmaf(q[c * VN + e + 1], kv[e + 1], s1);
+      }
+    }
+    const float s = (s0 + s1) * scale;
+    if (s > m) {
+      const float f = expf(m - s);
+      l *= f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] *= f;
+      m = s;
+    }
+    const float p = expf(s - m);
+    l += p;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      float vv[VN];
+      ld_vec<T, VN>(Vs + j * LDR + c * VN, vv);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) o[c * VN + e] = fmaf(p, vv[e], o[c * VN + e]);
+    }
+  }
+  const float inv = 1.0f / l;
+  T* dst = out + tok * C + head * HD;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    float r[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) r[e] = o[c * VN + e] * inv;
+    if constexpr (VN == 4) *reinterpret_cast<float4*>(dst + c * 4) = make_float4(r[0], r[1], r[2], r[3]);
+    else store8(reinterpret_cast<bf16*>(dst) + c * 8, r);
+  }
+}
+
+template <typename T, int HD, int TPP>
+int launch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st) {
+  constexpr int PPB = 256 / TPP;
+  constexpr int LDR = HD + Vec16<T>::N;
+  const int n_prob = n_seq * heads;
+  const size_t lds = (size_t)PPB * 2 * map.n_tok * LDR * sizeof(T);
+  if (lds > 160 * 1024) return -2;
+  auto kern = attn_rows_kernel<T, HD, TPP>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) return -3;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((n_prob + PPB - 1) / PPB), dim3(256), lds, st, (const T*)qkv, (T*)out, n_prob, map, C,
+                     heads);
+  return 0;
+}
+
+template <typename T>
+int dispatch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st) {
+  const int hd = C / heads;
+  const bool small = map.n_tok <= 32;
+  if (map.n_tok > 256) return -2;
+  switch (hd) {
+    case 64: return small ? launch_rows<T, 64, 32>(qkv, out, n_seq, map, C, heads, st)
+                          : launch_rows<T, 64, 256>(qkv, out, n_seq, map, C, heads, st);
+    case 32: return small ? launch_rows<T, 32, 32>(qkv, out, n_seq, map, C, heads, st)
+                          : launch_rows<T, 32, 256>(qkv, out, n_seq, map, C, heads, st);
+    case 16: return small ? launch_rows<T, 16, 32>(qkv, out, n_seq, map, C, heads, st)
+                          : launch_rows<T, 16, 256>(qkv, out, n_seq, map, C, heads, st);
+    case 8:  return small ? launch_rows<T, 8, 32>(qkv, out, n_seq, map, C, heads, st)
+                          : launch_rows<T, 8, 256>(qkv, out, n_seq, map, C, heads, st);
+    default: return -2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST temporal attention on bf16 MFMA (head dim 64)
+// ------------------------------------------------------------------------------------------------
+template <int NKT>   // number of 16-key tiles (keys padded to 16*NKT <= 256)
+__global__ __launch_bounds__(256, 2) void attn_temporal_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                                 SeqMap map, int C, int heads) {
+  constexpr int NK = 16 * NKT;            // padded keys
+  constexpr int VSTR = (NK + 8) * 2;      // V^T row stride in bytes (16-B multiple, bank-spreading pad)
+  constexpr int KS_BYTES = NK * 128;
+  constexpr int ITER = (NK * 8 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* KS = smem;                         // K rows, 128 B each, 16-B slots XOR-swizzled; first used as V staging
+  char* VT = smem + KS_BYTES;              // V^T: [64 d][NK keys] bf16
+
+  const int n = map.n_tok;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
+  const int base = seq_base(map, seq);
+  const int ts = map.tok_stride;
+  const size_t ld = (size_t)3 * C;
+  const bf16* qbase = qkv + (size_t)head * 64;
+
+  // ---- phase 1: V rows -> LDS staging (row-major), K rows -> registers -------------------------
+  float4 kreg[ITER];
+#pragma unroll
+  for (int i = 0; i < ITER; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx >> 3, slot = idx & 7;
+    float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
+    kreg[i] = vv;
+    if (idx < NK * 8 && row < n) {
+      const bf16* src = qbase + (size_t)(base + row * ts) * ld + slot * 8;
+      kreg[i] = *reinterpret_cast<const float4*>(src + C);
+      vv = *reinterpret_cast<const float4*>(src + 2 * C);
+    }
+    if (idx < NK * 8) *reinterpret_cast<float4*>(KS + row * 128 + slot * 16) = vv;
+  }
+  __syncthreads();
+  // ---- phase 2: transpose staging -> V^T ---------------------------------------------------------
+  for (int u = tid; u < 64 * (NK / 8); u += 256) {
+    const int d = u & 63, kg = u >> 6;
+    unsigned short e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = *reinterpret_cast<const unsigned short*>(KS + (kg * 8 + j) * 128 + d * 2);
+    uint4 pk;
+    pk.x = e[0] | ((unsigned)e[1] << 16); pk.y = e[2] | ((unsigned)e[3] << 16);
+    pk.z = e[4] | ((unsigned)e[5] << 16); pk.w = e[6] | ((unsigned)e[7] << 16);
+    *reinterpret_cast<uint4*>(VT + d * VSTR + kg * 16) = pk;
+  }
+  __syncthreads();
+  // ---- phase 3: K registers -> swizzled LDS ------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < ITER; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx >> 3, slot = idx & 7;
+    if (idx < NK * 8) *reinterpret_cast<float4*>(KS + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = kreg[i];
+  }
+  __syncthreads();
+
+  const int fi = lane & 15, fg = lane >> 4;
+  const float cexp = 0.125f * 1.44269504088896340736f;   // hd^-0.5 * log2(e), hd = 64
+  const int n_qt = (n + 15) >> 4;
+  for (int qt = wave; qt < n_qt; qt += 4) {
+    const int q = qt * 16 + fi;
+    const int qc = min(q, n - 1);
+    const bf16* qsrc = qbase + (size_t)(base + qc * ts) * ld + fg * 8;
+    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(qsrc);
+    const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(qsrc + 32);
+
+    // S^T tile t: rows = keys 16t + 4*fg + r, column = query fi
+    f32x4 s[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      const int key = t * 16 + fi;
+      const int sw = (key >> 1) & 7;
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(KS + key * 128 + ((fg ^ sw) << 4));
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(KS + key * 128 + (((4 + fg) ^ sw) << 4));
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q0, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q1, a, 0, 0, 0);
+      s[t] = a;
+      if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the ds_read hoisting window (VGPR pressure)
+    }
+    // mask padded keys, row max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      if (16 * (t + 1) > n) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * t + 4 * fg + r >= n) s[t][r] = -INFINITY;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mc = mx * cexp;
+    float sum = 0.f;
+    bf16x8 pf[NKT / 2];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], cexp, -mc));
+        sum += p;
+        pf[t >> 1][(t & 1) * 4 + r] = (bf16)p;
+      }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+
+    // O^T[d][q] = sum_keys V^T[d][key] P^T[key][q]
+    f32x4 o[4];
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NKT / 2; ++c) {
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) {
+        const char* vrow = VT + (dn * 16 + fi) * VSTR + (32 * c + 4 * fg) * 2;
+        const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vrow);
+        const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vrow + 32);
+        const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[c], o[dn], 0, 0, 0);
+      }
+      if (c & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (q < n) {
+      const float inv = 1.0f / sum;
+      bf16* dst = out + (size_t)(base + q * ts) * C + head * 64 + fg * 4;
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) {
+        bf16x4 r = {(bf16)(o[dn][0] * inv), (bf16)(o[dn][1] * inv), (bf16)(o[dn][2] * inv), (bf16)(o[dn][3] * inv)};
+        *reinterpret_cast<bf16x4*>(dst + dn * 16) = r;
+      }
+    }
+  }
+}
+
+template <int NKT>
+int launch_temporal(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st) {
+  constexpr int NK = 16 * NKT;
+  const size_t lds = (size_t)NK * 128 + (size_t)64 * (NK + 8) * 2;
+  auto kern = attn_temporal_bf16_kernel<NKT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) return -3;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(256), lds, st, (const bf16*)qkv, (bf16*)out, map, C, heads);
+  return 0;
+}
+
+}  // namespace
+
+int d3dp_launch_attn_rows(int act_bf16, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
+                          hipStream_t st) {
+  return act_bf16 ? dispatch_rows<bf16>(qkv, out, n_seq, map, C, heads, st)
+                  : dispatch_rows<float>(qkv, out, n_seq, map, C, heads, st);
+}
+
+int d3dp_launch_attn_temporal_bf16(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
+                                   hipStream_t st) {
+  if (C / heads != 64 || map.n_tok > 256 || map.n_tok < 1) return -2;
+  const int n = map.n_tok;
+  if (n <= 32) return launch_temporal<2>(qkv, out, n_seq, map, C, heads, st);
+  if (n <= 64) return launch_temporal<4>(qkv, out, n_seq, map, C, heads, st);
+  if (n <= 128) return launch_temporal<8>(qkv, out, n_seq, map, C, heads, st);
+  return launch_temporal<16>(qkv, out, n_seq, map, C, heads, st);
+}

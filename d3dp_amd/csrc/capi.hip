@@ -1,0 +1,436 @@
+// C-ABI layer of libd3dp_hip.so (see include/d3dp_hip.h): context, weight packing, the denoiser schedule
+// (which kernels run in which order over which buffers) and per-kernel HIP-event timing.
+//
+// Data layout in HBM (per internal pass over `n` (clip,hypothesis) sequences, Tc = n*F*J tokens, token order
+// (sequence, frame, joint), channels fastest):
+//   x    [Tc, C]   fp32   residual stream -- stays fp32 in both modes
+//   bufA [Tc, C]   act    normalised input of the next GEMM / attention output      (act = bf16 FAST, fp32 EXACT)
+//   bufB [Tc, 3C]  act    qkv; reused as the [Tc, 2C] MLP hidden
+// The reference keeps two physical layouts and transposes between them 16 times per call
+// (mixste.py:244,270,274); here spatial and temporal attention both index the single layout by stride.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/d3dp_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e__ = (expr);                                                               \
+    if (e__ != hipSuccess) return fail(D3DP_EHIP, "%s: %s", #expr, hipGetErrorString(e__)); \
+  } while (0)
+
+#define LAUNCH_TRY(expr)                                                          \
+  do {                                                                            \
+    int r__ = (expr);                                                             \
+    if (r__ != 0) return fail(r__ == -1 ? D3DP_EINVAL : D3DP_ENOTSUP, "%s -> %d", #expr, r__); \
+  } while (0)
+
+enum ProfClass { P_QKV = 0, P_PROJ, P_FC1, P_FC2, P_ATTN_S, P_ATTN_T, P_LN, P_LN2, P_EMBED, P_HEAD, P_TIME, P_OTHER };
+const char* kClassNames[D3DP_PROFILE_CLASSES] = {"gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "attn_spatial",
+                                                 "attn_temporal", "layernorm", "norm_pair", "embed_ln", "head",
+                                                 "time_mlp", "other"};
+
+struct BlockDev {
+  const float *n1w, *n1b, *n2w, *n2b, *qkv_b, *proj_b, *fc1_b, *fc2_b;
+  const void *qkv_w, *proj_w, *fc1_w, *fc2_w;   // bf16 (FAST) or fp32 (EXACT)
+};
+
+__global__ void to_bf16_kernel(const float* __restrict__ s, bf16* __restrict__ d, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) d[i] = (bf16)s[i];
+}
+
+void launch_to_bf16(const float* s, void* d, size_t n, hipStream_t st) {
+  const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(to_bf16_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, s, (bf16*)d, n);
+}
+
+constexpr size_t kAlign = 256;
+size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+
+}  // namespace
+
+struct d3dp_ctx {
+  d3dp_cfg cfg{};
+  int device = 0;
+  bool weights_set = false;
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  const float *spos = nullptr, *tpos = nullptr, *ew = nullptr, *eb = nullptr, *freq = nullptr, *t1w = nullptr,
+              *t1b = nullptr, *t3w = nullptr, *t3b = nullptr, *snw = nullptr, *snb = nullptr, *tnw = nullptr,
+              *tnb = nullptr, *hnw = nullptr, *hnb = nullptr, *hw = nullptr, *hb = nullptr;
+  std::vector<BlockDev> ste, tte;
+  // profiling
+  bool prof = false;
+  struct Ev { hipEvent_t a, b; int cls; };
+  std::vector<Ev> pool;
+  size_t used = 0;
+  int64_t counts[D3DP_PROFILE_CLASSES] = {0};
+  double total_ms[D3DP_PROFILE_CLASSES] = {0};
+
+  bool fast() const { return cfg.mode == D3DP_MODE_FAST; }
+  size_t act_size() const { return fast() ? 2 : 4; }
+  int chunk() const { return cfg.chunk_seqs > 0 ? cfg.chunk_seqs : 16; }
+
+  int flush_events() {
+    for (size_t i = 0; i < used; ++i) {
+      if (hipEventSynchronize(pool[i].b) != hipSuccess) return -1;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, pool[i].a, pool[i].b) != hipSuccess) return -1;
+      counts[pool[i].cls]++;
+      total_ms[pool[i].cls] += ms;
+    }
+    used = 0;
+    return 0;
+  }
+  // returns slot index or -1
+  int begin(int cls, hipStream_t st) {
+    if (!prof) return -1;
+    if (used == pool.size()) {
+      if (pool.size() >= 32768) { if (flush_events() != 0) return -1; }
+      else {
+        Ev e{};
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return -1;
+        pool.push_back(e);
+      }
+    }
+    pool[used].cls = cls;
+    (void)hipEventRecord(pool[used].a, st);
+    return (int)used++;
+  }
+  void end(int slot, hipStream_t st) {
+    if (slot >= 0) (void)hipEventRecord(pool[slot].b, st);
+  }
+};
+
+namespace {
+
+struct Scope {
+  d3dp_ctx* c; int slot; hipStream_t st;
+  Scope(d3dp_ctx* c_, int cls, hipStream_t st_) : c(c_), slot(c_->begin(cls, st_)), st(st_) {}
+  ~Scope() { c->end(slot, st); }
+};
+
+int linear(d3dp_ctx* c, int cls, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N,
+           int K, hipStream_t st) {
+  Scope s(c, cls, st);
+  if (c->fast()) return d3dp_launch_linear_bf16(epi, 0, A, W, bias, out, M, N, K, st);
+  return d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, st);
+}
+
+SeqMap spatial_map(int F, int J) { return SeqMap{J, 1, J, 0, 1}; }
+SeqMap temporal_map(int F, int J) { return SeqMap{F, J, F * J, 1, J}; }
+
+int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, hipStream_t st) {
+  const d3dp_cfg& g = c->cfg;
+  Scope s(c, axis == 0 ? P_ATTN_S : P_ATTN_T, st);
+  if (axis == 0) return d3dp_launch_attn_rows(c->fast(), qkv, out, n_bh * g.frames, spatial_map(g.frames, g.joints),
+                                              g.channels, g.heads, st);
+  if (c->fast() && g.channels / g.heads == 64)
+    return d3dp_launch_attn_temporal_bf16(qkv, out, n_bh * g.joints, temporal_map(g.frames, g.joints), g.channels,
+                                          g.heads, st);
+  return d3dp_launch_attn_rows(c->fast(), qkv, out, n_bh * g.joints, temporal_map(g.frames, g.joints), g.channels,
+                               g.heads, st);
+}
+
+// x = x + proj(attn(qkv(xn)));  x = x + fc2(gelu(fc1(LN2(x))))        (mixste.py:113-115)
+int run_block(d3dp_ctx* c, const BlockDev& w, int axis, float* x, void* bufA, void* bufB, int n_bh, hipStream_t st) {
+  const d3dp_cfg& g = c->cfg;
+  const int Tc = n_bh * g.frames * g.joints, C = g.channels;
+  LAUNCH_TRY(linear(c, P_QKV, EPI_BIAS, bufA, w.qkv_w, w.qkv_b, bufB, Tc, 3 * C, C, st));
+  LAUNCH_TRY(attention(c, axis, bufB, bufA, n_bh, st));
+  LAUNCH_TRY(linear(c, P_PROJ, EPI_RESID, bufA, w.proj_w, w.proj_b, x, Tc, C, C, st));
+  {
+    Scope s(c, P_LN, st);
+    LAUNCH_TRY(d3dp_launch_ln(c->fast(), x, w.n2w, w.n2b, g.eps_block, bufA, Tc, C, st));
+  }
+  LAUNCH_TRY(linear(c, P_FC1, EPI_GELU, bufA, w.fc1_w, w.fc1_b, bufB, Tc, g.hidden, C, st));
+  LAUNCH_TRY(linear(c, P_FC2, EPI_RESID, bufB, w.fc2_w, w.fc2_b, x, Tc, C, g.hidden, st));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int d3dp_abi_version(void) { return D3DP_ABI_VERSION; }
+const char* d3dp_last_error(void) { return g_err.c_str(); }
+const char* d3dp_profile_class_name(int32_t cls) {
+  return (cls >= 0 && cls < D3DP_PROFILE_CLASSES) ? kClassNames[cls] : "";
+}
+
+int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
+  if (!cfg || !out) return fail(D3DP_EINVAL, "d3dp_create: null argument");
+  const d3dp_cfg& g = *cfg;
+  if (g.frames < 1 || g.frames > 256) return fail(D3DP_ENOTSUP, "frames=%d not in [1,256]", g.frames);
+  if (g.joints < 1 || g.joints > 32) return fail(D3DP_ENOTSUP, "joints=%d not in [1,32]", g.joints);
+  if (g.channels != 64 && g.channels != 128 && g.channels != 256 && g.channels != 512)
+    return fail(D3DP_ENOTSUP, "channels=%d not in {64,128,256,512}", g.channels);
+  if (g.heads < 1 || g.channels % g.heads) return fail(D3DP_EINVAL, "heads=%d does not divide channels", g.heads);
+  const int hd = g.channels / g.heads;
+  if (hd != 8 && hd != 16 && hd != 32 && hd != 64) return fail(D3DP_ENOTSUP, "head dim %d not in {8,16,32,64}", hd);
+  if (g.hidden % 64 || g.hidden < 64) return fail(D3DP_ENOTSUP, "hidden=%d must be a multiple of 64", g.hidden);
+  if (g.depth < 1) return fail(D3DP_EINVAL, "depth=%d", g.depth);
+  if (g.mode != D3DP_MODE_EXACT && g.mode != D3DP_MODE_FAST) return fail(D3DP_EINVAL, "mode=%d", g.mode);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(D3DP_EHIP, "no HIP device visible: libd3dp_hip has no CPU fallback");
+  d3dp_ctx* c = new d3dp_ctx();
+  c->cfg = g;
+  HIP_TRY(hipGetDevice(&c->device));
+  *out = c;
+  return D3DP_OK;
+}
+
+int d3dp_destroy(d3dp_ctx* c) {
+  if (!c) return D3DP_OK;
+  for (auto& e : c->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (c->arena) (void)hipFree(c->arena);
+  delete c;
+  return D3DP_OK;
+}
+
+int d3dp_set_weights(d3dp_ctx* c, const d3dp_weights* w, void* stream) {
+  if (!c || !w || !w->ste || !w->tte) return fail(D3DP_EINVAL, "d3dp_set_weights: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const d3dp_cfg& g = c->cfg;
+  const size_t C = g.channels, Hd = g.hidden, J = g.joints, F = g.frames;
+  const size_t ws = c->act_size();
+  // ---- arena layout ----
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+  struct Item { const void* src; size_t n; bool mat; size_t off; };
+  std::vector<Item> items;
+  auto add = [&](const void* src, size_t n, bool mat) {
+    items.push_back({src, n, mat, take(n * (mat ? ws : 4))});
+    return items.size() - 1;
+  };
+  const size_t i_spos = add(w->spatial_pos, J * C, false), i_tpos = add(w->temporal_pos, F * C, false);
+  const size_t i_ew = add(w->embed_w, C * 5, false), i_eb = add(w->embed_b, C, false);
+  const size_t i_fr = add(w->time_freq, C / 2, false);
+  const size_t i_t1w = add(w->time1_w, 2 * C * C, false), i_t1b = add(w->time1_b, 2 * C, false);
+  const size_t i_t3w = add(w->time3_w, 2 * C * C, false), i_t3b = add(w->time3_b, C, false);
+  const size_t i_snw = add(w->spatial_norm_w, C, false), i_snb = add(w->spatial_norm_b, C, false);
+  const size_t i_tnw = add(w->temporal_norm_w, C, false), i_tnb = add(w->temporal_norm_b, C, false);
+  const size_t i_hnw = add(w->head_norm_w, C, false), i_hnb = add(w->head_norm_b, C, false);
+  const size_t i_hw = add(w->head_w, 3 * C, false), i_hb = add(w->head_b, 3, false);
+  struct BI { size_t v[12]; };
+  std::vector<BI> bis;
+  for (int kind = 0; kind < 2; ++kind)
+    for (int d = 0; d < g.depth; ++d) {
+      const d3dp_block_weights& b = (kind == 0 ? w->ste : w->tte)[d];
+      BI bi;
+      bi.v[0] = add(b.norm1_w, C, false); bi.v[1] = add(b.norm1_b, C, false);
+      bi.v[2] = add(b.qkv_w, 3 * C * C, true); bi.v[3] = add(b.qkv_b, 3 * C, false);
+      bi.v[4] = add(b.proj_w, C * C, true); bi.v[5] = add(b.proj_b, C, false);
+      bi.v[6] = add(b.norm2_w, C, false); bi.v[7] = add(b.norm2_b, C, false);
+      bi.v[8] = add(b.fc1_w, Hd * C, true); bi.v[9] = add(b.fc1_b, Hd, false);
+      bi.v[10] = add(b.fc2_w, C * Hd, true); bi.v[11] = add(b.fc2_b, C, false);
+      bis.push_back(bi);
+    }
+  for (auto& it : items)
+    if (!it.src) return fail(D3DP_EINVAL, "d3dp_set_weights: a weight pointer is null");
+  if (!c->arena || c->arena_bytes < off) {
+    if (c->arena) HIP_TRY(hipFree(c->arena));
+    c->arena = nullptr;
+    HIP_TRY(hipMalloc((void**)&c->arena, off));
+    c->arena_bytes = off;
+  }
+  for (auto& it : items) {
+    if (it.mat && c->fast()) launch_to_bf16((const float*)it.src, c->arena + it.off, it.n, st);
+    else HIP_TRY(hipMemcpyAsync(c->arena + it.off, it.src, it.n * 4, hipMemcpyDeviceToDevice, st));
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  auto F32 = [&](size_t i) { return (const float*)(c->arena + items[i].off); };
+  auto ANY = [&](size_t i) { return (const void*)(c->arena + items[i].off); };
+  c->spos = F32(i_spos); c->tpos = F32(i_tpos); c->ew = F32(i_ew); c->eb = F32(i_eb); c->freq = F32(i_fr);
+  c->t1w = F32(i_t1w); c->t1b = F32(i_t1b); c->t3w = F32(i_t3w); c->t3b = F32(i_t3b);
+  c->snw = F32(i_snw); c->snb = F32(i_snb); c->tnw = F32(i_tnw); c->tnb = F32(i_tnb);
+  c->hnw = F32(i_hnw); c->hnb = F32(i_hnb); c->hw = F32(i_hw); c->hb = F32(i_hb);
+  c->ste.clear(); c->tte.clear();
+  for (size_t k = 0; k < bis.size(); ++k) {
+    const BI& bi = bis[k];
+    BlockDev b{F32(bi.v[0]), F32(bi.v[1]), F32(bi.v[6]), F32(bi.v[7]), F32(bi.v[3]), F32(bi.v[5]), F32(bi.v[9]),
+               F32(bi.v[11]), ANY(bi.v[2]), ANY(bi.v[4]), ANY(bi.v[8]), ANY(bi.v[10])};
+    (k < (size_t)g.depth ? c->ste : c->tte).push_back(b);
+  }
+  c->weights_set = true;
+  return D3DP_OK;
+}
+
+int d3dp_workspace_bytes(const d3dp_ctx* c, int32_t B, int32_t H, size_t* bytes) {
+  if (!c || !bytes || B < 1 || H < 1) return fail(D3DP_EINVAL, "d3dp_workspace_bytes: bad argument");
+  const d3dp_cfg& g = c->cfg;
+  const size_t n = (size_t)std::min(c->chunk(), B * H);
+  const size_t Tc = n * g.frames * g.joints, C = g.channels;
+  const size_t wide = (size_t)std::max(3 * g.channels, g.hidden);
+  *bytes = align_up((size_t)B * C * 4) + align_up(Tc * C * 4) + align_up(Tc * C * c->act_size()) +
+           align_up(Tc * wide * c->act_size());
+  return D3DP_OK;
+}
+
+int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t* t, float* out, int32_t B, int32_t H,
+                 void* workspace, size_t workspace_bytes, void* stream) {
+  if (!c || !x2d || !x_t || !t || !out || !workspace || B < 1 || H < 1)
+    return fail(D3DP_EINVAL, "d3dp_denoise: bad argument");
+  if (!c->weights_set) return fail(D3DP_ESTATE, "d3dp_denoise: weights not set");
+  size_t need = 0;
+  d3dp_workspace_bytes(c, B, H, &need);
+  if (workspace_bytes < need) return fail(D3DP_ESTATE, "workspace %zu < required %zu bytes", workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  const d3dp_cfg& g = c->cfg;
+  const int C = g.channels, F = g.frames, J = g.joints, FJ = F * J;
+  const int BH = B * H, chunk = std::min(c->chunk(), BH);
+  const size_t Tmax = (size_t)chunk * FJ;
+  char* p = (char*)workspace;
+  float* temb = (float*)p; p += align_up((size_t)B * C * 4);
+  float* x = (float*)p;    p += align_up(Tmax * C * 4);
+  void* bufA = p;          p += align_up(Tmax * C * c->act_size());
+  void* bufB = p;
+
+  {
+    Scope s(c, P_TIME, st);
+    LAUNCH_TRY(d3dp_launch_time_mlp(t, c->freq, c->t1w, c->t1b, c->t3w, c->t3b, temb, B, C, st));
+  }
+  for (int seq0 = 0; seq0 < BH; seq0 += chunk) {
+    const int n = std::min(chunk, BH - seq0);
+    const int Tc = n * FJ;
+    {
+      Scope s(c, P_EMBED, st);
+      LAUNCH_TRY(d3dp_launch_embed_ln(c->fast(), x2d, x_t, temb, c->ew, c->eb, c->spos, c->ste[0].n1w, c->ste[0].n1b,
+                                      g.eps_block, x, bufA, seq0, n, H, F, J, C, st));
+    }
+    for (int d = 0; d < g.depth; ++d) {
+      int r = run_block(c, c->ste[d], 0, x, bufA, bufB, n, st);
+      if (r) return r;
+      {
+        Scope s(c, P_LN2, st);   // Spatial_norm (+ Temporal_pos after block 0) fused with TTE block d's norm1
+        LAUNCH_TRY(d3dp_launch_ln2(c->fast(), x, c->snw, c->snb, d == 0 ? c->tpos : nullptr, c->tte[d].n1w,
+                                   c->tte[d].n1b, g.eps_block, bufA, Tc, C, F, J, st));
+      }
+      r = run_block(c, c->tte[d], 1, x, bufA, bufB, n, st);
+      if (r) return r;
+      if (d + 1 < g.depth) {
+        Scope s(c, P_LN2, st);   // Temporal_norm fused with STE block d+1's norm1
+        LAUNCH_TRY(d3dp_launch_ln2(c->fast(), x, c->tnw, c->tnb, nullptr, c->ste[d + 1].n1w, c->ste[d + 1].n1b,
+                                   g.eps_block, bufA, Tc, C, F, J, st));
+      }
+    }
+    {
+      Scope s(c, P_HEAD, st);
+      LAUNCH_TRY(d3dp_launch_head(x, c->tnw, c->tnb, g.eps_block, c->hnw, c->hnb, g.eps_head, c->hw, c->hb,
+                                  out + (size_t)seq0 * FJ * 3, Tc, C, st));
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
+int d3dp_ddim_pre(const float* img, float* xt2, const int32_t* perm, float scale, int32_t B, int32_t H, int32_t F,
+                  int32_t J, void* stream) {
+  if (!img || !xt2 || !perm || B < 1) return fail(D3DP_EINVAL, "d3dp_ddim_pre: bad argument");
+  LAUNCH_TRY(d3dp_launch_ddim_pre(img, xt2, perm, scale, B, H * F * J * 3, J, (hipStream_t)stream));
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
+int d3dp_ddim_post(const float* pred2, const float* img, const float* noise, const int32_t* perm, float scale,
+                   double sqrt_recip, double sqrt_recipm1, float c_xstart, float c_noise, float sigma, int32_t last,
+                   float* x_start, size_t xs_bstride, float* img_next, int32_t B, int32_t H, int32_t F, int32_t J,
+                   void* stream) {
+  if (!pred2 || !perm || !x_start || B < 1) return fail(D3DP_EINVAL, "d3dp_ddim_post: bad argument");
+  if (!last && (!img || !noise || !img_next)) return fail(D3DP_EINVAL, "d3dp_ddim_post: img/noise/img_next required");
+  LAUNCH_TRY(d3dp_launch_ddim_post(pred2, img, noise, perm, scale, sqrt_recip, sqrt_recipm1, c_xstart, c_noise, sigma,
+                                   last, x_start, xs_bstride, img_next, B, H * F * J * 3, J, (hipStream_t)stream));
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
+int d3dp_q_sample(const float* x0, const float* noise, const double* a, const double* s, float scale, float* out,
+                  int32_t B, int32_t per_b, void* stream) {
+  if (!x0 || !noise || !a || !s || !out || B < 1 || per_b < 1) return fail(D3DP_EINVAL, "d3dp_q_sample: bad argument");
+  LAUNCH_TRY(d3dp_launch_q_sample(x0, noise, a, s, scale, out, B, per_b, (hipStream_t)stream));
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
+int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, const float* bias, void* out, int32_t M,
+                   int32_t N, int32_t K, void* stream) {
+  if (!A || !W || !bias || !out) return fail(D3DP_EINVAL, "d3dp_op_linear: null argument");
+  if (mode == D3DP_MODE_FAST) LAUNCH_TRY(d3dp_launch_linear_bf16(epi, 0, A, W, bias, out, M, N, K, (hipStream_t)stream));
+  else LAUNCH_TRY(d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, (hipStream_t)stream));
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
+int d3dp_op_attention(int32_t act_bf16, int32_t impl, int32_t axis, const void* qkv, void* out, int32_t n_bh, int32_t F,
+                      int32_t J, int32_t C, int32_t heads, void* stream) {
+  if (!qkv || !out || n_bh < 1) return fail(D3DP_EINVAL, "d3dp_op_attention: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (axis == 0) LAUNCH_TRY(d3dp_launch_attn_rows(act_bf16, qkv, out, n_bh * F, spatial_map(F, J), C, heads, st));
+  else if (impl == 1) {
+    if (!act_bf16) return fail(D3DP_EINVAL, "MFMA temporal attention needs bf16 activations");
+    LAUNCH_TRY(d3dp_launch_attn_temporal_bf16(qkv, out, n_bh * J, temporal_map(F, J), C, heads, st));
+  } else LAUNCH_TRY(d3dp_launch_attn_rows(act_bf16, qkv, out, n_bh * J, temporal_map(F, J), C, heads, st));
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
+int d3dp_op_layernorm(int32_t out_bf16, const float* x, const float* w, const float* b, float eps, void* out, int32_t T,
+                      int32_t C, void* stream) {
+  if (!x || !w || !b || !out) return fail(D3DP_EINVAL, "d3dp_op_layernorm: null argument");
+  LAUNCH_TRY(d3dp_launch_ln(out_bf16, x, w, b, eps, out, T, C, (hipStream_t)stream));
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
+int d3dp_op_to_bf16(const float* src, void* dst, size_t n, void* stream) {
+  if (!src || !dst) return fail(D3DP_EINVAL, "d3dp_op_to_bf16: null argument");
+  launch_to_bf16(src, dst, n, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
+int d3dp_profile_enable(d3dp_ctx* c, int32_t on) {
+  if (!c) return fail(D3DP_EINVAL, "null ctx");
+  c->prof = on != 0;
+  c->used = 0;
+  memset(c->counts, 0, sizeof c->counts);
+  for (auto& v : c->total_ms) v = 0.0;
+  return D3DP_OK;
+}
+
+int d3dp_profile_read(d3dp_ctx* c, int64_t* counts, double* total_ms) {
+  if (!c || !counts || !total_ms) return fail(D3DP_EINVAL, "null argument");
+  if (c->flush_events() != 0) return fail(D3DP_EHIP, "event read failed");
+  for (int i = 0; i < D3DP_PROFILE_CLASSES; ++i) { counts[i] = c->counts[i]; total_ms[i] = c->total_ms[i]; }
+  memset(c->counts, 0, sizeof c->counts);
+  for (auto& v : c->total_ms) v = 0.0;
+  return D3DP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,281 @@
+// Linear layers of the MixSTE2 denoiser:  out[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N])
+// (reference: every nn.Linear on the path -- common/mixste.py:65 qkv, :80 proj, :38-41 fc1/fc2).
+//
+// W is the nn.Linear weight as stored in the reference state_dict ([out, in], K contiguous), so both
+// MFMA operands are read along K and no transpose is ever materialised.
+//
+//   gemm_bf16_kernel : FAST mode.  bf16 operands, fp32 accumulate on v_mfma_f32_16x16x32_bf16.
+//                      128x128x64 block tile, 4 waves (2x2), 64x64 per wave = 4x4 MFMA tiles.
+//                      Tiles are DMA'd HBM->LDS with global_load_lds_dwordx4 (16 B/lane); the LDS image
+//                      is lane-linear, so the bank swizzle is applied on the per-lane SOURCE address
+//                      and again on the ds_read_b128 fragment address (same involution).
+//   gemm_f32_kernel  : EXACT mode.  fp32 operands on v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fmaf
+//                      chain over k).  128x128x16 block tile, 2x2 32x32 tiles per wave.
+//
+// Both compute the TRANSPOSED product per wave (weight fragment as the MFMA A operand) so that each
+// lane ends up with 4 consecutive output columns of one row -> vector stores, bias as one float4.
+//
+// Epilogues: EPI_BIAS (out = acc+b), EPI_GELU (out = gelu_erf(acc+b)), EPI_RESID (resid += acc+b, fp32).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+
+template <int EPI, typename OutT>
+__device__ __forceinline__ void epilogue4(const float* v, const float* __restrict__ bias, OutT* out,
+                                          size_t row_off, int n) {
+  const float4 b = *reinterpret_cast<const float4*>(bias + n);
+  float r[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
+  if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = gelu_erf(r[i]);
+  }
+  if constexpr (EPI == EPI_RESID) {
+    float* o = reinterpret_cast<float*>(out) + row_off + n;
+    float4 x = *reinterpret_cast<float4*>(o);
+    x.x += r[0]; x.y += r[1]; x.z += r[2]; x.w += r[3];
+    *reinterpret_cast<float4*>(o) = x;
+  } else if constexpr (sizeof(OutT) == 4) {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + row_off + n) = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+    bf16x4 p = {(bf16)r[0], (bf16)r[1], (bf16)r[2], (bf16)r[3]};
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(out) + row_off + n) = p;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST: bf16 MFMA
+// ------------------------------------------------------------------------------------------------
+constexpr int FBK = 64;                         // K per stage (128 B per tile row)
+constexpr int TILE_BYTES = BM * FBK * 2;        // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;     // A + W
+
+// physical 16-B slot of logical slot s in row `row` (8 slots per 128-B row)
+__device__ __forceinline__ int swz(int row, int s) { return s ^ ((row >> 1) & 7); }
+
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
+                                                        const float* __restrict__ bias, OutT* out, int M, int N,
+                                                        int K, int n_tiles_n) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+  const int nblk = gridDim.x;
+  const int L = xcd_remap(blockIdx.x, nblk);
+  const int m0 = (L / n_tiles_n) * BM;
+  const int n0 = (L % n_tiles_n) * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // ---- per-lane DMA source pointers: wave w issues tile pieces j = 4w .. 4w+3 (8 rows each) ----
+  const bf16* srcA[4];
+  const bf16* srcW[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = (wave * 4 + q) * 8 + (lane >> 3);
+    const int s = swz(row, lane & 7);
+    const int ra = min(m0 + row, M - 1), rw = min(n0 + row, N - 1);
+    srcA[q] = A + (size_t)ra * K + s * 8;
+    srcW[q] = W + (size_t)rw * K + s * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int piece = (wave * 4 + q) * 1024;
+      __builtin_amdgcn_global_load_lds(GPTR(srcA[q] + kt * FBK), LPTR(base + piece), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GPTR(srcW[q] + kt * FBK), LPTR(base + TILE_BYTES + piece), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / FBK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int fi = lane & 15, fg = lane >> 4;
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* sa = smem + cur * STAGE_BYTES;
+    const char* sw = sa + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = wr * 64 + i * 16 + fi;
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * 128 + swz(ra, kk * 4 + fg) * 16);
+        const int rw = wc * 64 + i * 16 + fi;
+        wf[i] = *reinterpret_cast<const bf16x8*>(sw + rw * 128 + swz(rw, kk * 4 + fg) * 16);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane holds out[m = .. + fi][n = .. + 4*fg .. +3] ----
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wr * 64 + mi * 16 + fi;
+    if (m >= M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wc * 64 + ni * 16 + fg * 4;
+      if (n >= N) continue;
+      float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+      epilogue4<EPI, OutT>(v, bias, out, (size_t)m * N, n);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// EXACT: fp32 MFMA
+// ------------------------------------------------------------------------------------------------
+constexpr int XBK = 16;
+constexpr int XLD = BM + 4;   // padded leading dimension of the k-major LDS tiles
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* out, int M, int N,
+                                                       int K, int n_tiles_n) {
+  __shared__ float As[2][XBK][XLD];
+  __shared__ float Ws[2][XBK][XLD];
+
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (L / n_tiles_n) * BM;
+  const int n0 = (L % n_tiles_n) * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // global->register staging: 128 rows x 4 float4 per operand tile, 2 float4 per thread each
+  const float* pa[2];
+  const float* pw[2];
+  int lrow[2], lk[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * 256;
+    lrow[i] = idx >> 2;
+    lk[i] = (idx & 3) * 4;
+    pa[i] = A + (size_t)min(m0 + lrow[i], M - 1) * K + lk[i];
+    pw[i] = W + (size_t)min(n0 + lrow[i], N - 1) * K + lk[i];
+  }
+  float4 ra[2], rw[2];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ra[i] = *reinterpret_cast<const float4*>(pa[i] + kt * XBK);
+      rw[i] = *reinterpret_cast<const float4*>(pw[i] + kt * XBK);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      As[buf][lk[i] + 0][lrow[i]] = ra[i].x; As[buf][lk[i] + 1][lrow[i]] = ra[i].y;
+      As[buf][lk[i] + 2][lrow[i]] = ra[i].z; As[buf][lk[i] + 3][lrow[i]] = ra[i].w;
+      Ws[buf][lk[i] + 0][lrow[i]] = rw[i].x; Ws[buf][lk[i] + 1][lrow[i]] = rw[i].y;
+      Ws[buf][lk[i] + 2][lrow[i]] = rw[i].z; Ws[buf][lk[i] + 3][lrow[i]] = rw[i].w;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = K / XBK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int l31 = lane & 31, lh = lane >> 5;
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < XBK / 2; ++kk) {
+      float wv[2], av[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        wv[i] = Ws[cur][kk * 2 + lh][wc * 64 + i * 32 + l31];
+        av[i] = As[cur][kk * 2 + lh][wr * 64 + i * 32 + l31];
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[ni], av[mi], acc[mi][ni], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // lane holds out[m = .. + l31][n = .. + 8q + 4*lh + (0..3)], q = 0..3
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = m0 + wr * 64 + mi * 32 + l31;
+    if (m >= M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wc * 64 + ni * 32 + q * 8 + lh * 4;
+        if (n >= N) continue;
+        float v[4] = {acc[mi][ni][q * 4 + 0], acc[mi][ni][q * 4 + 1], acc[mi][ni][q * 4 + 2], acc[mi][ni][q * 4 + 3]};
+        epilogue4<EPI, float>(v, bias, out, (size_t)m * N, n);
+      }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+template <int EPI, typename OutT>
+static void launch_bf16(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                        hipStream_t st) {
+  const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OutT>), dim3(tm * tn), dim3(256), 0, st, (const bf16*)A, (const bf16*)W,
+                     bias, (OutT*)out, M, N, K, tn);
+}
+
+int d3dp_launch_linear_bf16(int epi, int out_f32, const void* A, const void* W, const float* bias, void* out, int M,
+                            int N, int K, hipStream_t st) {
+  if (K % FBK != 0 || N % 4 != 0 || M <= 0) return -1;
+  if (epi == EPI_RESID) launch_bf16<EPI_RESID, float>(A, W, bias, out, M, N, K, st);
+  else if (epi == EPI_GELU && !out_f32) launch_bf16<EPI_GELU, bf16>(A, W, bias, out, M, N, K, st);
+  else if (epi == EPI_BIAS && !out_f32) launch_bf16<EPI_BIAS, bf16>(A, W, bias, out, M, N, K, st);
+  else if (epi == EPI_BIAS && out_f32) launch_bf16<EPI_BIAS, float>(A, W, bias, out, M, N, K, st);
+  else return -1;
+  return 0;
+}
+
+int d3dp_launch_linear_f32(int epi, const float* A, const float* W, const float* bias, float* out, int M, int N,
+                           int K, hipStream_t st) {
+  if (K % XBK != 0 || N % 4 != 0 || M <= 0) return -1;
+  const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+  dim3 g(tm * tn), b(256);
+  if (epi == EPI_RESID) hipLaunchKernelGGL((gemm_f32_kernel<EPI_RESID>), g, b, 0, st, A, W, bias, out, M, N, K, tn);
+  else if (epi == EPI_GELU) hipLaunchKernelGGL((gemm_f32_kernel<EPI_GELU>), g, b, 0, st, A, W, bias, out, M, N, K, tn);
+  else if (epi == EPI_BIAS) hipLaunchKernelGGL((gemm_f32_kernel<EPI_BIAS>), g, b, 0, st, A, W, bias, out, M, N, K, tn);
+  else return -1;
+  return 0;
+}

@@ -1,0 +1,50 @@
+// Internal launcher interface between the C-ABI layer (capi.hip) and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2 };
+
+// ---- gemm.hip ----------------------------------------------------------------------------------
+int d3dp_launch_linear_bf16(int epi, int out_f32, const void* A, const void* W, const float* bias, void* out, int M,
+                            int N, int K, hipStream_t st);
+int d3dp_launch_linear_f32(int epi, const float* A, const float* W, const float* bias, float* out, int M, int N,
+                           int K, hipStream_t st);
+
+// ---- attention.hip -----------------------------------------------------------------------------
+// qkv: [T, 3C] (q | k | v, each head-major hd-minor), out: [T, C].  A "sequence" s of length n_tok has
+// token index  tok(s, i) = (s / inner) * outer_stride + (s % inner) * inner_stride + i * tok_stride.
+//   spatial : n_tok = J, inner = 1,  outer_stride = J,   inner_stride = 0, tok_stride = 1   (s = bh*F + f)
+//   temporal: n_tok = F, inner = J,  outer_stride = F*J, inner_stride = 1, tok_stride = J   (s = bh*J + n)
+struct SeqMap { int n_tok, inner, outer_stride, inner_stride, tok_stride; };
+int d3dp_launch_attn_rows(int act_bf16, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
+                          hipStream_t st);
+int d3dp_launch_attn_temporal_bf16(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
+                                   hipStream_t st);
+
+// ---- pointwise.hip -----------------------------------------------------------------------------
+int d3dp_launch_time_mlp(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2,
+                         const float* b2, float* temb, int B, int C, hipStream_t st);
+// x[T,C] = embed(x2d, x3d) + spos + temb ;  xn = LN1(x)
+int d3dp_launch_embed_ln(int act_bf16, const float* x2d, const float* x3d, const float* temb, const float* ew,
+                         const float* eb, const float* spos, const float* lnw, const float* lnb, float eps, float* x,
+                         void* xn, int seq0, int n_seq, int H, int F, int J, int C, hipStream_t st);
+// xn = LN(x)
+int d3dp_launch_ln(int act_bf16, const float* x, const float* w, const float* b, float eps, void* xn, int T, int C,
+                   hipStream_t st);
+// x = LN_a(x) (+ pos[f]) in place ; xn = LN_b(x)   (shared Spatial/Temporal norm fused with the next block's norm1)
+int d3dp_launch_ln2(int act_bf16, float* x, const float* wa, const float* ba, const float* pos, const float* wb,
+                    const float* bb, float eps, void* xn, int T, int C, int F, int J, hipStream_t st);
+// out[T,3] = Linear(LN_head(LN_a(x)))
+int d3dp_launch_head(const float* x, const float* wa, const float* ba, float eps_a, const float* wh, const float* bh,
+                     float eps_h, const float* w, const float* b, float* out, int T, int C, hipStream_t st);
+
+// ---- sampler.hip -------------------------------------------------------------------------------
+int d3dp_launch_ddim_pre(const float* img, float* xt2, const int* perm, float scale, int B, int per_b, int J,
+                         hipStream_t st);
+int d3dp_launch_ddim_post(const float* pred2, const float* img, const float* noise, const int* perm, float scale,
+                          double sqrt_recip, double sqrt_recipm1, float c_xstart, float c_noise, float sigma,
+                          int last, float* x_start, size_t xs_bstride, float* img_next, int B, int per_b, int J,
+                          hipStream_t st);
+int d3dp_launch_q_sample(const float* x0, const float* noise, const double* a, const double* b, float scale,
+                         float* out, int B, int per_b, hipStream_t st);

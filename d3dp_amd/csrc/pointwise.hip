@@ -1,0 +1,262 @@
+// Token-wise (HBM-bound) pieces of the MixSTE2 denoiser.  One wavefront owns one token's C channels;
+// LayerNorm statistics are two-pass fp32 reductions with wavefront shuffles (no LDS, no atomics).
+//
+//   time_mlp_kernel : sinusoid(t) -> Linear(C,2C) -> GELU(erf) -> Linear(2C,C)   (mixste.py:127-139,179-184)
+//   embed_ln_kernel : cat(x2d,x3d) -> Linear(5,C) + Spatial_pos + time embed, fused with STE block 0's
+//                     norm1 (mixste.py:227-235, :114).  The reference materialises the time embedding as a
+//                     (B,H,F,J,C) repeat; here it is a broadcast read of a (B,C) table.
+//   ln_kernel       : xn = LN(x)                                               (mixste.py:114-115 norm1/norm2)
+//   ln2_kernel      : x = LN_shared(x) [+ Temporal_pos[f]] ; xn = LN_next(x)   (mixste.py:243,250,257,269,273
+//                     fused with the following block's norm1)
+//   head_kernel     : Temporal_norm -> head LayerNorm(eps 1e-5) -> Linear(C,3) (mixste.py:257/273, :207-210)
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// per-lane slice of a C-channel row: NV = C/64 values; for NV % 4 == 0 they are float4 groups at
+// element (g*64 + lane)*4, otherwise scalars at i*64 + lane.
+template <int C> struct Row {
+  static constexpr int NV = C / 64;
+  static constexpr bool V4 = (NV % 4 == 0);
+  static __device__ __forceinline__ int elem(int lane, int i) {
+    if constexpr (V4) return ((i >> 2) * 64 + lane) * 4 + (i & 3);
+    else return i * 64 + lane;
+  }
+  static __device__ __forceinline__ void load(const float* p, int lane, float* v) {
+    if constexpr (V4) {
+#pragma unroll
+      for (int g = 0; g < NV / 4; ++g) {
+        float4 a = *reinterpret_cast<const float4*>(p + (g * 64 + lane) * 4);
+        v[g * 4] = a.x; v[g * 4 + 1] = a.y; v[g * 4 + 2] = a.z; v[g * 4 + 3] = a.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = p[i * 64 + lane];
+    }
+  }
+  static __device__ __forceinline__ void store(float* p, int lane, const float* v) {
+    if constexpr (V4) {
+#pragma unroll
+      for (int g = 0; g < NV / 4; ++g)
+        *reinterpret_cast<float4*>(p + (g * 64 + lane) * 4) = make_float4(v[g * 4], v[g * 4 + 1], v[g * 4 + 2], v[g * 4 + 3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) p[i * 64 + lane] = v[i];
+    }
+  }
+  static __device__ __forceinline__ void store(bf16* p, int lane, const float* v) {
+    if constexpr (V4) {
+#pragma unroll
+      for (int g = 0; g < NV / 4; ++g) {
+        bf16x4 a = {(bf16)v[g * 4], (bf16)v[g * 4 + 1], (bf16)v[g * 4 + 2], (bf16)v[g * 4 + 3]};
+        *reinterpret_cast<bf16x4*>(p + (g * 64 + lane) * 4) = a;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) p[i * 64 + lane] = (bf16)v[i];
+    }
+  }
+  // y = (v - mean) * rstd * w + b   (two-pass statistics, biased variance as torch LayerNorm)
+  static __device__ __forceinline__ void norm(const float* v, const float* w, const float* b, float eps, int lane,
+                                              float* y) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += v[i];
+    const float mean = wave_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+    float wv[NV], bv[NV];
+    load(w, lane, wv);
+    load(b, lane, bv);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) y[i] = fmaf((v[i] - mean) * rstd, wv[i], bv[i]);
+  }
+};
+
+template <int C, typename XN>
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                 const float* __restrict__ b, float eps, XN* __restrict__ xn, int T) {
+  using R = Row<C>;
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= T) return;
+  float v[R::NV], y[R::NV];
+  R::load(x + (size_t)tok * C, lane, v);
+  R::norm(v, w, b, eps, lane, y);
+  R::store(xn + (size_t)tok * C, lane, y);
+}
+
+template <int C, typename XN>
+__global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const float* __restrict__ wa,
+                                                  const float* __restrict__ ba, const float* __restrict__ pos,
+                                                  const float* __restrict__ wb, const float* __restrict__ bb, float eps,
+                                                  XN* __restrict__ xn, int T, int F, int J) {
+  using R = Row<C>;
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= T) return;
+  float v[R::NV], y[R::NV], z[R::NV];
+  R::load(x + (size_t)tok * C, lane, v);
+  R::norm(v, wa, ba, eps, lane, y);
+  if (pos != nullptr) {
+    const int f = (tok / J) % F;
+    float pv[R::NV];
+    R::load(pos + (size_t)f * C, lane, pv);
+#pragma unroll
+    for (int i = 0; i < R::NV; ++i) y[i] += pv[i];
+  }
+  R::store(x + (size_t)tok * C, lane, y);
+  R::norm(y, wb, bb, eps, lane, z);
+  R::store(xn + (size_t)tok * C, lane, z);
+}
+
+template <int C, typename XN>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__ x2d, const float* __restrict__ x3d,
+                                                       const float* __restrict__ temb, const float* __restrict__ ew,
+                                                       const float* __restrict__ eb, const float* __restrict__ spos,
+                                                       const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                                       float eps, float* __restrict__ x, XN* __restrict__ xn, int seq0,
+                                                       int n_seq, int H, int F, int J) {
+  using R = Row<C>;
+  const int lane = threadIdx.x & 63;
+  const int tl = blockIdx.x * 4 + (threadIdx.x >> 6);          // chunk-local token
+  const int FJ = F * J;
+  if (tl >= n_seq * FJ) return;
+  const int seq = seq0 + tl / FJ, fj = tl % FJ, nj = fj % J;
+  const int b = seq / H;
+  const float* p2 = x2d + ((size_t)b * FJ + fj) * 2;
+  const float* p3 = x3d + ((size_t)seq * FJ + fj) * 3;
+  const float in5[5] = {p2[0], p2[1], p3[0], p3[1], p3[2]};    // channel order [u, v, x, y, z], mixste.py:228
+  float v[R::NV], y[R::NV];
+#pragma unroll
+  for (int i = 0; i < R::NV; ++i) {
+    const int c = R::elem(lane, i);
+    const float* wr = ew + c * 5;
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) a = fmaf(in5[k], wr[k], a);
+    a += eb[c];
+    a += spos[nj * C + c];
+    a += temb[b * C + c];
+    v[i] = a;
+  }
+  R::store(x + (size_t)tl * C, lane, v);
+  R::norm(v, lnw, lnb, eps, lane, y);
+  R::store(xn + (size_t)tl * C, lane, y);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const float* __restrict__ wa,
+                                                   const float* __restrict__ ba, float eps_a,
+                                                   const float* __restrict__ wh, const float* __restrict__ bh,
+                                                   float eps_h, const float* __restrict__ w, const float* __restrict__ b,
+                                                   float* __restrict__ out, int T) {
+  using R = Row<C>;
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= T) return;
+  float v[R::NV], y[R::NV], z[R::NV];
+  R::load(x + (size_t)tok * C, lane, v);
+  R::norm(v, wa, ba, eps_a, lane, y);
+  R::norm(y, wh, bh, eps_h, lane, z);
+  float acc[3];
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    float wv[R::NV];
+    R::load(w + o * C, lane, wv);
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < R::NV; ++i) a = fmaf(z[i], wv[i], a);
+    acc[o] = wave_sum(a) + b[o];
+  }
+  if (lane < 3) out[(size_t)tok * 3 + lane] = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : acc[2]);
+}
+
+// one workgroup per batch element; sin/cos table `freq` is supplied by the host (computed with the
+// reference's own fp32 expression, mixste.py:135-136) so no device exp() enters the argument.
+__global__ __launch_bounds__(256) void time_mlp_kernel(const int64_t* __restrict__ t, const float* __restrict__ freq,
+                                                       const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       float* __restrict__ temb, int C) {
+  extern __shared__ float sm[];            // [C] sinusoid | [2C] hidden
+  float* e = sm;
+  float* h = sm + C;
+  const int b = blockIdx.x, half = C / 2;
+  const float tv = (float)t[b];
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    const float a = tv * freq[i];
+    e[i] = sinf(a);
+    e[half + i] = cosf(a);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * C; o += blockDim.x) {
+    const float* wr = w1 + (size_t)o * C;
+    float a = 0.f;
+    for (int k = 0; k < C; ++k) a = fmaf(e[k], wr[k], a);
+    h[o] = gelu_erf(a + b1[o]);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < C; o += blockDim.x) {
+    const float* wr = w2 + (size_t)o * 2 * C;
+    float a = 0.f;
+    for (int k = 0; k < 2 * C; ++k) a = fmaf(h[k], wr[k], a);
+    temb[(size_t)b * C + o] = a + b2[o];
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_C(C, ...)                          \
+  switch (C) {                                      \
+    case 512: { constexpr int CC = 512; __VA_ARGS__; break; } \
+    case 256: { constexpr int CC = 256; __VA_ARGS__; break; } \
+    case 128: { constexpr int CC = 128; __VA_ARGS__; break; } \
+    case 64:  { constexpr int CC = 64;  __VA_ARGS__; break; } \
+    default: return -2;                             \
+  }
+
+int d3dp_launch_time_mlp(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2,
+                         const float* b2, float* temb, int B, int C, hipStream_t st) {
+  hipLaunchKernelGGL(time_mlp_kernel, dim3(B), dim3(256), (size_t)3 * C * sizeof(float), st, t, freq, w1, b1, w2, b2,
+                     temb, C);
+  return 0;
+}
+
+int d3dp_launch_embed_ln(int act_bf16, const float* x2d, const float* x3d, const float* temb, const float* ew,
+                         const float* eb, const float* spos, const float* lnw, const float* lnb, float eps, float* x,
+                         void* xn, int seq0, int n_seq, int H, int F, int J, int C, hipStream_t st) {
+  const int T = n_seq * F * J;
+  dim3 g((T + 3) / 4), blk(256);
+  DISPATCH_C(C,
+    if (act_bf16) hipLaunchKernelGGL((embed_ln_kernel<CC, bf16>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, seq0, n_seq, H, F, J);
+    else hipLaunchKernelGGL((embed_ln_kernel<CC, float>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (float*)xn, seq0, n_seq, H, F, J))
+  return 0;
+}
+
+int d3dp_launch_ln(int act_bf16, const float* x, const float* w, const float* b, float eps, void* xn, int T, int C,
+                   hipStream_t st) {
+  dim3 g((T + 3) / 4), blk(256);
+  DISPATCH_C(C,
+    if (act_bf16) hipLaunchKernelGGL((ln_kernel<CC, bf16>), g, blk, 0, st, x, w, b, eps, (bf16*)xn, T);
+    else hipLaunchKernelGGL((ln_kernel<CC, float>), g, blk, 0, st, x, w, b, eps, (float*)xn, T))
+  return 0;
+}
+
+int d3dp_launch_ln2(int act_bf16, float* x, const float* wa, const float* ba, const float* pos, const float* wb,
+                    const float* bb, float eps, void* xn, int T, int C, int F, int J, hipStream_t st) {
+  dim3 g((T + 3) / 4), blk(256);
+  DISPATCH_C(C,
+    if (act_bf16) hipLaunchKernelGGL((ln2_kernel<CC, bf16>), g, blk, 0, st, x, wa, ba, pos, wb, bb, eps, (bf16*)xn, T, F, J);
+    else hipLaunchKernelGGL((ln2_kernel<CC, float>), g, blk, 0, st, x, wa, ba, pos, wb, bb, eps, (float*)xn, T, F, J))
+  return 0;
+}
+
+int d3dp_launch_head(const float* x, const float* wa, const float* ba, float eps_a, const float* wh, const float* bh,
+                     float eps_h, const float* w, const float* b, float* out, int T, int C, hipStream_t st) {
+  dim3 g((T + 3) / 4), blk(256);
+  DISPATCH_C(C, hipLaunchKernelGGL((head_kernel<CC>), g, blk, 0, st, x, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T))
+  return 0;
+}

@@ -1,0 +1,442 @@
+"""Host-side mirror of the reference's plugin interface for the hot path.
+
+``D3DP`` and ``MixSTE2`` keep the reference's constructor/forward signatures, parameter and
+buffer names (reference common/diffusionpose.py:60-126, common/mixste.py:141-210), so the
+reference's callers (main.py:228-257, 450, 698; in_the_wild/utils.py:284) and its checkpoints work
+unchanged -- but no arithmetic happens here: parameters are plain containers and every forward
+goes through libd3dp_hip.so (include/d3dp_hip.h).  There is no PyTorch/CPU fallback.
+
+Extensions over the reference API (default-off):
+  * ``noise=[...]`` / ``generator=`` on the samplers for fixed-noise parity tests;
+  * ``numerics='exact'|'fast'`` (or ``args.numerics`` / env ``D3DP_NUMERICS``): exact = fp32 MFMA
+    (<= 1e-3 mm vs the reference), fast = bf16 MFMA with fp32 accumulation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+
+__all__ = ["D3DP", "MixSTE2", "cosine_beta_schedule"]
+
+NUM_JOINTS = 17
+
+
+def cosine_beta_schedule(timesteps: int, s: float = 0.008) -> torch.Tensor:
+    """fp64 cosine schedule, reference common/diffusionpose.py:42-52."""
+    steps = timesteps + 1
+    x = torch.linspace(0, timesteps, steps, dtype=torch.float64)
+    ac = torch.cos(((x / timesteps) + s) / (1 + s) * math.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    return torch.clip(1 - (ac[1:] / ac[:-1]), 0, 0.999)
+
+
+def _resolve_mode(numerics: Optional[str]) -> int:
+    name = (numerics or os.environ.get("D3DP_NUMERICS", "exact")).lower()
+    if name not in ("exact", "fast"):
+        raise ValueError(f"numerics must be 'exact' or 'fast', got {name!r}")
+    return _lib.MODE_FAST if name == "fast" else _lib.MODE_EXACT
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter containers (names = reference state_dict keys)
+# ----------------------------------------------------------------------------------------------
+class _Attention(nn.Module):          # mixste.py:46-61
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _Mlp(nn.Module):                # mixste.py:24-35
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _Block(nn.Module):              # mixste.py:84-111
+    def __init__(self, dim, hidden, eps):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = _Attention(dim)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = _Mlp(dim, hidden)
+
+
+class _NoParams(nn.Module):
+    """Placeholder keeping nn.Sequential indices aligned with the reference (time_mlp.0 / .2)."""
+
+
+class MixSTE2(nn.Module):
+    """Denoiser with the reference's signature (mixste.py:141-147, forward :278) running on libd3dp_hip."""
+
+    def __init__(self, num_frame=9, num_joints=17, in_chans=2, embed_dim_ratio=32, depth=4, num_heads=8,
+                 mlp_ratio=2., qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2,
+                 norm_layer=None, is_train=True, numerics: Optional[str] = None, chunk_seqs: int = 0):
+        super().__init__()
+        if in_chans != 2 or not qkv_bias or qk_scale is not None or drop_rate or attn_drop_rate:
+            raise NotImplementedError("libd3dp_hip implements the configuration D3DP instantiates "
+                                      "(in_chans=2, qkv_bias=True, no dropout), diffusionpose.py:123-124")
+        C_ = embed_dim_ratio
+        self.is_train = is_train
+        self.num_frame, self.num_joints, self.embed_dim, self.block_depth = num_frame, num_joints, C_, depth
+        self.num_heads, self.hidden = num_heads, int(C_ * mlp_ratio)
+        self.drop_path_rate = drop_path_rate
+        self.eps_block, self.eps_head = 1e-6, 1e-5
+        self.Spatial_patch_to_embedding = nn.Linear(in_chans + 3, C_)
+        self.Spatial_pos_embed = nn.Parameter(torch.zeros(1, num_joints, C_))
+        self.Temporal_pos_embed = nn.Parameter(torch.zeros(1, num_frame, C_))
+        self.time_mlp = nn.Sequential(_NoParams(), nn.Linear(C_, C_ * 2), _NoParams(), nn.Linear(C_ * 2, C_))
+        self.STEblocks = nn.ModuleList([_Block(C_, self.hidden, self.eps_block) for _ in range(depth)])
+        self.TTEblocks = nn.ModuleList([_Block(C_, self.hidden, self.eps_block) for _ in range(depth)])
+        self.Spatial_norm = nn.LayerNorm(C_, eps=self.eps_block)
+        self.Temporal_norm = nn.LayerNorm(C_, eps=self.eps_block)
+        self.head = nn.Sequential(nn.LayerNorm(C_), nn.Linear(C_, 3))
+        self._mode = _resolve_mode(numerics)
+        self._chunk_seqs = int(chunk_seqs)
+        self._ctx = None
+        self._ctx_device = None
+        self._weights_sig = None
+        self._keep = None
+        self._ws = None
+
+    # -- library context ------------------------------------------------------------------------
+    @property
+    def numerics(self) -> str:
+        return "fast" if self._mode == _lib.MODE_FAST else "exact"
+
+    def set_numerics(self, numerics: str, chunk_seqs: Optional[int] = None) -> None:
+        self._mode = _resolve_mode(numerics)
+        if chunk_seqs is not None:
+            self._chunk_seqs = int(chunk_seqs)
+        self._drop_ctx()
+
+    def _drop_ctx(self):
+        if self._ctx is not None:
+            _lib.load().d3dp_destroy(self._ctx)
+        self._ctx, self._weights_sig, self._ws, self._keep = None, None, None, None
+
+    def __del__(self):
+        try:
+            self._drop_ctx()
+        except Exception:
+            pass
+
+    def _context(self, device: torch.device):
+        if device.type != "cuda":
+            raise _lib.D3DPHipError("MixSTE2 runs only on an MI355X (tensor on %s); there is no CPU fallback" % device)
+        lib = _lib.load()
+        if self._ctx is None or self._ctx_device != device:
+            self._drop_ctx()
+            cfg = _lib.Cfg(self.num_frame, self.num_joints, self.embed_dim, self.block_depth, self.num_heads,
+                           self.hidden, self.eps_block, self.eps_head, self._mode, self._chunk_seqs)
+            h = C.c_void_p()
+            with torch.cuda.device(device):
+                _lib.check(lib.d3dp_create(C.byref(cfg), C.byref(h)), "d3dp_create")
+            self._ctx, self._ctx_device = h, device
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if sig != self._weights_sig:
+            self._push_weights(device)
+            self._weights_sig = sig
+        return self._ctx
+
+    def _push_weights(self, device):
+        lib = _lib.load()
+        keep: List[torch.Tensor] = []
+
+        def dev(t):
+            t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        def blocks(mods):
+            arr = (_lib.BlockWeights * len(mods))()
+            for i, b in enumerate(mods):
+                arr[i] = _lib.BlockWeights(dev(b.norm1.weight), dev(b.norm1.bias), dev(b.attn.qkv.weight),
+                                           dev(b.attn.qkv.bias), dev(b.attn.proj.weight), dev(b.attn.proj.bias),
+                                           dev(b.norm2.weight), dev(b.norm2.bias), dev(b.mlp.fc1.weight),
+                                           dev(b.mlp.fc1.bias), dev(b.mlp.fc2.weight), dev(b.mlp.fc2.bias))
+            return arr
+
+        half = self.embed_dim // 2
+        freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))    # mixste.py:134-136, fp32 on host
+        ste, tte = blocks(self.STEblocks), blocks(self.TTEblocks)
+        w = _lib.Weights(dev(self.Spatial_pos_embed), dev(self.Temporal_pos_embed),
+                         dev(self.Spatial_patch_to_embedding.weight), dev(self.Spatial_patch_to_embedding.bias),
+                         dev(freq), dev(self.time_mlp[1].weight), dev(self.time_mlp[1].bias),
+                         dev(self.time_mlp[3].weight), dev(self.time_mlp[3].bias),
+                         dev(self.Spatial_norm.weight), dev(self.Spatial_norm.bias),
+                         dev(self.Temporal_norm.weight), dev(self.Temporal_norm.bias),
+                         dev(self.head[0].weight), dev(self.head[0].bias), dev(self.head[1].weight),
+                         dev(self.head[1].bias), ste, tte)
+        with torch.cuda.device(device):
+            _lib.check(lib.d3dp_set_weights(self._ctx, C.byref(w), _lib.current_stream()), "d3dp_set_weights")
+        self._keep = None   # the library owns packed copies; originals may go
+
+    def _workspace(self, ctx, B, H, device):
+        n = C.c_size_t()
+        _lib.check(_lib.load().d3dp_workspace_bytes(ctx, B, H, C.byref(n)), "d3dp_workspace_bytes")
+        if self._ws is None or self._ws.numel() < n.value or self._ws.device != device:
+            self._ws = torch.empty(n.value, dtype=torch.uint8, device=device)
+        return self._ws, n.value
+
+    def denoise(self, x_2d: torch.Tensor, x_3d: torch.Tensor, t: torch.Tensor, out: Optional[torch.Tensor] = None):
+        """x_2d (B,F,J,2), x_3d (B,H,F,J,3), t (B,) int64 -> (B,H,F,J,3) fp32 (all on the GPU)."""
+        B, H, Fr, J, _ = x_3d.shape
+        assert x_2d.shape == (B, Fr, J, 2), (x_2d.shape, x_3d.shape)
+        assert Fr == self.num_frame and J == self.num_joints, "clip shape differs from the model's (F, J)"
+        assert t.shape == (B,)
+        dev = x_3d.device
+        ctx = self._context(dev)
+        x_2d = x_2d.to(dtype=torch.float32).contiguous()
+        x_3d = x_3d.to(dtype=torch.float32).contiguous()
+        t = t.to(device=dev, dtype=torch.int64).contiguous()
+        if out is None:
+            out = torch.empty((B, H, Fr, J, 3), dtype=torch.float32, device=dev)
+        ws, nbytes = self._workspace(ctx, B, H, dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().d3dp_denoise(ctx, x_2d.data_ptr(), x_3d.data_ptr(), t.data_ptr(), out.data_ptr(),
+                                                B, H, ws.data_ptr(), nbytes, _lib.current_stream()), "d3dp_denoise")
+        return out
+
+    def forward(self, x_2d, x_3d, t):
+        """Reference signature (mixste.py:278): eval -> x_3d (B,H,F,J,3); train -> x_3d (B,F,J,3).
+        Forward only: DropPath is the identity and no autograd graph is recorded (training backward is not part
+        of this round)."""
+        if x_3d.dim() == 4:
+            return self.denoise(x_2d, x_3d[:, None], t)[:, 0]
+        return self.denoise(x_2d, x_3d, t)
+
+    # -- profiling passthrough --------------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        assert self._ctx is not None, "run one forward first"
+        _lib.check(_lib.load().d3dp_profile_enable(self._ctx, int(on)))
+
+    def profile_read(self):
+        lib = _lib.load()
+        cnt = (C.c_int64 * _lib.PROFILE_CLASSES)()
+        ms = (C.c_double * _lib.PROFILE_CLASSES)()
+        _lib.check(lib.d3dp_profile_read(self._ctx, cnt, ms))
+        return {lib.d3dp_profile_class_name(i).decode(): (int(cnt[i]), float(ms[i])) for i in range(_lib.PROFILE_CLASSES)}
+
+
+# ----------------------------------------------------------------------------------------------
+# diffusion wrapper
+# ----------------------------------------------------------------------------------------------
+class D3DP(nn.Module):
+    """Drop-in for the reference's ``D3DP`` (common/diffusionpose.py:55-126)."""
+
+    def __init__(self, args, joints_left, joints_right, is_train=True, num_proposals=1, sampling_timesteps=1,
+                 numerics: Optional[str] = None):
+        super().__init__()
+        self.frames = args.number_of_frames
+        self.num_proposals = num_proposals
+        self.flip = args.test_time_augmentation
+        self.joints_left = list(joints_left)
+        self.joints_right = list(joints_right)
+        self.is_train = is_train
+
+        betas = cosine_beta_schedule(args.timestep)
+        alphas = 1. - betas
+        alphas_cumprod = torch.cumprod(alphas, dim=0)
+        alphas_cumprod_prev = F.pad(alphas_cumprod[:-1], (1, 0), value=1.)
+        timesteps, = betas.shape
+        self.num_timesteps = int(timesteps)
+        self.sampling_timesteps = sampling_timesteps if sampling_timesteps is not None else timesteps
+        assert self.sampling_timesteps <= timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = 1.
+        self.objective = 'pred_x0'
+        self.self_condition = False
+        self.scale = args.scale
+        self.box_renewal = True
+        self.use_ensemble = True
+
+        # the 12 fp64 buffers of the reference state_dict (diffusionpose.py:92-117)
+        self.register_buffer('betas', betas)
+        self.register_buffer('alphas_cumprod', alphas_cumprod)
+        self.register_buffer('alphas_cumprod_prev', alphas_cumprod_prev)
+        self.register_buffer('sqrt_alphas_cumprod', torch.sqrt(alphas_cumprod))
+        self.register_buffer('sqrt_one_minus_alphas_cumprod', torch.sqrt(1. - alphas_cumprod))
+        self.register_buffer('log_one_minus_alphas_cumprod', torch.log(1. - alphas_cumprod))
+        self.register_buffer('sqrt_recip_alphas_cumprod', torch.sqrt(1. / alphas_cumprod))
+        self.register_buffer('sqrt_recipm1_alphas_cumprod', torch.sqrt(1. / alphas_cumprod - 1))
+        posterior_variance = betas * (1. - alphas_cumprod_prev) / (1. - alphas_cumprod)
+        self.register_buffer('posterior_variance', posterior_variance)
+        self.register_buffer('posterior_log_variance_clipped', torch.log(posterior_variance.clamp(min=1e-20)))
+        self.register_buffer('posterior_mean_coef1', betas * torch.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod))
+        self.register_buffer('posterior_mean_coef2',
+                             (1. - alphas_cumprod_prev) * torch.sqrt(alphas) / (1. - alphas_cumprod))
+
+        numerics = numerics or getattr(args, "numerics", None)
+        self.pose_estimator = MixSTE2(num_frame=self.frames, num_joints=NUM_JOINTS, in_chans=2,
+                                      embed_dim_ratio=args.cs, depth=args.dep, num_heads=8, mlp_ratio=2.,
+                                      qkv_bias=True, qk_scale=None, drop_path_rate=0.1 if is_train else 0,
+                                      is_train=is_train, numerics=numerics,
+                                      chunk_seqs=int(getattr(args, "chunk_seqs", 0) or 0))
+        self._perm_cache = {}
+        self._sched_cache = None
+
+    # ---- helpers ----------------------------------------------------------------------------------
+    def _perm(self, device):
+        """perm[j] = source joint of joint j under the left/right swap (diffusionpose.py:152-153)."""
+        if device not in self._perm_cache:
+            perm = list(range(NUM_JOINTS))
+            for dst, src in zip(self.joints_left + self.joints_right, self.joints_right + self.joints_left):
+                perm[dst] = src
+            self._perm_cache[device] = torch.tensor(perm, dtype=torch.int32, device=device)
+        return self._perm_cache[device]
+
+    def _sched(self):
+        """Host fp64 copies of the buffers the sampler reads as scalars."""
+        if self._sched_cache is None:
+            self._sched_cache = {k: getattr(self, k).detach().cpu().numpy().astype("float64")
+                                 for k in ("alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod")}
+        return self._sched_cache
+
+    def _load_from_state_dict(self, *a, **k):
+        self._sched_cache = None
+        return super()._load_from_state_dict(*a, **k)
+
+    def time_pairs(self):
+        times = torch.linspace(-1, self.num_timesteps - 1, steps=self.sampling_timesteps + 1)
+        times = list(reversed(times.int().tolist()))
+        return list(zip(times[:-1], times[1:]))
+
+    def _draw(self, shape, device, noise, idx, generator):
+        if noise is not None:
+            n = noise[idx].to(device=device, dtype=torch.float32).contiguous()
+            assert tuple(n.shape) == tuple(shape), (n.shape, shape)
+            return n
+        return torch.randn(shape, device=device, generator=generator)
+
+    # ---- samplers ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def ddim_sample_flip(self, inputs_2d, inputs_3d, clip_denoised=True, do_postprocess=True, input_2d_flip=None,
+                         noise: Optional[Sequence[torch.Tensor]] = None, generator=None):
+        """reference diffusionpose.py:214-256.  Returns (B, K, H, F, 17, 3) fp32."""
+        lib = _lib.load()
+        dev = inputs_2d.device
+        if dev.type != "cuda":
+            raise _lib.D3DPHipError("D3DP samples only on an MI355X (inputs on %s); there is no CPU fallback" % dev)
+        B, H, Fr, J, K = inputs_2d.shape[0], self.num_proposals, self.frames, NUM_JOINTS, self.sampling_timesteps
+        shape = (B, H, Fr, J, 3)
+        sch = self._sched()
+        perm = self._perm(dev)
+        x2 = torch.cat((inputs_2d, input_2d_flip), dim=0).to(dtype=torch.float32).contiguous()
+        img = self._draw(shape, dev, noise, 0, generator).clone()
+        xt2 = torch.empty((2 * B,) + shape[1:], dtype=torch.float32, device=dev)
+        pred2 = torch.empty_like(xt2)
+        preds = torch.empty((B, K, H, Fr, J, 3), dtype=torch.float32, device=dev)
+        per_b = H * Fr * J * 3
+        scale = float(self.scale)
+        eta = self.ddim_sampling_eta
+        ac = sch["alphas_cumprod"]
+        with torch.cuda.device(dev):
+            for k, (time, time_next) in enumerate(self.time_pairs()):
+                st = _lib.current_stream()
+                _lib.check(lib.d3dp_ddim_pre(img.data_ptr(), xt2.data_ptr(), perm.data_ptr(), scale, B, H, Fr, J, st),
+                           "d3dp_ddim_pre")
+                t2 = torch.full((2 * B,), time, dtype=torch.long, device=dev)
+                self.pose_estimator.denoise(x2, xt2, t2, out=pred2)
+                last = time_next < 0
+                if last:
+                    c_x, c_n, sigma, nz = 0.0, 0.0, 0.0, None
+                else:
+                    alpha, alpha_next = ac[time], ac[time_next]
+                    sg = eta * math.sqrt((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha))
+                    c_n = math.sqrt(1 - alpha_next - sg ** 2)
+                    c_x, sigma = math.sqrt(alpha_next), sg
+                    nz = self._draw(shape, dev, noise, k + 1, generator)
+                xs = preds[:, k]
+                _lib.check(lib.d3dp_ddim_post(pred2.data_ptr(), img.data_ptr(), _lib.ptr(nz), perm.data_ptr(), scale,
+                                              float(sch["sqrt_recip_alphas_cumprod"][time]),
+                                              float(sch["sqrt_recipm1_alphas_cumprod"][time]),
+                                              c_x, c_n, sigma, int(last), xs.data_ptr(), K * per_b, img.data_ptr(),
+                                              B, H, Fr, J, st), "d3dp_ddim_post")
+        return preds
+
+    @torch.no_grad()
+    def ddim_sample(self, inputs_2d, inputs_3d, clip_denoised=True, do_postprocess=True,
+                    noise: Optional[Sequence[torch.Tensor]] = None, generator=None):
+        """reference diffusionpose.py:171-212 (dead there: it reads an undefined ``self.device``).  Made to work
+        and to return the list of K x_start tensors it was written to return.  No flip augmentation; the
+        elementwise glue is a handful of torch ops on the GPU around the HIP denoiser."""
+        dev = inputs_2d.device
+        B, H = inputs_2d.shape[0], self.num_proposals
+        shape = (B, H, self.frames, NUM_JOINTS, 3)
+        img = self._draw(shape, dev, noise, 0, generator).clone()
+        scale, preds_all = self.scale, []
+        for k, (time, time_next) in enumerate(self.time_pairs()):
+            t = torch.full((B,), time, device=dev, dtype=torch.long)
+            x_t = torch.clamp(img, min=-1.1 * scale, max=1.1 * scale) / scale
+            x_start = torch.clamp(self.pose_estimator.denoise(inputs_2d, x_t, t) * scale, min=-1.1 * scale, max=1.1 * scale)
+            pred_noise = self.predict_noise_from_start(img, t, x_start)
+            preds_all.append(x_start)
+            if time_next < 0:
+                img = x_start
+                continue
+            alpha, alpha_next = self.alphas_cumprod[time], self.alphas_cumprod[time_next]
+            sigma = self.ddim_sampling_eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+            c = (1 - alpha_next - sigma ** 2).sqrt()
+            nz = self._draw(shape, dev, noise, k + 1, generator)
+            img = x_start * alpha_next.sqrt() + c * pred_noise + sigma * nz
+        return preds_all
+
+    def predict_noise_from_start(self, x_t, t, x0):
+        """reference diffusionpose.py:129-133 (fp64 by buffer promotion)."""
+        shp = (t.shape[0],) + (1,) * (x_t.dim() - 1)
+        a = self.sqrt_recip_alphas_cumprod.gather(-1, t).reshape(shp)
+        b = self.sqrt_recipm1_alphas_cumprod.gather(-1, t).reshape(shp)
+        return (a * x_t - x0) / b
+
+    def q_sample(self, x_start, t, noise=None):
+        """reference diffusionpose.py:260-267 (returns fp64 like the reference)."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        shp = (t.shape[0],) + (1,) * (x_start.dim() - 1)
+        a = self.sqrt_alphas_cumprod.gather(-1, t).reshape(shp)
+        b = self.sqrt_one_minus_alphas_cumprod.gather(-1, t).reshape(shp)
+        return a * x_start + b * noise
+
+    def prepare_targets(self, targets, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
+        """reference diffusionpose.py:290-320 as ONE fused kernel over the batch (the reference loops over samples
+        in Python).  ``t`` (B,1) int64 and ``noise`` (B,F,17,3) may be injected; otherwise drawn like the reference
+        (per sample: randint then randn)."""
+        lib = _lib.load()
+        dev = targets.device
+        B = targets.shape[0]
+        if t is None or noise is None:
+            ts, ns = [], []
+            for _ in range(B):
+                ts.append(torch.randint(0, self.num_timesteps, (1,), device=dev).long())
+                ns.append(torch.randn(self.frames, NUM_JOINTS, 3, device=dev))
+            t = torch.stack(ts) if t is None else t
+            noise = torch.stack(ns) if noise is None else noise
+        t = t.to(dev).long().reshape(B, 1)
+        noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+        x0 = targets.to(dtype=torch.float32).contiguous()
+        a = self.sqrt_alphas_cumprod.to(dev).gather(-1, t[:, 0]).contiguous()
+        s = self.sqrt_one_minus_alphas_cumprod.to(dev).gather(-1, t[:, 0]).contiguous()
+        out = torch.empty_like(x0)
+        with torch.cuda.device(dev):
+            _lib.check(lib.d3dp_q_sample(x0.data_ptr(), noise.data_ptr(), a.data_ptr(), s.data_ptr(), float(self.scale),
+                                         out.data_ptr(), B, x0[0].numel(), _lib.current_stream()), "d3dp_q_sample")
+        return out, noise, t
+
+    def forward(self, input_2d, input_3d, input_2d_flip=None, **kw):
+        """reference diffusionpose.py:269-287."""
+        if not self.is_train:
+            if self.flip:
+                return self.ddim_sample_flip(input_2d, input_3d, input_2d_flip=input_2d_flip, **kw)
+            return self.ddim_sample(input_2d, input_3d, **kw)
+        x_poses, _, t = self.prepare_targets(input_3d, **kw)
+        return self.pose_estimator(input_2d, x_poses.float(), t.squeeze(-1))

@@ -1,0 +1,166 @@
+/* d3dp_hip.h -- C ABI of libd3dp_hip.so: the MI355X (gfx950) implementation of the D3DP hot path.
+ *
+ * The reference (paTRICK-swk/D3DP) is pure PyTorch: it has no FFI, its "plugin boundary" for this path is
+ * the Python API D3DP.forward / ddim_sample_flip / q_sample and MixSTE2.forward.  This header is what a
+ * Python (ctypes), C++ or any other FFI host binds INSTEAD of the ATen call sites listed per function.
+ * d3dp_amd/_lib.py is the ctypes binding shipped here; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *  - plain C types only; every pointer is a DEVICE pointer to a contiguous buffer unless marked "host";
+ *  - `stream` is a hipStream_t passed as void* (0 = the null stream); every call is asynchronous on it, does
+ *    not allocate and does not synchronise (exceptions: d3dp_create/d3dp_set_weights/d3dp_destroy and the
+ *    d3dp_profile_* calls);
+ *  - every function returns 0 on success, a negative D3DP_E* code otherwise; d3dp_last_error() returns a
+ *    thread-local message for the last failure;
+ *  - a context is bound to the HIP device current at d3dp_create and is not thread-safe (one ctx per rank).
+ *
+ * Tensor layouts (row-major, last index fastest) follow the reference:
+ *   x2d  (B, F, J, 2) fp32      2D keypoints                       common/mixste.py:278
+ *   x_t  (B, H, F, J, 3) fp32   noisy 3D hypotheses                common/mixste.py:278
+ *   t    (B) int64              diffusion timestep per batch item  common/diffusionpose.py:230
+ *   out  (B, H, F, J, 3) fp32   predicted x0                       common/mixste.py:296
+ */
+#ifndef D3DP_HIP_H
+#define D3DP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D3DP_ABI_VERSION 1
+
+enum {
+  D3DP_OK = 0,
+  D3DP_EINVAL = -1,      /* bad argument / unsupported shape */
+  D3DP_ENOTSUP = -2,     /* configuration not supported by the kernels (e.g. head dim) */
+  D3DP_EHIP = -3,        /* a HIP runtime call failed */
+  D3DP_ESTATE = -4,      /* call out of order (weights not set, workspace too small, ...) */
+};
+
+/* numerics mode of the denoiser */
+enum {
+  D3DP_MODE_EXACT = 0,   /* fp32 activations, fp32 MFMA (v_mfma_f32_32x32x2_f32): <= 1e-3 mm vs the reference   */
+  D3DP_MODE_FAST = 1,    /* bf16 activations/weights into v_mfma_f32_16x16x32_bf16, fp32 accumulate/LN/softmax */
+};
+
+/* MixSTE2 hyper-parameters -- reference common/diffusionpose.py:123-124, common/mixste.py:142-163 */
+typedef struct d3dp_cfg {
+  int32_t frames;        /* F: args.number_of_frames                 */
+  int32_t joints;        /* J: 17                                    */
+  int32_t channels;      /* C: args.cs (embed_dim_ratio)             */
+  int32_t depth;         /* args.dep: number of (spatial, temporal) block pairs */
+  int32_t heads;         /* 8                                        */
+  int32_t hidden;        /* mlp hidden = 2*C (mlp_ratio 2.)          */
+  float eps_block;       /* 1e-6: LayerNorm eps of blocks and Spatial/Temporal_norm (mixste.py:163) */
+  float eps_head;        /* 1e-5: nn.LayerNorm default in head (mixste.py:208)                     */
+  int32_t mode;          /* D3DP_MODE_*                              */
+  int32_t chunk_seqs;    /* (clip,hypothesis) sequences processed per internal pass; 0 = library default */
+} d3dp_cfg;
+
+/* One transformer Block's parameters, fp32, reference state_dict names in comments (mixste.py:96-101) */
+typedef struct d3dp_block_weights {
+  const float* norm1_w; const float* norm1_b;     /* norm1.weight/bias   (C)      */
+  const float* qkv_w;   const float* qkv_b;       /* attn.qkv.weight (3C,C)/bias  */
+  const float* proj_w;  const float* proj_b;      /* attn.proj.weight (C,C)/bias  */
+  const float* norm2_w; const float* norm2_b;     /* norm2.weight/bias            */
+  const float* fc1_w;   const float* fc1_b;       /* mlp.fc1.weight (2C,C)/bias   */
+  const float* fc2_w;   const float* fc2_b;       /* mlp.fc2.weight (C,2C)/bias   */
+} d3dp_block_weights;
+
+/* All MixSTE2 parameters (device fp32, caller-owned; the library keeps its own packed copies). */
+typedef struct d3dp_weights {
+  const float* spatial_pos;       /* Spatial_pos_embed (1,J,C)                 mixste.py:169 */
+  const float* temporal_pos;      /* Temporal_pos_embed (1,F,C)                mixste.py:172 */
+  const float* embed_w;           /* Spatial_patch_to_embedding.weight (C,5)   mixste.py:166 */
+  const float* embed_b;
+  const float* time_freq;         /* (C/2) fp32: exp(arange(C/2) * -ln(1e4)/(C/2-1)), mixste.py:135-136 (host-computed) */
+  const float* time1_w;           /* time_mlp.1.weight (2C,C)                  mixste.py:181 */
+  const float* time1_b;
+  const float* time3_w;           /* time_mlp.3.weight (C,2C)                  mixste.py:183 */
+  const float* time3_b;
+  const float* spatial_norm_w;    /* Spatial_norm (shared by all depths)       mixste.py:203 */
+  const float* spatial_norm_b;
+  const float* temporal_norm_w;   /* Temporal_norm                             mixste.py:204 */
+  const float* temporal_norm_b;
+  const float* head_norm_w;       /* head.0 (LayerNorm)                        mixste.py:208 */
+  const float* head_norm_b;
+  const float* head_w;            /* head.1.weight (3,C)                       mixste.py:209 */
+  const float* head_b;
+  const d3dp_block_weights* ste;  /* host array [depth]: STEblocks.i           mixste.py:190 */
+  const d3dp_block_weights* tte;  /* host array [depth]: TTEblocks.i           mixste.py:197 */
+} d3dp_weights;
+
+typedef struct d3dp_ctx d3dp_ctx;
+
+int d3dp_abi_version(void);
+const char* d3dp_last_error(void);
+
+/* Lifetime.  Replaces: MixSTE2.__init__ (mixste.py:142-210) + .cuda() (main.py:243). */
+int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out);
+int d3dp_destroy(d3dp_ctx* ctx);
+/* Replaces: load_state_dict (main.py:257).  Converts/packs weights for cfg.mode (synchronises `stream`). */
+int d3dp_set_weights(d3dp_ctx* ctx, const d3dp_weights* w, void* stream);
+
+/* Scratch needed by d3dp_denoise for a (B, H) call. */
+int d3dp_workspace_bytes(const d3dp_ctx* ctx, int32_t B, int32_t H, size_t* bytes);
+
+/* One denoiser evaluation.  Replaces: MixSTE2.forward(x_2d, x_3d, t), eval branch (mixste.py:278-298) and,
+ * with H = 1, the train branch's forward (mixste.py:215-225). */
+int d3dp_denoise(d3dp_ctx* ctx, const float* x2d, const float* x_t, const int64_t* t, float* out, int32_t B,
+                 int32_t H, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Flip-TTA pre-step.  Replaces diffusionpose.py:148-153.
+ *   xt2[0:B]  = clamp(img, +-1.1 scale) / scale
+ *   xt2[B:2B] = x negated, joints permuted (perm[j] = source joint of joint j; device int32[J])
+ * img (B,H,F,J,3) -> xt2 (2B,H,F,J,3). */
+int d3dp_ddim_pre(const float* img, float* xt2, const int32_t* perm, float scale, int32_t B, int32_t H, int32_t F,
+                  int32_t J, void* stream);
+
+/* Flip-TTA post-step + DDIM update.  Replaces diffusionpose.py:158-169 and :244-254.
+ *   pred    = (pred2[b] + unflip(pred2[B+b])) / 2
+ *   x_start = clamp(pred * scale, +-1.1 scale)                    -> x_start (row b at x_start + b*xs_bstride)
+ *   pn      = float((sqrt_recip * img - x_start) / sqrt_recipm1)  (fp64, predict_noise_from_start :129-133)
+ *   img_next= x_start*c_xstart + c_noise*pn + sigma*noise         (fp32, unless `last`)
+ * `noise` may be NULL only when `last` != 0.  img_next may alias img. */
+int d3dp_ddim_post(const float* pred2, const float* img, const float* noise, const int32_t* perm, float scale,
+                   double sqrt_recip, double sqrt_recipm1, float c_xstart, float c_noise, float sigma, int32_t last,
+                   float* x_start, size_t xs_bstride, float* img_next, int32_t B, int32_t H, int32_t F, int32_t J,
+                   void* stream);
+
+/* Train-time forward diffusion.  Replaces prepare_diffusion_concat/q_sample (diffusionpose.py:260-267, 290-306):
+ *   out[b] = float(clamp(a[b]*(x0[b]*scale) + s[b]*noise[b], +-1.1 scale) / scale); a, s are device fp64 (B). */
+int d3dp_q_sample(const float* x0, const float* noise, const double* sqrt_ac, const double* sqrt_1mac, float scale,
+                  float* out, int32_t B, int32_t per_b, void* stream);
+
+/* ---- single operators (unit parity tests; same kernels the denoiser launches) ---------------------------- */
+/* out[M,N] = epi(A[M,K] W[N,K]^T + bias).  mode FAST: A, W bf16 (uint16 storage), out bf16 unless epi==RESID;
+ * mode EXACT: everything fp32.  epi: 0 bias, 1 bias+GELU(erf), 2 out(fp32) += result. */
+int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, const float* bias, void* out, int32_t M,
+                   int32_t N, int32_t K, void* stream);
+/* Multi-head attention over qkv[T,3C] -> out[T,C]; axis 0 = spatial (sequences of J joints), 1 = temporal
+ * (sequences of F frames); tokens ordered (seq_batch, f, n).  impl 0 = fp32 row kernel, 1 = bf16 MFMA (temporal). */
+int d3dp_op_attention(int32_t act_bf16, int32_t impl, int32_t axis, const void* qkv, void* out, int32_t n_bh,
+                      int32_t F, int32_t J, int32_t C, int32_t heads, void* stream);
+int d3dp_op_layernorm(int32_t out_bf16, const float* x, const float* w, const float* b, float eps, void* out,
+                      int32_t T, int32_t C, void* stream);
+/* fp32 <-> bf16 conversion helper (round-to-nearest-even), n elements */
+int d3dp_op_to_bf16(const float* src, void* dst, size_t n, void* stream);
+
+/* ---- per-kernel timing (HIP events on the launch stream) -------------------------------------------------
+ * While enabled, every kernel launched by d3dp_denoise is bracketed by hipEventRecord on `stream`.
+ * d3dp_profile_read synchronises the recorded events and returns, per kernel class, the launch count and the
+ * summed duration in milliseconds.  Classes are listed by d3dp_profile_class_name. */
+#define D3DP_PROFILE_CLASSES 12
+int d3dp_profile_enable(d3dp_ctx* ctx, int32_t on);
+int d3dp_profile_read(d3dp_ctx* ctx, int64_t* counts /*host[D3DP_PROFILE_CLASSES]*/,
+                      double* total_ms /*host[D3DP_PROFILE_CLASSES]*/);
+const char* d3dp_profile_class_name(int32_t cls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D3DP_HIP_H */

@@ -1,0 +1,108 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol that
+include/d3dp_hip.h declares; the Python mirror keeps the reference's state_dict contract; and the product path
+fails loudly without a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+from types import SimpleNamespace
+
+import __graft_entry__ as entry
+from d3dp_amd import D3DP, _lib
+from d3dp_amd.weights import H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, make_state_dict, param_shapes
+from oracle import d3dp_oracle as orc
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        entry.build()
+    return _lib.load()
+
+
+def header_functions():
+    src = open(os.path.join(REPO, "include", "d3dp_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(d3dp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree(lib):
+    declared = header_functions()
+    assert declared, "no functions parsed from include/d3dp_hip.h"
+    assert sorted(_lib.PROTOTYPES) == declared
+
+
+def test_every_declared_symbol_is_exported(lib):
+    for name in header_functions():
+        assert hasattr(lib, name), name
+    assert lib.d3dp_abi_version() == _lib.ABI_VERSION
+    names = [lib.d3dp_profile_class_name(i).decode() for i in range(_lib.PROFILE_CLASSES)]
+    assert names[0] == "gemm_qkv" and len(set(names)) == _lib.PROFILE_CLASSES
+
+
+def make_model(frames=243, cs=512, dep=8, H=20, K=10, is_train=False):
+    args = SimpleNamespace(number_of_frames=frames, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
+    return D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=is_train, num_proposals=H, sampling_timesteps=K)
+
+
+def test_state_dict_contract_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g0_state_dict_contract.npz"))
+    sd = make_model().state_dict()
+    assert list(sd.keys()) == [str(n) for n in g["names"]]
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in g["shapes"]]
+    assert [str(v.dtype) for v in sd.values()] == [str(s) for s in g["dtypes"]]
+    m = make_model()
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"])
+    # the seed-generated weights cover exactly the pose_estimator parameters
+    assert ["pose_estimator." + k for k in param_shapes(512, 8, 243)] == [k for k in sd if k.startswith("pose_estimator.")]
+
+
+def test_schedule_buffers_and_time_pairs(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_schedule.npz"))
+    for K in (1, 5, 10):
+        m = make_model(frames=9, cs=64, dep=1, H=1, K=K)
+        for k in ("betas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                  "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod"):
+            assert np.array_equal(getattr(m, k).numpy(), g[k]), k
+        assert np.array_equal(np.array(m.time_pairs(), dtype=np.int64), g[f"pairs_K{K}"])
+
+
+def test_flip_permutation_matches_reference_indexing():
+    m = make_model(frames=9, cs=64, dep=1, H=1, K=1)
+    perm = m._perm(torch.device("cpu")).tolist()
+    x = torch.arange(17.0).reshape(1, 17, 1).repeat(1, 1, 3)
+    assert torch.equal(orc.flip_pose(x, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT)[0, :, 1], x[0, perm, 1])
+
+
+def test_loads_module_prefixed_checkpoint_via_dataparallel():
+    m = make_model(frames=9, cs=64, dep=2, H=1, K=1)
+    sd = {"module." + k: v for k, v in make_state_dict(3, 64, 2, 9).items()}
+    missing, unexpected = torch.nn.DataParallel(m).load_state_dict(sd, strict=False)
+    assert not unexpected and all("pose_estimator" not in k for k in missing)
+    assert torch.equal(m.pose_estimator.head[1].weight.detach(), sd["module.pose_estimator.head.1.weight"])
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu(lib):
+    import ctypes as C
+    cfg = _lib.Cfg(27, 17, 512, 8, 8, 1024, 1e-6, 1e-5, _lib.MODE_EXACT, 0)
+    h = C.c_void_p()
+    rc = lib.d3dp_create(C.byref(cfg), C.byref(h))
+    assert rc == -3 and b"no CPU fallback" in lib.d3dp_last_error()
+    m = make_model(frames=9, cs=64, dep=1, H=1, K=1).eval()
+    with pytest.raises(_lib.D3DPHipError):
+        m(torch.zeros(1, 9, 17, 2), None, input_2d_flip=torch.zeros(1, 9, 17, 2))
+    with pytest.raises(_lib.D3DPHipError):
+        m.pose_estimator(torch.zeros(1, 9, 17, 2), torch.zeros(1, 1, 9, 17, 3), torch.zeros(1, dtype=torch.long))
+
+
+def test_product_code_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "d3dp_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f

@@ -131,6 +131,16 @@ def save(name, **arrs):
 
 
 # ----------------------------------------------------------------------------- fixtures
+def g0(D3DP):
+    """state_dict contract: every key, shape and dtype of the reference D3DP at the shipped defaults."""
+    m = build_ref(D3DP, 243, 512, 8, seed=1, H=20, K=10)
+    sd = m.state_dict()
+    save("g0_state_dict_contract", names=np.array(list(sd.keys())),
+         shapes=np.array([",".join(map(str, v.shape)) for v in sd.values()]),
+         dtypes=np.array([str(v.dtype) for v in sd.values()]),
+         n_params=np.int64(sum(p.numel() for p in m.parameters())))
+
+
 def g1(D3DP):
     """Schedule buffers (fp64) + DDIM time pairs."""
     m = build_ref(D3DP, 9, 32, 1, seed=1)
@@ -293,7 +303,7 @@ def g5(D3DP):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g1,g2,g3,g4,g5,g6")
+    ap.add_argument("--only", default="g0,g1,g2,g3,g4,g5,g6")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     D3DP = import_reference()
