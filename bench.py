@@ -32,8 +32,7 @@ PEAK_F32_TFLOPS = 157.3        # fp32 MFMA / vector peak
 def flops_per_denoiser_call(frames=F_, joints=J_, c=C_, depth=DEPTH):
     """Algorithmic FLOP of one MixSTE2.forward per (clip, hypothesis) -- SURVEY.md §8 D4 (multiply-add = 2)."""
     tseq = frames * joints
-    per_tok = 2 * depth * (2 * 8 * c * c) / 2        # 16 blocks x (3+1+2+2) C^2 MACs x 2
-    per_tok = depth * 2 * 8 * c * c * 2              # = 16 * 16 * C^2
+    per_tok = depth * 2 * 8 * c * c * 2              # 16 blocks x (3+1+2+2) C^2 MACs x 2 = 16*16*C^2
     attn = depth * 4 * joints * c + depth * 4 * frames * c
     return tseq * (per_tok + attn + 2 * 5 * c + 2 * c * 3) + 2 * 2 * c * 2 * c
 
