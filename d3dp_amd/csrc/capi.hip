@@ -6,6 +6,7 @@
 //   x    [Tc, C]   fp32   residual stream -- stays fp32 in both modes
 //   bufA [Tc, C]   act    normalised input of the next GEMM / attention output      (act = bf16 FAST, fp32 EXACT)
 //   bufB [Tc, 3C]  act    qkv; reused as the [Tc, 2C] MLP hidden
+//   y    [Tc, C]   act    output of the residual-feeding Linears (proj, fc2); added to x by the next row-wise kernel
 // The reference keeps two physical layouts and transposes between them 16 times per call
 // (mixste.py:244,270,274); here spatial and temporal attention both index the single layout by stride.
 #include <hip/hip_runtime.h>
@@ -13,6 +14,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -93,7 +95,8 @@ struct d3dp_ctx {
 
   bool fast() const { return cfg.mode == D3DP_MODE_FAST; }
   size_t act_size() const { return fast() ? 2 : 4; }
-  int chunk() const { return cfg.chunk_seqs > 0 ? cfg.chunk_seqs : 16; }
+  int chunk() const { return cfg.chunk_seqs > 0 ? cfg.chunk_seqs : 15; }
+  bool gemm_v1 = false;   // env D3DP_GEMM_V1=1: per-tile 128x128 kernel instead of the persistent streaming one (A/B)
 
   int flush_events() {
     for (size_t i = 0; i < used; ++i) {
@@ -134,10 +137,14 @@ struct Scope {
   ~Scope() { c->end(slot, st); }
 };
 
-int linear(d3dp_ctx* c, int cls, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N,
-           int K, hipStream_t st) {
+// out = epi(A W^T + bias).  out_f32: fp32 output even in FAST mode (the Linear outputs that feed a residual add).
+int linear(d3dp_ctx* c, int cls, int epi, int out_f32, const void* A, const void* W, const float* bias, void* out, int M,
+           int N, int K, hipStream_t st) {
   Scope s(c, cls, st);
-  if (c->fast()) return d3dp_launch_linear_bf16(epi, 0, A, W, bias, out, M, N, K, st);
+  if (c->fast()) {
+    if (c->gemm_v1) return d3dp_launch_linear_bf16(epi, out_f32, A, W, bias, out, M, N, K, st);
+    return d3dp_launch_linear_bf16_stream(epi, out_f32, A, W, bias, out, M, N, K, st);
+  }
   return d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, st);
 }
 
@@ -157,18 +164,23 @@ int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, hipSt
 }
 
 // x = x + proj(attn(qkv(xn)));  x = x + fc2(gelu(fc1(LN2(x))))        (mixste.py:113-115)
-int run_block(d3dp_ctx* c, const BlockDev& w, int axis, float* x, void* bufA, void* bufB, int n_bh, hipStream_t st) {
+// The two residual adds are not done by the GEMMs: each residual-feeding Linear writes y = A W^T + b (fp32) and the
+// (activation type: bf16 in FAST mode -- one more bf16 rounding on the branch output, none on the fp32 residual
+// stream itself) and the next row-wise kernel (LN2 here; the norm pair / head in the caller) performs x += y while it has the row in
+// registers anyway.  On return y holds the fc2 output that the CALLER's next kernel must add.
+int run_block(d3dp_ctx* c, const BlockDev& w, int axis, float* x, void* y, void* bufA, void* bufB, int n_bh,
+              hipStream_t st) {
   const d3dp_cfg& g = c->cfg;
   const int Tc = n_bh * g.frames * g.joints, C = g.channels;
-  LAUNCH_TRY(linear(c, P_QKV, EPI_BIAS, bufA, w.qkv_w, w.qkv_b, bufB, Tc, 3 * C, C, st));
+  LAUNCH_TRY(linear(c, P_QKV, EPI_BIAS, 0, bufA, w.qkv_w, w.qkv_b, bufB, Tc, 3 * C, C, st));
   LAUNCH_TRY(attention(c, axis, bufB, bufA, n_bh, st));
-  LAUNCH_TRY(linear(c, P_PROJ, EPI_RESID, bufA, w.proj_w, w.proj_b, x, Tc, C, C, st));
+  LAUNCH_TRY(linear(c, P_PROJ, EPI_BIAS, 0, bufA, w.proj_w, w.proj_b, y, Tc, C, C, st));
   {
     Scope s(c, P_LN, st);
-    LAUNCH_TRY(d3dp_launch_ln(c->fast(), x, w.n2w, w.n2b, g.eps_block, bufA, Tc, C, st));
+    LAUNCH_TRY(d3dp_launch_ln(c->fast(), x, y, w.n2w, w.n2b, g.eps_block, bufA, Tc, C, st));
   }
-  LAUNCH_TRY(linear(c, P_FC1, EPI_GELU, bufA, w.fc1_w, w.fc1_b, bufB, Tc, g.hidden, C, st));
-  LAUNCH_TRY(linear(c, P_FC2, EPI_RESID, bufB, w.fc2_w, w.fc2_b, x, Tc, C, g.hidden, st));
+  LAUNCH_TRY(linear(c, P_FC1, EPI_GELU, 0, bufA, w.fc1_w, w.fc1_b, bufB, Tc, g.hidden, C, st));
+  LAUNCH_TRY(linear(c, P_FC2, EPI_BIAS, 0, bufB, w.fc2_w, w.fc2_b, y, Tc, C, g.hidden, st));
   return 0;
 }
 
@@ -200,6 +212,8 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
     return fail(D3DP_EHIP, "no HIP device visible: libd3dp_hip has no CPU fallback");
   d3dp_ctx* c = new d3dp_ctx();
   c->cfg = g;
+  const char* v1 = getenv("D3DP_GEMM_V1");
+  c->gemm_v1 = v1 && v1[0] == '1';
   HIP_TRY(hipGetDevice(&c->device));
   *out = c;
   return D3DP_OK;
@@ -288,7 +302,7 @@ int d3dp_workspace_bytes(const d3dp_ctx* c, int32_t B, int32_t H, size_t* bytes)
   const size_t n = (size_t)std::min(c->chunk(), B * H);
   const size_t Tc = n * g.frames * g.joints, C = g.channels;
   const size_t wide = (size_t)std::max(3 * g.channels, g.hidden);
-  *bytes = align_up((size_t)B * C * 4) + align_up(Tc * C * 4) + align_up(Tc * C * c->act_size()) +
+  *bytes = align_up((size_t)B * C * 4) + align_up(Tc * C * 4) + 2 * align_up(Tc * C * c->act_size()) +
            align_up(Tc * wide * c->act_size());
   return D3DP_OK;
 }
@@ -309,6 +323,7 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
   char* p = (char*)workspace;
   float* temb = (float*)p; p += align_up((size_t)B * C * 4);
   float* x = (float*)p;    p += align_up(Tmax * C * 4);
+  void* y = p;             p += align_up(Tmax * C * c->act_size());
   void* bufA = p;          p += align_up(Tmax * C * c->act_size());
   void* bufB = p;
 
@@ -325,24 +340,24 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
                                       g.eps_block, x, bufA, seq0, n, H, F, J, C, st));
     }
     for (int d = 0; d < g.depth; ++d) {
-      int r = run_block(c, c->ste[d], 0, x, bufA, bufB, n, st);
+      int r = run_block(c, c->ste[d], 0, x, y, bufA, bufB, n, st);
       if (r) return r;
       {
-        Scope s(c, P_LN2, st);   // Spatial_norm (+ Temporal_pos after block 0) fused with TTE block d's norm1
-        LAUNCH_TRY(d3dp_launch_ln2(c->fast(), x, c->snw, c->snb, d == 0 ? c->tpos : nullptr, c->tte[d].n1w,
+        Scope s(c, P_LN2, st);   // x += fc2 out; Spatial_norm (+ Temporal_pos after block 0); TTE block d's norm1
+        LAUNCH_TRY(d3dp_launch_ln2(c->fast(), x, y, c->snw, c->snb, d == 0 ? c->tpos : nullptr, c->tte[d].n1w,
                                    c->tte[d].n1b, g.eps_block, bufA, Tc, C, F, J, st));
       }
-      r = run_block(c, c->tte[d], 1, x, bufA, bufB, n, st);
+      r = run_block(c, c->tte[d], 1, x, y, bufA, bufB, n, st);
       if (r) return r;
       if (d + 1 < g.depth) {
-        Scope s(c, P_LN2, st);   // Temporal_norm fused with STE block d+1's norm1
-        LAUNCH_TRY(d3dp_launch_ln2(c->fast(), x, c->tnw, c->tnb, nullptr, c->ste[d + 1].n1w, c->ste[d + 1].n1b,
+        Scope s(c, P_LN2, st);   // x += fc2 out; Temporal_norm; STE block d+1's norm1
+        LAUNCH_TRY(d3dp_launch_ln2(c->fast(), x, y, c->tnw, c->tnb, nullptr, c->ste[d + 1].n1w, c->ste[d + 1].n1b,
                                    g.eps_block, bufA, Tc, C, F, J, st));
       }
     }
     {
-      Scope s(c, P_HEAD, st);
-      LAUNCH_TRY(d3dp_launch_head(x, c->tnw, c->tnb, g.eps_block, c->hnw, c->hnb, g.eps_head, c->hw, c->hb,
+      Scope s(c, P_HEAD, st);    // x += fc2 out; Temporal_norm; head LayerNorm; Linear(C,3)
+      LAUNCH_TRY(d3dp_launch_head(c->fast(), x, y, c->tnw, c->tnb, g.eps_block, c->hnw, c->hnb, g.eps_head, c->hw, c->hb,
                                   out + (size_t)seq0 * FJ * 3, Tc, C, st));
     }
   }
@@ -381,7 +396,13 @@ int d3dp_q_sample(const float* x0, const float* noise, const double* a, const do
 int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, const float* bias, void* out, int32_t M,
                    int32_t N, int32_t K, void* stream) {
   if (!A || !W || !bias || !out) return fail(D3DP_EINVAL, "d3dp_op_linear: null argument");
-  if (mode == D3DP_MODE_FAST) LAUNCH_TRY(d3dp_launch_linear_bf16(epi, 0, A, W, bias, out, M, N, K, (hipStream_t)stream));
+  if (mode == D3DP_MODE_FAST) {
+    // epi 0/1: the persistent streaming kernel the denoiser uses (epi | 16 selects its fp32-output form);
+    // epi 2 (in-place residual) and epi | 32: the per-tile 128x128 kernel.
+    const int e = epi & 3, f32 = (epi & 16) != 0;
+    if (e != EPI_RESID && !(epi & 32)) LAUNCH_TRY(d3dp_launch_linear_bf16_stream(e, f32, A, W, bias, out, M, N, K, (hipStream_t)stream));
+    else LAUNCH_TRY(d3dp_launch_linear_bf16(e, f32, A, W, bias, out, M, N, K, (hipStream_t)stream));
+  }
   else LAUNCH_TRY(d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, (hipStream_t)stream));
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
@@ -403,7 +424,7 @@ int d3dp_op_attention(int32_t act_bf16, int32_t impl, int32_t axis, const void* 
 int d3dp_op_layernorm(int32_t out_bf16, const float* x, const float* w, const float* b, float eps, void* out, int32_t T,
                       int32_t C, void* stream) {
   if (!x || !w || !b || !out) return fail(D3DP_EINVAL, "d3dp_op_layernorm: null argument");
-  LAUNCH_TRY(d3dp_launch_ln(out_bf16, x, w, b, eps, out, T, C, (hipStream_t)stream));
+  LAUNCH_TRY(d3dp_launch_ln(out_bf16, const_cast<float*>(x), nullptr, w, b, eps, out, T, C, (hipStream_t)stream));
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
 }

@@ -16,6 +16,8 @@
 // lane ends up with 4 consecutive output columns of one row -> vector stores, bias as one float4.
 //
 // Epilogues: EPI_BIAS (out = acc+b), EPI_GELU (out = gelu_erf(acc+b)), EPI_RESID (resid += acc+b, fp32).
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -278,4 +280,253 @@ int d3dp_launch_linear_f32(int epi, const float* A, const float* W, const float*
   else if (epi == EPI_BIAS) hipLaunchKernelGGL((gemm_f32_kernel<EPI_BIAS>), g, b, 0, st, A, W, bias, out, M, N, K, tn);
   else return -1;
   return 0;
+}
+
+// ================================================================================================
+// FAST mode, persistent streaming GEMM ("v2"): the kernel the denoiser launches for every Linear.
+//
+//   * 256x128 output tile per workgroup pass, BK = 64, 8 compute waves (4 x 2, 64x64 each = 4x4 MFMA tiles)
+//     + 4 LOADER waves.  Workgroups are persistent (<= 256, one per CU) and walk tiles L, L+G, L+2G, ...
+//   * A and W k-slabs stream through a 3-stage LDS ring (48 KiB per stage) as one continuous sequence of
+//     k-steps across tile boundaries: the next tile's first slabs are already in flight while the current
+//     tile's epilogue stores drain -- no per-tile prologue.
+//   * Only the loader waves issue global_load_lds and wait on vmcnt (counted: one k-step stays in flight
+//     across every barrier).  Compute waves never wait on vmcnt, so their epilogue stores (which also count
+//     in vmcnt on gfx950) cannot stall the operand pipeline.  One raw s_barrier per k-step.
+//   * bias sits in LDS (read with ds_read, lgkmcnt), so the epilogue issues no vector loads at all.
+// ================================================================================================
+namespace {
+
+constexpr int SBM = 256, SBN = 128, SBK = 64;
+constexpr int SA_BYTES = SBM * SBK * 2;              // 32 KiB
+constexpr int SW_BYTES = SBN * SBK * 2;              // 16 KiB
+constexpr int SSTAGE = SA_BYTES + SW_BYTES;          // 48 KiB
+constexpr int SNSTAGE = 3;
+constexpr int SBIAS_MAX = 2048;                      // floats of bias kept in LDS
+constexpr int SLDS_BYTES = SNSTAGE * SSTAGE + SBIAS_MAX * 4;
+
+// GELU for the FAST path's bf16 outputs: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16
+// resolution), ~14 VALU instead of the ~40 of the correctly-rounded erff the EXACT path uses.
+__device__ __forceinline__ float gelu_as(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+  const float erf_abs = fmaf(-p, e, 1.0f);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+// Column permutation inside a wave's 64-wide output strip.  MFMA tile ni, operand row i (= LDS row ni*16 + i of
+// the wave's W strip) holds output column  sperm(ni, i); an output lane (fi, fg) then owns, for each of its 4 row
+// blocks, the columns  h*32 + fg*8 + [0..7], h = 0,1  -> two 16-byte (bf16) / four 16-byte (fp32) stores per row
+// block, 64 contiguous bytes per row per store instruction.  The loader applies the same map when it picks the
+// W row for an LDS row, so the MFMA-side reads stay in natural (conflict-free) order.
+__device__ __forceinline__ int sperm(int q) {   // q = ni*16 + i in [0,64)
+  const int ni = q >> 4, i = q & 15;
+  return (ni >> 1) * 32 + (i >> 2) * 8 + (ni & 1) * 4 + (i & 3);
+}
+
+template <int EPI, typename OutT, int NK>
+__global__ __launch_bounds__(768) void gemm_bf16_stream_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
+                                                               const float* __restrict__ bias, OutT* __restrict__ out,
+                                                               int M, int N, int tiles_n, int total_tiles, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sbias = reinterpret_cast<float*>(smem + SNSTAGE * SSTAGE);
+  constexpr int K = NK * SBK;
+
+  const int G = gridDim.x;
+  const int L = xcd_remap(blockIdx.x, G);
+  const int n_my = (total_tiles - L + G - 1) / G;      // tiles L, L+G, ...
+  const int gtot = n_my * NK;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  for (int i = tid; i < N; i += 768) sbias[i] = bias[i];
+  __syncthreads();
+
+  if (wave >= 8) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = wave - 8;
+    const int lrow = lane >> 3, lslot = lane & 7;
+    auto issue = [&](int g) {
+      const int ti = g / NK, ks = g - ti * NK;
+      const int t = L + ti * G;
+      const int m0 = (t / tiles_n) * SBM, n0 = (t % tiles_n) * SBN;
+      char* stage = smem + (g % SNSTAGE) * SSTAGE;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = lw * 64 + i * 8 + lrow;
+        const int gr = min(m0 + row, M - 1);
+        const bf16* src = A + (size_t)gr * K + ks * SBK + swz(row, lslot) * 8;
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(stage + (lw * 8 + i) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = lw * 32 + i * 8 + lrow;                    // LDS row of the W slab
+        const int wrow = (row & 64) + sperm(row & 63);              // output column it carries
+        const int gr = min(n0 + wrow, N - 1);
+        const bf16* src = W + (size_t)gr * K + ks * SBK + swz(row, lslot) * 8;
+        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(stage + SA_BYTES + (lw * 4 + i) * 1024), 16, 0, 0);
+      }
+    };
+    if (gtot > 0 && !(dbg & 1)) issue(0);
+    if (gtot > 1 && !(dbg & 1)) issue(1);
+    for (int g = 0; g < gtot; ++g) {
+      // 12 glds per loader wave per k-step (8 A + 4 W pieces): loads(g) landed, loads(g+1) stay in flight
+      if (g + 1 < gtot) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!(dbg & 8)) asm volatile("s_barrier" ::: "memory");
+      if (g + 2 < gtot && !(dbg & 1)) issue(g + 2);
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute waves
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fi = lane & 15, fg = lane >> 4;
+  f32x4 acc[4][4];
+  // Finished tile waiting to be stored: 8 units (mi, h) of 8 packed bf16 (acc + bias).  One unit is drained behind
+  // the MFMAs of each k-step of the NEXT tile, so output traffic is a steady trickle instead of a per-tile burst in
+  // which every CU of the (phase-locked) persistent grid hits the HBM write path at once.
+  bf16x8 pend[4][2];
+  int pm0 = 0, pn0 = 0;
+  bool have_pend = false;
+
+  // store the unit at the head of the pending queue (unit index u -> rows mi = u>>1, column half h = u&1), then
+  // rotate the queue by one so the head index stays compile-time constant (no runtime-indexed register arrays)
+  auto drain_one = [&](int u) {
+    const int mi = u >> 1, h = u & 1;
+    const int m = pm0 + wr * 64 + mi * 16 + fi;
+    const int n = pn0 + wc * 64 + h * 32 + fg * 8;
+    bf16x8 v = pend[0][0];
+    if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16)gelu_as((float)v[e]);
+    }
+    if (m < M && n < N) {
+      if constexpr (sizeof(OutT) == 2) {
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(out) + (size_t)m * N + n) = v;
+      } else {
+        float r[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (float)v[e];
+        store8(reinterpret_cast<float*>(out) + (size_t)m * N + n, r);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) pend[q >> 1][q & 1] = pend[(q + 1) >> 1][(q + 1) & 1];
+  };
+  constexpr int UPS = NK >= 8 ? 1 : (8 + NK - 1) / NK;   // units drained per draining k-step
+  constexpr int DRAIN_EVERY = NK >= 16 ? NK / 8 : 1;     // NK = 16: every other k-step
+  if (!(dbg & 16)) __builtin_amdgcn_s_setprio(1);
+  for (int ti = 0; ti < n_my; ++ti) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int unit = 0;
+#pragma unroll 1
+    for (int ks = 0; ks < NK; ++ks) {
+      const int g = ti * NK + ks;
+      if (!(dbg & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const char* sa = smem + (g % SNSTAGE) * SSTAGE;
+      const char* sw = sa + SA_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 af[4], wf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ra = wr * 64 + i * 16 + fi;
+          af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * 128 + swz(ra, kk * 4 + fg) * 16);
+          const int rw = wc * 64 + i * 16 + fi;
+          wf[i] = *reinterpret_cast<const bf16x8*>(sw + rw * 128 + swz(rw, kk * 4 + fg) * 16);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      }
+      // drain a slice of the previous tile's results behind this k-step's MFMAs
+      if (have_pend && !(dbg & 2) && (ks % DRAIN_EVERY) == 0 && unit < 8) {
+#pragma unroll
+        for (int r = 0; r < UPS; ++r)
+          if (unit < 8) { drain_one(unit); ++unit; }
+      }
+    }
+    const int t = L + ti * G;
+    pm0 = (t / tiles_n) * SBM;
+    pn0 = (t % tiles_n) * SBN;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int n = pn0 + wc * 64 + h * 32 + fg * 8;
+        const float4 b0 = *reinterpret_cast<const float4*>(sbias + n);
+        const float4 b1 = *reinterpret_cast<const float4*>(sbias + n + 4);
+        const f32x4 a0 = acc[mi][2 * h], a1 = acc[mi][2 * h + 1];
+        pend[mi][h] = (bf16x8){(bf16)(a0[0] + b0.x), (bf16)(a0[1] + b0.y), (bf16)(a0[2] + b0.z), (bf16)(a0[3] + b0.w),
+                               (bf16)(a1[0] + b1.x), (bf16)(a1[1] + b1.y), (bf16)(a1[2] + b1.z), (bf16)(a1[3] + b1.w)};
+      }
+    have_pend = true;
+  }
+  if (have_pend && !(dbg & 2)) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) drain_one(u);
+  }
+}
+
+template <int EPI, typename OutT, int NK>
+int launch_stream_nk(const void* A, const void* W, const float* bias, void* out, int M, int N, hipStream_t st) {
+  const int tm = (M + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
+  const int total = tm * tn;
+  auto kern = gemm_bf16_stream_kernel<EPI, OutT, NK>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            SLDS_BYTES) != hipSuccess) return -3;
+    attr_set = true;
+  }
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -3;
+    n_cu = prop.multiProcessorCount;
+  }
+  const int grid = total < n_cu ? total : n_cu;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("D3DP_GEMM_DBG"); dbg = e ? atoi(e) : 0; }   // timing ablations only (results invalid)
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(768), SLDS_BYTES, st, (const bf16*)A, (const bf16*)W, bias, (OutT*)out, M, N,
+                     tn, total, dbg);
+  return 0;
+}
+
+template <int EPI, typename OutT>
+int launch_stream(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, hipStream_t st) {
+  switch (K / SBK) {
+    case 1: return launch_stream_nk<EPI, OutT, 1>(A, W, bias, out, M, N, st);
+    case 2: return launch_stream_nk<EPI, OutT, 2>(A, W, bias, out, M, N, st);
+    case 4: return launch_stream_nk<EPI, OutT, 4>(A, W, bias, out, M, N, st);
+    case 8: return launch_stream_nk<EPI, OutT, 8>(A, W, bias, out, M, N, st);
+    case 16: return launch_stream_nk<EPI, OutT, 16>(A, W, bias, out, M, N, st);
+    default: return -1;
+  }
+}
+
+}  // namespace
+
+// out[M,N] = epi(A W^T + bias); epi in {EPI_BIAS, EPI_GELU}; out bf16 or fp32.
+int d3dp_launch_linear_bf16_stream(int epi, int out_f32, const void* A, const void* W, const float* bias, void* out,
+                                   int M, int N, int K, hipStream_t st) {
+  if (K % SBK != 0 || N % 8 != 0 || N > SBIAS_MAX || M <= 0) return -1;
+  if (epi == EPI_BIAS && out_f32) return launch_stream<EPI_BIAS, float>(A, W, bias, out, M, N, K, st);
+  if (epi == EPI_BIAS && !out_f32) return launch_stream<EPI_BIAS, bf16>(A, W, bias, out, M, N, K, st);
+  if (epi == EPI_GELU && !out_f32) return launch_stream<EPI_GELU, bf16>(A, W, bias, out, M, N, K, st);
+  return -1;
 }

@@ -8,6 +8,8 @@ enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2 };
 // ---- gemm.hip ----------------------------------------------------------------------------------
 int d3dp_launch_linear_bf16(int epi, int out_f32, const void* A, const void* W, const float* bias, void* out, int M,
                             int N, int K, hipStream_t st);
+int d3dp_launch_linear_bf16_stream(int epi, int out_f32, const void* A, const void* W, const float* bias, void* out,
+                                   int M, int N, int K, hipStream_t st);
 int d3dp_launch_linear_f32(int epi, const float* A, const float* W, const float* bias, float* out, int M, int N,
                            int K, hipStream_t st);
 
@@ -30,14 +32,17 @@ int d3dp_launch_embed_ln(int act_bf16, const float* x2d, const float* x3d, const
                          const float* eb, const float* spos, const float* lnw, const float* lnb, float eps, float* x,
                          void* xn, int seq0, int n_seq, int H, int F, int J, int C, hipStream_t st);
 // xn = LN(x)
-int d3dp_launch_ln(int act_bf16, const float* x, const float* w, const float* b, float eps, void* xn, int T, int C,
-                   hipStream_t st);
+// (all three: if yadd != nullptr the row is first updated x += yadd -- the residual add of the preceding Linear;
+//  yadd has the activation type: bf16 in FAST mode, fp32 in EXACT mode)
+int d3dp_launch_ln(int act_bf16, float* x, const void* yadd, const float* w, const float* b, float eps, void* xn, int T,
+                   int C, hipStream_t st);
 // x = LN_a(x) (+ pos[f]) in place ; xn = LN_b(x)   (shared Spatial/Temporal norm fused with the next block's norm1)
-int d3dp_launch_ln2(int act_bf16, float* x, const float* wa, const float* ba, const float* pos, const float* wb,
-                    const float* bb, float eps, void* xn, int T, int C, int F, int J, hipStream_t st);
+int d3dp_launch_ln2(int act_bf16, float* x, const void* yadd, const float* wa, const float* ba, const float* pos,
+                    const float* wb, const float* bb, float eps, void* xn, int T, int C, int F, int J, hipStream_t st);
 // out[T,3] = Linear(LN_head(LN_a(x)))
-int d3dp_launch_head(const float* x, const float* wa, const float* ba, float eps_a, const float* wh, const float* bh,
-                     float eps_h, const float* w, const float* b, float* out, int T, int C, hipStream_t st);
+int d3dp_launch_head(int act_bf16, const float* x, const void* yadd, const float* wa, const float* ba, float eps_a, const float* wh,
+                     const float* bh, float eps_h, const float* w, const float* b, float* out, int T, int C,
+                     hipStream_t st);
 
 // ---- sampler.hip -------------------------------------------------------------------------------
 int d3dp_launch_ddim_pre(const float* img, float* xt2, const int* perm, float scale, int B, int per_b, int J,

@@ -35,6 +35,18 @@ template <int C> struct Row {
       for (int i = 0; i < NV; ++i) v[i] = p[i * 64 + lane];
     }
   }
+  static __device__ __forceinline__ void load(const bf16* p, int lane, float* v) {
+    if constexpr (V4) {
+#pragma unroll
+      for (int g = 0; g < NV / 4; ++g) {
+        bf16x4 a = *reinterpret_cast<const bf16x4*>(p + (g * 64 + lane) * 4);
+        v[g * 4] = (float)a[0]; v[g * 4 + 1] = (float)a[1]; v[g * 4 + 2] = (float)a[2]; v[g * 4 + 3] = (float)a[3];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = (float)p[i * 64 + lane];
+    }
+  }
   static __device__ __forceinline__ void store(float* p, int lane, const float* v) {
     if constexpr (V4) {
 #pragma unroll
@@ -76,21 +88,30 @@ template <int C> struct Row {
   }
 };
 
+// if yadd != nullptr: x += yadd (written back) first -- the residual add of the preceding Linear (mixste.py:113-115)
 template <int C, typename XN>
-__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                 const float* __restrict__ b, float eps, XN* __restrict__ xn, int T) {
+__global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const XN* __restrict__ yadd,
+                                                 const float* __restrict__ w, const float* __restrict__ b, float eps,
+                                                 XN* __restrict__ xn, int T) {
   using R = Row<C>;
   const int lane = threadIdx.x & 63;
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= T) return;
   float v[R::NV], y[R::NV];
   R::load(x + (size_t)tok * C, lane, v);
+  if (yadd != nullptr) {
+    R::load(yadd + (size_t)tok * C, lane, y);
+#pragma unroll
+    for (int i = 0; i < R::NV; ++i) v[i] += y[i];
+    R::store(x + (size_t)tok * C, lane, v);
+  }
   R::norm(v, w, b, eps, lane, y);
   R::store(xn + (size_t)tok * C, lane, y);
 }
 
 template <int C, typename XN>
-__global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const float* __restrict__ wa,
+__global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const XN* __restrict__ yadd,
+                                                  const float* __restrict__ wa,
                                                   const float* __restrict__ ba, const float* __restrict__ pos,
                                                   const float* __restrict__ wb, const float* __restrict__ bb, float eps,
                                                   XN* __restrict__ xn, int T, int F, int J) {
@@ -100,6 +121,11 @@ __global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const f
   if (tok >= T) return;
   float v[R::NV], y[R::NV], z[R::NV];
   R::load(x + (size_t)tok * C, lane, v);
+  if (yadd != nullptr) {
+    R::load(yadd + (size_t)tok * C, lane, y);
+#pragma unroll
+    for (int i = 0; i < R::NV; ++i) v[i] += y[i];
+  }
   R::norm(v, wa, ba, eps, lane, y);
   if (pos != nullptr) {
     const int f = (tok / J) % F;
@@ -148,8 +174,9 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
   R::store(xn + (size_t)tl * C, lane, y);
 }
 
-template <int C>
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const float* __restrict__ wa,
+template <int C, typename XN>
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const XN* __restrict__ yadd,
+                                                   const float* __restrict__ wa,
                                                    const float* __restrict__ ba, float eps_a,
                                                    const float* __restrict__ wh, const float* __restrict__ bh,
                                                    float eps_h, const float* __restrict__ w, const float* __restrict__ b,
@@ -160,6 +187,11 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
   if (tok >= T) return;
   float v[R::NV], y[R::NV], z[R::NV];
   R::load(x + (size_t)tok * C, lane, v);
+  if (yadd != nullptr) {
+    R::load(yadd + (size_t)tok * C, lane, y);
+#pragma unroll
+    for (int i = 0; i < R::NV; ++i) v[i] += y[i];
+  }
   R::norm(v, wa, ba, eps_a, lane, y);
   R::norm(y, wh, bh, eps_h, lane, z);
   float acc[3];
@@ -236,27 +268,30 @@ int d3dp_launch_embed_ln(int act_bf16, const float* x2d, const float* x3d, const
   return 0;
 }
 
-int d3dp_launch_ln(int act_bf16, const float* x, const float* w, const float* b, float eps, void* xn, int T, int C,
-                   hipStream_t st) {
+int d3dp_launch_ln(int act_bf16, float* x, const void* yadd, const float* w, const float* b, float eps, void* xn, int T,
+                   int C, hipStream_t st) {
   dim3 g((T + 3) / 4), blk(256);
   DISPATCH_C(C,
-    if (act_bf16) hipLaunchKernelGGL((ln_kernel<CC, bf16>), g, blk, 0, st, x, w, b, eps, (bf16*)xn, T);
-    else hipLaunchKernelGGL((ln_kernel<CC, float>), g, blk, 0, st, x, w, b, eps, (float*)xn, T))
+    if (act_bf16) hipLaunchKernelGGL((ln_kernel<CC, bf16>), g, blk, 0, st, x, (const bf16*)yadd, w, b, eps, (bf16*)xn, T);
+    else hipLaunchKernelGGL((ln_kernel<CC, float>), g, blk, 0, st, x, (const float*)yadd, w, b, eps, (float*)xn, T))
   return 0;
 }
 
-int d3dp_launch_ln2(int act_bf16, float* x, const float* wa, const float* ba, const float* pos, const float* wb,
-                    const float* bb, float eps, void* xn, int T, int C, int F, int J, hipStream_t st) {
+int d3dp_launch_ln2(int act_bf16, float* x, const void* yadd, const float* wa, const float* ba, const float* pos,
+                    const float* wb, const float* bb, float eps, void* xn, int T, int C, int F, int J, hipStream_t st) {
   dim3 g((T + 3) / 4), blk(256);
   DISPATCH_C(C,
-    if (act_bf16) hipLaunchKernelGGL((ln2_kernel<CC, bf16>), g, blk, 0, st, x, wa, ba, pos, wb, bb, eps, (bf16*)xn, T, F, J);
-    else hipLaunchKernelGGL((ln2_kernel<CC, float>), g, blk, 0, st, x, wa, ba, pos, wb, bb, eps, (float*)xn, T, F, J))
+    if (act_bf16) hipLaunchKernelGGL((ln2_kernel<CC, bf16>), g, blk, 0, st, x, (const bf16*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, T, F, J);
+    else hipLaunchKernelGGL((ln2_kernel<CC, float>), g, blk, 0, st, x, (const float*)yadd, wa, ba, pos, wb, bb, eps, (float*)xn, T, F, J))
   return 0;
 }
 
-int d3dp_launch_head(const float* x, const float* wa, const float* ba, float eps_a, const float* wh, const float* bh,
-                     float eps_h, const float* w, const float* b, float* out, int T, int C, hipStream_t st) {
+int d3dp_launch_head(int act_bf16, const float* x, const void* yadd, const float* wa, const float* ba, float eps_a, const float* wh,
+                     const float* bh, float eps_h, const float* w, const float* b, float* out, int T, int C,
+                     hipStream_t st) {
   dim3 g((T + 3) / 4), blk(256);
-  DISPATCH_C(C, hipLaunchKernelGGL((head_kernel<CC>), g, blk, 0, st, x, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T))
+  DISPATCH_C(C,
+    if (act_bf16) hipLaunchKernelGGL((head_kernel<CC, bf16>), g, blk, 0, st, x, (const bf16*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T);
+    else hipLaunchKernelGGL((head_kernel<CC, float>), g, blk, 0, st, x, (const float*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T))
   return 0;
 }

@@ -137,8 +137,10 @@ int d3dp_q_sample(const float* x0, const float* noise, const double* sqrt_ac, co
                   float* out, int32_t B, int32_t per_b, void* stream);
 
 /* ---- single operators (unit parity tests; same kernels the denoiser launches) ---------------------------- */
-/* out[M,N] = epi(A[M,K] W[N,K]^T + bias).  mode FAST: A, W bf16 (uint16 storage), out bf16 unless epi==RESID;
- * mode EXACT: everything fp32.  epi: 0 bias, 1 bias+GELU(erf), 2 out(fp32) += result. */
+/* out[M,N] = epi(A[M,K] W[N,K]^T + bias).  epi & 3: 0 bias, 1 bias+GELU(erf), 2 out(fp32) += result.
+ * mode EXACT: everything fp32 (fp32 MFMA).  mode FAST: A, W bf16 (uint16 storage), fp32 accumulate; out is bf16
+ * unless (epi & 16) or epi == 2 (fp32).  FAST epi 0/1 run the persistent streaming kernel the denoiser uses;
+ * (epi & 32) or epi == 2 select the per-tile 128x128 kernel instead. */
 int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, const float* bias, void* out, int32_t M,
                    int32_t N, int32_t K, void* stream);
 /* Multi-head attention over qkv[T,3C] -> out[T,C]; axis 0 = spatial (sequences of J joints), 1 = temporal

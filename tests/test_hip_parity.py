@@ -56,7 +56,8 @@ def test_native_library_is_loaded(lib):
 
 # ------------------------------------------------------------------------------------------------ single ops
 @pytest.mark.parametrize("mode", ["exact", "fast"])
-@pytest.mark.parametrize("M,N,K", [(4131, 1536, 512), (300, 512, 1024), (17, 1024, 512), (1000, 64, 128)])
+@pytest.mark.parametrize("M,N,K", [(4131, 1536, 512), (300, 512, 1024), (17, 1024, 512), (1000, 64, 128),
+                                   (70000, 512, 512)])
 def test_linear_all_epilogues(lib, mode, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g)
@@ -69,17 +70,22 @@ def test_linear_all_epilogues(lib, mode, M, N, K):
     Ad = (A.to(torch.bfloat16) if fast else A).cuda().contiguous()
     Wd = (W.to(torch.bfloat16) if fast else W).cuda().contiguous()
     bd = bias.cuda()
-    for epi, want in ((_lib.EPI_BIAS, lin), (_lib.EPI_GELU, torch.nn.functional.gelu(lin)),
-                      (_lib.EPI_RESID, R.double() + lin)):
+    cases = [(_lib.EPI_BIAS, lin), (_lib.EPI_GELU, torch.nn.functional.gelu(lin)), (_lib.EPI_RESID, R.double() + lin)]
+    if fast:   # fp32-output form of the streaming kernel, and the per-tile kernel's bf16/fp32 forms
+        cases += [(_lib.EPI_BIAS | 16, lin), (_lib.EPI_BIAS | 32, lin), (_lib.EPI_GELU | 32, torch.nn.functional.gelu(lin)),
+                  (_lib.EPI_BIAS | 16 | 32, lin)]
+    for epi, want in cases:
+        f32_out = (not fast) or epi == _lib.EPI_RESID or bool(epi & 16)
         if epi == _lib.EPI_RESID:
             out = R.clone().cuda()
         else:
-            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16 if fast else torch.float32, device="cuda")
+            out = torch.full((M, N), float("nan"), dtype=torch.float32 if f32_out else torch.bfloat16, device="cuda")
         _lib.check(lib.d3dp_op_linear(_lib.MODE_FAST if fast else _lib.MODE_EXACT, epi, Ad.data_ptr(), Wd.data_ptr(),
                                       bd.data_ptr(), out.data_ptr(), M, N, K, stream()))
         torch.cuda.synchronize()
         got = out.float().cpu().double()
-        out_is_bf16 = fast and epi != _lib.EPI_RESID
+        # the streaming kernel keeps finished tiles as packed bf16 before storing: bf16 precision even for fp32 output
+        out_is_bf16 = (not f32_out) or (fast and not (epi & 32) and epi != _lib.EPI_RESID)
         atol = 2e-2 if out_is_bf16 else 2e-5 * K ** 0.5
         rtol = 1e-2 if out_is_bf16 else 1e-5
         assert torch.allclose(got, want, atol=atol, rtol=rtol), (mode, epi, (got - want).abs().max().item())

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the Linear kernels through the C ABI (d3dp_op_linear) at the denoiser's shapes.
+Usage: python tools/gemm_bench.py [--m 61965] [--iters 20] [--tile]   (run on the GPU box; wrap with rocprofv3 for PMC)"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from d3dp_amd import _lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--m", type=int, default=15 * 4131)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--tile", action="store_true", help="per-tile 128x128 kernel instead of the streaming one")
+    ap.add_argument("--shapes", default="qkv,proj,fc1,fc2")
+    a = ap.parse_args()
+    lib = _lib.load()
+    M = a.m
+    shapes = {"qkv": (1536, 512, 0), "proj": (512, 512, 16), "fc1": (1024, 512, 1), "fc2": (512, 1024, 16)}
+    st = torch.cuda.current_stream().cuda_stream
+    for name in a.shapes.split(","):
+        N, K, epi = shapes[name]
+        if a.tile:
+            epi |= 32
+        A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+        W = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
+        b = torch.randn(N, device="cuda")
+        out = torch.empty(M, N, device="cuda", dtype=torch.float32 if epi & 16 else torch.bfloat16)
+        for _ in range(3):
+            _lib.check(lib.d3dp_op_linear(1, epi, A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, st))
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.iters)]
+        for e0, e1 in evs:
+            e0.record()
+            _lib.check(lib.d3dp_op_linear(1, epi, A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, st))
+            e1.record()
+        torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        med = ts[len(ts) // 2]
+        print(f"{name:5s} M={M} N={N} K={K} epi={epi:2d}: median {med * 1e3:8.1f} us  min {ts[0] * 1e3:8.1f} us  "
+              f"{2 * M * N * K / med / 1e9:7.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
