@@ -1,0 +1,165 @@
+"""`main.py --evaluate`-compatible entrypoint of the hot path (reference main.py:596-794, README.md:39).
+
+Keeps the reference's flag names for everything the path consumes (-c, --evaluate, -num_proposals,
+-sampling_timesteps, -b, -f, -cs, -dep, -scale, -timestep, -gpu, --nolog, --debug) and its control flow:
+flipped 2D copy (main.py:646-648), clip chunking (267-299), -b batching (682-698), root-joint zeroing (700),
+trajectory add + reprojection (706-712), the four MPJPE aggregations (715-718), N-weighted accumulation (720-736)
+and the `step %d : Protocol #1 Error (MPJPE) ...` lines written to <checkpoint>/h36m_test_log_H%d_K%d.txt (745-774).
+
+Out of scope: the Human3.6M/3DHP dataset loaders, training loop, rendering and P-MPJPE (--p2).
+`--synthetic` replaces main.py:83-145 with seeded synthetic sequences; without it the script explains what is missing.
+Run under `python -m torch.distributed.run --nproc-per-node N main.py ...` to shard hypotheses over N GPUs.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import D3DP, jpma
+from .dist import all_gather_hypotheses, hypothesis_slice, init_from_env, rank_generator
+from .weights import H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, make_state_dict
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="D3DP evaluation on MI355X (libd3dp_hip)")
+    p.add_argument('-d', '--dataset', default='h36m', type=str)
+    p.add_argument('-k', '--keypoints', default='cpn_ft_h36m_dbb', type=str)
+    p.add_argument('-c', '--checkpoint', default='checkpoint', type=str, help='checkpoint directory')
+    p.add_argument('--evaluate', default='', type=str, metavar='FILENAME', help='checkpoint to evaluate (file name)')
+    p.add_argument('--nolog', action='store_true')
+    p.add_argument('-gpu', default='0', type=str)
+    p.add_argument('-b', '--batch-size', default=4, type=int, help='clips per model call')
+    p.add_argument('-cs', default=512, type=int)
+    p.add_argument('-dep', default=8, type=int)
+    p.add_argument('-f', '--number-of-frames', default=243, type=int)
+    p.add_argument('-scale', default=1.0, type=float)
+    p.add_argument('-timestep', type=int, default=1000)
+    p.add_argument('-sampling_timesteps', type=int, default=5)
+    p.add_argument('-num_proposals', type=int, default=300)
+    p.add_argument('--debug', action='store_true', default=False)
+    p.add_argument('--p2', action='store_true', default=False)
+    # additions
+    p.add_argument('--synthetic', action='store_true', help='seeded synthetic sequences instead of data/*.npz')
+    p.add_argument('--synthetic-sequences', type=int, default=2)
+    p.add_argument('--synthetic-frames', type=int, default=600)
+    p.add_argument('--numerics', default=None, choices=['exact', 'fast'])
+    p.add_argument('--seed', type=int, default=1)
+    a = p.parse_args(argv)
+    a.test_time_augmentation = True          # arguments.py:112 (no flag turns it off in the reference)
+    return a
+
+
+def synthetic_sequences(n_seq, n_frames, seed):
+    """(cam(9), gt3d (N,17,3) camera space, kp2d (N,17,2) normalised) per sequence; 2D = projection of the 3D + noise."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cam = np.array([2.29, 2.287, 0.0254, 0.0289, -0.2070, 0.2477, -0.0030, -0.0009, -0.0014], np.float32)
+    out = []
+    for _ in range(n_seq):
+        t = np.linspace(0, 6.0, n_frames, dtype=np.float32)[:, None, None]
+        base = (rng.standard_normal((1, 17, 3)) * 0.25).astype(np.float32)
+        sway = (rng.standard_normal((1, 17, 3)) * 0.05).astype(np.float32) * np.sin(t * (1 + rng.uniform(size=(1, 17, 3)).astype(np.float32)))
+        pose = base + sway
+        pose[:, 0] = 0
+        traj = np.concatenate([0.3 * np.sin(t[:, 0]), 0.1 * np.cos(t[:, 0]), 4.0 + 0.2 * np.sin(0.5 * t[:, 0])], axis=-1)[:, None]
+        gt = (pose + traj).astype(np.float32)
+        kp = jpma.project_to_2d(torch.from_numpy(gt), torch.from_numpy(cam)).numpy()
+        kp = kp + rng.normal(0, 0.005, kp.shape).astype(np.float32)
+        out.append((cam, gt, kp.astype(np.float32)))
+    return out
+
+
+def load_model(args, device, h_local):
+    model = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=False, num_proposals=h_local,
+                 sampling_timesteps=args.sampling_timesteps, numerics=args.numerics)
+    path = os.path.join(args.checkpoint, args.evaluate) if args.evaluate else ''
+    if path and os.path.exists(path):
+        print('Loading evaluate checkpoint', path)
+        ck = torch.load(path, map_location='cpu')
+        sd = {k[len('module.'):] if k.startswith('module.') else k: v for k, v in ck['model_pos'].items()}
+        model.load_state_dict(sd)
+    elif args.synthetic:
+        print('No checkpoint file: using seed-generated weights (d3dp_amd.weights, seed 7)')
+        model.load_state_dict(make_state_dict(7, args.cs, args.dep, args.number_of_frames), strict=False)
+    else:
+        raise SystemExit(f"checkpoint {path!r} not found (pass --synthetic to run on seed-generated weights)")
+    return model.to(device).eval()
+
+
+def evaluate(args, model, sequences, device, rank, world, gen):
+    K = args.sampling_timesteps
+    sums = {k: torch.zeros(K, device=device) for k in ("J_Best", "P_Best", "P_Agg", "J_Agg")}
+    N = 0
+    F_ = args.number_of_frames
+    kl, kr = H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT
+    with torch.no_grad():
+        for cam, batch, batch_2d in sequences:
+            inputs_2d = torch.from_numpy(batch_2d.astype('float32'))[None]
+            inputs_3d = torch.from_numpy(batch.astype('float32'))[None]
+            camt = torch.from_numpy(cam.astype('float32')).to(device)
+            flip = inputs_2d.clone()                       # main.py:646-648
+            flip[:, :, :, 0] *= -1
+            flip[:, :, kl + kr, :] = flip[:, :, kr + kl, :]
+            x2, x3 = jpma.eval_data_prepare(F_, inputs_2d, inputs_3d)
+            x2f, _ = jpma.eval_data_prepare(F_, flip, inputs_3d)
+            x2, x2f, x3 = x2.to(device), x2f.to(device), x3.to(device)
+            traj = x3[:, :, :1].clone()
+            x3[:, :, 0] = 0
+            bs = args.batch_size
+            for i in range(0, x3.shape[0], bs):
+                a2, a2f, a3, tr = x2[i:i + bs], x2f[i:i + bs], x3[i:i + bs], traj[i:i + bs]
+                pred = model(a2.contiguous(), a3, input_2d_flip=a2f.contiguous(), generator=gen)   # (b,K,H_local,F,17,3)
+                pred = all_gather_hypotheses(pred)                                                   # (b,K,H,F,17,3)
+                pred[:, :, :, :, 0] = 0                                                              # main.py:700
+                rp = jpma.reproject(pred, tr, camt)
+                m = jpma.jpma_metrics(pred, a3, rp, a2)
+                w = a3.shape[0] * a3.shape[1]
+                for k in sums:
+                    sums[k] += w * m[k]
+                N += w
+                if args.debug:
+                    break
+            if args.debug:
+                break
+    return {k: (v / N) * 1000 for k, v in sums.items()}, N
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    rank, world, local = init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("main.py --evaluate needs an MI355X: libd3dp_hip has no CPU fallback")
+    if args.p2:
+        print("--p2 (P-MPJPE, numpy Procrustes) is outside this build's scope (SURVEY.md §2 row 3): ignored")
+    if not args.synthetic:
+        raise SystemExit("dataset loading (data/data_3d_h36m.npz, data_2d_*.npz) is out of scope for this build "
+                         "(SURVEY.md §2 rows 7-8); run with --synthetic")
+    torch.cuda.set_device(local if world > 1 else int(args.gpu.split(',')[0]))
+    device = torch.device('cuda', torch.cuda.current_device())
+    sl = hypothesis_slice(args.num_proposals, rank, world)
+    model = load_model(args, device, sl.stop - sl.start)
+    seqs = synthetic_sequences(args.synthetic_sequences, args.synthetic_frames, args.seed)
+    errs, N = evaluate(args, model, seqs, device, rank, world, rank_generator(args.seed, rank, device))
+    if rank == 0:
+        os.makedirs(args.checkpoint, exist_ok=True)
+        log_path = os.path.join(args.checkpoint, 'h36m_test_log_H%d_K%d.txt' % (args.num_proposals, args.sampling_timesteps))
+        with open(log_path, mode='a') as f:
+            print('----synthetic----')
+            f.write('----synthetic----\n')
+            print('Test time augmentation:', True)
+            for ii in range(args.sampling_timesteps):
+                for name in ("J_Best", "P_Best", "P_Agg", "J_Agg"):
+                    print('step %d : Protocol #1 Error (MPJPE) %s:' % (ii, name), errs[name][ii].item(), 'mm')
+                    f.write('step %d : Protocol #1 Error (MPJPE) %s: %f mm\n' % (ii, name, errs[name][ii].item()))
+            print('----------')
+            f.write('----------\n')
+        print(f'evaluated {N} frames; log appended to {log_path}')
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

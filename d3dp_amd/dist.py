@@ -61,10 +61,11 @@ def all_gather_hypotheses(preds_local: torch.Tensor, group=None) -> torch.Tensor
     world = dist.get_world_size(group)
     B, K, Hl = preds_local.shape[:3]
     src = preds_local.contiguous()
-    gathered = torch.empty((world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
-    dist.all_gather_into_tensor(gathered, src, group=group)
+    gathered = torch.empty((world * B,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(gathered, src, group=group)      # rank-major concatenation along dim 0
     # (world, B, K, Hl, ...) -> (B, K, world*Hl, ...)
-    return gathered.permute(1, 2, 0, 3, 4, 5, 6).reshape(B, K, world * Hl, *src.shape[3:])
+    return gathered.view(world, B, K, Hl, *src.shape[3:]).permute(1, 2, 0, 3, 4, 5, 6).reshape(
+        B, K, world * Hl, *src.shape[3:])
 
 
 def rank_generator(seed: int, rank: int, device) -> torch.Generator:
