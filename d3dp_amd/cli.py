@@ -66,9 +66,11 @@ def synthetic_sequences(n_seq, n_frames, seed):
         pose = base + sway
         pose[:, 0] = 0
         traj = np.concatenate([0.3 * np.sin(t[:, 0]), 0.1 * np.cos(t[:, 0]), 4.0 + 0.2 * np.sin(0.5 * t[:, 0])], axis=-1)[:, None]
-        gt = (pose + traj).astype(np.float32)
-        kp = jpma.project_to_2d(torch.from_numpy(gt), torch.from_numpy(cam)).numpy()
+        absol = (pose + traj).astype(np.float32)
+        kp = jpma.project_to_2d(torch.from_numpy(absol), torch.from_numpy(cam)).numpy()
         kp = kp + rng.normal(0, 0.005, kp.shape).astype(np.float32)
+        gt = pose.astype(np.float32).copy()      # joints 1.. root-relative, joint 0 carries the trajectory
+        gt[:, 0] = traj[:, 0]                    # (the layout main.py:99-103 gives the generator's 3D batches)
         out.append((cam, gt, kp.astype(np.float32)))
     return out
 

@@ -13,6 +13,8 @@
 //                               (keys <= 256), so softmax is a plain two-pass fp32 softmax with wavefront
 //                               shuffles -- no online rescaling.  S^T = K Q^T is computed transposed so the
 //                               probabilities land directly in the A/B fragment layout of the P.V MFMA.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -313,6 +315,210 @@ int launch_temporal(const void* qkv, void* out, int n_seq, SeqMap map, int C, in
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// FAST-mode attention, second generation (head dim 64): no transposes anywhere.
+//   K rows sit in LDS row-major (128 B per key) with the 16-byte-slot XOR swizzle ds_read_b128 wants;
+//   V rows sit row-major too, swizzled at 32-byte-chunk granularity, and are consumed with
+//   ds_read_b64_tr_b16: within each 16-lane group the instruction returns, to lane i, column i of the
+//   4-key x 16-column block the group's lanes point at (lanes 4j..4j+3 -> key j) -- exactly the
+//   "8 consecutive keys of one output channel" fragment the O^T = V^T P^T MFMA needs.  (Mapping measured on
+//   gfx950 with tools/probe_tr.hip.)
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 v4bf16 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int vchunk_swz(int key, int chunk) { return chunk ^ ((key >> 1) & 3); }
+
+// V^T fragment for output channels dn*16 + (lane&15), keys {k0 + 4g + j} and {k0 + 16 + 4g + j}, j = 0..3
+__device__ __forceinline__ bf16x8 load_vt_frag(const char* VS, int k0, int dn, int lane) {
+  const int g = lane >> 4, ip = lane & 15, j = ip >> 2, qd = ip & 3;
+  const int ka = k0 + 4 * g + j, kb = ka + 16;
+  const v4bf16 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+      (__attribute__((address_space(3))) v4bf16*)(VS + ka * 128 + vchunk_swz(ka, dn) * 32 + qd * 8));
+  const v4bf16 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+      (__attribute__((address_space(3))) v4bf16*)(VS + kb * 128 + vchunk_swz(kb, dn) * 32 + qd * 8));
+  return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+// One 16-query tile against NKT 16-key tiles resident in LDS.  q0/q1: the tile's Q fragments (d 0..31 / 32..63).
+// Returns O^T accumulators (4 channel tiles) and the softmax denominator of query (lane & 15).
+template <int NKT>
+__device__ __forceinline__ void attn_tile(const char* KS, const char* VS, bf16x8 q0, bf16x8 q1, int n, int lane,
+                                          f32x4 (&o)[4], float& denom) {
+  const int fi = lane & 15, fg = lane >> 4;
+  const float cexp = 0.125f * 1.44269504088896340736f;   // hd^-0.5 * log2(e), hd = 64
+  f32x4 s[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    const int key = t * 16 + fi;
+    const int sw = (key >> 1) & 7;
+    const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(KS + key * 128 + ((fg ^ sw) << 4));
+    const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(KS + key * 128 + (((4 + fg) ^ sw) << 4));
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q0, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q1, a, 0, 0, 0);
+    s[t] = a;
+    if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the ds_read hoisting window (VGPR pressure)
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    if (16 * (t + 1) > n) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * t + 4 * fg + r >= n) s[t][r] = -INFINITY;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float mc = mx * cexp;
+  float sum = 0.f;
+  bf16x8 pf[NKT / 2];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], cexp, -mc));
+      sum += p;
+      pf[t >> 1][(t & 1) * 4 + r] = (bf16)p;
+    }
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  denom = sum;
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < NKT / 2; ++c) {
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(load_vt_frag(VS, 32 * c, dn, lane), pf[c], o[dn], 0, 0, 0);
+    if (c & 1) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// rows [0, n) of K and V (128 B per row for this head) -> swizzled LDS images; rows [n, NK) of V zeroed.
+template <int NK, int NTHREADS>
+__device__ __forceinline__ void stage_kv(const bf16* __restrict__ kbase, size_t row_stride, int n, char* KS, char* VS,
+                                         int tid, int C) {
+  for (int idx = tid; idx < NK * 8; idx += NTHREADS) {
+    const int row = idx >> 3, slot = idx & 7;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (row < n) {
+      const bf16* src = kbase + (size_t)row * row_stride + slot * 8;
+      kv = *reinterpret_cast<const float4*>(src);
+      vv = *reinterpret_cast<const float4*>(src + C);
+    }
+    *reinterpret_cast<float4*>(KS + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = kv;
+    *reinterpret_cast<float4*>(VS + row * 128 + ((slot ^ (((row >> 1) & 3) << 1)) << 4)) = vv;
+  }
+}
+
+template <int NKT>   // temporal axis: one workgroup per (sequence, head), 4 waves share the K/V images
+__global__ __launch_bounds__(256, 2) void attn_temporal2_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                                     SeqMap map, int C, int heads) {
+  constexpr int NK = 16 * NKT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* KS = smem;
+  char* VS = smem + NK * 128;
+  const int n = map.n_tok;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
+  const int base = seq_base(map, seq);
+  const int ts = map.tok_stride;
+  const size_t ld = (size_t)3 * C;
+  const bf16* qbase = qkv + (size_t)base * ld + (size_t)head * 64;
+  // This wave's Q fragments for ALL of its query tiles are requested before K/V staging, so their HBM latency
+  // overlaps the staging loads instead of being paid once per tile in the compute loop.
+  const int fi = lane & 15, fg = lane >> 4;
+  const int n_qt = (n + 15) >> 4;
+  constexpr int QPW = (NKT + 3) / 4;                 // query tiles per wave
+  bf16x8 qf[QPW][2];
+#pragma unroll
+  for (int i = 0; i < QPW; ++i) {
+    const int q = min((wave + 4 * i) * 16 + fi, n - 1);
+    const bf16* qsrc = qbase + (size_t)q * ts * ld + fg * 8;
+    qf[i][0] = *reinterpret_cast<const bf16x8*>(qsrc);
+    qf[i][1] = *reinterpret_cast<const bf16x8*>(qsrc + 32);
+  }
+  stage_kv<NK, 256>(qbase + C, (size_t)ts * ld, n, KS, VS, tid, C);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < QPW; ++i) {
+    const int qt = wave + 4 * i;
+    if (qt >= n_qt) break;
+    const int q = qt * 16 + fi;
+    f32x4 o[4];
+    float denom;
+    attn_tile<NKT>(KS, VS, qf[i][0], qf[i][1], n, lane, o, denom);
+    if (q < n) {
+      const float inv = 1.0f / denom;
+      bf16* dst = out + (size_t)(base + q * ts) * C + head * 64 + fg * 4;
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) {
+        bf16x4 r = {(bf16)(o[dn][0] * inv), (bf16)(o[dn][1] * inv), (bf16)(o[dn][2] * inv), (bf16)(o[dn][3] * inv)};
+        *reinterpret_cast<bf16x4*>(dst + dn * 16) = r;
+      }
+    }
+  }
+}
+
+// spatial axis (<= 32 tokens per sequence): one WAVE per (sequence, head) with a private 8 KiB K/V image;
+// a 256-thread workgroup covers 4 heads of one sequence.
+__global__ __launch_bounds__(256) void attn_spatial_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                                int n_prob, SeqMap map, int C, int heads) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * 8192];
+  const int n = map.n_tok;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pid = blockIdx.x * 4 + wave;
+  if (pid >= n_prob) return;
+  const int seq = pid / heads, head = pid % heads;
+  const int base = seq_base(map, seq);
+  const int ts = map.tok_stride;
+  const size_t ld = (size_t)3 * C;
+  const bf16* qbase = qkv + (size_t)base * ld + (size_t)head * 64;
+  char* KS = smem + wave * 8192;
+  char* VS = KS + 4096;
+  stage_kv<32, 64>(qbase + C, (size_t)ts * ld, n, KS, VS, lane, C);
+  // (wave-private LDS image: the LDS pipe executes one wave's accesses in order, no barrier needed)
+  const int fi = lane & 15, fg = lane >> 4;
+  const int n_qt = (n + 15) >> 4;
+  for (int qt = 0; qt < n_qt; ++qt) {
+    const int q = qt * 16 + fi;
+    const bf16* qsrc = qbase + (size_t)min(q, n - 1) * ts * ld + fg * 8;
+    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(qsrc);
+    const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(qsrc + 32);
+    f32x4 o[4];
+    float denom;
+    attn_tile<2>(KS, VS, q0, q1, n, lane, o, denom);
+    if (q < n) {
+      const float inv = 1.0f / denom;
+      bf16* dst = out + (size_t)(base + q * ts) * C + head * 64 + fg * 4;
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) {
+        bf16x4 r = {(bf16)(o[dn][0] * inv), (bf16)(o[dn][1] * inv), (bf16)(o[dn][2] * inv), (bf16)(o[dn][3] * inv)};
+        *reinterpret_cast<bf16x4*>(dst + dn * 16) = r;
+      }
+    }
+  }
+}
+
+template <int NKT>
+int launch_temporal2(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st) {
+  constexpr int NK = 16 * NKT;
+  const size_t lds = (size_t)NK * 256;
+  auto kern = attn_temporal2_bf16_kernel<NKT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) return -3;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(256), lds, st, (const bf16*)qkv, (bf16*)out, map, C, heads);
+  return 0;
+}
+
 }  // namespace
 
 int d3dp_launch_attn_rows(int act_bf16, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
@@ -325,8 +531,25 @@ int d3dp_launch_attn_temporal_bf16(const void* qkv, void* out, int n_seq, SeqMap
                                    hipStream_t st) {
   if (C / heads != 64 || map.n_tok > 256 || map.n_tok < 1) return -2;
   const int n = map.n_tok;
-  if (n <= 32) return launch_temporal<2>(qkv, out, n_seq, map, C, heads, st);
-  if (n <= 64) return launch_temporal<4>(qkv, out, n_seq, map, C, heads, st);
-  if (n <= 128) return launch_temporal<8>(qkv, out, n_seq, map, C, heads, st);
-  return launch_temporal<16>(qkv, out, n_seq, map, C, heads, st);
+  static int v1 = -1;
+  if (v1 < 0) { const char* e = getenv("D3DP_ATTN_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }   // A/B: first-generation kernel
+  if (v1) {
+    if (n <= 32) return launch_temporal<2>(qkv, out, n_seq, map, C, heads, st);
+    if (n <= 64) return launch_temporal<4>(qkv, out, n_seq, map, C, heads, st);
+    if (n <= 128) return launch_temporal<8>(qkv, out, n_seq, map, C, heads, st);
+    return launch_temporal<16>(qkv, out, n_seq, map, C, heads, st);
+  }
+  if (n <= 32) return launch_temporal2<2>(qkv, out, n_seq, map, C, heads, st);
+  if (n <= 64) return launch_temporal2<4>(qkv, out, n_seq, map, C, heads, st);
+  if (n <= 128) return launch_temporal2<8>(qkv, out, n_seq, map, C, heads, st);
+  return launch_temporal2<16>(qkv, out, n_seq, map, C, heads, st);
+}
+
+// spatial axis on MFMA (bf16, head dim 64, <= 32 tokens per sequence)
+int d3dp_launch_attn_spatial_bf16(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st) {
+  if (C / heads != 64 || map.n_tok > 32 || map.n_tok < 1) return -2;
+  const int n_prob = n_seq * heads;
+  hipLaunchKernelGGL(attn_spatial_bf16_kernel, dim3((n_prob + 3) / 4), dim3(256), 0, st, (const bf16*)qkv, (bf16*)out,
+                     n_prob, map, C, heads);
+  return 0;
 }

@@ -96,6 +96,7 @@ struct d3dp_ctx {
   bool fast() const { return cfg.mode == D3DP_MODE_FAST; }
   size_t act_size() const { return fast() ? 2 : 4; }
   int chunk() const { return cfg.chunk_seqs > 0 ? cfg.chunk_seqs : 15; }
+  bool attn_rows_spatial = false;   // env D3DP_ATTN_V1=1: fp32-VALU row kernel for the spatial axis (A/B)
   bool gemm_v1 = false;   // env D3DP_GEMM_V1=1: per-tile 128x128 kernel instead of the persistent streaming one (A/B)
 
   int flush_events() {
@@ -154,8 +155,13 @@ SeqMap temporal_map(int F, int J) { return SeqMap{F, J, F * J, 1, J}; }
 int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, hipStream_t st) {
   const d3dp_cfg& g = c->cfg;
   Scope s(c, axis == 0 ? P_ATTN_S : P_ATTN_T, st);
-  if (axis == 0) return d3dp_launch_attn_rows(c->fast(), qkv, out, n_bh * g.frames, spatial_map(g.frames, g.joints),
-                                              g.channels, g.heads, st);
+  if (axis == 0) {
+    if (c->fast() && g.channels / g.heads == 64 && g.joints <= 32 && !c->attn_rows_spatial)
+      return d3dp_launch_attn_spatial_bf16(qkv, out, n_bh * g.frames, spatial_map(g.frames, g.joints), g.channels,
+                                           g.heads, st);
+    return d3dp_launch_attn_rows(c->fast(), qkv, out, n_bh * g.frames, spatial_map(g.frames, g.joints), g.channels,
+                                 g.heads, st);
+  }
   if (c->fast() && g.channels / g.heads == 64)
     return d3dp_launch_attn_temporal_bf16(qkv, out, n_bh * g.joints, temporal_map(g.frames, g.joints), g.channels,
                                           g.heads, st);
@@ -214,6 +220,8 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->cfg = g;
   const char* v1 = getenv("D3DP_GEMM_V1");
   c->gemm_v1 = v1 && v1[0] == '1';
+  const char* a1 = getenv("D3DP_ATTN_V1");
+  c->attn_rows_spatial = a1 && a1[0] == '1';
   HIP_TRY(hipGetDevice(&c->device));
   *out = c;
   return D3DP_OK;
@@ -412,7 +420,10 @@ int d3dp_op_attention(int32_t act_bf16, int32_t impl, int32_t axis, const void* 
                       int32_t J, int32_t C, int32_t heads, void* stream) {
   if (!qkv || !out || n_bh < 1) return fail(D3DP_EINVAL, "d3dp_op_attention: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  if (axis == 0) LAUNCH_TRY(d3dp_launch_attn_rows(act_bf16, qkv, out, n_bh * F, spatial_map(F, J), C, heads, st));
+  if (axis == 0 && impl == 1) {
+    if (!act_bf16) return fail(D3DP_EINVAL, "MFMA spatial attention needs bf16 activations");
+    LAUNCH_TRY(d3dp_launch_attn_spatial_bf16(qkv, out, n_bh * F, spatial_map(F, J), C, heads, st));
+  } else if (axis == 0) LAUNCH_TRY(d3dp_launch_attn_rows(act_bf16, qkv, out, n_bh * F, spatial_map(F, J), C, heads, st));
   else if (impl == 1) {
     if (!act_bf16) return fail(D3DP_EINVAL, "MFMA temporal attention needs bf16 activations");
     LAUNCH_TRY(d3dp_launch_attn_temporal_bf16(qkv, out, n_bh * J, temporal_map(F, J), C, heads, st));

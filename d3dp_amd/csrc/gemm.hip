@@ -409,8 +409,10 @@ __global__ __launch_bounds__(768) void gemm_bf16_stream_kernel(const bf16* __res
     if constexpr (EPI == EPI_GELU) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (bf16)gelu_fast((float)v[e]);
+      // keep the activation OUT of the store's bounds branch (LLVM would sink it there, behind the MFMA block)
+      asm volatile("" : "+v"(v));
     }
-    if (m < M && n < N) {
+    if (m < M && n < N && !(dbg & 2)) {
       if constexpr (sizeof(OutT) == 2) {
         *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(out) + (size_t)m * N + n) = v;
       } else {
@@ -423,39 +425,58 @@ __global__ __launch_bounds__(768) void gemm_bf16_stream_kernel(const bf16* __res
 #pragma unroll
     for (int q = 0; q < 7; ++q) pend[q >> 1][q & 1] = pend[(q + 1) >> 1][(q + 1) & 1];
   };
-  constexpr int UPS = NK >= 8 ? 1 : (8 + NK - 1) / NK;   // units drained per draining k-step
-  constexpr int DRAIN_EVERY = NK >= 16 ? NK / 8 : 1;     // NK = 16: every other k-step
+  constexpr int UPS = NK >= 8 ? 1 : (8 + NK - 1) / NK;   // units drained per draining k-step (NK < 8: tests only)
+  // one k-step: 16 ds_read_b128 + 32 MFMA (64 x 64 x 64 per wave)
+  auto kstep = [&](int g) {
+    if (!(dbg & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const char* sa = smem + (g % SNSTAGE) * SSTAGE;
+    const char* sw = sa + SA_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = wr * 64 + i * 16 + fi;
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * 128 + swz(ra, kk * 4 + fg) * 16);
+        const int rw = wc * 64 + i * 16 + fi;
+        wf[i] = *reinterpret_cast<const bf16x8*>(sw + rw * 128 + swz(rw, kk * 4 + fg) * 16);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+  };
   if (!(dbg & 16)) __builtin_amdgcn_s_setprio(1);
   for (int ti = 0; ti < n_my; ++ti) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int unit = 0;
+    const int g0 = ti * NK;
+    // The drain of the previous tile sits in the SAME basic block as the MFMAs of the draining k-step (no runtime
+    // branch around it), so the scheduler can put its VALU work between MFMAs: both compute waves of a SIMD leave
+    // each barrier together and a trailing VALU block would leave the matrix pipe idle.
+    if (!have_pend) {
 #pragma unroll 1
-    for (int ks = 0; ks < NK; ++ks) {
-      const int g = ti * NK + ks;
-      if (!(dbg & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      const char* sa = smem + (g % SNSTAGE) * SSTAGE;
-      const char* sw = sa + SA_BYTES;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 af[4], wf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int ra = wr * 64 + i * 16 + fi;
-          af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * 128 + swz(ra, kk * 4 + fg) * 16);
-          const int rw = wc * 64 + i * 16 + fi;
-          wf[i] = *reinterpret_cast<const bf16x8*>(sw + rw * 128 + swz(rw, kk * 4 + fg) * 16);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      for (int ks = 0; ks < NK; ++ks) kstep(g0 + ks);
+    } else if constexpr (NK >= 16) {
+      int unit = 0;                                   // one unit every NK/8 k-steps (uniform scalar branch)
+#pragma unroll 1
+      for (int ks = 0; ks < NK; ++ks) {
+        kstep(g0 + ks);
+        if (ks % (NK / 8) == 0) drain_one(unit++);
       }
-      // drain a slice of the previous tile's results behind this k-step's MFMAs
-      if (have_pend && !(dbg & 2) && (ks % DRAIN_EVERY) == 0 && unit < 8) {
+    } else if constexpr (NK == 8) {
+      int unit = 0;
+#pragma unroll 1
+      for (int ks = 0; ks < NK; ++ks) { kstep(g0 + ks); drain_one(unit++); }
+    } else {
+      int unit = 0;
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        kstep(g0 + ks);
 #pragma unroll
         for (int r = 0; r < UPS; ++r)
           if (unit < 8) { drain_one(unit); ++unit; }
@@ -477,7 +498,7 @@ __global__ __launch_bounds__(768) void gemm_bf16_stream_kernel(const bf16* __res
       }
     have_pend = true;
   }
-  if (have_pend && !(dbg & 2)) {
+  if (have_pend) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) drain_one(u);
   }

@@ -23,6 +23,7 @@ int d3dp_launch_attn_rows(int act_bf16, const void* qkv, void* out, int n_seq, S
                           hipStream_t st);
 int d3dp_launch_attn_temporal_bf16(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
                                    hipStream_t st);
+int d3dp_launch_attn_spatial_bf16(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st);
 
 // ---- pointwise.hip -----------------------------------------------------------------------------
 int d3dp_launch_time_mlp(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2,

@@ -107,7 +107,7 @@ def ref_attention(qkv, n_bh, F, J, C, heads, axis):
 
 @pytest.mark.parametrize("act,impl,axis,F,C", [
     ("f32", 0, 0, 27, 512), ("f32", 0, 1, 27, 512), ("f32", 0, 1, 243, 512), ("f32", 0, 0, 9, 64), ("f32", 0, 1, 9, 64),
-    ("bf16", 0, 0, 27, 512), ("bf16", 1, 1, 27, 512), ("bf16", 1, 1, 243, 512), ("bf16", 1, 1, 100, 512),
+    ("bf16", 0, 0, 27, 512), ("bf16", 1, 0, 27, 512), ("bf16", 1, 0, 243, 512), ("bf16", 1, 1, 27, 512), ("bf16", 1, 1, 243, 512), ("bf16", 1, 1, 100, 512),
     ("bf16", 0, 1, 243, 512)])
 def test_attention(lib, act, impl, axis, F, C):
     n_bh, J, heads = 2, 17, 8
