@@ -329,31 +329,57 @@ typedef __bf16 v4bf16 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int vchunk_swz(int key, int chunk) { return chunk ^ ((key >> 1) & 3); }
 
-// V^T fragment for output channels dn*16 + (lane&15), keys {k0 + 4g + j} and {k0 + 16 + 4g + j}, j = 0..3
-__device__ __forceinline__ bf16x8 load_vt_frag(const char* VS, int k0, int dn, int lane) {
-  const int g = lane >> 4, ip = lane & 15, j = ip >> 2, qd = ip & 3;
-  const int ka = k0 + 4 * g + j, kb = ka + 16;
-  const v4bf16 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-      (__attribute__((address_space(3))) v4bf16*)(VS + ka * 128 + vchunk_swz(ka, dn) * 32 + qd * 8));
-  const v4bf16 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-      (__attribute__((address_space(3))) v4bf16*)(VS + kb * 128 + vchunk_swz(kb, dn) * 32 + qd * 8));
+// Per-lane LDS base addresses of the K and V^T fragments.  Both swizzles depend only on the lane (not on the key
+// tile), so every fragment read in the tile loop is  base register + compile-time immediate.
+struct FragBases {
+  const char* k0;      // K row (lane&15), d-slot  (lane>>4)      ; tile t at +t*2048
+  const char* k1;      // K row (lane&15), d-slot 4+(lane>>4)
+  const char* v[4];    // V row 4g+j, 32-B chunk dn (swizzled), + qd*8 ; key chunk c at +c*4096, second half +2048
+};
+__device__ __forceinline__ FragBases make_frag_bases(const char* KS, const char* VS, int lane) {
+  FragBases fb;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int sw = (fi >> 1) & 7;                       // ((16t + fi) >> 1) & 7 is independent of t
+  fb.k0 = KS + fi * 128 + ((fg ^ sw) << 4);
+  fb.k1 = KS + fi * 128 + (((4 + fg) ^ sw) << 4);
+  const int j = fi >> 2, qd = fi & 3, key = 4 * fg + j;
+  const int vs = (key >> 1) & 3;                      // ((32c [+16] + key) >> 1) & 3 is independent of c
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) fb.v[dn] = VS + key * 128 + ((dn ^ vs) << 5) + qd * 8;
+  return fb;
+}
+
+// V^T fragment (MFMA A operand) for output channels dn*16 + (lane&15), keys {32c + 4g + j} and {32c + 16 + 4g + j}
+template <int C0>
+__device__ __forceinline__ bf16x8 load_vt_frag(const char* vb) {
+  const v4bf16 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) v4bf16*)(vb + C0 * 4096));
+  const v4bf16 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) v4bf16*)(vb + C0 * 4096 + 2048));
   return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+template <int NKT, int C0>
+__device__ __forceinline__ void pv_chunks(const FragBases& fb, const bf16x8 (&pf)[NKT / 2], f32x4 (&o)[4]) {
+  if constexpr (C0 < NKT / 2) {
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn)
+      o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(load_vt_frag<C0>(fb.v[dn]), pf[C0], o[dn], 0, 0, 0);
+    if (C0 & 1) __builtin_amdgcn_sched_barrier(0);
+    pv_chunks<NKT, C0 + 1>(fb, pf, o);
+  }
 }
 
 // One 16-query tile against NKT 16-key tiles resident in LDS.  q0/q1: the tile's Q fragments (d 0..31 / 32..63).
 // Returns O^T accumulators (4 channel tiles) and the softmax denominator of query (lane & 15).
 template <int NKT>
-__device__ __forceinline__ void attn_tile(const char* KS, const char* VS, bf16x8 q0, bf16x8 q1, int n, int lane,
-                                          f32x4 (&o)[4], float& denom) {
-  const int fi = lane & 15, fg = lane >> 4;
+__device__ __forceinline__ void attn_tile(const FragBases& fb, bf16x8 q0, bf16x8 q1, int n, int lane, f32x4 (&o)[4],
+                                          float& denom) {
+  const int fg = lane >> 4;
   const float cexp = 0.125f * 1.44269504088896340736f;   // hd^-0.5 * log2(e), hd = 64
   f32x4 s[NKT];
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
-    const int key = t * 16 + fi;
-    const int sw = (key >> 1) & 7;
-    const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(KS + key * 128 + ((fg ^ sw) << 4));
-    const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(KS + key * 128 + (((4 + fg) ^ sw) << 4));
+    const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(fb.k0 + t * 2048);
+    const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(fb.k1 + t * 2048);
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q0, a, 0, 0, 0);
     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q1, a, 0, 0, 0);
@@ -390,12 +416,7 @@ __device__ __forceinline__ void attn_tile(const char* KS, const char* VS, bf16x8
   denom = sum;
 #pragma unroll
   for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int c = 0; c < NKT / 2; ++c) {
-#pragma unroll
-    for (int dn = 0; dn < 4; ++dn) o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(load_vt_frag(VS, 32 * c, dn, lane), pf[c], o[dn], 0, 0, 0);
-    if (c & 1) __builtin_amdgcn_sched_barrier(0);
-  }
+  pv_chunks<NKT, 0>(fb, pf, o);
 }
 
 // rows [0, n) of K and V (128 B per row for this head) -> swizzled LDS images; rows [n, NK) of V zeroed.
@@ -415,8 +436,8 @@ __device__ __forceinline__ void stage_kv(const bf16* __restrict__ kbase, size_t 
   }
 }
 
-template <int NKT>   // temporal axis: one workgroup per (sequence, head), 4 waves share the K/V images
-__global__ __launch_bounds__(256, 2) void attn_temporal2_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+template <int NKT>   // temporal axis: one workgroup per (sequence, head), 8 waves share the K/V images
+__global__ __launch_bounds__(512, 4) void attn_temporal2_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                                      SeqMap map, int C, int heads) {
   constexpr int NK = 16 * NKT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -433,25 +454,26 @@ __global__ __launch_bounds__(256, 2) void attn_temporal2_bf16_kernel(const bf16*
   // overlaps the staging loads instead of being paid once per tile in the compute loop.
   const int fi = lane & 15, fg = lane >> 4;
   const int n_qt = (n + 15) >> 4;
-  constexpr int QPW = (NKT + 3) / 4;                 // query tiles per wave
+  constexpr int QPW = (NKT + 7) / 8;                 // query tiles per wave
   bf16x8 qf[QPW][2];
 #pragma unroll
   for (int i = 0; i < QPW; ++i) {
-    const int q = min((wave + 4 * i) * 16 + fi, n - 1);
+    const int q = min((wave + 8 * i) * 16 + fi, n - 1);
     const bf16* qsrc = qbase + (size_t)q * ts * ld + fg * 8;
     qf[i][0] = *reinterpret_cast<const bf16x8*>(qsrc);
     qf[i][1] = *reinterpret_cast<const bf16x8*>(qsrc + 32);
   }
-  stage_kv<NK, 256>(qbase + C, (size_t)ts * ld, n, KS, VS, tid, C);
+  stage_kv<NK, 512>(qbase + C, (size_t)ts * ld, n, KS, VS, tid, C);
+  const FragBases fb = make_frag_bases(KS, VS, lane);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < QPW; ++i) {
-    const int qt = wave + 4 * i;
+    const int qt = wave + 8 * i;
     if (qt >= n_qt) break;
     const int q = qt * 16 + fi;
     f32x4 o[4];
     float denom;
-    attn_tile<NKT>(KS, VS, qf[i][0], qf[i][1], n, lane, o, denom);
+    attn_tile<NKT>(fb, qf[i][0], qf[i][1], n, lane, o, denom);
     if (q < n) {
       const float inv = 1.0f / denom;
       bf16* dst = out + (size_t)(base + q * ts) * C + head * 64 + fg * 4;
@@ -481,6 +503,7 @@ __global__ __launch_bounds__(256) void attn_spatial_bf16_kernel(const bf16* __re
   char* KS = smem + wave * 8192;
   char* VS = KS + 4096;
   stage_kv<32, 64>(qbase + C, (size_t)ts * ld, n, KS, VS, lane, C);
+  const FragBases fb = make_frag_bases(KS, VS, lane);
   // (wave-private LDS image: the LDS pipe executes one wave's accesses in order, no barrier needed)
   const int fi = lane & 15, fg = lane >> 4;
   const int n_qt = (n + 15) >> 4;
@@ -491,7 +514,7 @@ __global__ __launch_bounds__(256) void attn_spatial_bf16_kernel(const bf16* __re
     const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(qsrc + 32);
     f32x4 o[4];
     float denom;
-    attn_tile<2>(KS, VS, q0, q1, n, lane, o, denom);
+    attn_tile<2>(fb, q0, q1, n, lane, o, denom);
     if (q < n) {
       const float inv = 1.0f / denom;
       bf16* dst = out + (size_t)(base + q * ts) * C + head * 64 + fg * 4;
@@ -515,7 +538,7 @@ int launch_temporal2(const void* qkv, void* out, int n_seq, SeqMap map, int C, i
                             160 * 1024) != hipSuccess) return -3;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(256), lds, st, (const bf16*)qkv, (bf16*)out, map, C, heads);
+  hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(512), lds, st, (const bf16*)qkv, (bf16*)out, map, C, heads);
   return 0;
 }
 
