@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libd3dp_hip.so")
 
-MODE_EXACT, MODE_FAST = 0, 1
+MODE_EXACT, MODE_FAST, MODE_SPLIT3 = 0, 1, 2   # MODE_SPLIT3: d3dp_op_linear only
 EPI_BIAS, EPI_GELU, EPI_RESID = 0, 1, 2
 PROFILE_CLASSES = 12
 ABI_VERSION = 1
@@ -67,6 +67,7 @@ PROTOTYPES = {
     "d3dp_op_layernorm": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32,
                                     C.c_int32, C.c_void_p]),
     "d3dp_op_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "d3dp_op_split3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "d3dp_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "d3dp_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "d3dp_profile_class_name": (C.c_char_p, [C.c_int32]),

@@ -41,9 +41,11 @@ __device__ __forceinline__ void ld_vec(const T* p, float* v) {
   }
 }
 
-template <typename T, int HD, int TPP>
-__global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qkv, T* __restrict__ out, int n_prob,
-                                                        SeqMap map, int C, int heads) {
+// OUT3: write the result as three split-bf16 planes (`plane` elements apart) instead of T -- the A operand
+// format of the bf16x3 EXACT-mode Linear.
+template <typename T, int HD, int TPP, bool OUT3>
+__global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qkv, void* __restrict__ out_v, int n_prob,
+                                                        SeqMap map, int C, int heads, size_t plane) {
   constexpr int PPB = 256 / TPP;
   constexpr int VN = Vec16<T>::N;                 // elements per 16-byte vector
   constexpr int LDR = HD + VN;                    // padded LDS row (elements)
@@ -112,52 +114,66 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qk
     }
   }
   const float inv = 1.0f / l;
-  T* dst = out + tok * C + head * HD;
+  if constexpr (OUT3) {
+    bf16* dst = reinterpret_cast<bf16*>(out_v) + tok * C + head * HD;
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    float r[VN];
+    for (int c = 0; c < HD / 4; ++c) {
+      bf16x4 p0, p1, p2;
 #pragma unroll
-    for (int e = 0; e < VN; ++e) r[e] = o[c * VN + e] * inv;
-    if constexpr (VN == 4) *reinterpret_cast<float4*>(dst + c * 4) = make_float4(r[0], r[1], r[2], r[3]);
-    else store8(reinterpret_cast<bf16*>(dst) + c * 8, r);
+      for (int e = 0; e < 4; ++e) {
+        bf16 a0, a1, a2;
+        split3(o[c * 4 + e] * inv, a0, a1, a2);
+        p0[e] = a0; p1[e] = a1; p2[e] = a2;
+      }
+      *reinterpret_cast<bf16x4*>(dst + c * 4) = p0;
+      *reinterpret_cast<bf16x4*>(dst + plane + c * 4) = p1;
+      *reinterpret_cast<bf16x4*>(dst + 2 * plane + c * 4) = p2;
+    }
+  } else {
+    T* dst = reinterpret_cast<T*>(out_v) + tok * C + head * HD;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      float r[VN];
+#pragma unroll
+      for (int e = 0; e < VN; ++e) r[e] = o[c * VN + e] * inv;
+      if constexpr (VN == 4) *reinterpret_cast<float4*>(dst + c * 4) = make_float4(r[0], r[1], r[2], r[3]);
+      else store8(reinterpret_cast<bf16*>(dst) + c * 8, r);
+    }
   }
 }
 
-template <typename T, int HD, int TPP>
-int launch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st) {
+template <typename T, int HD, int TPP, bool OUT3>
+int launch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, hipStream_t st) {
   constexpr int PPB = 256 / TPP;
   constexpr int LDR = HD + Vec16<T>::N;
   const int n_prob = n_seq * heads;
   const size_t lds = (size_t)PPB * 2 * map.n_tok * LDR * sizeof(T);
   if (lds > 160 * 1024) return -2;
-  auto kern = attn_rows_kernel<T, HD, TPP>;
+  auto kern = attn_rows_kernel<T, HD, TPP, OUT3>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) return -3;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((n_prob + PPB - 1) / PPB), dim3(256), lds, st, (const T*)qkv, (T*)out, n_prob, map, C,
-                     heads);
+  hipLaunchKernelGGL(kern, dim3((n_prob + PPB - 1) / PPB), dim3(256), lds, st, (const T*)qkv, out, n_prob, map, C, heads,
+                     plane);
   return 0;
 }
 
-template <typename T>
-int dispatch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st) {
+template <typename T, bool OUT3>
+int dispatch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, hipStream_t st) {
   const int hd = C / heads;
   const bool small = map.n_tok <= 32;
   if (map.n_tok > 256) return -2;
+#define ROWS_CASE(HD_)                                                                                          \
+  case HD_: return small ? launch_rows<T, HD_, 32, OUT3>(qkv, out, n_seq, map, C, heads, plane, st)             \
+                         : launch_rows<T, HD_, 256, OUT3>(qkv, out, n_seq, map, C, heads, plane, st);
   switch (hd) {
-    case 64: return small ? launch_rows<T, 64, 32>(qkv, out, n_seq, map, C, heads, st)
-                          : launch_rows<T, 64, 256>(qkv, out, n_seq, map, C, heads, st);
-    case 32: return small ? launch_rows<T, 32, 32>(qkv, out, n_seq, map, C, heads, st)
-                          : launch_rows<T, 32, 256>(qkv, out, n_seq, map, C, heads, st);
-    case 16: return small ? launch_rows<T, 16, 32>(qkv, out, n_seq, map, C, heads, st)
-                          : launch_rows<T, 16, 256>(qkv, out, n_seq, map, C, heads, st);
-    case 8:  return small ? launch_rows<T, 8, 32>(qkv, out, n_seq, map, C, heads, st)
-                          : launch_rows<T, 8, 256>(qkv, out, n_seq, map, C, heads, st);
+    ROWS_CASE(64) ROWS_CASE(32) ROWS_CASE(16) ROWS_CASE(8)
     default: return -2;
   }
+#undef ROWS_CASE
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -544,10 +560,12 @@ int launch_temporal2(const void* qkv, void* out, int n_seq, SeqMap map, int C, i
 
 }  // namespace
 
-int d3dp_launch_attn_rows(int act_bf16, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
-                          hipStream_t st) {
-  return act_bf16 ? dispatch_rows<bf16>(qkv, out, n_seq, map, C, heads, st)
-                  : dispatch_rows<float>(qkv, out, n_seq, map, C, heads, st);
+// act: 0 = fp32 in/out, 1 = bf16 in/out, 2 = fp32 in, split-bf16 planes out
+int d3dp_launch_attn_rows(int act, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st) {
+  const size_t plane = (size_t)n_seq * map.n_tok * C;
+  if (act == 1) return dispatch_rows<bf16, false>(qkv, out, n_seq, map, C, heads, plane, st);
+  if (act == 2) return dispatch_rows<float, true>(qkv, out, n_seq, map, C, heads, plane, st);
+  return dispatch_rows<float, false>(qkv, out, n_seq, map, C, heads, plane, st);
 }
 
 int d3dp_launch_attn_temporal_bf16(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,

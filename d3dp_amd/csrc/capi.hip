@@ -4,6 +4,7 @@
 // Data layout in HBM (per internal pass over `n` (clip,hypothesis) sequences, Tc = n*F*J tokens, token order
 // (sequence, frame, joint), channels fastest):
 //   x    [Tc, C]   fp32   residual stream -- stays fp32 in both modes
+//   (EXACT mode: bufA / the MLP hidden are three bf16 planes of the fp32 value, qkv and y are fp32)
 //   bufA [Tc, C]   act    normalised input of the next GEMM / attention output      (act = bf16 FAST, fp32 EXACT)
 //   bufB [Tc, 3C]  act    qkv; reused as the [Tc, 2C] MLP hidden
 //   y    [Tc, C]   act    output of the residual-feeding Linears (proj, fc2); added to x by the next row-wise kernel
@@ -56,7 +57,7 @@ const char* kClassNames[D3DP_PROFILE_CLASSES] = {"gemm_qkv", "gemm_proj", "gemm_
 
 struct BlockDev {
   const float *n1w, *n1b, *n2w, *n2b, *qkv_b, *proj_b, *fc1_b, *fc2_b;
-  const void *qkv_w, *proj_w, *fc1_w, *fc2_w;   // bf16 (FAST) or fp32 (EXACT)
+  const void *qkv_w, *proj_w, *fc1_w, *fc2_w;   // bf16 (FAST), 3 bf16 planes (EXACT) or fp32 (EXACT, D3DP_EXACT_F32=1)
 };
 
 __global__ void to_bf16_kernel(const float* __restrict__ s, bf16* __restrict__ d, size_t n) {
@@ -94,7 +95,14 @@ struct d3dp_ctx {
   double total_ms[D3DP_PROFILE_CLASSES] = {0};
 
   bool fast() const { return cfg.mode == D3DP_MODE_FAST; }
-  size_t act_size() const { return fast() ? 2 : 4; }
+  // EXACT mode runs its Linears as split-bf16 (3 planes, 6 MFMA passes) unless env D3DP_EXACT_F32=1 selects the
+  // fp32-MFMA kernels (A/B and fallback).  Activations that feed a Linear are then three bf16 planes.
+  bool exact_f32 = false;
+  bool x3() const { return !fast() && !exact_f32; }
+  int act() const { return fast() ? 1 : (x3() ? 2 : 0); }            // code understood by the row-wise launchers
+  size_t act_size() const { return fast() ? 2 : (x3() ? 6 : 4); }    // bytes per element of a Linear-input activation
+  size_t wide_size() const { return fast() ? 2 : 4; }                // bytes per element of bufB (qkv fp32 / hidden planes = 12C either way)
+  size_t y_size() const { return fast() ? 2 : 4; }
   int chunk() const { return cfg.chunk_seqs > 0 ? cfg.chunk_seqs : 15; }
   bool attn_rows_spatial = false;   // env D3DP_ATTN_V1=1: fp32-VALU row kernel for the spatial axis (A/B)
   bool gemm_v1 = false;   // env D3DP_GEMM_V1=1: per-tile 128x128 kernel instead of the persistent streaming one (A/B)
@@ -146,6 +154,7 @@ int linear(d3dp_ctx* c, int cls, int epi, int out_f32, const void* A, const void
     if (c->gemm_v1) return d3dp_launch_linear_bf16(epi, out_f32, A, W, bias, out, M, N, K, st);
     return d3dp_launch_linear_bf16_stream(epi, out_f32, A, W, bias, out, M, N, K, st);
   }
+  if (c->x3()) return d3dp_launch_linear_bf16x3(epi, A, W, bias, (float*)out, out, M, N, K, st);
   return d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, st);
 }
 
@@ -159,13 +168,13 @@ int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, hipSt
     if (c->fast() && g.channels / g.heads == 64 && g.joints <= 32 && !c->attn_rows_spatial)
       return d3dp_launch_attn_spatial_bf16(qkv, out, n_bh * g.frames, spatial_map(g.frames, g.joints), g.channels,
                                            g.heads, st);
-    return d3dp_launch_attn_rows(c->fast(), qkv, out, n_bh * g.frames, spatial_map(g.frames, g.joints), g.channels,
+    return d3dp_launch_attn_rows(c->act(), qkv, out, n_bh * g.frames, spatial_map(g.frames, g.joints), g.channels,
                                  g.heads, st);
   }
   if (c->fast() && g.channels / g.heads == 64)
     return d3dp_launch_attn_temporal_bf16(qkv, out, n_bh * g.joints, temporal_map(g.frames, g.joints), g.channels,
                                           g.heads, st);
-  return d3dp_launch_attn_rows(c->fast(), qkv, out, n_bh * g.joints, temporal_map(g.frames, g.joints), g.channels,
+  return d3dp_launch_attn_rows(c->act(), qkv, out, n_bh * g.joints, temporal_map(g.frames, g.joints), g.channels,
                                g.heads, st);
 }
 
@@ -183,7 +192,7 @@ int run_block(d3dp_ctx* c, const BlockDev& w, int axis, float* x, void* y, void*
   LAUNCH_TRY(linear(c, P_PROJ, EPI_BIAS, 0, bufA, w.proj_w, w.proj_b, y, Tc, C, C, st));
   {
     Scope s(c, P_LN, st);
-    LAUNCH_TRY(d3dp_launch_ln(c->fast(), x, y, w.n2w, w.n2b, g.eps_block, bufA, Tc, C, st));
+    LAUNCH_TRY(d3dp_launch_ln(c->act(), x, y, w.n2w, w.n2b, g.eps_block, bufA, Tc, C, st));
   }
   LAUNCH_TRY(linear(c, P_FC1, EPI_GELU, 0, bufA, w.fc1_w, w.fc1_b, bufB, Tc, g.hidden, C, st));
   LAUNCH_TRY(linear(c, P_FC2, EPI_BIAS, 0, bufB, w.fc2_w, w.fc2_b, y, Tc, C, g.hidden, st));
@@ -220,6 +229,8 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->cfg = g;
   const char* v1 = getenv("D3DP_GEMM_V1");
   c->gemm_v1 = v1 && v1[0] == '1';
+  const char* xf = getenv("D3DP_EXACT_F32");
+  c->exact_f32 = xf && xf[0] == '1';
   const char* a1 = getenv("D3DP_ATTN_V1");
   c->attn_rows_spatial = a1 && a1[0] == '1';
   HIP_TRY(hipGetDevice(&c->device));
@@ -240,7 +251,7 @@ int d3dp_set_weights(d3dp_ctx* c, const d3dp_weights* w, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const d3dp_cfg& g = c->cfg;
   const size_t C = g.channels, Hd = g.hidden, J = g.joints, F = g.frames;
-  const size_t ws = c->act_size();
+  const size_t ws = c->fast() ? 2 : (c->x3() ? 6 : 4);   // bytes per weight-matrix element (bf16 / 3 bf16 planes / fp32)
   // ---- arena layout ----
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
@@ -283,6 +294,7 @@ int d3dp_set_weights(d3dp_ctx* c, const d3dp_weights* w, void* stream) {
   }
   for (auto& it : items) {
     if (it.mat && c->fast()) launch_to_bf16((const float*)it.src, c->arena + it.off, it.n, st);
+    else if (it.mat && c->x3()) d3dp_launch_split3((const float*)it.src, c->arena + it.off, it.n, st);
     else HIP_TRY(hipMemcpyAsync(c->arena + it.off, it.src, it.n * 4, hipMemcpyDeviceToDevice, st));
   }
   HIP_TRY(hipGetLastError());
@@ -310,8 +322,8 @@ int d3dp_workspace_bytes(const d3dp_ctx* c, int32_t B, int32_t H, size_t* bytes)
   const size_t n = (size_t)std::min(c->chunk(), B * H);
   const size_t Tc = n * g.frames * g.joints, C = g.channels;
   const size_t wide = (size_t)std::max(3 * g.channels, g.hidden);
-  *bytes = align_up((size_t)B * C * 4) + align_up(Tc * C * 4) + 2 * align_up(Tc * C * c->act_size()) +
-           align_up(Tc * wide * c->act_size());
+  *bytes = align_up((size_t)B * C * 4) + align_up(Tc * C * 4) + align_up(Tc * C * c->y_size()) +
+           align_up(Tc * C * c->act_size()) + align_up(Tc * wide * c->wide_size());
   return D3DP_OK;
 }
 
@@ -331,7 +343,7 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
   char* p = (char*)workspace;
   float* temb = (float*)p; p += align_up((size_t)B * C * 4);
   float* x = (float*)p;    p += align_up(Tmax * C * 4);
-  void* y = p;             p += align_up(Tmax * C * c->act_size());
+  void* y = p;             p += align_up(Tmax * C * c->y_size());
   void* bufA = p;          p += align_up(Tmax * C * c->act_size());
   void* bufB = p;
 
@@ -344,7 +356,7 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
     const int Tc = n * FJ;
     {
       Scope s(c, P_EMBED, st);
-      LAUNCH_TRY(d3dp_launch_embed_ln(c->fast(), x2d, x_t, temb, c->ew, c->eb, c->spos, c->ste[0].n1w, c->ste[0].n1b,
+      LAUNCH_TRY(d3dp_launch_embed_ln(c->act(), x2d, x_t, temb, c->ew, c->eb, c->spos, c->ste[0].n1w, c->ste[0].n1b,
                                       g.eps_block, x, bufA, seq0, n, H, F, J, C, st));
     }
     for (int d = 0; d < g.depth; ++d) {
@@ -352,20 +364,20 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
       if (r) return r;
       {
         Scope s(c, P_LN2, st);   // x += fc2 out; Spatial_norm (+ Temporal_pos after block 0); TTE block d's norm1
-        LAUNCH_TRY(d3dp_launch_ln2(c->fast(), x, y, c->snw, c->snb, d == 0 ? c->tpos : nullptr, c->tte[d].n1w,
+        LAUNCH_TRY(d3dp_launch_ln2(c->act(), x, y, c->snw, c->snb, d == 0 ? c->tpos : nullptr, c->tte[d].n1w,
                                    c->tte[d].n1b, g.eps_block, bufA, Tc, C, F, J, st));
       }
       r = run_block(c, c->tte[d], 1, x, y, bufA, bufB, n, st);
       if (r) return r;
       if (d + 1 < g.depth) {
         Scope s(c, P_LN2, st);   // x += fc2 out; Temporal_norm; STE block d+1's norm1
-        LAUNCH_TRY(d3dp_launch_ln2(c->fast(), x, y, c->tnw, c->tnb, nullptr, c->ste[d + 1].n1w, c->ste[d + 1].n1b,
+        LAUNCH_TRY(d3dp_launch_ln2(c->act(), x, y, c->tnw, c->tnb, nullptr, c->ste[d + 1].n1w, c->ste[d + 1].n1b,
                                    g.eps_block, bufA, Tc, C, F, J, st));
       }
     }
     {
       Scope s(c, P_HEAD, st);    // x += fc2 out; Temporal_norm; head LayerNorm; Linear(C,3)
-      LAUNCH_TRY(d3dp_launch_head(c->fast(), x, y, c->tnw, c->tnb, g.eps_block, c->hnw, c->hnb, g.eps_head, c->hw, c->hb,
+      LAUNCH_TRY(d3dp_launch_head(c->fast() ? 1 : 0, x, y, c->tnw, c->tnb, g.eps_block, c->hnw, c->hnb, g.eps_head, c->hw, c->hb,
                                   out + (size_t)seq0 * FJ * 3, Tc, C, st));
     }
   }
@@ -411,7 +423,18 @@ int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, cons
     if (e != EPI_RESID && !(epi & 32)) LAUNCH_TRY(d3dp_launch_linear_bf16_stream(e, f32, A, W, bias, out, M, N, K, (hipStream_t)stream));
     else LAUNCH_TRY(d3dp_launch_linear_bf16(e, f32, A, W, bias, out, M, N, K, (hipStream_t)stream));
   }
+  else if (mode == 2) {
+    // split-bf16: A, W are three bf16 planes each (d3dp_op_split3); epi 0 -> fp32 out, epi 1 -> three bf16 planes out
+    LAUNCH_TRY(d3dp_launch_linear_bf16x3(epi, A, W, bias, (float*)out, out, M, N, K, (hipStream_t)stream));
+  }
   else LAUNCH_TRY(d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, (hipStream_t)stream));
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
+int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream) {
+  if (!src || !dst) return fail(D3DP_EINVAL, "d3dp_op_split3: null argument");
+  d3dp_launch_split3(src, dst, n, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
 }
@@ -420,6 +443,7 @@ int d3dp_op_attention(int32_t act_bf16, int32_t impl, int32_t axis, const void* 
                       int32_t J, int32_t C, int32_t heads, void* stream) {
   if (!qkv || !out || n_bh < 1) return fail(D3DP_EINVAL, "d3dp_op_attention: bad argument");
   hipStream_t st = (hipStream_t)stream;
+  if (act_bf16 != 0 && act_bf16 != 1) return fail(D3DP_EINVAL, "act_bf16 must be 0 or 1");
   if (axis == 0 && impl == 1) {
     if (!act_bf16) return fail(D3DP_EINVAL, "MFMA spatial attention needs bf16 activations");
     LAUNCH_TRY(d3dp_launch_attn_spatial_bf16(qkv, out, n_bh * F, spatial_map(F, J), C, heads, st));

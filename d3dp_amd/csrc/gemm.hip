@@ -283,6 +283,184 @@ int d3dp_launch_linear_f32(int epi, const float* A, const float* W, const float*
 }
 
 // ================================================================================================
+// EXACT mode on the bf16 matrix cores: split-bf16 ("bf16x3") GEMM.
+//   A3 [3][M][K], W3 [3][N][K] bf16 planes (x = x0 + x1 + x2 exactly).  out = sum over the six leading plane pairs
+//   (a_i, w_j), i + j <= 2, accumulated in fp32: fp32-class accuracy (better than an fp32 fmaf chain, because each
+//   v_mfma_f32_16x16x32_bf16 sums 32 exact products before one rounding).
+//   256x128x32 tile, 8 waves (4x2, 64x64 each), 2-stage LDS ring of 72 KiB filled by global_load_lds_dwordx4.
+//   Per k-step and wave: 24 ds_read_b128 feed 96 MFMA -> the kernel is bound by the matrix pipe, not by issue slots.
+//   Epilogues: EPI_BIAS -> fp32 out; EPI_GELU -> gelu_erf(acc + b) re-split into three bf16 planes (the next
+//   Linear's A operand).
+// ================================================================================================
+namespace {
+
+constexpr int TBM = 256, TBN = 128, TBK = 32;
+constexpr int TA_PLANE = TBM * TBK * 2;            // 16 KiB
+constexpr int TW_PLANE = TBN * TBK * 2;            //  8 KiB
+constexpr int TSTAGE = 3 * TA_PLANE + 3 * TW_PLANE;   // 72 KiB
+constexpr int TLDS = 2 * TSTAGE;
+
+// 64-byte rows (4 slots of 16 B): XOR bit 1 of the slot with bit 3 of the row -> conflict-free ds_read_b128 fragments
+__device__ __forceinline__ int swz3(int row, int s) { return s ^ (((row >> 3) & 1) << 1); }
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16x3_kernel(const bf16* __restrict__ A3, const bf16* __restrict__ W3,
+                                                          const float* __restrict__ bias, float* __restrict__ outf,
+                                                          bf16* __restrict__ out3, int M, int N, int K, int n_tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (L / n_tiles_n) * TBM;
+  const int n0 = (L % n_tiles_n) * TBN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const size_t planeA = (size_t)M * K, planeW = (size_t)N * K;
+
+  // 72 pieces of 1 KiB (16 rows x 64 B) per stage: A plane p rows 16j.. (48 pieces), then W (24 pieces); wave w
+  // issues pieces w, w+8, ..., w+64.
+  const bf16* src[9];
+  int dst[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int q = wave + 8 * i;
+    const int r = lane >> 2, ps = lane & 3;
+    if (q < 48) {
+      const int pl = q >> 4, row = (q & 15) * 16 + r;
+      src[i] = A3 + pl * planeA + (size_t)min(m0 + row, M - 1) * K + swz3(row, ps) * 8;
+      dst[i] = pl * TA_PLANE + (q & 15) * 1024;
+    } else {
+      const int q2 = q - 48, pl = q2 >> 3, row = (q2 & 7) * 16 + r;
+      src[i] = W3 + pl * planeW + (size_t)min(n0 + row, N - 1) * K + swz3(row, ps) * 8;
+      dst[i] = 3 * TA_PLANE + pl * TW_PLANE + (q2 & 7) * 1024;
+    }
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * TSTAGE;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      __builtin_amdgcn_global_load_lds(GPTR(src[i] + kt * TBK), LPTR(base + dst[i]), 16, 0, 0);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / TBK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int fi = lane & 15, fg = lane >> 4;
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* sa = smem + cur * TSTAGE;
+    const char* sw = sa + 3 * TA_PLANE;
+    bf16x8 wf[4][3];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int rw = wc * 64 + ni * 16 + fi;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        wf[ni][pl] = *reinterpret_cast<const bf16x8*>(sw + pl * TW_PLANE + rw * 64 + swz3(rw, fg) * 16);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int ra = wr * 64 + mi * 16 + fi;
+      bf16x8 af[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        af[pl] = *reinterpret_cast<const bf16x8*>(sa + pl * TA_PLANE + ra * 64 + swz3(ra, fg) * 16);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        f32x4 c = acc[mi][ni];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][0], af[2], c, 0, 0, 0);   // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][1], af[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][2], af[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][0], af[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][1], af[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][0], af[0], c, 0, 0, 0);
+        acc[mi][ni] = c;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // lane holds out[m = .. + fi][n = .. + 4*fg .. +3]
+  const size_t planeO = (size_t)M * N;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wr * 64 + mi * 16 + fi;
+    if (m >= M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wc * 64 + ni * 16 + fg * 4;
+      if (n >= N) continue;
+      const float4 b = *reinterpret_cast<const float4*>(bias + n);
+      float r[4] = {acc[mi][ni][0] + b.x, acc[mi][ni][1] + b.y, acc[mi][ni][2] + b.z, acc[mi][ni][3] + b.w};
+      if constexpr (EPI == EPI_GELU) {
+        bf16x4 p0, p1, p2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bf16 a0, a1, a2;
+          split3(gelu_erf(r[e]), a0, a1, a2);
+          p0[e] = a0; p1[e] = a1; p2[e] = a2;
+        }
+        bf16* o = out3 + (size_t)m * N + n;
+        *reinterpret_cast<bf16x4*>(o) = p0;
+        *reinterpret_cast<bf16x4*>(o + planeO) = p1;
+        *reinterpret_cast<bf16x4*>(o + 2 * planeO) = p2;
+      } else {
+        *reinterpret_cast<float4*>(outf + (size_t)m * N + n) = make_float4(r[0], r[1], r[2], r[3]);
+      }
+    }
+  }
+}
+
+__global__ void split3_kernel(const float* __restrict__ s, bf16* __restrict__ d, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    bf16 a0, a1, a2;
+    split3(s[i], a0, a1, a2);
+    d[i] = a0; d[i + n] = a1; d[i + 2 * n] = a2;
+  }
+}
+
+}  // namespace
+
+// out = epi(A W^T + bias) with A3/W3 split-bf16 planes; EPI_BIAS: fp32 `outf`; EPI_GELU: three bf16 planes `out3`.
+int d3dp_launch_linear_bf16x3(int epi, const void* A3, const void* W3, const float* bias, float* outf, void* out3, int M,
+                              int N, int K, hipStream_t st) {
+  if (K % TBK != 0 || N % 4 != 0 || M <= 0) return -1;
+  const int tm = (M + TBM - 1) / TBM, tn = (N + TBN - 1) / TBN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<EPI_BIAS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, TLDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<EPI_GELU>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, TLDS) != hipSuccess) return -3;
+    attr_set = true;
+  }
+  if (epi == EPI_BIAS)
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI_BIAS>), dim3(tm * tn), dim3(512), TLDS, st, (const bf16*)A3, (const bf16*)W3,
+                       bias, outf, (bf16*)out3, M, N, K, tn);
+  else if (epi == EPI_GELU)
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI_GELU>), dim3(tm * tn), dim3(512), TLDS, st, (const bf16*)A3, (const bf16*)W3,
+                       bias, outf, (bf16*)out3, M, N, K, tn);
+  else return -1;
+  return 0;
+}
+
+void d3dp_launch_split3(const float* src, void* dst, size_t n, hipStream_t st) {
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(split3_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, (bf16*)dst, n);
+}
+
+// ================================================================================================
 // FAST mode, persistent streaming GEMM ("v2"): the kernel the denoiser launches for every Linear.
 //
 //   * 256x128 output tile per workgroup pass, BK = 64, 8 compute waves (4 x 2, 64x64 each = 4x4 MFMA tiles)

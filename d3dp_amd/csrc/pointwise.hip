@@ -69,6 +69,19 @@ template <int C> struct Row {
       for (int i = 0; i < NV; ++i) p[i * 64 + lane] = (bf16)v[i];
     }
   }
+  // split-bf16 activation: three planes `plane` elements apart
+  static __device__ __forceinline__ void store3(bf16* p, size_t plane, int lane, const float* v) {
+    float a0[NV], a1[NV], a2[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      bf16 q0, q1, q2;
+      split3(v[i], q0, q1, q2);
+      a0[i] = (float)q0; a1[i] = (float)q1; a2[i] = (float)q2;
+    }
+    store(p, lane, a0);
+    store(p + plane, lane, a1);
+    store(p + 2 * plane, lane, a2);
+  }
   // y = (v - mean) * rstd * w + b   (two-pass statistics, biased variance as torch LayerNorm)
   static __device__ __forceinline__ void norm(const float* v, const float* w, const float* b, float eps, int lane,
                                               float* y) {
@@ -89,10 +102,24 @@ template <int C> struct Row {
 };
 
 // if yadd != nullptr: x += yadd (written back) first -- the residual add of the preceding Linear (mixste.py:113-115)
-template <int C, typename XN>
-__global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const XN* __restrict__ yadd,
+// activation store: XN = float / bf16 (one plane) or b3 (three bf16 planes, `plane` elements apart)
+template <int C, typename XN> struct ActOut {
+  using ptr = XN*;
+  static __device__ __forceinline__ void st(ptr base, size_t, size_t off, int lane, const float* v) {
+    Row<C>::store(base + off, lane, v);
+  }
+};
+template <int C> struct ActOut<C, b3> {
+  using ptr = bf16*;
+  static __device__ __forceinline__ void st(ptr base, size_t plane, size_t off, int lane, const float* v) {
+    Row<C>::store3(base + off, plane, lane, v);
+  }
+};
+
+template <int C, typename XN, typename YT>
+__global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const YT* __restrict__ yadd,
                                                  const float* __restrict__ w, const float* __restrict__ b, float eps,
-                                                 XN* __restrict__ xn, int T) {
+                                                 typename ActOut<C, XN>::ptr xn, size_t plane, int T) {
   using R = Row<C>;
   const int lane = threadIdx.x & 63;
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -106,15 +133,15 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const XN
     R::store(x + (size_t)tok * C, lane, v);
   }
   R::norm(v, w, b, eps, lane, y);
-  R::store(xn + (size_t)tok * C, lane, y);
+  ActOut<C, XN>::st(xn, plane, (size_t)tok * C, lane, y);
 }
 
-template <int C, typename XN>
-__global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const XN* __restrict__ yadd,
+template <int C, typename XN, typename YT>
+__global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const YT* __restrict__ yadd,
                                                   const float* __restrict__ wa,
                                                   const float* __restrict__ ba, const float* __restrict__ pos,
                                                   const float* __restrict__ wb, const float* __restrict__ bb, float eps,
-                                                  XN* __restrict__ xn, int T, int F, int J) {
+                                                  typename ActOut<C, XN>::ptr xn, size_t plane, int T, int F, int J) {
   using R = Row<C>;
   const int lane = threadIdx.x & 63;
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -136,7 +163,7 @@ __global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const X
   }
   R::store(x + (size_t)tok * C, lane, y);
   R::norm(y, wb, bb, eps, lane, z);
-  R::store(xn + (size_t)tok * C, lane, z);
+  ActOut<C, XN>::st(xn, plane, (size_t)tok * C, lane, z);
 }
 
 template <int C, typename XN>
@@ -144,7 +171,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
                                                        const float* __restrict__ temb, const float* __restrict__ ew,
                                                        const float* __restrict__ eb, const float* __restrict__ spos,
                                                        const float* __restrict__ lnw, const float* __restrict__ lnb,
-                                                       float eps, float* __restrict__ x, XN* __restrict__ xn, int seq0,
+                                                       float eps, float* __restrict__ x,
+                                                       typename ActOut<C, XN>::ptr xn, size_t plane, int seq0,
                                                        int n_seq, int H, int F, int J) {
   using R = Row<C>;
   const int lane = threadIdx.x & 63;
@@ -171,11 +199,11 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
   }
   R::store(x + (size_t)tl * C, lane, v);
   R::norm(v, lnw, lnb, eps, lane, y);
-  R::store(xn + (size_t)tl * C, lane, y);
+  ActOut<C, XN>::st(xn, plane, (size_t)tl * C, lane, y);
 }
 
-template <int C, typename XN>
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const XN* __restrict__ yadd,
+template <int C, typename YT>
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const YT* __restrict__ yadd,
                                                    const float* __restrict__ wa,
                                                    const float* __restrict__ ba, float eps_a,
                                                    const float* __restrict__ wh, const float* __restrict__ bh,
@@ -257,32 +285,39 @@ int d3dp_launch_time_mlp(const int64_t* t, const float* freq, const float* w1, c
   return 0;
 }
 
+// `act`: 0 = fp32 activations (y fp32), 1 = bf16 activations (y bf16), 2 = split-bf16 activation planes (y fp32)
 int d3dp_launch_embed_ln(int act_bf16, const float* x2d, const float* x3d, const float* temb, const float* ew,
                          const float* eb, const float* spos, const float* lnw, const float* lnb, float eps, float* x,
                          void* xn, int seq0, int n_seq, int H, int F, int J, int C, hipStream_t st) {
   const int T = n_seq * F * J;
   dim3 g((T + 3) / 4), blk(256);
+  const size_t plane = (size_t)T * C;
   DISPATCH_C(C,
-    if (act_bf16) hipLaunchKernelGGL((embed_ln_kernel<CC, bf16>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, seq0, n_seq, H, F, J);
-    else hipLaunchKernelGGL((embed_ln_kernel<CC, float>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (float*)xn, seq0, n_seq, H, F, J))
+    if (act_bf16 == 1) hipLaunchKernelGGL((embed_ln_kernel<CC, bf16>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, plane, seq0, n_seq, H, F, J);
+    else if (act_bf16 == 2) hipLaunchKernelGGL((embed_ln_kernel<CC, b3>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, plane, seq0, n_seq, H, F, J);
+    else hipLaunchKernelGGL((embed_ln_kernel<CC, float>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (float*)xn, plane, seq0, n_seq, H, F, J))
   return 0;
 }
 
 int d3dp_launch_ln(int act_bf16, float* x, const void* yadd, const float* w, const float* b, float eps, void* xn, int T,
                    int C, hipStream_t st) {
   dim3 g((T + 3) / 4), blk(256);
+  const size_t plane = (size_t)T * C;
   DISPATCH_C(C,
-    if (act_bf16) hipLaunchKernelGGL((ln_kernel<CC, bf16>), g, blk, 0, st, x, (const bf16*)yadd, w, b, eps, (bf16*)xn, T);
-    else hipLaunchKernelGGL((ln_kernel<CC, float>), g, blk, 0, st, x, (const float*)yadd, w, b, eps, (float*)xn, T))
+    if (act_bf16 == 1) hipLaunchKernelGGL((ln_kernel<CC, bf16, bf16>), g, blk, 0, st, x, (const bf16*)yadd, w, b, eps, (bf16*)xn, plane, T);
+    else if (act_bf16 == 2) hipLaunchKernelGGL((ln_kernel<CC, b3, float>), g, blk, 0, st, x, (const float*)yadd, w, b, eps, (bf16*)xn, plane, T);
+    else hipLaunchKernelGGL((ln_kernel<CC, float, float>), g, blk, 0, st, x, (const float*)yadd, w, b, eps, (float*)xn, plane, T))
   return 0;
 }
 
 int d3dp_launch_ln2(int act_bf16, float* x, const void* yadd, const float* wa, const float* ba, const float* pos,
                     const float* wb, const float* bb, float eps, void* xn, int T, int C, int F, int J, hipStream_t st) {
   dim3 g((T + 3) / 4), blk(256);
+  const size_t plane = (size_t)T * C;
   DISPATCH_C(C,
-    if (act_bf16) hipLaunchKernelGGL((ln2_kernel<CC, bf16>), g, blk, 0, st, x, (const bf16*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, T, F, J);
-    else hipLaunchKernelGGL((ln2_kernel<CC, float>), g, blk, 0, st, x, (const float*)yadd, wa, ba, pos, wb, bb, eps, (float*)xn, T, F, J))
+    if (act_bf16 == 1) hipLaunchKernelGGL((ln2_kernel<CC, bf16, bf16>), g, blk, 0, st, x, (const bf16*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, plane, T, F, J);
+    else if (act_bf16 == 2) hipLaunchKernelGGL((ln2_kernel<CC, b3, float>), g, blk, 0, st, x, (const float*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, plane, T, F, J);
+    else hipLaunchKernelGGL((ln2_kernel<CC, float, float>), g, blk, 0, st, x, (const float*)yadd, wa, ba, pos, wb, bb, eps, (float*)xn, plane, T, F, J))
   return 0;
 }
 
@@ -291,7 +326,7 @@ int d3dp_launch_head(int act_bf16, const float* x, const void* yadd, const float
                      hipStream_t st) {
   dim3 g((T + 3) / 4), blk(256);
   DISPATCH_C(C,
-    if (act_bf16) hipLaunchKernelGGL((head_kernel<CC, bf16>), g, blk, 0, st, x, (const bf16*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T);
+    if (act_bf16 == 1) hipLaunchKernelGGL((head_kernel<CC, bf16>), g, blk, 0, st, x, (const bf16*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T);
     else hipLaunchKernelGGL((head_kernel<CC, float>), g, blk, 0, st, x, (const float*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T))
   return 0;
 }

@@ -43,7 +43,8 @@ enum {
 
 /* numerics mode of the denoiser */
 enum {
-  D3DP_MODE_EXACT = 0,   /* fp32 activations, fp32 MFMA (v_mfma_f32_32x32x2_f32): <= 1e-3 mm vs the reference   */
+  D3DP_MODE_EXACT = 0,   /* fp32-equivalent: split-bf16 (3 planes, 6 passes) MFMA Linears, fp32 everything else:
+                            <= 1e-3 mm vs the reference (env D3DP_EXACT_F32=1: plain fp32 MFMA Linears)       */
   D3DP_MODE_FAST = 1,    /* bf16 activations/weights into v_mfma_f32_16x16x32_bf16, fp32 accumulate/LN/softmax */
 };
 
@@ -149,6 +150,9 @@ int d3dp_op_attention(int32_t act_bf16, int32_t impl, int32_t axis, const void* 
                       int32_t F, int32_t J, int32_t C, int32_t heads, void* stream);
 int d3dp_op_layernorm(int32_t out_bf16, const float* x, const float* w, const float* b, float eps, void* out,
                       int32_t T, int32_t C, void* stream);
+/* mode 2 of d3dp_op_linear: split-bf16.  A and W are three bf16 planes each (x = x0 + x1 + x2, made by
+ * d3dp_op_split3: dst[0..n) | dst[n..2n) | dst[2n..3n)); epi 0 -> fp32 out, epi 1 -> GELU then three bf16 planes out. */
+int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream);
 /* fp32 <-> bf16 conversion helper (round-to-nearest-even), n elements */
 int d3dp_op_to_bf16(const float* src, void* dst, size_t n, void* stream);
 

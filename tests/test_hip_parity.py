@@ -91,6 +91,36 @@ def test_linear_all_epilogues(lib, mode, M, N, K):
         assert torch.allclose(got, want, atol=atol, rtol=rtol), (mode, epi, (got - want).abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(4131, 1536, 512), (1000, 512, 1024), (300, 64, 128), (66000, 512, 512)])
+def test_linear_split_bf16_is_fp32_class(lib, M, N, K):
+    """EXACT-mode Linear: three bf16 planes per operand, six MFMA passes.  Must be at least as accurate as an fp32
+    GEMM: mean error vs fp64 within 3x of torch's own (blocked, vectorised) fp32 matmul and far below one bf16 pass."""
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    A = torch.randn(M, K, generator=g) * 2
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    want = A.double() @ W.double().t() + bias.double()
+    f32_err = ((A @ W.t() + bias).double() - want).abs().mean().item()
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    A3 = torch.empty(3, M, K, dtype=torch.bfloat16, device="cuda")
+    W3 = torch.empty(3, N, K, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.d3dp_op_split3(Ad.data_ptr(), A3.data_ptr(), M * K, stream()))
+    _lib.check(lib.d3dp_op_split3(Wd.data_ptr(), W3.data_ptr(), N * K, stream()))
+    assert torch.equal(A3.float().sum(0).cpu(), A)            # the split is exact
+    out = torch.full((M, N), float("nan"), device="cuda")
+    _lib.check(lib.d3dp_op_linear(_lib.MODE_SPLIT3, _lib.EPI_BIAS, A3.data_ptr(), W3.data_ptr(), bd.data_ptr(),
+                                  out.data_ptr(), M, N, K, stream()))
+    err = (out.cpu().double() - want).abs().mean().item()
+    print(f"split-bf16 linear M={M} N={N} K={K}: mean |err| {err:.3e} (torch fp32 matmul {f32_err:.3e})")
+    assert err <= 3.0 * f32_err and err < 2e-6
+    # GELU epilogue re-split into planes
+    out3 = torch.empty(3, M, N, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.d3dp_op_linear(_lib.MODE_SPLIT3, _lib.EPI_GELU, A3.data_ptr(), W3.data_ptr(), bd.data_ptr(),
+                                  out3.data_ptr(), M, N, K, stream()))
+    got = out3.float().sum(0).cpu().double()
+    assert torch.allclose(got, torch.nn.functional.gelu(want), atol=2e-5, rtol=1e-5)
+
+
 def ref_attention(qkv, n_bh, F, J, C, heads, axis):
     """fp64 reference on the (n_bh, F, J, 3C) layout."""
     hd = C // heads
@@ -275,6 +305,17 @@ def test_full_size_properties(numerics):
     d = m1(torch.from_numpy(x2d).cuda(), None, input_2d_flip=torch.from_numpy(x2f).cuda(),
            noise=[n[:, 1:2].contiguous() for n in noises])
     assert torch.equal(d[:, :, 0], a[:, :, 1])
+
+
+def test_exact_mode_fp32_mfma_fallback(golden_dir, monkeypatch):
+    """env D3DP_EXACT_F32=1 keeps the plain fp32-MFMA Linears alive (A/B + fallback) at the same tolerance."""
+    monkeypatch.setenv("D3DP_EXACT_F32", "1")
+    g = load_g(golden_dir, "g3_denoiser_F27")
+    x2d = torch.from_numpy(synthetic_inputs_2d(int(g["x2d_seed"]), 1, 27)).cuda()
+    x3d = torch.from_numpy(synthetic_noise(int(g["x3d_seed"]), (1, 1, 27, 17, 3))).cuda()
+    m = make_model(27, 512, 8, 1, 1, "exact", int(g["seed"]))
+    e = orc.mpjpe_mm(m.pose_estimator(x2d, x3d, torch.tensor([999], device="cuda")).cpu(), torch.from_numpy(g["out_t999"]))
+    assert e <= EXACT_TOL_MM
 
 
 def test_ddim_sample_no_flip_runs():
