@@ -192,6 +192,15 @@ def main():
                            "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / peak, "traffic": None,
                            "launches": n, "avg_launch_ms": ms / max(n, 1),
                            "algorithmic_gflop_per_launch": fl / max(n, 1) / 1e9}
+        # HBM bytes per launch of the dominant kernel come from a SEPARATE rocprofv3 --pmc pass (FETCH_SIZE doubled per
+        # MI355X_MICROARCH.md, WRITE_SIZE), committed under profiles/; valid for the default 15-sequence chunk shape.
+        tpath = os.path.join(REPO, "profiles", "r01_gemm_traffic.json")
+        if dom == "gemm_qkv" and a.numerics == "fast" and a.chunk_seqs in (0, 15) and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            res["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
+            res["roofline"]["traffic_note"] = ("bytes/launch at M=61965 (15-sequence chunk), separate rocprofv3 --pmc pass; "
+                                               f"algorithmic bytes/launch {tj['algorithmic_bytes_per_launch']}; "
+                                               f"hardware MFMA busy {tj['mfma_util_hw']:.3f} of kernel cycles")
         res["kernel_time_share"] = {k: round(ms / total, 4) for k, (_, ms) in prof.items() if ms > 0}
         res["kernel_ms_per_step"] = {k: round(ms, 3) for k, (_, ms) in prof.items() if ms > 0}
 

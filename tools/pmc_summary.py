@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Average rocprofv3 --pmc counter values per dispatch for kernels whose name contains a substring.
+usage: pmc_summary.py <counter_collection.csv> <substring> [out.md]"""
+import collections
+import csv
+import sys
+
+
+def main(path, sub, out=None):
+    rows = list(csv.DictReader(open(path)))
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    for r in rows:
+        k = r["Kernel_Name"]
+        if sub not in k:
+            continue
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[(k, r["Counter_Name"])] += 1
+    lines = []
+    for k, v in agg.items():
+        lines.append(f"### `{k[:120]}`")
+        lines.append("| counter | mean per dispatch | dispatches |")
+        lines.append("|---|---:|---:|")
+        for c, val in sorted(v.items()):
+            lines.append(f"| {c} | {val / cnt[(k, c)]:.0f} | {cnt[(k, c)]} |")
+        lines.append("")
+    text = "\n".join(lines)
+    if out:
+        open(out, "a").write(text + "\n")
+    print(text)
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
