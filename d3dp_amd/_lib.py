@@ -60,6 +60,7 @@ PROTOTYPES = {
                                  C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "d3dp_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32,
                                 C.c_int32, C.c_void_p]),
+    "d3dp_jpma": (C.c_int, [C.c_void_p] * 9 + [C.c_int32] * 6 + [C.c_void_p]),
     "d3dp_op_linear": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                  C.c_int32, C.c_int32, C.c_void_p]),
     "d3dp_op_attention": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,

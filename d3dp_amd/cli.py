@@ -119,6 +119,9 @@ def evaluate(args, model, sequences, device, rank, world, gen):
                 pred[:, :, :, :, 0] = 0                                                              # main.py:700
                 rp = jpma.reproject(pred, tr, camt)
                 m = jpma.jpma_metrics(pred, a3, rp, a2)
+                # the fused HIP kernel gives the aggregated poses (what a serving caller consumes) and the same J_Agg
+                _, _, es, _ = jpma.jpma_hip(pred, tr, camt, a2, a3, zero_root=False, want_errors=True)
+                m["J_Agg"] = es.permute(1, 0, 2, 3).reshape(K, -1).mean(-1)
                 w = a3.shape[0] * a3.shape[1]
                 for k in sums:
                     sums[k] += w * m[k]

@@ -413,6 +413,18 @@ int d3dp_q_sample(const float* x0, const float* noise, const double* a, const do
   return D3DP_OK;
 }
 
+int d3dp_jpma(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d, float* agg,
+              int32_t* sel, float* err_sel, float* err_min, int32_t B, int32_t K, int32_t H, int32_t F, int32_t J,
+              int32_t zero_root, void* stream) {
+  if (!pred || !traj || !cam || !gt2d || !agg || B < 1 || K < 1 || H < 1)
+    return fail(D3DP_EINVAL, "d3dp_jpma: bad argument");
+  if ((err_sel || err_min) && !gt3d) return fail(D3DP_EINVAL, "d3dp_jpma: error outputs need gt3d");
+  LAUNCH_TRY(d3dp_launch_jpma(pred, traj, cam, gt2d, gt3d, agg, sel, err_sel, err_min, B, K, H, F, J, zero_root,
+                              (hipStream_t)stream));
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
 int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, const float* bias, void* out, int32_t M,
                    int32_t N, int32_t K, void* stream) {
   if (!A || !W || !bias || !out) return fail(D3DP_EINVAL, "d3dp_op_linear: null argument");

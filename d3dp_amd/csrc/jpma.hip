@@ -1,0 +1,77 @@
+// JPMA: joint-wise reprojection-based multi-hypothesis aggregation, the consumer of the sampler's (and, on N GPUs,
+// the all-gather's) output -- SURVEY.md §8(f) row N1.  One fused pass replaces the reference's chain of
+// (B,K,H,F,J,*) temporaries (main.py:700-712 root zeroing + trajectory add, camera.py:30-60 project_to_2d,
+// loss.py:54-76 per-joint argmin of the 2D error over hypotheses + gather; main_3dhp.py:797-835 materialises the
+// aggregated poses the same way).
+//
+// One thread per (b, k, f, j): loops over the H hypotheses (stride F*J*3 floats: coalesced across threads), keeps the
+// first minimum like torch.min, writes the selected 3D joint and, optionally, the 3D errors needed for the four
+// metrics.  HBM-bound: reads B*K*H*F*J*3 floats once.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float clamp1(float v) { return fminf(fmaxf(v, -1.f), 1.f); }
+
+// Human3.6M projection with radial + tangential distortion, camera.py:30-60 (same fp32 operation order)
+__device__ __forceinline__ void project(const float* X, const float* cam, float& u, float& v) {
+  const float xx = clamp1(X[0] / X[2]), yy = clamp1(X[1] / X[2]);
+  const float r2 = xx * xx + yy * yy;
+  const float radial = 1.f + (cam[4] * r2 + cam[5] * (r2 * r2) + cam[6] * (r2 * r2 * r2));
+  const float tan = cam[7] * xx + cam[8] * yy;
+  u = cam[0] * (xx * (radial + tan) + cam[7] * r2) + cam[2];
+  v = cam[1] * (yy * (radial + tan) + cam[8] * r2) + cam[3];
+}
+
+__global__ __launch_bounds__(256) void jpma_kernel(const float* __restrict__ pred, const float* __restrict__ traj,
+                                                   const float* __restrict__ cam, const float* __restrict__ gt2d,
+                                                   const float* __restrict__ gt3d, float* __restrict__ agg,
+                                                   int* __restrict__ sel, float* __restrict__ err_sel,
+                                                   float* __restrict__ err_min, int B, int K, int H, int F, int J,
+                                                   int zero_root) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t FJ = (size_t)F * J, total = (size_t)B * K * FJ;
+  if (i >= total) return;
+  const size_t fj = i % FJ, bk = i / FJ, b = bk / K;
+  const int j = (int)(fj % J);
+  const size_t f = fj / J;
+  float c[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) c[q] = cam[q];
+  const float* tr = traj + (b * F + f) * 3;
+  const float g2u = gt2d[(b * FJ + fj) * 2], g2v = gt2d[(b * FJ + fj) * 2 + 1];
+  float g3[3] = {0.f, 0.f, 0.f};
+  if (gt3d != nullptr) { g3[0] = gt3d[(b * FJ + fj) * 3]; g3[1] = gt3d[(b * FJ + fj) * 3 + 1]; g3[2] = gt3d[(b * FJ + fj) * 3 + 2]; }
+  const float* p = pred + (bk * H * FJ + fj) * 3;
+  float best2 = INFINITY, bx = 0.f, by = 0.f, bz = 0.f, best3 = 0.f, min3 = INFINITY;
+  int bh = 0;
+  for (int h = 0; h < H; ++h, p += FJ * 3) {
+    float x[3] = {p[0], p[1], p[2]};
+    if (zero_root && j == 0) { x[0] = 0.f; x[1] = 0.f; x[2] = 0.f; }       // main.py:700
+    const float a[3] = {x[0] + tr[0], x[1] + tr[1], x[2] + tr[2]};        // main.py:706-707
+    float u, v;
+    project(a, c, u, v);
+    const float du = u - g2u, dv = v - g2v;
+    const float e2 = sqrtf(du * du + dv * dv);
+    const float d0 = x[0] - g3[0], d1 = x[1] - g3[1], d2 = x[2] - g3[2];
+    const float e3 = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    min3 = fminf(min3, e3);
+    if (e2 < best2) { best2 = e2; bh = h; bx = x[0]; by = x[1]; bz = x[2]; best3 = e3; }
+  }
+  agg[i * 3] = bx; agg[i * 3 + 1] = by; agg[i * 3 + 2] = bz;
+  if (sel != nullptr) sel[i] = bh;
+  if (err_sel != nullptr) err_sel[i] = best3;     // J_Agg per-joint error (loss.py:70-72)
+  if (err_min != nullptr) err_min[i] = min3;      // J_Best per-joint error (loss.py:38-41)
+}
+
+}  // namespace
+
+int d3dp_launch_jpma(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d,
+                     float* agg, int* sel, float* err_sel, float* err_min, int B, int K, int H, int F, int J,
+                     int zero_root, hipStream_t st) {
+  const size_t total = (size_t)B * K * F * J;
+  hipLaunchKernelGGL(jpma_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pred, traj, cam, gt2d, gt3d,
+                     agg, sel, err_sel, err_min, B, K, H, F, J, zero_root);
+  return 0;
+}

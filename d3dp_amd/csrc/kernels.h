@@ -57,3 +57,8 @@ int d3dp_launch_ddim_post(const float* pred2, const float* img, const float* noi
                           hipStream_t st);
 int d3dp_launch_q_sample(const float* x0, const float* noise, const double* a, const double* b, float scale,
                          float* out, int B, int per_b, hipStream_t st);
+
+// ---- jpma.hip ----------------------------------------------------------------------------------
+int d3dp_launch_jpma(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d,
+                     float* agg, int* sel, float* err_sel, float* err_min, int B, int K, int H, int F, int J,
+                     int zero_root, hipStream_t st);

@@ -1,7 +1,9 @@
 """Caller-side steps either side of the hot path, device-agnostic torch code.
 
-These are the "next" rows of the scope table, NOT yet hand-written HIP: they are small elementwise/reduction
-steps over (B,K,H,F,17,*) tensors that run on whatever device the sampler output lives on.  They exist so that
+These are the "next" rows of the scope table.  The JPMA selection itself (root zeroing + trajectory add + projection +
+per-joint argmin over hypotheses + gather) is a fused HIP kernel (``jpma_hip`` -> d3dp_jpma); the remaining functions
+are small torch steps over (B,K,H,F,17,*) tensors that run on whatever device the sampler output lives on and double
+as the readable statement of what the kernel computes.  They exist so that
 the `--evaluate` entrypoint and the multi-GPU path have their consumer, and they are pinned against the
 reference by fixture g5 (tests/test_caller_side.py).
 
@@ -74,6 +76,34 @@ def jpma_metrics(pred: torch.Tensor, gt: torch.Tensor, reproj: torch.Tensor, gt_
     sel = err2d.min(dim=2, keepdim=True).indices                           # first minimal h, like torch.min
     j_agg = torch.gather(err, 2, sel).permute(1, 2, 0, 3, 4).reshape(K, -1).mean(-1)             # loss.py:70-76
     return {"J_Best": j_best, "P_Best": p_best, "P_Agg": p_agg, "J_Agg": j_agg}
+
+
+def jpma_hip(pred: torch.Tensor, traj: torch.Tensor, cam: torch.Tensor, gt_2d: torch.Tensor,
+             gt_3d: torch.Tensor = None, zero_root: bool = True, want_errors: bool = False):
+    """The fused HIP kernel (include/d3dp_hip.h: d3dp_jpma) for GPU tensors: returns the aggregated poses (B,K,F,J,3),
+    the selected hypothesis index (B,K,F,J) and, with ``want_errors``, the per-joint J_Agg / J_Best errors."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    assert pred.is_cuda, "jpma_hip needs GPU tensors (no CPU fallback); use jpma_aggregate for host tensors"
+    B, K, H, Fr, J, _ = pred.shape
+    pred = pred.to(torch.float32).contiguous()
+    traj = traj.to(torch.float32).reshape(B, Fr, 3).contiguous()
+    cam = cam.to(device=pred.device, dtype=torch.float32).reshape(-1)[:9].contiguous()
+    gt_2d = gt_2d.to(torch.float32).contiguous()
+    agg = torch.empty((B, K, Fr, J, 3), dtype=torch.float32, device=pred.device)
+    sel = torch.empty((B, K, Fr, J), dtype=torch.int32, device=pred.device)
+    es = em = None
+    if want_errors:
+        assert gt_3d is not None
+        gt_3d = gt_3d.to(torch.float32).contiguous()
+        es = torch.empty((B, K, Fr, J), dtype=torch.float32, device=pred.device)
+        em = torch.empty_like(es)
+    with torch.cuda.device(pred.device):
+        _lib.check(lib.d3dp_jpma(pred.data_ptr(), traj.data_ptr(), cam.data_ptr(), gt_2d.data_ptr(), _lib.ptr(gt_3d),
+                                 agg.data_ptr(), sel.data_ptr(), _lib.ptr(es), _lib.ptr(em), B, K, H, Fr, J,
+                                 int(zero_root), _lib.current_stream()), "d3dp_jpma")
+    return (agg, sel, es, em) if want_errors else (agg, sel)
 
 
 def jpma_aggregate(pred: torch.Tensor, reproj: torch.Tensor, gt_2d: torch.Tensor) -> torch.Tensor:

@@ -137,6 +137,17 @@ int d3dp_ddim_post(const float* pred2, const float* img, const float* noise, con
 int d3dp_q_sample(const float* x0, const float* noise, const double* sqrt_ac, const double* sqrt_1mac, float scale,
                   float* out, int32_t B, int32_t per_b, void* stream);
 
+/* JPMA: joint-wise reprojection-based multi-hypothesis aggregation (the consumer of the sampler / all-gather output).
+ * Replaces main.py:700 (root zeroing, if zero_root), :706-712 (trajectory add + project_to_2d, camera.py:30-60) and
+ * the per-joint argmin + gather of loss.py:54-76 / main_3dhp.py:797-835 in ONE pass, without (B,K,H,F,J,*) temporaries.
+ *   pred (B,K,H,F,J,3), traj (B,F,1,3), cam (9) = f(2) c(2) k(3) p(2), gt2d (B,F,J,2), gt3d (B,F,J,3) or NULL
+ *   agg (B,K,F,J,3)  <- the hypothesis whose reprojection is closest to gt2d (first minimum, like torch.min)
+ *   sel (B,K,F,J) int32 or NULL; err_sel / err_min (B,K,F,J) or NULL: |selected - gt3d| and min_h |pred_h - gt3d|
+ *   (their means over (B,F,J) are the reference's J_Agg and J_Best errors per step). */
+int d3dp_jpma(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d, float* agg,
+              int32_t* sel, float* err_sel, float* err_min, int32_t B, int32_t K, int32_t H, int32_t F, int32_t J,
+              int32_t zero_root, void* stream);
+
 /* ---- single operators (unit parity tests; same kernels the denoiser launches) ---------------------------- */
 /* out[M,N] = epi(A[M,K] W[N,K]^T + bias).  epi & 3: 0 bias, 1 bias+GELU(erf), 2 out(fp32) += result.
  * mode EXACT: everything fp32 (fp32 MFMA).  mode FAST: A, W bf16 (uint16 storage), fp32 accumulate; out is bf16

@@ -336,3 +336,26 @@ def test_profile_counters():
     m.pose_estimator.profile_enable(False)
     assert prof["gemm_qkv"][0] == 4 and prof["gemm_fc2"][0] == 4 and prof["head"][0] == 1
     assert all(ms >= 0 for _, ms in prof.values()) and prof["gemm_qkv"][1] > 0
+
+
+def test_jpma_kernel_matches_reference_metrics(golden_dir):
+    """d3dp_jpma (fused root zeroing + trajectory + projection + per-joint argmin + gather) against fixture g5, i.e.
+    the reference's own camera.project_to_2d + loss.mpjpe_diffusion_reproj / mpjpe_diffusion_all_min."""
+    from d3dp_amd import jpma
+    g = load_g(golden_dir, "g5_caller")
+    Fr = int(g["frames"])
+    x2, x3 = jpma.eval_data_prepare(Fr, torch.from_numpy(g["seq2d"])[None], torch.from_numpy(g["seq3d"])[None])
+    traj = x3[:, :, :1].clone()
+    x3[:, :, 0] = 0
+    pred = torch.from_numpy(g["pred"])                       # root joint NOT yet zeroed: the kernel does it
+    agg, sel, es, em = jpma.jpma_hip(pred.cuda(), traj.cuda(), torch.from_numpy(g["cam"]).cuda(), x2.cuda(), x3.cuda(),
+                                     zero_root=True, want_errors=True)
+    K = pred.shape[1]
+    j_agg = es.permute(1, 0, 2, 3).reshape(K, -1).mean(-1).cpu()
+    j_best = em.permute(1, 0, 2, 3).reshape(K, -1).mean(-1).cpu()
+    assert torch.allclose(j_agg, torch.from_numpy(g["e_jagg"]), atol=1e-6, rtol=1e-5)
+    assert torch.allclose(j_best, torch.from_numpy(g["e_jbest"]), atol=1e-6, rtol=1e-5)
+    pz = pred.clone()
+    pz[:, :, :, :, 0] = 0
+    want = jpma.jpma_aggregate(pz, torch.from_numpy(g["reproj"]), x2)
+    assert torch.equal(agg.cpu(), want)
