@@ -13,7 +13,8 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libd3dp_hip.so")
 
-MODE_EXACT, MODE_FAST, MODE_SPLIT3 = 0, 1, 2   # MODE_SPLIT3: d3dp_op_linear only
+MODE_EXACT, MODE_FAST, MODE_TRAIN = 0, 1, 2
+MODE_SPLIT3 = 2   # d3dp_op_linear only: split-bf16 operands
 EPI_BIAS, EPI_GELU, EPI_RESID = 0, 1, 2
 PROFILE_CLASSES = 12
 ABI_VERSION = 1
@@ -60,6 +61,11 @@ PROTOTYPES = {
                                  C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "d3dp_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32,
                                 C.c_int32, C.c_void_p]),
+    "d3dp_train_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t)]),
+    "d3dp_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "d3dp_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.POINTER(Weights), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "d3dp_jpma": (C.c_int, [C.c_void_p] * 9 + [C.c_int32] * 6 + [C.c_void_p]),
     "d3dp_op_linear": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                  C.c_int32, C.c_int32, C.c_void_p]),

@@ -98,7 +98,8 @@ struct d3dp_ctx {
   // EXACT mode runs its Linears as split-bf16 (3 planes, 6 MFMA passes) unless env D3DP_EXACT_F32=1 selects the
   // fp32-MFMA kernels (A/B and fallback).  Activations that feed a Linear are then three bf16 planes.
   bool exact_f32 = false;
-  bool x3() const { return !fast() && !exact_f32; }
+  bool train() const { return cfg.mode == D3DP_MODE_TRAIN; }
+  bool x3() const { return !fast() && !exact_f32 && !train(); }
   int act() const { return fast() ? 1 : (x3() ? 2 : 0); }            // code understood by the row-wise launchers
   size_t act_size() const { return fast() ? 2 : (x3() ? 6 : 4); }    // bytes per element of a Linear-input activation
   size_t wide_size() const { return fast() ? 2 : 4; }                // bytes per element of bufB (qkv fp32 / hidden planes = 12C either way)
@@ -221,7 +222,8 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   if (hd != 8 && hd != 16 && hd != 32 && hd != 64) return fail(D3DP_ENOTSUP, "head dim %d not in {8,16,32,64}", hd);
   if (g.hidden % 64 || g.hidden < 64) return fail(D3DP_ENOTSUP, "hidden=%d must be a multiple of 64", g.hidden);
   if (g.depth < 1) return fail(D3DP_EINVAL, "depth=%d", g.depth);
-  if (g.mode != D3DP_MODE_EXACT && g.mode != D3DP_MODE_FAST) return fail(D3DP_EINVAL, "mode=%d", g.mode);
+  if (g.mode != D3DP_MODE_EXACT && g.mode != D3DP_MODE_FAST && g.mode != D3DP_MODE_TRAIN)
+    return fail(D3DP_EINVAL, "mode=%d", g.mode);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
     return fail(D3DP_EHIP, "no HIP device visible: libd3dp_hip has no CPU fallback");
@@ -498,6 +500,229 @@ int d3dp_profile_read(d3dp_ctx* c, int64_t* counts, double* total_ms) {
   for (int i = 0; i < D3DP_PROFILE_CLASSES; ++i) { counts[i] = c->counts[i]; total_ms[i] = c->total_ms[i]; }
   memset(c->counts, 0, sizeof c->counts);
   for (auto& v : c->total_ms) v = 0.0;
+  return D3DP_OK;
+}
+
+}  // extern "C"
+
+// ==================================================================================================================
+// Training step: forward of the MixSTE2 train branch (mixste.py:215-225, H = 1) with saved
+// activations, and the full backward.  Context must be created with D3DP_MODE_TRAIN (fp32 weights and activations;
+// Linears on the fp32 matrix cores).  Not tuned -- correctness first: every Linear gradient is an fp32-MFMA GEMM over
+// explicitly transposed operands, everything else is a row-wise fp32 kernel (train.hip).
+// ==================================================================================================================
+namespace {
+
+struct TrainLayout {
+  size_t T, Tpad, C, Hd, unit;      // unit = T*C floats
+  // offsets in floats
+  size_t temb, x_final, zero_bias, saved0, saved_stride, tmp0;
+  // per-block saved tensors (offsets inside a block's slab)
+  size_t o_xin, o_qkv, o_att, o_xmid, o_hpre, o_xout;
+  // temporaries
+  size_t xn, y, hid, dA, dB, dC, dqkv, dh, z, At, Xt, Wt, dtemb, stats;
+  size_t total_floats;
+};
+
+TrainLayout train_layout(const d3dp_cfg& g, int B) {
+  TrainLayout L{};
+  L.T = (size_t)B * g.frames * g.joints;
+  L.Tpad = (L.T + 15) / 16 * 16;
+  L.C = g.channels; L.Hd = g.hidden; L.unit = L.T * L.C;
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += (n + 63) / 64 * 64; return o; };
+  L.temb = take((size_t)B * L.C);
+  L.x_final = take(L.unit);
+  L.zero_bias = take(4 * L.C);
+  L.o_xin = 0; L.o_qkv = L.unit; L.o_att = 4 * L.unit; L.o_xmid = 5 * L.unit; L.o_hpre = 6 * L.unit;
+  L.o_xout = 6 * L.unit + L.T * L.Hd;
+  L.saved_stride = (7 * L.unit + L.T * L.Hd + 63) / 64 * 64;
+  L.saved0 = take(L.saved_stride * 2 * g.depth);
+  L.xn = take(L.unit); L.y = take(L.unit); L.hid = take(L.T * L.Hd);
+  L.dA = take(L.unit); L.dB = take(L.unit); L.dC = take(L.unit);
+  L.dqkv = take(3 * L.unit); L.dh = take(L.T * L.Hd); L.z = take(L.unit);
+  const size_t wide = std::max<size_t>(3 * L.C, L.Hd);
+  L.At = take(wide * L.Tpad); L.Xt = take(wide * L.Tpad); L.Wt = take(wide * wide);
+  L.dtemb = take((size_t)B * L.C);
+  L.stats = take(d3dp_train_attn_stats_bytes(B * std::max(g.frames, g.joints), std::max(g.frames, g.joints), g.heads) / 4 + 64);
+  L.total_floats = off;
+  return L;
+}
+
+const float* mask_ptr(const float* masks, const d3dp_cfg& g, int B, int blk, int branch) {
+  if (!masks) return nullptr;
+  const size_t smax = (size_t)B * std::max(g.frames, g.joints);
+  return masks + ((size_t)blk * 2 + branch) * smax;
+}
+
+int lin32(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, hipStream_t st) {
+  return d3dp_launch_linear_f32(EPI_BIAS, A, W, bias, out, M, N, K, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int d3dp_train_workspace_bytes(const d3dp_ctx* c, int32_t B, size_t* bytes) {
+  if (!c || !bytes || B < 1) return fail(D3DP_EINVAL, "d3dp_train_workspace_bytes: bad argument");
+  *bytes = train_layout(c->cfg, B).total_floats * 4;
+  return D3DP_OK;
+}
+
+int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const int64_t* t, const float* masks, float* out,
+                       int32_t B, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!c || !x2d || !x3d || !t || !out || !workspace || B < 1) return fail(D3DP_EINVAL, "d3dp_train_forward: bad argument");
+  if (!c->train()) return fail(D3DP_ESTATE, "d3dp_train_forward needs a D3DP_MODE_TRAIN context");
+  if (!c->weights_set) return fail(D3DP_ESTATE, "weights not set");
+  const d3dp_cfg& g = c->cfg;
+  const TrainLayout L = train_layout(g, B);
+  if (workspace_bytes < L.total_floats * 4) return fail(D3DP_ESTATE, "train workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const int T = (int)L.T, C = g.channels, F = g.frames, J = g.joints, Hd = g.hidden;
+  float *xn = ws + L.xn, *y = ws + L.y, *hid = ws + L.hid;
+  LAUNCH_TRY(d3dp_launch_time_mlp(t, c->freq, c->t1w, c->t1b, c->t3w, c->t3b, ws + L.temb, B, C, st));
+  float* slab0 = ws + L.saved0;
+  LAUNCH_TRY(d3dp_launch_embed_ln(0, x2d, x3d, ws + L.temb, c->ew, c->eb, c->spos, c->ste[0].n1w, c->ste[0].n1b,
+                                  g.eps_block, slab0 + L.o_xin, xn, 0, B, 1, F, J, C, st));
+  for (int blk = 0; blk < 2 * g.depth; ++blk) {
+    const int kind = blk & 1, d = blk >> 1;
+    const BlockDev& w = kind ? c->tte[d] : c->ste[d];
+    float* S = ws + L.saved0 + (size_t)blk * L.saved_stride;
+    LAUNCH_TRY(lin32(xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C, st));
+    if (kind == 0) LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * F, spatial_map(F, J), C, g.heads, st));
+    else LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st));
+    LAUNCH_TRY(lin32(S + L.o_att, (const float*)w.proj_w, w.proj_b, y, T, C, C, st));
+    LAUNCH_TRY(d3dp_train_add_mask_ln(S + L.o_xin, y, mask_ptr(masks, g, B, blk, 0), kind, F, J, w.n2w, w.n2b, g.eps_block,
+                                      S + L.o_xmid, xn, T, C, st));
+    LAUNCH_TRY(lin32(xn, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, st));
+    LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, st));
+    LAUNCH_TRY(lin32(hid, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd, st));
+    LAUNCH_TRY(d3dp_train_add_mask_ln(S + L.o_xmid, y, mask_ptr(masks, g, B, blk, 1), kind, F, J, nullptr, nullptr,
+                                      g.eps_block, S + L.o_xout, nullptr, T, C, st));
+    // shared norm -> next block's input (or x_final)
+    const bool last = blk == 2 * g.depth - 1;
+    float* x_next = last ? ws + L.x_final : S + L.saved_stride + L.o_xin;
+    if (kind == 0) LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xout, c->snw, c->snb, g.eps_block, d == 0 ? c->tpos : nullptr, F, J,
+                                                x_next, T, C, st));
+    else LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xout, c->tnw, c->tnb, g.eps_block, nullptr, F, J, x_next, T, C, st));
+    if (!last) {
+      const BlockDev& wn = kind ? c->ste[d + 1] : c->tte[d];
+      LAUNCH_TRY(d3dp_train_ln_pos(x_next, wn.n1w, wn.n1b, g.eps_block, nullptr, F, J, xn, T, C, st));
+    }
+  }
+  LAUNCH_TRY(d3dp_train_ln_pos(ws + L.x_final, c->hnw, c->hnb, g.eps_head, nullptr, F, J, ws + L.z, T, C, st));
+  LAUNCH_TRY(d3dp_train_head_linear(ws + L.z, c->hw, c->hb, out, T, C, st));
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
+// grads: device fp32 buffers with the shapes of the corresponding weights (time_freq ignored); they are ZEROED here
+// and then accumulated.  Must be called after d3dp_train_forward with the same inputs, masks and workspace.
+int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const int64_t* t, const float* masks,
+                        const float* grad_out, const d3dp_weights* grads, int32_t B, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  if (!c || !x2d || !x3d || !t || !grad_out || !grads || !grads->ste || !grads->tte || !workspace || B < 1)
+    return fail(D3DP_EINVAL, "d3dp_train_backward: bad argument");
+  if (!c->train()) return fail(D3DP_ESTATE, "d3dp_train_backward needs a D3DP_MODE_TRAIN context");
+  const d3dp_cfg& g = c->cfg;
+  const TrainLayout L = train_layout(g, B);
+  if (workspace_bytes < L.total_floats * 4) return fail(D3DP_ESTATE, "train workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const int T = (int)L.T, Tp = (int)L.Tpad, C = g.channels, F = g.frames, J = g.joints, Hd = g.hidden;
+  auto G = [](const float* p) { return const_cast<float*>(p); };
+  auto zero = [&](const float* p, size_t n) { return hipMemsetAsync(G(p), 0, n * 4, st); };
+  // ---- zero every gradient buffer -------------------------------------------------------------------------------
+  const size_t CC = (size_t)C * C;
+  HIP_TRY(zero(grads->spatial_pos, (size_t)J * C)); HIP_TRY(zero(grads->temporal_pos, (size_t)F * C));
+  HIP_TRY(zero(grads->embed_w, (size_t)C * 5)); HIP_TRY(zero(grads->embed_b, C));
+  HIP_TRY(zero(grads->time1_w, 2 * CC)); HIP_TRY(zero(grads->time1_b, 2 * C));
+  HIP_TRY(zero(grads->time3_w, 2 * CC)); HIP_TRY(zero(grads->time3_b, C));
+  HIP_TRY(zero(grads->spatial_norm_w, C)); HIP_TRY(zero(grads->spatial_norm_b, C));
+  HIP_TRY(zero(grads->temporal_norm_w, C)); HIP_TRY(zero(grads->temporal_norm_b, C));
+  HIP_TRY(zero(grads->head_norm_w, C)); HIP_TRY(zero(grads->head_norm_b, C));
+  HIP_TRY(zero(grads->head_w, 3 * (size_t)C)); HIP_TRY(zero(grads->head_b, 3));
+  for (int kind = 0; kind < 2; ++kind)
+    for (int d = 0; d < g.depth; ++d) {
+      const d3dp_block_weights& b = (kind ? grads->tte : grads->ste)[d];
+      HIP_TRY(zero(b.norm1_w, C)); HIP_TRY(zero(b.norm1_b, C)); HIP_TRY(zero(b.norm2_w, C)); HIP_TRY(zero(b.norm2_b, C));
+      HIP_TRY(zero(b.qkv_b, 3 * (size_t)C)); HIP_TRY(zero(b.proj_b, C)); HIP_TRY(zero(b.fc1_b, Hd)); HIP_TRY(zero(b.fc2_b, C));
+      // weight matrices are written (not accumulated) by their wgrad GEMM
+    }
+  HIP_TRY(hipMemsetAsync(ws + L.zero_bias, 0, 4 * (size_t)C * 4, st));
+  const float* zb = ws + L.zero_bias;
+  float *xn = ws + L.xn, *hid = ws + L.hid, *dA = ws + L.dA, *dB = ws + L.dB, *dC = ws + L.dC, *dqkv = ws + L.dqkv,
+        *dh = ws + L.dh, *At = ws + L.At, *Xt = ws + L.Xt, *Wt = ws + L.Wt;
+
+  // wgrad: dW[N, K] = dY[T, N]^T X[T, K]  (both operands transposed to [*, Tpad], zero padded)
+  auto wgrad = [&](const float* dY, int N, const float* X, int K, float* dW) -> int {
+    int r;
+    if ((r = d3dp_train_transpose_pad(dY, At, T, N, Tp, st))) return r;
+    if ((r = d3dp_train_transpose_pad(X, Xt, T, K, Tp, st))) return r;
+    return lin32(At, Xt, zb, dW, N, K, Tp, st);
+  };
+  // dgrad: dX[T, K] = dY[T, N] W[N, K]   (W transposed to [K, N])
+  auto dgrad = [&](const float* dY, int N, const float* W, int K, float* dX) -> int {
+    int r;
+    if ((r = d3dp_train_transpose_pad(W, Wt, N, K, N, st))) return r;
+    return lin32(dY, Wt, zb, dX, T, K, N, st);
+  };
+
+  // ---- head ------------------------------------------------------------------------------------------------------
+  LAUNCH_TRY(d3dp_train_ln_pos(ws + L.x_final, c->hnw, c->hnb, g.eps_head, nullptr, F, J, ws + L.z, T, C, st));
+  LAUNCH_TRY(d3dp_train_head_bwd(grad_out, ws + L.z, c->hw, dC, G(grads->head_w), G(grads->head_b), T, C, st));
+  LAUNCH_TRY(d3dp_train_ln_bwd(dC, ws + L.x_final, c->hnw, g.eps_head, nullptr, dA, G(grads->head_norm_w),
+                               G(grads->head_norm_b), T, C, st));
+  // dA = gradient w.r.t. the output of the last shared norm
+  for (int blk = 2 * g.depth - 1; blk >= 0; --blk) {
+    const int kind = blk & 1, d = blk >> 1;
+    const BlockDev& w = kind ? c->tte[d] : c->ste[d];
+    const d3dp_block_weights& gw = (kind ? grads->tte : grads->ste)[d];
+    float* S = ws + L.saved0 + (size_t)blk * L.saved_stride;
+    const float* snw = kind ? c->tnw : c->snw;
+    float* gsnw = G(kind ? grads->temporal_norm_w : grads->spatial_norm_w);
+    float* gsnb = G(kind ? grads->temporal_norm_b : grads->spatial_norm_b);
+    if (kind == 0 && d == 0) LAUNCH_TRY(d3dp_train_groupsum(dA, G(grads->temporal_pos), T, C, 1, F, J, st));
+    // shared norm backward: dB = d x_out
+    LAUNCH_TRY(d3dp_train_ln_bwd(dA, S + L.o_xout, snw, g.eps_block, nullptr, dB, gsnw, gsnb, T, C, st));
+    // ---- MLP branch ----
+    LAUNCH_TRY(d3dp_train_scale_mask(dB, mask_ptr(masks, g, B, blk, 1), kind, F, J, dC, T, C, st));        // dy2
+    LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, st));
+    LAUNCH_TRY(wgrad(dC, C, hid, Hd, G(gw.fc2_w)));
+    LAUNCH_TRY(d3dp_train_colsum(dC, G(gw.fc2_b), T, C, st));
+    LAUNCH_TRY(dgrad(dC, C, (const float*)w.fc2_w, Hd, dh));                                               // d hidden
+    LAUNCH_TRY(d3dp_train_gelu_bwd(dh, S + L.o_hpre, dh, (size_t)T * Hd, st));                             // d h_pre
+    LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xmid, w.n2w, w.n2b, g.eps_block, nullptr, F, J, xn, T, C, st));   // xn2
+    LAUNCH_TRY(wgrad(dh, Hd, xn, C, G(gw.fc1_w)));
+    LAUNCH_TRY(d3dp_train_colsum(dh, G(gw.fc1_b), T, Hd, st));
+    LAUNCH_TRY(dgrad(dh, Hd, (const float*)w.fc1_w, C, dC));                                               // d xn2
+    LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xmid, w.n2w, g.eps_block, dB, dA, G(gw.norm2_w), G(gw.norm2_b), T, C, st));
+    // dA = d x_mid
+    // ---- attention branch ----
+    LAUNCH_TRY(d3dp_train_scale_mask(dA, mask_ptr(masks, g, B, blk, 0), kind, F, J, dC, T, C, st));        // dy1
+    LAUNCH_TRY(wgrad(dC, C, S + L.o_att, C, G(gw.proj_w)));
+    LAUNCH_TRY(d3dp_train_colsum(dC, G(gw.proj_b), T, C, st));
+    LAUNCH_TRY(dgrad(dC, C, (const float*)w.proj_w, C, dB));                                               // d att
+    if (kind == 0) LAUNCH_TRY(d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * F, spatial_map(F, J), C, g.heads, st));
+    else LAUNCH_TRY(d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * J, temporal_map(F, J), C, g.heads, st));
+    LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xin, w.n1w, w.n1b, g.eps_block, nullptr, F, J, xn, T, C, st));    // xn1
+    LAUNCH_TRY(wgrad(dqkv, 3 * C, xn, C, G(gw.qkv_w)));
+    LAUNCH_TRY(d3dp_train_colsum(dqkv, G(gw.qkv_b), T, 3 * C, st));
+    LAUNCH_TRY(dgrad(dqkv, 3 * C, (const float*)w.qkv_w, C, dC));                                          // d xn1
+    LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xin, w.n1w, g.eps_block, dA, dB, G(gw.norm1_w), G(gw.norm1_b), T, C, st));
+    // dB = d x_in of this block = gradient w.r.t. the previous shared norm's output
+    std::swap(dA, dB);
+  }
+  // ---- embedding, position and time embeddings -------------------------------------------------------------------
+  LAUNCH_TRY(d3dp_train_embed_bwd(dA, x2d, x3d, G(grads->embed_w), T, C, st));
+  LAUNCH_TRY(d3dp_train_colsum(dA, G(grads->embed_b), T, C, st));
+  LAUNCH_TRY(d3dp_train_groupsum(dA, G(grads->spatial_pos), T, C, 0, F, J, st));
+  HIP_TRY(hipMemsetAsync(ws + L.dtemb, 0, (size_t)B * C * 4, st));
+  LAUNCH_TRY(d3dp_train_groupsum(dA, ws + L.dtemb, T, C, 2, F, J, st));
+  LAUNCH_TRY(d3dp_train_time_mlp_bwd(t, c->freq, c->t1w, c->t1b, c->t3w, ws + L.dtemb, G(grads->time1_w),
+                                     G(grads->time1_b), G(grads->time3_w), G(grads->time3_b), B, C, st));
+  HIP_TRY(hipGetLastError());
   return D3DP_OK;
 }
 

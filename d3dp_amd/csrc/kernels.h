@@ -62,3 +62,28 @@ int d3dp_launch_q_sample(const float* x0, const float* noise, const double* a, c
 int d3dp_launch_jpma(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d,
                      float* agg, int* sel, float* err_sel, float* err_min, int B, int K, int H, int F, int J,
                      int zero_root, hipStream_t st);
+
+// ---- train.hip (training step, fp32) -------------------------------------------------------------------------
+int d3dp_train_add_mask_ln(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* w,
+                           const float* b, float eps, float* x_out, float* xn, int T, int C, hipStream_t st);
+int d3dp_train_ln_pos(const float* x, const float* w, const float* b, float eps, const float* pos, int F, int J, float* y,
+                      int T, int C, hipStream_t st);
+int d3dp_train_ln_bwd(const float* dy, const float* x, const float* w, float eps, const float* dres, float* dx,
+                      float* dgamma, float* dbeta, int T, int C, hipStream_t st);
+int d3dp_train_gelu_fwd(const float* x, float* y, size_t n, hipStream_t st);
+int d3dp_train_gelu_bwd(const float* dh, const float* x, float* dpre, size_t n, hipStream_t st);
+int d3dp_train_scale_mask(const float* in, const float* mask, int axis, int F, int J, float* out, int T, int C,
+                          hipStream_t st);
+int d3dp_train_colsum(const float* in, float* out, int T, int C, hipStream_t st);
+int d3dp_train_groupsum(const float* in, float* out, int T, int C, int mode, int F, int J, hipStream_t st);
+int d3dp_train_transpose_pad(const float* in, float* out, int R, int C, int Rpad, hipStream_t st);
+size_t d3dp_train_attn_stats_bytes(int n_seq, int n_tok, int heads);
+int d3dp_train_attn_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, void* stats, int n_seq,
+                        SeqMap map, int C, int heads, hipStream_t st);
+int d3dp_train_embed_bwd(const float* dx, const float* x2d, const float* x3d, float* dW, int T, int C, hipStream_t st);
+int d3dp_train_head_linear(const float* z, const float* w, const float* b, float* out, int T, int C, hipStream_t st);
+int d3dp_train_head_bwd(const float* g, const float* z, const float* w, float* dz, float* dW, float* db, int T, int C,
+                        hipStream_t st);
+int d3dp_train_time_mlp_bwd(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2,
+                            const float* dtemb, float* dw1, float* db1, float* dw2, float* db2, int B, int C,
+                            hipStream_t st);

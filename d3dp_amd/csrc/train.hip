@@ -1,0 +1,547 @@
+// Row-wise / elementwise kernels of the TRAINING step (reference main.py:387-401 around
+// common/diffusionpose.py:279-287 and the MixSTE2 train branch, common/mixste.py:215-225).  fp32 throughout.
+// Linears (forward, dgrad, wgrad) reuse gemm_f32_kernel; attention forward reuses attn_rows_kernel<float>.
+//
+//   forward helpers : masked residual add (+LayerNorm), GELU
+//   backward        : LayerNorm backward (dx, d-gamma, d-beta), GELU backward, column sums (bias grads), transposes
+//                     (operands of the dgrad / wgrad GEMMs), attention backward (dQ | dK,dV), grouped row sums
+//                     (position-embedding and time-embedding grads), embedding / head / time-MLP backward.
+// DropPath (timm semantics: per-sample mask in {0, 1/keep}) enters as an optional per-sample scale of the branch
+// output: sample = token / J for spatial blocks ((b f) n c), = (b, n) for temporal blocks ((b n) f c).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ int sample_of(int tok, int axis, int F, int J) {
+  return axis == 0 ? tok / J : (tok / (F * J)) * J + tok % J;
+}
+
+constexpr float kInvSqrt2 = 0.70710678118654752440f;
+constexpr float kInvSqrt2Pi = 0.39894228040143267794f;
+
+// ---- x_out = x_in + m[sample] * y ; optionally xn = LN(x_out) ---------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void add_mask_ln_kernel(const float* __restrict__ x_in, const float* __restrict__ y,
+                                                          const float* __restrict__ mask, int axis, int F, int J,
+                                                          const float* __restrict__ w, const float* __restrict__ b,
+                                                          float eps, float* __restrict__ x_out, float* __restrict__ xn,
+                                                          int T) {
+  constexpr int NV = C / 64;
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= T) return;
+  const float m = mask ? mask[sample_of(tok, axis, F, J)] : 1.0f;
+  float v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const size_t o = (size_t)tok * C + i * 64 + lane;
+    v[i] = x_in[o] + m * y[o];
+    x_out[o] = v[i];
+    s += v[i];
+  }
+  if (xn == nullptr) return;
+  const float mean = wave_sum(s) * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 64 + lane;
+    xn[(size_t)tok * C + c] = fmaf((v[i] - mean) * rstd, w[c], b[c]);
+  }
+}
+
+// ---- y = LN(x) (+ pos[f]) -----------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void ln_pos_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float eps, const float* __restrict__ pos,
+                                                     int F, int J, float* __restrict__ y, int T) {
+  constexpr int NV = C / 64;
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= T) return;
+  float v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { v[i] = x[(size_t)tok * C + i * 64 + lane]; s += v[i]; }
+  const float mean = wave_sum(s) * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+  const int f = (tok / J) % F;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 64 + lane;
+    float r = fmaf((v[i] - mean) * rstd, w[c], b[c]);
+    if (pos) r += pos[(size_t)f * C + c];
+    y[(size_t)tok * C + c] = r;
+  }
+}
+
+// ---- LayerNorm backward: dx (+= dres), dgamma/dbeta accumulated with atomics ------------------------------------
+//   xhat = (x - mean) rstd ; g = dy * gamma ; dx = rstd (g - mean(g) - xhat mean(g xhat))  [+ dres]
+template <int C>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ w, float eps,
+                                                     const float* __restrict__ dres, float* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int T) {
+  constexpr int NV = C / 64;
+  __shared__ float sg[4][C], sb[4][C];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float ag[NV], ab[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+  for (int tok = blockIdx.x * 4 + wv; tok < T; tok += gridDim.x * 4) {
+    float v[NV], g[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i] = x[(size_t)tok * C + i * 64 + lane]; s += v[i]; }
+    const float mean = wave_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i] -= mean; q = fmaf(v[i], v[i], q); }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+    float sg1 = 0.f, sg2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = i * 64 + lane;
+      const float d = dy[(size_t)tok * C + c];
+      v[i] *= rstd;                    // xhat
+      g[i] = d * w[c];
+      sg1 += g[i];
+      sg2 = fmaf(g[i], v[i], sg2);
+      ag[i] = fmaf(d, v[i], ag[i]);
+      ab[i] += d;
+    }
+    sg1 = wave_sum(sg1) * (1.0f / C);
+    sg2 = wave_sum(sg2) * (1.0f / C);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const size_t o = (size_t)tok * C + i * 64 + lane;
+      float r = rstd * (g[i] - sg1 - v[i] * sg2);
+      if (dres) r += dres[o];
+      dx[o] = r;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { sg[wv][i * 64 + lane] = ag[i]; sb[wv][i * 64 + lane] = ab[i]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgamma + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+    atomicAdd(dbeta + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = gelu_erf(x[i]);
+}
+
+// dpre = dh * (Phi(x) + x phi(x))
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* dh, const float* __restrict__ x, float* dpre,
+                                                       size_t n) {   // dpre may alias dh
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  const float cdf = 0.5f * (1.0f + erff(v * kInvSqrt2));
+  const float pdf = kInvSqrt2Pi * expf(-0.5f * v * v);
+  dpre[i] = dh[i] * (cdf + v * pdf);
+}
+
+// out[t, :] = m[sample(t)] * in[t, :]
+__global__ __launch_bounds__(256) void scale_mask_kernel(const float* __restrict__ in, const float* __restrict__ mask,
+                                                         int axis, int F, int J, float* __restrict__ out, int T, int C) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)T * C) return;
+  const int tok = (int)(i / C);
+  out[i] = in[i] * (mask ? mask[sample_of(tok, axis, F, J)] : 1.0f);
+}
+
+// out[c] += sum_t in[t, c]     (bias grads)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int T, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int t = blockIdx.y; t < T; t += gridDim.y) s += in[(size_t)t * C + c];
+  atomicAdd(out + c, s);
+}
+
+// out[g, c] += sum over tokens of group g of in[t, c]; group: 0 -> n = t % J, 1 -> f = (t / J) % F, 2 -> b = t / (F J)
+__global__ __launch_bounds__(256) void groupsum_kernel(const float* __restrict__ in, float* __restrict__ out, int T, int C,
+                                                       int mode, int F, int J) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (c >= C) return;
+  float s = 0.f;
+  if (mode == 0) { for (int t = g + blockIdx.z * J; t < T; t += J * gridDim.z) s += in[(size_t)t * C + c]; }
+  else if (mode == 1) {
+    for (int b = blockIdx.z; b < T / (F * J); b += gridDim.z)
+      for (int n = 0; n < J; ++n) s += in[((size_t)b * F * J + (size_t)g * J + n) * C + c];
+  } else {
+    for (int t = blockIdx.z; t < F * J; t += gridDim.z) s += in[((size_t)g * F * J + t) * C + c];
+  }
+  atomicAdd(out + (size_t)g * C + c, s);
+}
+
+// out[c, r] = in[r, c] for r < R, 0 for R <= r < Rpad     (in [R, C] -> out [C, Rpad])
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
+                                                            int C, int Rpad) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    tile[k][tx] = (r < R && c < C) ? in[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (c < C && r < Rpad) out[(size_t)c * Rpad + r] = tile[tx][k];
+  }
+}
+
+// ---- attention backward --------------------------------------------------------------------------------------------
+// Per (sequence, head): P = softmax(Q K^T s), O = P V.  Given dO:
+//   D_i = dO_i . O_i ;  dS_ij = P_ij (dO_i . V_j - D_i) ;  dQ_i = s sum_j dS_ij K_j ; dK_j = s sum_i dS_ij Q_i ;
+//   dV_j = sum_i P_ij dO_i.
+// Pass 1 (thread per query row; K, V in LDS): row max m_i, denominator l_i, D_i, and dQ_i.
+// Pass 2 (thread per key row; Q, dO in LDS, m/l/D from pass 1): dK_j, dV_j.
+struct AttnStats { float m, l, D; };
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                         const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                         AttnStats* __restrict__ stats, SeqMap map, int C, int heads) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* Ks = reinterpret_cast<float*>(smem_raw);
+  const int n = map.n_tok;
+  constexpr int LDR = HD + 4;
+  float* Vs = Ks + (size_t)n * LDR;
+  const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
+  const int base = (seq / map.inner) * map.outer_stride + (seq % map.inner) * map.inner_stride;
+  for (int u = threadIdx.x; u < n * (HD / 4); u += blockDim.x) {
+    const int j = u / (HD / 4), c = u % (HD / 4);
+    const float* src = qkv + (size_t)(base + j * map.tok_stride) * 3 * C + C + head * HD + c * 4;
+    *reinterpret_cast<float4*>(Ks + j * LDR + c * 4) = *reinterpret_cast<const float4*>(src);
+    *reinterpret_cast<float4*>(Vs + j * LDR + c * 4) = *reinterpret_cast<const float4*>(src + C);
+  }
+  __syncthreads();
+  const int i = threadIdx.x;
+  if (i >= n) return;
+  const size_t tok = (size_t)(base + i * map.tok_stride);
+  const float scale = 1.0f / sqrtf((float)HD);
+  float q[HD], dO[HD], dq[HD];
+  float D = 0.f;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    q[d] = qkv[tok * 3 * C + head * HD + d];
+    dO[d] = dout[tok * C + head * HD + d];
+    D = fmaf(dO[d], o[tok * C + head * HD + d], D);
+    dq[d] = 0.f;
+  }
+  float m = -INFINITY;
+  for (int j = 0; j < n; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) s = fmaf(q[d], Ks[j * LDR + d], s);
+    m = fmaxf(m, s * scale);
+  }
+  float l = 0.f;
+  for (int j = 0; j < n; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) s = fmaf(q[d], Ks[j * LDR + d], s);
+    l += expf(s * scale - m);
+  }
+  const float inv = 1.0f / l;
+  for (int j = 0; j < n; ++j) {
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { s = fmaf(q[d], Ks[j * LDR + d], s); dp = fmaf(dO[d], Vs[j * LDR + d], dp); }
+    const float p = expf(s * scale - m) * inv;
+    const float ds = p * (dp - D) * scale;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dq[d] = fmaf(ds, Ks[j * LDR + d], dq[d]);
+  }
+#pragma unroll
+  for (int d = 0; d < HD; ++d) dqkv[tok * 3 * C + head * HD + d] = dq[d];
+  stats[(size_t)blockIdx.x * n + i] = AttnStats{m, l, D};
+}
+
+template <int HD>
+__global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                          float* __restrict__ dqkv, const AttnStats* __restrict__ stats,
+                                                          SeqMap map, int C, int heads) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* Qs = reinterpret_cast<float*>(smem_raw);
+  const int n = map.n_tok;
+  constexpr int LDR = HD + 4;
+  float* Os = Qs + (size_t)n * LDR;
+  AttnStats* st = reinterpret_cast<AttnStats*>(Os + (size_t)n * LDR);
+  const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
+  const int base = (seq / map.inner) * map.outer_stride + (seq % map.inner) * map.inner_stride;
+  for (int u = threadIdx.x; u < n * (HD / 4); u += blockDim.x) {
+    const int i = u / (HD / 4), c = u % (HD / 4);
+    const size_t tok = (size_t)(base + i * map.tok_stride);
+    *reinterpret_cast<float4*>(Qs + i * LDR + c * 4) =
+        *reinterpret_cast<const float4*>(qkv + tok * 3 * C + head * HD + c * 4);
+    *reinterpret_cast<float4*>(Os + i * LDR + c * 4) =
+        *reinterpret_cast<const float4*>(dout + tok * C + head * HD + c * 4);
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) st[i] = stats[(size_t)blockIdx.x * n + i];
+  __syncthreads();
+  // two threads per key: each owns half of the head dimension of dK_j and dV_j (register budget)
+  const int j = threadIdx.x >> 1, half = threadIdx.x & 1;
+  if (j >= n) return;
+  constexpr int HH = HD / 2;
+  const size_t tok = (size_t)(base + j * map.tok_stride);
+  const float scale = 1.0f / sqrtf((float)HD);
+  float k[HD], v[HD], dk[HH], dv[HH];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    k[d] = qkv[tok * 3 * C + C + head * HD + d];
+    v[d] = qkv[tok * 3 * C + 2 * C + head * HD + d];
+  }
+#pragma unroll
+  for (int d = 0; d < HH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+  for (int i = 0; i < n; ++i) {
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { s = fmaf(Qs[i * LDR + d], k[d], s); dp = fmaf(Os[i * LDR + d], v[d], dp); }
+    const float p = expf(s * scale - st[i].m) / st[i].l;
+    const float ds = p * (dp - st[i].D) * scale;
+#pragma unroll
+    for (int d = 0; d < HH; ++d) {
+      dk[d] = fmaf(ds, Qs[i * LDR + half * HH + d], dk[d]);
+      dv[d] = fmaf(p, Os[i * LDR + half * HH + d], dv[d]);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < HH; ++d) {
+    dqkv[tok * 3 * C + C + head * HD + half * HH + d] = dk[d];
+    dqkv[tok * 3 * C + 2 * C + head * HD + half * HH + d] = dv[d];
+  }
+}
+
+// ---- embedding backward: dW[c, i] += sum_t dx[t, c] in5[t, i] ; in5 = (u, v, x, y, z) ----------------------------
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ x2d,
+                                                        const float* __restrict__ x3d, float* __restrict__ dW, int T, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int t = blockIdx.y; t < T; t += gridDim.y) {
+    const float d = dx[(size_t)t * C + c];
+    a[0] = fmaf(d, x2d[(size_t)t * 2], a[0]);
+    a[1] = fmaf(d, x2d[(size_t)t * 2 + 1], a[1]);
+    a[2] = fmaf(d, x3d[(size_t)t * 3], a[2]);
+    a[3] = fmaf(d, x3d[(size_t)t * 3 + 1], a[3]);
+    a[4] = fmaf(d, x3d[(size_t)t * 3 + 2], a[4]);
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) atomicAdd(dW + c * 5 + i, a[i]);
+}
+
+// ---- head: pred[t, o] = sum_c z[t, c] W[o, c] + b[o]  (o < 3) -------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void head_linear_kernel(const float* __restrict__ z, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ out, int T) {
+  constexpr int NV = C / 64;
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= T) return;
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 64 + lane;
+    const float v = z[(size_t)tok * C + c];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) acc[o] = fmaf(v, w[o * C + c], acc[o]);
+  }
+#pragma unroll
+  for (int o = 0; o < 3; ++o) acc[o] = wave_sum(acc[o]) + b[o];
+  if (lane < 3) out[(size_t)tok * 3 + lane] = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : acc[2]);
+}
+
+// dz[t, c] = sum_o g[t, o] W[o, c] ; dW[o, c] += sum_t g[t, o] z[t, c] ; db[o] += sum_t g[t, o]
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                       const float* __restrict__ w, float* __restrict__ dz,
+                                                       float* __restrict__ dW, float* __restrict__ db, int T, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
+  const float w0 = w[c], w1 = w[C + c], w2 = w[2 * C + c];
+  for (int t = blockIdx.y; t < T; t += gridDim.y) {
+    const float g0 = g[(size_t)t * 3], g1 = g[(size_t)t * 3 + 1], g2 = g[(size_t)t * 3 + 2];
+    const float zz = z[(size_t)t * C + c];
+    dz[(size_t)t * C + c] = g0 * w0 + g1 * w1 + g2 * w2;
+    a[0] = fmaf(g0, zz, a[0]); a[1] = fmaf(g1, zz, a[1]); a[2] = fmaf(g2, zz, a[2]);
+    if (c == 0) { sb[0] += g0; sb[1] += g1; sb[2] += g2; }
+  }
+#pragma unroll
+  for (int o = 0; o < 3; ++o) atomicAdd(dW + o * C + c, a[o]);
+  if (c == 0) { atomicAdd(db, sb[0]); atomicAdd(db + 1, sb[1]); atomicAdd(db + 2, sb[2]); }
+}
+
+// ---- time MLP backward (B rows; one workgroup per batch element, atomics into the shared weight grads) -----------
+__global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const int64_t* __restrict__ t, const float* __restrict__ freq,
+                                                           const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           const float* __restrict__ w2, const float* __restrict__ dtemb,
+                                                           float* __restrict__ dw1, float* __restrict__ db1,
+                                                           float* __restrict__ dw2, float* __restrict__ db2, int C) {
+  extern __shared__ float sm[];            // e[C] | pre[2C] | act[2C] | dpre[2C]
+  float* e = sm;
+  float* pre = sm + C;
+  float* act = pre + 2 * C;
+  float* dpre = act + 2 * C;
+  const int b = blockIdx.x, half = C / 2;
+  const float tv = (float)t[b];
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    const float a = tv * freq[i];
+    e[i] = sinf(a);
+    e[half + i] = cosf(a);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * C; o += blockDim.x) {
+    float a = 0.f;
+    for (int k = 0; k < C; ++k) a = fmaf(e[k], w1[(size_t)o * C + k], a);
+    pre[o] = a + b1[o];
+    act[o] = gelu_erf(pre[o]);
+  }
+  __syncthreads();
+  const float* dy = dtemb + (size_t)b * C;
+  for (int o = threadIdx.x; o < C; o += blockDim.x) atomicAdd(db2 + o, dy[o]);
+  for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) {
+    float dg = 0.f;
+    for (int o = 0; o < C; ++o) {
+      dg = fmaf(dy[o], w2[(size_t)o * 2 * C + k], dg);
+      atomicAdd(dw2 + (size_t)o * 2 * C + k, dy[o] * act[k]);
+    }
+    const float v = pre[k];
+    const float cdf = 0.5f * (1.0f + erff(v * kInvSqrt2));
+    const float pdf = kInvSqrt2Pi * expf(-0.5f * v * v);
+    dpre[k] = dg * (cdf + v * pdf);
+    atomicAdd(db1 + k, dpre[k]);
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * C * C; idx += blockDim.x) {
+    const int o = idx / C, k = idx % C;
+    atomicAdd(dw1 + idx, dpre[o] * e[k]);
+  }
+}
+
+}  // namespace
+
+#define TRAIN_DISPATCH_C(C, ...)                    \
+  switch (C) {                                      \
+    case 512: { constexpr int CC = 512; __VA_ARGS__; break; } \
+    case 256: { constexpr int CC = 256; __VA_ARGS__; break; } \
+    case 128: { constexpr int CC = 128; __VA_ARGS__; break; } \
+    case 64:  { constexpr int CC = 64;  __VA_ARGS__; break; } \
+    default: return -2;                             \
+  }
+
+int d3dp_train_add_mask_ln(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* w,
+                           const float* b, float eps, float* x_out, float* xn, int T, int C, hipStream_t st) {
+  TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((add_mask_ln_kernel<CC>), dim3((T + 3) / 4), dim3(256), 0, st, x_in, y, mask, axis,
+                                         F, J, w, b, eps, x_out, xn, T))
+  return 0;
+}
+int d3dp_train_ln_pos(const float* x, const float* w, const float* b, float eps, const float* pos, int F, int J, float* y,
+                      int T, int C, hipStream_t st) {
+  TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((ln_pos_kernel<CC>), dim3((T + 3) / 4), dim3(256), 0, st, x, w, b, eps, pos, F, J,
+                                         y, T))
+  return 0;
+}
+int d3dp_train_ln_bwd(const float* dy, const float* x, const float* w, float eps, const float* dres, float* dx,
+                      float* dgamma, float* dbeta, int T, int C, hipStream_t st) {
+  const int blocks = (T + 3) / 4 < 1024 ? (T + 3) / 4 : 1024;
+  TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd_kernel<CC>), dim3(blocks), dim3(256), 0, st, dy, x, w, eps, dres, dx,
+                                         dgamma, dbeta, T))
+  return 0;
+}
+int d3dp_train_gelu_fwd(const float* x, float* y, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
+  return 0;
+}
+int d3dp_train_gelu_bwd(const float* dh, const float* x, float* dpre, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dh, x, dpre, n);
+  return 0;
+}
+int d3dp_train_scale_mask(const float* in, const float* mask, int axis, int F, int J, float* out, int T, int C,
+                          hipStream_t st) {
+  const size_t n = (size_t)T * C;
+  hipLaunchKernelGGL(scale_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, mask, axis, F, J, out, T, C);
+  return 0;
+}
+int d3dp_train_colsum(const float* in, float* out, int T, int C, hipStream_t st) {
+  hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, 64), dim3(256), 0, st, in, out, T, C);
+  return 0;
+}
+int d3dp_train_groupsum(const float* in, float* out, int T, int C, int mode, int F, int J, hipStream_t st) {
+  const int groups = mode == 0 ? J : (mode == 1 ? F : T / (F * J));
+  hipLaunchKernelGGL(groupsum_kernel, dim3((C + 255) / 256, groups, 8), dim3(256), 0, st, in, out, T, C, mode, F, J);
+  return 0;
+}
+int d3dp_train_transpose_pad(const float* in, float* out, int R, int C, int Rpad, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_pad_kernel, dim3((Rpad + 31) / 32, (C + 31) / 32), dim3(256), 0, st, in, out, R, C, Rpad);
+  return 0;
+}
+size_t d3dp_train_attn_stats_bytes(int n_seq, int n_tok, int heads) { return (size_t)n_seq * heads * n_tok * sizeof(AttnStats); }
+
+template <int HD>
+static int launch_attn_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, void* stats, int n_seq,
+                           SeqMap map, int C, int heads, hipStream_t st) {
+  const int n = map.n_tok;
+  const size_t lds_q = (size_t)2 * n * (HD + 4) * 4;
+  const size_t lds_kv = lds_q + (size_t)n * sizeof(AttnStats);
+  if (lds_kv > 160 * 1024 || n > 256) return -2;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_q_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kv_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) return -3;
+    attr = true;
+  }
+  const int tq = n <= 64 ? 64 : 256, tkv = 2 * n <= 64 ? 64 : (2 * n <= 256 ? 256 : 512);
+  hipLaunchKernelGGL((attn_bwd_q_kernel<HD>), dim3(n_seq * heads), dim3(tq), lds_q, st, qkv, o, dout, dqkv,
+                     (AttnStats*)stats, map, C, heads);
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<HD>), dim3(n_seq * heads), dim3(tkv), lds_kv, st, qkv, dout, dqkv,
+                     (const AttnStats*)stats, map, C, heads);
+  return 0;
+}
+
+int d3dp_train_attn_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, void* stats, int n_seq,
+                        SeqMap map, int C, int heads, hipStream_t st) {
+  switch (C / heads) {
+    case 64: return launch_attn_bwd<64>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
+    case 32: return launch_attn_bwd<32>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
+    case 16: return launch_attn_bwd<16>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
+    case 8: return launch_attn_bwd<8>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
+    default: return -2;
+  }
+}
+int d3dp_train_embed_bwd(const float* dx, const float* x2d, const float* x3d, float* dW, int T, int C, hipStream_t st) {
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((C + 255) / 256, 64), dim3(256), 0, st, dx, x2d, x3d, dW, T, C);
+  return 0;
+}
+int d3dp_train_head_linear(const float* z, const float* w, const float* b, float* out, int T, int C, hipStream_t st) {
+  TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((head_linear_kernel<CC>), dim3((T + 3) / 4), dim3(256), 0, st, z, w, b, out, T))
+  return 0;
+}
+int d3dp_train_head_bwd(const float* g, const float* z, const float* w, float* dz, float* dW, float* db, int T, int C,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(head_bwd_kernel, dim3((C + 255) / 256, 1), dim3(256), 0, st, g, z, w, dz, dW, db, T, C);
+  return 0;
+}
+int d3dp_train_time_mlp_bwd(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2,
+                            const float* dtemb, float* dw1, float* db1, float* dw2, float* db2, int B, int C,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(time_mlp_bwd_kernel, dim3(B), dim3(256), (size_t)7 * C * sizeof(float), st, t, freq, w1, b1, w2, dtemb,
+                     dw1, db1, dw2, db2, C);
+  return 0;
+}

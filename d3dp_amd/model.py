@@ -40,9 +40,26 @@ def cosine_beta_schedule(timesteps: int, s: float = 0.008) -> torch.Tensor:
 
 def _resolve_mode(numerics: Optional[str]) -> int:
     name = (numerics or os.environ.get("D3DP_NUMERICS", "exact")).lower()
-    if name not in ("exact", "fast"):
-        raise ValueError(f"numerics must be 'exact' or 'fast', got {name!r}")
-    return _lib.MODE_FAST if name == "fast" else _lib.MODE_EXACT
+    if name not in ("exact", "fast", "train"):
+        raise ValueError(f"numerics must be 'exact', 'fast' or 'train', got {name!r}")
+    return {"fast": _lib.MODE_FAST, "exact": _lib.MODE_EXACT, "train": _lib.MODE_TRAIN}[name]
+
+
+class _TrainStep(torch.autograd.Function):
+    """Autograd bridge for the training step: forward = d3dp_train_forward (activations stay in the library
+    workspace), backward = d3dp_train_backward, which fills one gradient buffer per parameter."""
+
+    @staticmethod
+    def forward(ctx, net, x_2d, x_3d, t, masks, *params):
+        ctx.net, ctx.masks = net, masks
+        ctx.save_for_backward(x_2d, x_3d, t)
+        return net._train_forward(x_2d, x_3d, t, masks)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x_2d, x_3d, t = ctx.saved_tensors
+        grads = ctx.net._train_backward(x_2d, x_3d, t, ctx.masks, grad_out.contiguous())
+        return (None, None, None, None, None) + tuple(grads)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -111,7 +128,7 @@ class MixSTE2(nn.Module):
     # -- library context ------------------------------------------------------------------------
     @property
     def numerics(self) -> str:
-        return "fast" if self._mode == _lib.MODE_FAST else "exact"
+        return {_lib.MODE_FAST: "fast", _lib.MODE_EXACT: "exact", _lib.MODE_TRAIN: "train"}[self._mode]
 
     def set_numerics(self, numerics: str, chunk_seqs: Optional[int] = None) -> None:
         self._mode = _resolve_mode(numerics)
@@ -207,13 +224,97 @@ class MixSTE2(nn.Module):
                                                 B, H, ws.data_ptr(), nbytes, _lib.current_stream()), "d3dp_denoise")
         return out
 
-    def forward(self, x_2d, x_3d, t):
-        """Reference signature (mixste.py:278): eval -> x_3d (B,H,F,J,3); train -> x_3d (B,F,J,3).
-        Forward only: DropPath is the identity and no autograd graph is recorded (training backward is not part
-        of this round)."""
+    def forward(self, x_2d, x_3d, t, droppath=None):
+        """Reference signature (mixste.py:278): eval -> x_3d (B,H,F,J,3); train branch -> x_3d (B,F,J,3).
+        In 'train' numerics with grad enabled the train branch is differentiable w.r.t. every parameter
+        (d3dp_train_forward / d3dp_train_backward); DropPath is active in ``.train()`` mode like the reference
+        (mixste.py:100,187) and ``droppath={'STEblocks.i': (m_attn, m_mlp), ...}`` injects recorded masks."""
         if x_3d.dim() == 4:
+            if self._mode == _lib.MODE_TRAIN and torch.is_grad_enabled():
+                masks = self._droppath_masks(x_3d.shape[0], x_3d.device, droppath)
+                return _TrainStep.apply(self, x_2d, x_3d, t, masks, *self.parameters())
             return self.denoise(x_2d, x_3d[:, None], t)[:, 0]
         return self.denoise(x_2d, x_3d, t)
+
+    # -- training step ----------------------------------------------------------------------------
+    def _droppath_masks(self, B, device, injected=None):
+        """(2*depth, 2, B*max(F,J)) fp32 scales (0 or 1/keep) or None.  timm DropPath: per-sample Bernoulli(keep),
+        scaled by 1/keep; block i has rate linspace(0, drop_path_rate, depth)[i] (mixste.py:187); a rate of 0 builds
+        nn.Identity (mixste.py:100)."""
+        Fr, J, dep = self.num_frame, self.num_joints, self.block_depth
+        smax = B * max(Fr, J)
+        if injected is not None:
+            m = torch.ones((2 * dep, 2, smax), dtype=torch.float32)
+            for name, pair in injected.items():
+                kind, i = name.split(".")
+                blk = 2 * int(i) + (1 if kind == "TTEblocks" else 0)
+                for br in (0, 1):
+                    v = pair[br].reshape(-1).float()
+                    m[blk, br, :v.numel()] = v
+            return m.to(device).contiguous()
+        if not self.training or not self.drop_path_rate:
+            return None
+        rates = [x.item() for x in torch.linspace(0, self.drop_path_rate, dep)]
+        m = torch.ones((2 * dep, 2, smax), dtype=torch.float32, device=device)
+        for i, r in enumerate(rates):
+            if r == 0.0:
+                continue
+            keep = 1.0 - r
+            for kind, S in ((0, B * Fr), (1, B * J)):
+                for br in (0, 1):
+                    m[2 * i + kind, br, :S] = torch.empty(S, device=device).bernoulli_(keep) / keep
+        return m
+
+    def _train_io(self, x_2d, x_3d, t):
+        B, Fr, J, _ = x_3d.shape
+        assert x_2d.shape == (B, Fr, J, 2) and Fr == self.num_frame and J == self.num_joints and t.shape == (B,)
+        dev = x_3d.device
+        ctx = self._context(dev)
+        n = C.c_size_t()
+        _lib.check(_lib.load().d3dp_train_workspace_bytes(ctx, B, C.byref(n)), "d3dp_train_workspace_bytes")
+        if getattr(self, "_train_ws", None) is None or self._train_ws.numel() < n.value or self._train_ws.device != dev:
+            self._train_ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
+        return (ctx, B, dev, n.value, x_2d.float().contiguous(), x_3d.float().contiguous(),
+                t.to(device=dev, dtype=torch.int64).contiguous())
+
+    def _train_forward(self, x_2d, x_3d, t, masks):
+        ctx, B, dev, nbytes, x2, x3, tt = self._train_io(x_2d, x_3d, t)
+        out = torch.empty_like(x3)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().d3dp_train_forward(ctx, x2.data_ptr(), x3.data_ptr(), tt.data_ptr(), _lib.ptr(masks),
+                                                      out.data_ptr(), B, self._train_ws.data_ptr(), nbytes,
+                                                      _lib.current_stream()), "d3dp_train_forward")
+        return out
+
+    def _train_backward(self, x_2d, x_3d, t, masks, grad_out):
+        ctx, B, dev, nbytes, x2, x3, tt = self._train_io(x_2d, x_3d, t)
+        g = {id(p): torch.empty_like(p, dtype=torch.float32) for p in self.parameters()}
+
+        def gp(p):
+            return g[id(p)].data_ptr()
+
+        def blocks(mods):
+            arr = (_lib.BlockWeights * len(mods))()
+            for i, b in enumerate(mods):
+                arr[i] = _lib.BlockWeights(gp(b.norm1.weight), gp(b.norm1.bias), gp(b.attn.qkv.weight), gp(b.attn.qkv.bias),
+                                           gp(b.attn.proj.weight), gp(b.attn.proj.bias), gp(b.norm2.weight), gp(b.norm2.bias),
+                                           gp(b.mlp.fc1.weight), gp(b.mlp.fc1.bias), gp(b.mlp.fc2.weight), gp(b.mlp.fc2.bias))
+            return arr
+
+        ste, tte = blocks(self.STEblocks), blocks(self.TTEblocks)
+        dummy = torch.empty(self.embed_dim, dtype=torch.float32, device=dev)      # time_freq has no gradient
+        w = _lib.Weights(gp(self.Spatial_pos_embed), gp(self.Temporal_pos_embed), gp(self.Spatial_patch_to_embedding.weight),
+                         gp(self.Spatial_patch_to_embedding.bias), dummy.data_ptr(), gp(self.time_mlp[1].weight),
+                         gp(self.time_mlp[1].bias), gp(self.time_mlp[3].weight), gp(self.time_mlp[3].bias),
+                         gp(self.Spatial_norm.weight), gp(self.Spatial_norm.bias), gp(self.Temporal_norm.weight),
+                         gp(self.Temporal_norm.bias), gp(self.head[0].weight), gp(self.head[0].bias), gp(self.head[1].weight),
+                         gp(self.head[1].bias), ste, tte)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().d3dp_train_backward(ctx, x2.data_ptr(), x3.data_ptr(), tt.data_ptr(), _lib.ptr(masks),
+                                                       grad_out.float().contiguous().data_ptr(), C.byref(w), B,
+                                                       self._train_ws.data_ptr(), nbytes, _lib.current_stream()),
+                       "d3dp_train_backward")
+        return [g[id(p)] for p in self.parameters()]
 
     # -- profiling passthrough --------------------------------------------------------------------
     def profile_enable(self, on: bool = True):
@@ -276,7 +377,7 @@ class D3DP(nn.Module):
         self.register_buffer('posterior_mean_coef2',
                              (1. - alphas_cumprod_prev) * torch.sqrt(alphas) / (1. - alphas_cumprod))
 
-        numerics = numerics or getattr(args, "numerics", None)
+        numerics = numerics or getattr(args, "numerics", None) or ("train" if is_train else None)
         self.pose_estimator = MixSTE2(num_frame=self.frames, num_joints=NUM_JOINTS, in_chans=2,
                                       embed_dim_ratio=args.cs, depth=args.dep, num_heads=8, mlp_ratio=2.,
                                       qkv_bias=True, qk_scale=None, drop_path_rate=0.1 if is_train else 0,
@@ -438,5 +539,6 @@ class D3DP(nn.Module):
             if self.flip:
                 return self.ddim_sample_flip(input_2d, input_3d, input_2d_flip=input_2d_flip, **kw)
             return self.ddim_sample(input_2d, input_3d, **kw)
+        droppath = kw.pop("droppath", None)
         x_poses, _, t = self.prepare_targets(input_3d, **kw)
-        return self.pose_estimator(input_2d, x_poses.float(), t.squeeze(-1))
+        return self.pose_estimator(input_2d, x_poses.float(), t.squeeze(-1), droppath=droppath)

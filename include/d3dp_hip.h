@@ -46,6 +46,7 @@ enum {
   D3DP_MODE_EXACT = 0,   /* fp32-equivalent: split-bf16 (3 planes, 6 passes) MFMA Linears, fp32 everything else:
                             <= 1e-3 mm vs the reference (env D3DP_EXACT_F32=1: plain fp32 MFMA Linears)       */
   D3DP_MODE_FAST = 1,    /* bf16 activations/weights into v_mfma_f32_16x16x32_bf16, fp32 accumulate/LN/softmax */
+  D3DP_MODE_TRAIN = 2,   /* fp32 weights/activations, fp32-MFMA Linears: required by d3dp_train_*; inference also works */
 };
 
 /* MixSTE2 hyper-parameters -- reference common/diffusionpose.py:123-124, common/mixste.py:142-163 */
@@ -147,6 +148,19 @@ int d3dp_q_sample(const float* x0, const float* noise, const double* sqrt_ac, co
 int d3dp_jpma(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d, float* agg,
               int32_t* sel, float* err_sel, float* err_min, int32_t B, int32_t K, int32_t H, int32_t F, int32_t J,
               int32_t zero_root, void* stream);
+
+/* ---- training step (reference main.py:387-401 around diffusionpose.py:279-287 / mixste.py:215-225) ----------------
+ * Context must be D3DP_MODE_TRAIN.  x3d (B,F,J,3) is the diffused pose from d3dp_q_sample, t (B) int64.
+ * masks: NULL, or DropPath scales (timm semantics, values 0 or 1/keep) laid out [2*depth blocks (STE0,TTE0,STE1,..)]
+ * [2 branches (attention, MLP)][B*max(F,J)] floats; entry s of a spatial block is sample b*F+f, of a temporal block b*J+n.
+ * d3dp_train_forward keeps every activation the backward needs in `workspace`; d3dp_train_backward must follow with the
+ * same inputs/masks/workspace.  grads: device fp32 buffers shaped like the weights (zeroed, then filled, here). */
+int d3dp_train_workspace_bytes(const d3dp_ctx* ctx, int32_t B, size_t* bytes);
+int d3dp_train_forward(d3dp_ctx* ctx, const float* x2d, const float* x3d, const int64_t* t, const float* masks, float* out,
+                       int32_t B, void* workspace, size_t workspace_bytes, void* stream);
+int d3dp_train_backward(d3dp_ctx* ctx, const float* x2d, const float* x3d, const int64_t* t, const float* masks,
+                        const float* grad_out, const d3dp_weights* grads, int32_t B, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* ---- single operators (unit parity tests; same kernels the denoiser launches) ---------------------------- */
 /* out[M,N] = epi(A[M,K] W[N,K]^T + bias).  epi & 3: 0 bias, 1 bias+GELU(erf), 2 out(fp32) += result.

@@ -228,9 +228,68 @@ def test_train_branch_forward_matches_golden(golden_dir):
     m = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=True, numerics="exact")
     m.load_state_dict(make_state_dict(int(g["seed"]), cs, dep, Fr), strict=False)
     m = m.cuda()
-    pred = m(torch.from_numpy(g["x2d"]).cuda(), torch.from_numpy(g["gt"]).cuda(),
-             t=torch.from_numpy(g["t"]).reshape(-1, 1), noise=torch.from_numpy(g["noise"]))
+    with torch.no_grad():
+        pred = m(torch.from_numpy(g["x2d"]).cuda(), torch.from_numpy(g["gt"]).cuda(),
+                 t=torch.from_numpy(g["t"]).reshape(-1, 1), noise=torch.from_numpy(g["noise"]))
     assert orc.mpjpe_mm(pred.cpu(), torch.from_numpy(g["pred_nodrop"])) <= EXACT_TOL_MM
+
+
+@pytest.mark.parametrize("tag", ["nodrop", "drop"])
+def test_training_step_matches_reference(golden_dir, tag):
+    """BASELINE config 5 in miniature (fixture g6: F=27, B=4, cs=64, dep=2): q_sample + MixSTE2 train-branch forward,
+    MPJPE loss, backward seeded with the loss value (main.py:393) -- loss, prediction and the gradient norms of four
+    parameters against the reference's own autograd, without and with (recorded) DropPath masks."""
+    g = load_g(golden_dir, "g6_train_step")
+    cs, dep, Fr = int(g["cs"]), int(g["dep"]), int(g["frames"])
+    args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
+    m = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=True)
+    assert m.pose_estimator.numerics == "train"
+    m.load_state_dict(make_state_dict(int(g["seed"]), cs, dep, Fr), strict=False)
+    m = m.cuda().train()
+    if tag == "nodrop":
+        m.eval()                       # DropPath off (nn.Module.training False); D3DP.is_train keeps the train branch
+    dpd = None
+    if tag == "drop":
+        masks = [torch.from_numpy(g[f"drop_mask{k}"]) for k in range(int(g["drop_masks_n"]))]
+        it, dpd = iter(masks), {}
+        for i in range(1, dep):        # rate linspace(0, 0.1, dep)[0] == 0 -> Identity
+            dpd[f"STEblocks.{i}"] = (next(it), next(it))
+            dpd[f"TTEblocks.{i}"] = (next(it), next(it))
+    gt = torch.from_numpy(g["gt"]).cuda()
+    pred = m(torch.from_numpy(g["x2d"]).cuda(), gt, t=torch.from_numpy(g["t"]).reshape(-1, 1),
+             noise=torch.from_numpy(g["noise"]), droppath=dpd)
+    assert pred.requires_grad
+    assert orc.mpjpe_mm(pred.detach().cpu(), torch.from_numpy(g[f"pred_{tag}"])) <= EXACT_TOL_MM
+    loss = torch.mean(torch.norm(pred - gt, dim=-1))            # loss.py:13
+    assert abs(loss.item() - float(g[f"loss_{tag}"])) < 2e-6
+    loss.backward(loss.clone().detach())                         # main.py:393
+    params = dict(m.named_parameters())
+    checked = 0
+    for key in g.files:
+        if key.startswith(f"gradnorm_{tag}::"):
+            name = key.split("::", 1)[1]
+            got = params[name].grad.double().norm().item()
+            want = float(g[key])
+            print(f"[{tag}] |grad {name}| = {got:.6e} (reference {want:.6e})")
+            assert got == pytest.approx(want, rel=2e-4), name
+            checked += 1
+    assert checked == 4
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    # every parameter's gradient against torch autograd through the CPU oracle (same inputs, masks and seeding)
+    sd = make_state_dict(int(g["seed"]), cs, dep, Fr)
+    po = {k: v.clone().requires_grad_(True) for k, v in orc.strip_prefix(sd).items()}
+    xp = orc.prepare_targets(orc.cosine_schedule(1000), torch.from_numpy(g["gt"]), torch.from_numpy(g["t"]),
+                             torch.from_numpy(g["noise"]))
+    pred_o = orc.mixste_forward(po, torch.from_numpy(g["x2d"]), xp, torch.from_numpy(g["t"]), dep, droppath=dpd)
+    loss_o = torch.mean(torch.norm(pred_o - torch.from_numpy(g["gt"]), dim=-1))
+    loss_o.backward(loss_o.clone().detach())
+    worst = 0.0
+    for name, p in m.pose_estimator.named_parameters():
+        ref = po[name].grad
+        err = (p.grad.cpu().double() - ref.double()).norm().item() / max(ref.double().norm().item(), 1e-12)
+        worst = max(worst, err)
+        assert err < 2e-3, (name, err)
+    print(f"[{tag}] worst relative gradient error over {len(po)} parameters: {worst:.2e}")
 
 
 # ------------------------------------------------------------------------------------------------ sampler
