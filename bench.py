@@ -210,7 +210,7 @@ def main():
             me = build_model(H, K, "exact", a.chunk_seqs)
             dte, _ = timed_steps(me, x2d[:Be].contiguous(), x2f[:Be].contiguous(), 1, 1, gen, gather=False)
             res["exact_mode"] = {"value": Be * H / dte, "unit": "hypothesis-clips/s", "dtype": "f32",
-                                 "workload": f"same path, numerics=exact (fp32 MFMA), B={Be} H={H} K={K}, 1 step after 1 warmup",
+                                 "workload": f"same path, numerics=exact (split-bf16 MFMA Linears, fp32 elsewhere), B={Be} H={H} K={K}, 1 step after 1 warmup",
                                  "whole_path_tflops": Be * H / dte * flop_per_unit / 1e12}
             del me
         res["parity"] = quick_parity()

@@ -418,3 +418,56 @@ def test_jpma_kernel_matches_reference_metrics(golden_dir):
     pz[:, :, :, :, 0] = 0
     want = jpma.jpma_aggregate(pz, torch.from_numpy(g["reproj"]), x2)
     assert torch.equal(agg.cpu(), want)
+
+
+def test_training_step_config5_vs_oracle_autograd():
+    """BASELINE config 5 at full size: F=243, J=17, H=1, batch=4, cs=512, dep=8, q_sample + MixSTE2 fwd/bwd, MPJPE loss,
+    DropPath active (recorded masks).  Loss and EVERY parameter gradient against torch autograd through the CPU oracle."""
+    import time
+    Fr, B, cs, dep = 243, 4, 512, 8
+    args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
+    sd = make_state_dict(7, cs, dep, Fr)
+    m = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=True)
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda().train()
+    x2d = torch.from_numpy(synthetic_inputs_2d(901, B, Fr))
+    gt = torch.from_numpy(synthetic_noise(902, (B, Fr, 17, 3))) * 0.3
+    gt[:, :, 0] = 0
+    t = torch.tensor([[3], [250], [640], [999]], dtype=torch.long)
+    noise = torch.from_numpy(synthetic_noise(903, (B, Fr, 17, 3)))
+    rates = [x.item() for x in torch.linspace(0, 0.1, dep)]
+    gmask = torch.Generator().manual_seed(5)
+    dpd = {}
+    for i in range(1, dep):
+        keep = 1 - rates[i]
+        mk = lambda S: (torch.rand(S, 1, 1, generator=gmask) < keep).float() / keep
+        dpd[f"STEblocks.{i}"] = (mk(B * Fr), mk(B * Fr))
+        dpd[f"TTEblocks.{i}"] = (mk(B * 17), mk(B * 17))
+    def step():
+        m.zero_grad(set_to_none=True)
+        pred = m(x2d.cuda(), gt.cuda(), t=t, noise=noise, droppath=dpd)
+        loss = torch.mean(torch.norm(pred - gt.cuda(), dim=-1))
+        loss.backward(loss.clone().detach())
+        return pred, loss
+    pred, loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pred, loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"config-5 training step (fwd+bwd, fp32 MFMA): {dt * 1e3:.1f} ms = {3 * 4 * 294.86e9 / dt / 1e12:.1f} TFLOP/s")
+    po = {k: v.clone().requires_grad_(True) for k, v in orc.strip_prefix(sd).items()}
+    xp = orc.prepare_targets(orc.cosine_schedule(1000), gt, t[:, 0], noise)
+    pred_o = orc.mixste_forward(po, x2d, xp, t[:, 0], dep, droppath=dpd)
+    loss_o = torch.mean(torch.norm(pred_o - gt, dim=-1))
+    loss_o.backward(loss_o.clone().detach())
+    assert orc.mpjpe_mm(pred.detach().cpu(), pred_o.detach()) <= EXACT_TOL_MM
+    assert abs(loss.item() - loss_o.item()) < 2e-6
+    worst = ("", 0.0)
+    for name, p in m.pose_estimator.named_parameters():
+        ref = po[name].grad.double()
+        err = (p.grad.cpu().double() - ref).norm().item() / max(ref.norm().item(), 1e-12)
+        if err > worst[1]:
+            worst = (name, err)
+        assert err < 5e-3, (name, err)
+    print(f"config-5: worst relative gradient error over {len(po)} parameters: {worst[1]:.2e} ({worst[0]})")
