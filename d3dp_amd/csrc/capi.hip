@@ -660,7 +660,8 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     int r;
     if ((r = d3dp_train_transpose_pad(dY, At, T, N, Tp, st))) return r;
     if ((r = d3dp_train_transpose_pad(X, Xt, T, K, Tp, st))) return r;
-    return lin32(At, Xt, zb, dW, N, K, Tp, st);
+    if (hipMemsetAsync(dW, 0, (size_t)N * K * 4, st) != hipSuccess) return -3;
+    return d3dp_launch_linear_f32_splitk(At, Xt, dW, N, K, Tp, st);       // contraction over tokens: split-K
   };
   // dgrad: dX[T, K] = dY[T, N] W[N, K]   (W transposed to [K, N])
   auto dgrad = [&](const float* dY, int N, const float* W, int K, float* dX) -> int {

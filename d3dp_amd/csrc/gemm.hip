@@ -28,13 +28,17 @@ constexpr int BM = 128, BN = 128;
 template <int EPI, typename OutT>
 __device__ __forceinline__ void epilogue4(const float* v, const float* __restrict__ bias, OutT* out,
                                           size_t row_off, int n) {
-  const float4 b = *reinterpret_cast<const float4*>(bias + n);
+  const float4 b = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
   float r[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
   if constexpr (EPI == EPI_GELU) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = gelu_erf(r[i]);
   }
-  if constexpr (EPI == EPI_RESID) {
+  if constexpr (EPI == EPI_ATOMIC) {
+    float* o = reinterpret_cast<float*>(out) + row_off + n;     // split-K partial sums (out pre-zeroed by the caller)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) atomicAdd(o + i, r[i]);
+  } else if constexpr (EPI == EPI_RESID) {
     float* o = reinterpret_cast<float*>(out) + row_off + n;
     float4 x = *reinterpret_cast<float4*>(o);
     x.x += r[0]; x.y += r[1]; x.z += r[2]; x.w += r[3];
@@ -154,7 +158,7 @@ constexpr int XLD = BM + 4;   // padded leading dimension of the k-major LDS til
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                        const float* __restrict__ bias, float* out, int M, int N,
-                                                       int K, int n_tiles_n) {
+                                                       int K, int n_tiles_n, int nk_per_split) {
   __shared__ float As[2][XBK][XLD];
   __shared__ float Ws[2][XBK][XLD];
 
@@ -202,13 +206,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = K / XBK;
-  gload(0);
+  // split-K: blockIdx.y owns k-steps [kt0, nk) of the K / XBK total (gridDim.y == 1: everything)
+  const int kt0 = blockIdx.y * nk_per_split;
+  const int nk = min(K / XBK, kt0 + nk_per_split);
+  if (kt0 >= nk) return;
+  gload(kt0);
   lstore(0);
   __syncthreads();
   const int l31 = lane & 31, lh = lane >> 5;
   int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
     for (int kk = 0; kk < XBK / 2; ++kk) {
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         const int n = n0 + wc * 64 + ni * 32 + q * 8 + lh * 4;
         if (n >= N) continue;
         float v[4] = {acc[mi][ni][q * 4 + 0], acc[mi][ni][q * 4 + 1], acc[mi][ni][q * 4 + 2], acc[mi][ni][q * 4 + 3]};
-        epilogue4<EPI, float>(v, bias, out, (size_t)m * N, n);
+        epilogue4<EPI, float>(v, (EPI == EPI_ATOMIC && blockIdx.y != 0) ? nullptr : bias, out, (size_t)m * N, n);
       }
   }
 }
@@ -275,10 +282,25 @@ int d3dp_launch_linear_f32(int epi, const float* A, const float* W, const float*
   if (K % XBK != 0 || N % 4 != 0 || M <= 0) return -1;
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
   dim3 g(tm * tn), b(256);
-  if (epi == EPI_RESID) hipLaunchKernelGGL((gemm_f32_kernel<EPI_RESID>), g, b, 0, st, A, W, bias, out, M, N, K, tn);
-  else if (epi == EPI_GELU) hipLaunchKernelGGL((gemm_f32_kernel<EPI_GELU>), g, b, 0, st, A, W, bias, out, M, N, K, tn);
-  else if (epi == EPI_BIAS) hipLaunchKernelGGL((gemm_f32_kernel<EPI_BIAS>), g, b, 0, st, A, W, bias, out, M, N, K, tn);
+  const int nk = K / XBK;
+  if (epi == EPI_RESID) hipLaunchKernelGGL((gemm_f32_kernel<EPI_RESID>), g, b, 0, st, A, W, bias, out, M, N, K, tn, nk);
+  else if (epi == EPI_GELU) hipLaunchKernelGGL((gemm_f32_kernel<EPI_GELU>), g, b, 0, st, A, W, bias, out, M, N, K, tn, nk);
+  else if (epi == EPI_BIAS) hipLaunchKernelGGL((gemm_f32_kernel<EPI_BIAS>), g, b, 0, st, A, W, bias, out, M, N, K, tn, nk);
   else return -1;
+  return 0;
+}
+
+// split-K form for tall contractions (wgrad: K = tokens): `out` must be zeroed by the caller; partial products are
+// accumulated with fp32 atomics (summation order not fixed: last-bit run-to-run variation, fine for gradients).
+int d3dp_launch_linear_f32_splitk(const float* A, const float* W, float* out, int M, int N, int K, hipStream_t st) {
+  if (K % XBK != 0 || N % 4 != 0 || M <= 0) return -1;
+  const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+  const int nk = K / XBK;
+  int splits = (1024 + tm * tn - 1) / (tm * tn);                 // aim at >= 4 workgroups per CU
+  if (splits > nk / 8) splits = nk / 8 > 0 ? nk / 8 : 1;
+  const int per = (nk + splits - 1) / splits;
+  hipLaunchKernelGGL((gemm_f32_kernel<EPI_ATOMIC>), dim3(tm * tn, (nk + per - 1) / per), dim3(256), 0, st, A, W, nullptr,
+                     out, M, N, K, tn, per);
   return 0;
 }
 
