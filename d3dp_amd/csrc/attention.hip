@@ -83,34 +83,50 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qk
   for (int d = 0; d < HD; ++d) o[d] = 0.f;
   const float scale = 1.0f / sqrtf((float)HD);
   float m = -INFINITY, l = 0.f;
-  for (int j = 0; j < n; ++j) {
-    float s0 = 0.f, s1 = 0.f;
+  // online softmax over groups of KB keys: KB independent score accumulators per pass (the dot products are latency
+  // chains; with one wave per SIMD in the 243-key configuration nothing else hides them)
+  constexpr int KB = 4;
+  for (int j0 = 0; j0 < n; j0 += KB) {
+    float sc[KB];
+#pragma unroll
+    for (int u = 0; u < KB; ++u) sc[u] = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      float kv[VN];
-      ld_vec<T, VN>(Ks + j * LDR + c * VN, kv);
 #pragma unroll
-      for (int e = 0; e < VN; e += 2) {
-        s0 = fmaf(q[c * VN + e], kv[e], s0);
-        s1 = fmaf(q[c * VN + e + 1], kv[e + 1], s1);
+      for (int u = 0; u < KB; ++u) {
+        const int j = min(j0 + u, n - 1);
+        float kv[VN];
+        ld_vec<T, VN>(Ks + j * LDR + c * VN, kv);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) sc[u] = fmaf(q[c * VN + e], kv[e], sc[u]);
       }
     }
-    const float s = (s0 + s1) * scale;
-    if (s > m) {
-      const float f = expf(m - s);
+    float gm = m;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      sc[u] = (j0 + u < n) ? sc[u] * scale : -INFINITY;
+      gm = fmaxf(gm, sc[u]);
+    }
+    if (gm > m) {
+      const float f = expf(m - gm);
       l *= f;
 #pragma unroll
       for (int d = 0; d < HD; ++d) o[d] *= f;
-      m = s;
+      m = gm;
     }
-    const float p = expf(s - m);
-    l += p;
+    float p[KB];
+#pragma unroll
+    for (int u = 0; u < KB; ++u) { p[u] = expf(sc[u] - m); l += p[u]; }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      float vv[VN];
-      ld_vec<T, VN>(Vs + j * LDR + c * VN, vv);
 #pragma unroll
-      for (int e = 0; e < VN; ++e) o[c * VN + e] = fmaf(p, vv[e], o[c * VN + e]);
+      for (int u = 0; u < KB; ++u) {
+        const int j = min(j0 + u, n - 1);
+        float vv[VN];
+        ld_vec<T, VN>(Vs + j * LDR + c * VN, vv);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) o[c * VN + e] = fmaf(p[u], vv[e], o[c * VN + e]);
+      }
     }
   }
   const float inv = 1.0f / l;
