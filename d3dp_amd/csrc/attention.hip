@@ -559,6 +559,145 @@ __global__ __launch_bounds__(256) void attn_spatial_bf16_kernel(const bf16* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// EXACT-mode temporal attention on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: bitwise an fp32 fmaf chain).
+// Same dataflow as the bf16 kernel -- S^T = K Q^T so the probabilities are already the B operand of O^T = V^T P^T --
+// with fp32 K/V images in LDS (row strides 65 / 68 floats: conflict-free ds_read_b32 fragments), the whole score
+// row-block in registers, two-pass fp32 softmax.  Output: fp32, or three split-bf16 planes (OUT3) for the bf16x3
+// Linear that follows.
+// ------------------------------------------------------------------------------------------------
+constexpr int LDKF = 65, LDVF = 68;
+
+template <int NKT, bool OUT3>
+__global__ __launch_bounds__(256, 1) void attn_temporal_f32_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
+                                                                SeqMap map, int C, int heads, size_t plane) {
+  constexpr int NK = 16 * NKT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* KS = reinterpret_cast<float*>(smem);
+  float* VS = KS + NK * LDKF + 3;          // keep V rows 16-byte aligned (NK*65 + 3 is a multiple of 4 for NK % 16 == 0)
+  static_assert((16 * LDKF + 0) % 1 == 0, "");
+  const int n = map.n_tok;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
+  const int base = seq_base(map, seq);
+  const int ts = map.tok_stride;
+  const size_t ld = (size_t)3 * C;
+  const float* qbase = qkv + (size_t)base * ld + (size_t)head * 64;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int n_qt = (n + 15) >> 4;
+
+  // stage K (scalar stores, stride 65) and V (float4 stores, stride 68); zero the padding rows of V
+  for (int idx = tid; idx < NK * 16; idx += 256) {
+    const int row = idx >> 4, c4 = (idx & 15) * 4;
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (row < n) {
+      const float* src = qbase + (size_t)row * ts * ld + c4;
+      kv = *reinterpret_cast<const float4*>(src + C);
+      vv = *reinterpret_cast<const float4*>(src + 2 * C);
+    }
+    float* kd = KS + row * LDKF + c4;
+    kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+    *reinterpret_cast<float4*>(VS + row * LDVF + c4) = vv;
+  }
+  __syncthreads();
+  const float cexp = 0.125f * 1.44269504088896340736f;
+  for (int qt = wave; qt < n_qt; qt += 4) {
+    const int q = qt * 16 + fi;
+    // contraction index of MFMA step kk for lane group g is d = 16 g + kk (K fragments use the same map)
+    const float* qsrc = qbase + (size_t)min(q, n - 1) * ts * ld + fg * 16;
+    float qv[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(qsrc + c * 4);
+      qv[c * 4] = a.x; qv[c * 4 + 1] = a.y; qv[c * 4 + 2] = a.z; qv[c * 4 + 3] = a.w;
+    }
+    f32x4 s[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      const float* kr = KS + (t * 16 + fi) * LDKF + fg * 16;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) a = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[kk], qv[kk], a, 0, 0, 0);
+      s[t] = a;                                   // S^T[key = 16t + 4 fg + r][query fi]
+      __builtin_amdgcn_sched_barrier(0);          // bound the ds_read hoisting window (VGPR pressure)
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      if (16 * (t + 1) > n) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * t + 4 * fg + r >= n) s[t][r] = -INFINITY;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // exp(x) with x = (s - max) / 8 in natural units: exp2f keeps one rounding of the scaled argument
+        s[t][r] = exp2f((s[t][r] - mx) * cexp);
+        sum += s[t][r];
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    f32x4 o[4];
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* vr = VS + (t * 16 + 4 * fg + r) * LDVF + fi;   // V[key][dn*16 + fi]
+#pragma unroll
+        for (int dn = 0; dn < 4; ++dn) o[dn] = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[dn * 16], s[t][r], o[dn], 0, 0, 0);
+        if (r == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    if (q < n) {
+      const float inv = 1.0f / sum;
+      const size_t off = (size_t)(base + q * ts) * C + head * 64 + fg * 4;
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) {
+        float r4[4] = {o[dn][0] * inv, o[dn][1] * inv, o[dn][2] * inv, o[dn][3] * inv};
+        if constexpr (OUT3) {
+          bf16* dst = reinterpret_cast<bf16*>(out_v) + off + dn * 16;
+          bf16x4 p0, p1, p2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            bf16 a0, a1, a2;
+            split3(r4[e], a0, a1, a2);
+            p0[e] = a0; p1[e] = a1; p2[e] = a2;
+          }
+          *reinterpret_cast<bf16x4*>(dst) = p0;
+          *reinterpret_cast<bf16x4*>(dst + plane) = p1;
+          *reinterpret_cast<bf16x4*>(dst + 2 * plane) = p2;
+        } else {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(out_v) + off + dn * 16) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        }
+      }
+    }
+  }
+}
+
+template <int NKT, bool OUT3>
+int launch_temporal_f32(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, hipStream_t st) {
+  constexpr int NK = 16 * NKT;
+  const size_t lds = (size_t)(NK * LDKF + 3 + NK * LDVF) * 4 + 16;
+  auto kern = attn_temporal_f32_kernel<NKT, OUT3>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) return -3;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(256), lds, st, (const float*)qkv, out, map, C, heads, plane);
+  return 0;
+}
+
 template <int NKT>
 int launch_temporal2(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st) {
   constexpr int NK = 16 * NKT;
@@ -600,6 +739,22 @@ int d3dp_launch_attn_temporal_bf16(const void* qkv, void* out, int n_seq, SeqMap
   if (n <= 64) return launch_temporal2<4>(qkv, out, n_seq, map, C, heads, st);
   if (n <= 128) return launch_temporal2<8>(qkv, out, n_seq, map, C, heads, st);
   return launch_temporal2<16>(qkv, out, n_seq, map, C, heads, st);
+}
+
+// EXACT-mode temporal axis on the fp32 matrix cores (head dim 64); act 0 -> fp32 out, act 2 -> split-bf16 planes out
+int d3dp_launch_attn_temporal_f32(int act, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
+                                  hipStream_t st) {
+  if (C / heads != 64 || map.n_tok > 256 || map.n_tok < 1 || (act != 0 && act != 2)) return -2;
+  const size_t plane = (size_t)n_seq * map.n_tok * C;
+  const int n = map.n_tok;
+#define TF32_CASE(NKT_)                                                                                       \
+  return act == 2 ? launch_temporal_f32<NKT_, true>(qkv, out, n_seq, map, C, heads, plane, st)                \
+                  : launch_temporal_f32<NKT_, false>(qkv, out, n_seq, map, C, heads, plane, st);
+  if (n <= 32) { TF32_CASE(2) }
+  if (n <= 64) { TF32_CASE(4) }
+  if (n <= 128) { TF32_CASE(8) }
+  TF32_CASE(16)
+#undef TF32_CASE
 }
 
 // spatial axis on MFMA (bf16, head dim 64, <= 32 tokens per sequence)

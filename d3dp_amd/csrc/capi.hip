@@ -175,6 +175,9 @@ int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, hipSt
   if (c->fast() && g.channels / g.heads == 64)
     return d3dp_launch_attn_temporal_bf16(qkv, out, n_bh * g.joints, temporal_map(g.frames, g.joints), g.channels,
                                           g.heads, st);
+  if (!c->fast() && g.channels / g.heads == 64 && !c->attn_rows_spatial)     // fp32 matrix cores (D3DP_ATTN_V1=1: row kernel)
+    return d3dp_launch_attn_temporal_f32(c->act(), qkv, out, n_bh * g.joints, temporal_map(g.frames, g.joints),
+                                         g.channels, g.heads, st);
   return d3dp_launch_attn_rows(c->act(), qkv, out, n_bh * g.joints, temporal_map(g.frames, g.joints), g.channels,
                                g.heads, st);
 }
@@ -462,7 +465,9 @@ int d3dp_op_attention(int32_t act_bf16, int32_t impl, int32_t axis, const void* 
     if (!act_bf16) return fail(D3DP_EINVAL, "MFMA spatial attention needs bf16 activations");
     LAUNCH_TRY(d3dp_launch_attn_spatial_bf16(qkv, out, n_bh * F, spatial_map(F, J), C, heads, st));
   } else if (axis == 0) LAUNCH_TRY(d3dp_launch_attn_rows(act_bf16, qkv, out, n_bh * F, spatial_map(F, J), C, heads, st));
-  else if (impl == 1) {
+  else if (impl == 1 && !act_bf16) {
+    LAUNCH_TRY(d3dp_launch_attn_temporal_f32(0, qkv, out, n_bh * J, temporal_map(F, J), C, heads, st));   // fp32 MFMA
+  } else if (impl == 1) {
     if (!act_bf16) return fail(D3DP_EINVAL, "MFMA temporal attention needs bf16 activations");
     LAUNCH_TRY(d3dp_launch_attn_temporal_bf16(qkv, out, n_bh * J, temporal_map(F, J), C, heads, st));
   } else LAUNCH_TRY(d3dp_launch_attn_rows(act_bf16, qkv, out, n_bh * J, temporal_map(F, J), C, heads, st));

@@ -136,7 +136,8 @@ def ref_attention(qkv, n_bh, F, J, C, heads, axis):
 
 
 @pytest.mark.parametrize("act,impl,axis,F,C", [
-    ("f32", 0, 0, 27, 512), ("f32", 0, 1, 27, 512), ("f32", 0, 1, 243, 512), ("f32", 0, 0, 9, 64), ("f32", 0, 1, 9, 64),
+    ("f32", 0, 0, 27, 512), ("f32", 0, 1, 27, 512), ("f32", 0, 1, 243, 512), ("f32", 1, 1, 243, 512), ("f32", 1, 1, 27, 512),
+    ("f32", 1, 1, 100, 512), ("f32", 0, 0, 9, 64), ("f32", 0, 1, 9, 64),
     ("bf16", 0, 0, 27, 512), ("bf16", 1, 0, 27, 512), ("bf16", 1, 0, 243, 512), ("bf16", 1, 1, 27, 512), ("bf16", 1, 1, 243, 512), ("bf16", 1, 1, 100, 512),
     ("bf16", 0, 1, 243, 512)])
 def test_attention(lib, act, impl, axis, F, C):
@@ -164,7 +165,7 @@ def test_attention_softmax_spike(lib):
     qkv = torch.randn(n_bh * F * J, 3 * C, generator=g)
     qkv[100 * J + 3, :C] *= 30.0
     qkv[7 * J + 3, C:2 * C] = qkv[100 * J + 3, :C] / 30.0 * 4.0
-    for bf, impl in ((False, 0), (True, 1)):
+    for bf, impl in ((False, 0), (False, 1), (True, 1)):
         src = bf16_round(qkv) if bf else qkv
         want = ref_attention(src, n_bh, F, J, C, heads, 1)
         qd = (qkv.to(torch.bfloat16) if bf else qkv).cuda().contiguous()
