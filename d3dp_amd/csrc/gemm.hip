@@ -328,7 +328,8 @@ __device__ __forceinline__ int swz3(int row, int s) { return s ^ (((row >> 3) & 
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16x3_kernel(const bf16* __restrict__ A3, const bf16* __restrict__ W3,
                                                           const float* __restrict__ bias, float* __restrict__ outf,
-                                                          bf16* __restrict__ out3, int M, int N, int K, int n_tiles_n) {
+                                                          bf16* __restrict__ out3, int M, int N, int K, int n_tiles_n,
+                                                          int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (L / n_tiles_n) * TBM;
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_kernel(const bf16* __restrict
   const int fi = lane & 15, fg = lane >> 4;
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    if (kt + 1 < nk && !(dbg & 1)) stage(cur ^ 1, kt + 1);
     const char* sa = smem + cur * TSTAGE;
     const char* sw = sa + 3 * TA_PLANE;
     bf16x8 wf[4][3];
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_kernel(const bf16* __restrict
     for (int ni = 0; ni < 4; ++ni) {
       const int n = n0 + wc * 64 + ni * 16 + fg * 4;
       if (n >= N) continue;
+      if (dbg & 2) continue;
       const float4 b = *reinterpret_cast<const float4*>(bias + n);
       float r[4] = {acc[mi][ni][0] + b.x, acc[mi][ni][1] + b.y, acc[mi][ni][2] + b.z, acc[mi][ni][3] + b.w};
       if constexpr (EPI == EPI_GELU) {
@@ -467,12 +469,14 @@ int d3dp_launch_linear_bf16x3(int epi, const void* A3, const void* W3, const flo
                             hipFuncAttributeMaxDynamicSharedMemorySize, TLDS) != hipSuccess) return -3;
     attr_set = true;
   }
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("D3DP_GEMM_DBG"); dbg = e ? atoi(e) : 0; }   // timing ablations only (results invalid)
   if (epi == EPI_BIAS)
     hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI_BIAS>), dim3(tm * tn), dim3(512), TLDS, st, (const bf16*)A3, (const bf16*)W3,
-                       bias, outf, (bf16*)out3, M, N, K, tn);
+                       bias, outf, (bf16*)out3, M, N, K, tn, dbg);
   else if (epi == EPI_GELU)
     hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI_GELU>), dim3(tm * tn), dim3(512), TLDS, st, (const bf16*)A3, (const bf16*)W3,
-                       bias, outf, (bf16*)out3, M, N, K, tn);
+                       bias, outf, (bf16*)out3, M, N, K, tn, dbg);
   else return -1;
   return 0;
 }

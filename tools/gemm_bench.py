@@ -16,11 +16,38 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--tile", action="store_true", help="per-tile 128x128 kernel instead of the streaming one")
     ap.add_argument("--shapes", default="qkv,proj,fc1,fc2")
+    ap.add_argument("--x3", action="store_true", help="EXACT-mode split-bf16 kernel (three planes per operand)")
     a = ap.parse_args()
     lib = _lib.load()
     M = a.m
     shapes = {"qkv": (1536, 512, 0), "proj": (512, 512, 16), "fc1": (1024, 512, 1), "fc2": (512, 1024, 16)}
     st = torch.cuda.current_stream().cuda_stream
+    if a.x3:
+        for name in a.shapes.split(","):
+            N, K, epi = shapes[name]
+            epi = 1 if name == "fc1" else 0
+            A = torch.randn(M, K, device="cuda")
+            W = torch.randn(N, K, device="cuda") / K ** 0.5
+            A3 = torch.empty(3, M, K, dtype=torch.bfloat16, device="cuda")
+            W3 = torch.empty(3, N, K, dtype=torch.bfloat16, device="cuda")
+            _lib.check(lib.d3dp_op_split3(A.data_ptr(), A3.data_ptr(), M * K, st))
+            _lib.check(lib.d3dp_op_split3(W.data_ptr(), W3.data_ptr(), N * K, st))
+            b = torch.randn(N, device="cuda")
+            out = torch.empty(3 * M * N if epi else M * N * 2, device="cuda", dtype=torch.bfloat16)
+            ts = []
+            for i in range(a.iters + 3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.check(lib.d3dp_op_linear(2, epi, A3.data_ptr(), W3.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, st))
+                e1.record()
+                torch.cuda.synchronize()
+                if i >= 3:
+                    ts.append(e0.elapsed_time(e1))
+            ts.sort()
+            med = ts[len(ts) // 2]
+            print(f"x3 {name:5s} M={M} N={N} K={K}: median {med * 1e3:8.1f} us  {2 * M * N * K / med / 1e9:7.1f} TFLOP/s effective "
+                  f"({6 * 2 * M * N * K / med / 1e9:7.1f} TFLOP/s of MFMA work)")
+        return
     for name in a.shapes.split(","):
         N, K, epi = shapes[name]
         if a.tile:
