@@ -536,8 +536,11 @@ __device__ __forceinline__ int sperm(int q) {   // q = ni*16 + i in [0,64)
   return (ni >> 1) * 32 + (i >> 2) * 8 + (ni & 1) * 4 + (i & 3);
 }
 
-template <int EPI, typename OutT, int NK>
-__global__ __launch_bounds__(768) void gemm_bf16_stream_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
+// MI = 16-row MFMA blocks per compute wave: MI = 4 -> 8 compute waves (4 x 2, 64x64 each, two per SIMD);
+// MI = 8 -> 4 compute waves (2 x 2, 128x64 each, ONE per SIMD next to one loader wave: no matrix-pipe / issue
+// contention between compute waves, 0.375 instead of 0.5 LDS fragment reads per MFMA).
+template <int EPI, typename OutT, int NK, int MI>
+__global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                                const float* __restrict__ bias, OutT* __restrict__ out,
                                                                int M, int N, int tiles_n, int total_tiles, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -549,15 +552,17 @@ __global__ __launch_bounds__(768) void gemm_bf16_stream_kernel(const bf16* __res
   const int n_my = (total_tiles - L + G - 1) / G;      // tiles L, L+G, ...
   const int gtot = n_my * NK;
 
+  constexpr int NCW = (SBM / (MI * 16)) * 2;          // compute waves
+  constexpr int NU = 2 * MI;                          // pending 8-column units per wave and tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  for (int i = tid; i < N; i += 768) sbias[i] = bias[i];
+  for (int i = tid; i < N; i += (NCW + 4) * 64) sbias[i] = bias[i];
   __syncthreads();
 
-  if (wave >= 8) {
+  if (wave >= NCW) {
     // ------------------------------------------------------------------ loader waves
-    const int lw = wave - 8;
+    const int lw = wave - NCW;
     const int lrow = lane >> 3, lslot = lane & 7;
     auto issue = [&](int g) {
       const int ti = g / NK, ks = g - ti * NK;
@@ -595,11 +600,11 @@ __global__ __launch_bounds__(768) void gemm_bf16_stream_kernel(const bf16* __res
   // -------------------------------------------------------------------- compute waves
   const int wr = wave >> 1, wc = wave & 1;
   const int fi = lane & 15, fg = lane >> 4;
-  f32x4 acc[4][4];
+  f32x4 acc[MI][4];
   // Finished tile waiting to be stored: 8 units (mi, h) of 8 packed bf16 (acc + bias).  One unit is drained behind
   // the MFMAs of each k-step of the NEXT tile, so output traffic is a steady trickle instead of a per-tile burst in
   // which every CU of the (phase-locked) persistent grid hits the HBM write path at once.
-  bf16x8 pend[4][2];
+  bf16x8 pend[MI][2];
   int pm0 = 0, pn0 = 0;
   bool have_pend = false;
 
@@ -607,7 +612,7 @@ __global__ __launch_bounds__(768) void gemm_bf16_stream_kernel(const bf16* __res
   // rotate the queue by one so the head index stays compile-time constant (no runtime-indexed register arrays)
   auto drain_one = [&](int u) {
     const int mi = u >> 1, h = u & 1;
-    const int m = pm0 + wr * 64 + mi * 16 + fi;
+    const int m = pm0 + wr * (MI * 16) + mi * 16 + fi;
     const int n = pn0 + wc * 64 + h * 32 + fg * 8;
     bf16x8 v = pend[0][0];
     if constexpr (EPI == EPI_GELU) {
@@ -627,9 +632,10 @@ __global__ __launch_bounds__(768) void gemm_bf16_stream_kernel(const bf16* __res
       }
     }
 #pragma unroll
-    for (int q = 0; q < 7; ++q) pend[q >> 1][q & 1] = pend[(q + 1) >> 1][(q + 1) & 1];
+    for (int q = 0; q < NU - 1; ++q) pend[q >> 1][q & 1] = pend[(q + 1) >> 1][(q + 1) & 1];
   };
-  constexpr int UPS = NK >= 8 ? 1 : (8 + NK - 1) / NK;   // units drained per draining k-step (NK < 8: tests only)
+  constexpr int UPS = (NU + NK - 1) / NK;                // units drained per draining k-step
+  constexpr int DEVERY = NK / NU > 0 ? NK / NU : 1;      // drain every DEVERY-th k-step
   // one k-step: 16 ds_read_b128 + 32 MFMA (64 x 64 x 64 per wave)
   auto kstep = [&](int g) {
     if (!(dbg & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -637,16 +643,19 @@ __global__ __launch_bounds__(768) void gemm_bf16_stream_kernel(const bf16* __res
     const char* sw = sa + SA_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[4], wf[4];
+      bf16x8 af[MI], wf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int ra = wr * 64 + i * 16 + fi;
-        af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * 128 + swz(ra, kk * 4 + fg) * 16);
         const int rw = wc * 64 + i * 16 + fi;
         wf[i] = *reinterpret_cast<const bf16x8*>(sw + rw * 128 + swz(rw, kk * 4 + fg) * 16);
       }
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int i = 0; i < MI; ++i) {
+        const int ra = wr * (MI * 16) + i * 16 + fi;
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * 128 + swz(ra, kk * 4 + fg) * 16);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
@@ -655,7 +664,7 @@ __global__ __launch_bounds__(768) void gemm_bf16_stream_kernel(const bf16* __res
   if (!(dbg & 16)) __builtin_amdgcn_s_setprio(1);
   for (int ti = 0; ti < n_my; ++ti) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int g0 = ti * NK;
@@ -665,17 +674,21 @@ __global__ __launch_bounds__(768) void gemm_bf16_stream_kernel(const bf16* __res
     if (!have_pend) {
 #pragma unroll 1
       for (int ks = 0; ks < NK; ++ks) kstep(g0 + ks);
-    } else if constexpr (NK >= 16) {
-      int unit = 0;                                   // one unit every NK/8 k-steps (uniform scalar branch)
+    } else if constexpr (NK >= NU && DEVERY > 1) {
+      int unit = 0;                                   // one unit every DEVERY k-steps (uniform scalar branch)
 #pragma unroll 1
       for (int ks = 0; ks < NK; ++ks) {
         kstep(g0 + ks);
-        if (ks % (NK / 8) == 0) drain_one(unit++);
+        if (ks % DEVERY == 0) drain_one(unit++);
       }
-    } else if constexpr (NK == 8) {
-      int unit = 0;
+    } else if constexpr (NK * UPS == NU) {
+      int unit = 0;                                   // exactly UPS units behind every k-step, no branch
 #pragma unroll 1
-      for (int ks = 0; ks < NK; ++ks) { kstep(g0 + ks); drain_one(unit++); }
+      for (int ks = 0; ks < NK; ++ks) {
+        kstep(g0 + ks);
+#pragma unroll
+        for (int r = 0; r < UPS; ++r) drain_one(unit++);
+      }
     } else {
       int unit = 0;
 #pragma unroll
@@ -683,14 +696,14 @@ __global__ __launch_bounds__(768) void gemm_bf16_stream_kernel(const bf16* __res
         kstep(g0 + ks);
 #pragma unroll
         for (int r = 0; r < UPS; ++r)
-          if (unit < 8) { drain_one(unit); ++unit; }
+          if (unit < NU) { drain_one(unit); ++unit; }
       }
     }
     const int t = L + ti * G;
     pm0 = (t / tiles_n) * SBM;
     pn0 = (t % tiles_n) * SBN;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int n = pn0 + wc * 64 + h * 32 + fg * 8;
@@ -704,15 +717,15 @@ __global__ __launch_bounds__(768) void gemm_bf16_stream_kernel(const bf16* __res
   }
   if (have_pend) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) drain_one(u);
+    for (int u = 0; u < NU; ++u) drain_one(u);
   }
 }
 
-template <int EPI, typename OutT, int NK>
-int launch_stream_nk(const void* A, const void* W, const float* bias, void* out, int M, int N, hipStream_t st) {
+template <int EPI, typename OutT, int NK, int MI>
+int launch_stream_nk_mi(const void* A, const void* W, const float* bias, void* out, int M, int N, hipStream_t st) {
   const int tm = (M + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
   const int total = tm * tn;
-  auto kern = gemm_bf16_stream_kernel<EPI, OutT, NK>;
+  auto kern = gemm_bf16_stream_kernel<EPI, OutT, NK, MI>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -729,9 +742,17 @@ int launch_stream_nk(const void* A, const void* W, const float* bias, void* out,
   const int grid = total < n_cu ? total : n_cu;
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("D3DP_GEMM_DBG"); dbg = e ? atoi(e) : 0; }   // timing ablations only (results invalid)
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(768), SLDS_BYTES, st, (const bf16*)A, (const bf16*)W, bias, (OutT*)out, M, N,
-                     tn, total, dbg);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(MI == 4 ? 768 : 512), SLDS_BYTES, st, (const bf16*)A, (const bf16*)W, bias,
+                     (OutT*)out, M, N, tn, total, dbg);
   return 0;
+}
+
+template <int EPI, typename OutT, int NK>
+int launch_stream_nk(const void* A, const void* W, const float* bias, void* out, int M, int N, hipStream_t st) {
+  static int mi = -1;
+  if (mi < 0) { const char* e = getenv("D3DP_GEMM_MI"); mi = (e && atoi(e) == 8) ? 8 : 4; }   // A/B of the wave layout
+  if (mi == 8) return launch_stream_nk_mi<EPI, OutT, NK, 8>(A, W, bias, out, M, N, st);
+  return launch_stream_nk_mi<EPI, OutT, NK, 4>(A, W, bias, out, M, N, st);
 }
 
 template <int EPI, typename OutT>
