@@ -7,7 +7,8 @@
 //   (EXACT mode: bufA / the MLP hidden are three bf16 planes of the fp32 value, qkv and y are fp32)
 //   bufA [Tc, C]   act    normalised input of the next GEMM / attention output      (act = bf16 FAST, fp32 EXACT)
 //   bufB [Tc, 3C]  act    qkv; reused as the [Tc, 2C] MLP hidden
-//   y    [Tc, C]   act    output of the residual-feeding Linears (proj, fc2); added to x by the next row-wise kernel
+//   y1,y [Tc, C]   act    outputs of the residual-feeding Linears (proj, fc2); the norm pair after the block forms
+//                          (x + y1) + y in registers, so x is read and written once per block
 // The reference keeps two physical layouts and transposes between them 16 times per call
 // (mixste.py:244,270,274); here spatial and temporal attention both index the single layout by stride.
 #include <hip/hip_runtime.h>
@@ -186,17 +187,17 @@ int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, hipSt
 // The two residual adds are not done by the GEMMs: each residual-feeding Linear writes y = A W^T + b (fp32) and the
 // (activation type: bf16 in FAST mode -- one more bf16 rounding on the branch output, none on the fp32 residual
 // stream itself) and the next row-wise kernel (LN2 here; the norm pair / head in the caller) performs x += y while it has the row in
-// registers anyway.  On return y holds the fc2 output that the CALLER's next kernel must add.
-int run_block(d3dp_ctx* c, const BlockDev& w, int axis, float* x, void* y, void* bufA, void* bufB, int n_bh,
+// registers anyway.  On return y1 / y hold the proj / fc2 outputs that the CALLER's next kernel must add to x.
+int run_block(d3dp_ctx* c, const BlockDev& w, int axis, float* x, void* y1, void* y, void* bufA, void* bufB, int n_bh,
               hipStream_t st) {
   const d3dp_cfg& g = c->cfg;
   const int Tc = n_bh * g.frames * g.joints, C = g.channels;
   LAUNCH_TRY(linear(c, P_QKV, EPI_BIAS, 0, bufA, w.qkv_w, w.qkv_b, bufB, Tc, 3 * C, C, st));
   LAUNCH_TRY(attention(c, axis, bufB, bufA, n_bh, st));
-  LAUNCH_TRY(linear(c, P_PROJ, EPI_BIAS, 0, bufA, w.proj_w, w.proj_b, y, Tc, C, C, st));
+  LAUNCH_TRY(linear(c, P_PROJ, EPI_BIAS, 0, bufA, w.proj_w, w.proj_b, y1, Tc, C, C, st));
   {
-    Scope s(c, P_LN, st);
-    LAUNCH_TRY(d3dp_launch_ln(c->act(), x, y, w.n2w, w.n2b, g.eps_block, bufA, Tc, C, st));
+    Scope s(c, P_LN, st);      // xn = LN2(x + y1); x itself stays untouched (the caller's norm pair adds y1 and y)
+    LAUNCH_TRY(d3dp_launch_ln(c->act(), x, y1, 0, w.n2w, w.n2b, g.eps_block, bufA, Tc, C, st));
   }
   LAUNCH_TRY(linear(c, P_FC1, EPI_GELU, 0, bufA, w.fc1_w, w.fc1_b, bufB, Tc, g.hidden, C, st));
   LAUNCH_TRY(linear(c, P_FC2, EPI_BIAS, 0, bufB, w.fc2_w, w.fc2_b, y, Tc, C, g.hidden, st));
@@ -327,7 +328,7 @@ int d3dp_workspace_bytes(const d3dp_ctx* c, int32_t B, int32_t H, size_t* bytes)
   const size_t n = (size_t)std::min(c->chunk(), B * H);
   const size_t Tc = n * g.frames * g.joints, C = g.channels;
   const size_t wide = (size_t)std::max(3 * g.channels, g.hidden);
-  *bytes = align_up((size_t)B * C * 4) + align_up(Tc * C * 4) + align_up(Tc * C * c->y_size()) +
+  *bytes = align_up((size_t)B * C * 4) + align_up(Tc * C * 4) + 2 * align_up(Tc * C * c->y_size()) +
            align_up(Tc * C * c->act_size()) + align_up(Tc * wide * c->wide_size());
   return D3DP_OK;
 }
@@ -348,6 +349,7 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
   char* p = (char*)workspace;
   float* temb = (float*)p; p += align_up((size_t)B * C * 4);
   float* x = (float*)p;    p += align_up(Tmax * C * 4);
+  void* y1 = p;            p += align_up(Tmax * C * c->y_size());
   void* y = p;             p += align_up(Tmax * C * c->y_size());
   void* bufA = p;          p += align_up(Tmax * C * c->act_size());
   void* bufB = p;
@@ -365,24 +367,24 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
                                       g.eps_block, x, bufA, seq0, n, H, F, J, C, st));
     }
     for (int d = 0; d < g.depth; ++d) {
-      int r = run_block(c, c->ste[d], 0, x, y, bufA, bufB, n, st);
+      int r = run_block(c, c->ste[d], 0, x, y1, y, bufA, bufB, n, st);
       if (r) return r;
       {
         Scope s(c, P_LN2, st);   // x += fc2 out; Spatial_norm (+ Temporal_pos after block 0); TTE block d's norm1
-        LAUNCH_TRY(d3dp_launch_ln2(c->act(), x, y, c->snw, c->snb, d == 0 ? c->tpos : nullptr, c->tte[d].n1w,
+        LAUNCH_TRY(d3dp_launch_ln2(c->act(), x, y1, y, c->snw, c->snb, d == 0 ? c->tpos : nullptr, c->tte[d].n1w,
                                    c->tte[d].n1b, g.eps_block, bufA, Tc, C, F, J, st));
       }
-      r = run_block(c, c->tte[d], 1, x, y, bufA, bufB, n, st);
+      r = run_block(c, c->tte[d], 1, x, y1, y, bufA, bufB, n, st);
       if (r) return r;
       if (d + 1 < g.depth) {
         Scope s(c, P_LN2, st);   // x += fc2 out; Temporal_norm; STE block d+1's norm1
-        LAUNCH_TRY(d3dp_launch_ln2(c->act(), x, y, c->tnw, c->tnb, nullptr, c->ste[d + 1].n1w, c->ste[d + 1].n1b,
+        LAUNCH_TRY(d3dp_launch_ln2(c->act(), x, y1, y, c->tnw, c->tnb, nullptr, c->ste[d + 1].n1w, c->ste[d + 1].n1b,
                                    g.eps_block, bufA, Tc, C, F, J, st));
       }
     }
     {
       Scope s(c, P_HEAD, st);    // x += fc2 out; Temporal_norm; head LayerNorm; Linear(C,3)
-      LAUNCH_TRY(d3dp_launch_head(c->fast() ? 1 : 0, x, y, c->tnw, c->tnb, g.eps_block, c->hnw, c->hnb, g.eps_head, c->hw, c->hb,
+      LAUNCH_TRY(d3dp_launch_head(c->fast() ? 1 : 0, x, y1, y, c->tnw, c->tnb, g.eps_block, c->hnw, c->hnb, g.eps_head, c->hw, c->hb,
                                   out + (size_t)seq0 * FJ * 3, Tc, C, st));
     }
   }
@@ -478,7 +480,7 @@ int d3dp_op_attention(int32_t act_bf16, int32_t impl, int32_t axis, const void* 
 int d3dp_op_layernorm(int32_t out_bf16, const float* x, const float* w, const float* b, float eps, void* out, int32_t T,
                       int32_t C, void* stream) {
   if (!x || !w || !b || !out) return fail(D3DP_EINVAL, "d3dp_op_layernorm: null argument");
-  LAUNCH_TRY(d3dp_launch_ln(out_bf16, const_cast<float*>(x), nullptr, w, b, eps, out, T, C, (hipStream_t)stream));
+  LAUNCH_TRY(d3dp_launch_ln(out_bf16, const_cast<float*>(x), nullptr, 0, w, b, eps, out, T, C, (hipStream_t)stream));
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
 }

@@ -39,15 +39,15 @@ int d3dp_launch_embed_ln(int act_bf16, const float* x2d, const float* x3d, const
                          const float* eb, const float* spos, const float* lnw, const float* lnb, float eps, float* x,
                          void* xn, int seq0, int n_seq, int H, int F, int J, int C, hipStream_t st);
 // xn = LN(x)
-// (all three: if yadd != nullptr the row is first updated x += yadd -- the residual add of the preceding Linear;
+// (residual adds: ln normalises x + yadd (writing the sum back only if write_x); ln2 / head form (x + yadd0) + yadd;
 //  yadd has the activation type: bf16 in FAST mode, fp32 in EXACT mode)
-int d3dp_launch_ln(int act_bf16, float* x, const void* yadd, const float* w, const float* b, float eps, void* xn, int T,
-                   int C, hipStream_t st);
+int d3dp_launch_ln(int act_bf16, float* x, const void* yadd, int write_x, const float* w, const float* b, float eps,
+                   void* xn, int T, int C, hipStream_t st);
 // x = LN_a(x) (+ pos[f]) in place ; xn = LN_b(x)   (shared Spatial/Temporal norm fused with the next block's norm1)
-int d3dp_launch_ln2(int act_bf16, float* x, const void* yadd, const float* wa, const float* ba, const float* pos,
+int d3dp_launch_ln2(int act_bf16, float* x, const void* yadd0, const void* yadd, const float* wa, const float* ba, const float* pos,
                     const float* wb, const float* bb, float eps, void* xn, int T, int C, int F, int J, hipStream_t st);
 // out[T,3] = Linear(LN_head(LN_a(x)))
-int d3dp_launch_head(int act_bf16, const float* x, const void* yadd, const float* wa, const float* ba, float eps_a, const float* wh,
+int d3dp_launch_head(int act_bf16, const float* x, const void* yadd0, const void* yadd, const float* wa, const float* ba, float eps_a, const float* wh,
                      const float* bh, float eps_h, const float* w, const float* b, float* out, int T, int C,
                      hipStream_t st);
 

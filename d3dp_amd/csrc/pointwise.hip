@@ -101,7 +101,9 @@ template <int C> struct Row {
   }
 };
 
-// if yadd != nullptr: x += yadd (written back) first -- the residual add of the preceding Linear (mixste.py:113-115)
+// Residual adds (mixste.py:113-115) ride on the row-wise kernels.  ln_kernel normalises x + yadd; it writes the sum
+// back only if write_x (the denoiser does NOT: ln2/head re-form (x + yadd0) + yadd from the untouched x, which saves
+// one fp32 row write + read per token and block).
 // activation store: XN = float / bf16 (one plane) or b3 (three bf16 planes, `plane` elements apart)
 template <int C, typename XN> struct ActOut {
   using ptr = XN*;
@@ -119,7 +121,7 @@ template <int C> struct ActOut<C, b3> {
 template <int C, typename XN, typename YT>
 __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const YT* __restrict__ yadd,
                                                  const float* __restrict__ w, const float* __restrict__ b, float eps,
-                                                 typename ActOut<C, XN>::ptr xn, size_t plane, int T) {
+                                                 typename ActOut<C, XN>::ptr xn, size_t plane, int T, int write_x) {
   using R = Row<C>;
   const int lane = threadIdx.x & 63;
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -130,15 +132,15 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const YT
     R::load(yadd + (size_t)tok * C, lane, y);
 #pragma unroll
     for (int i = 0; i < R::NV; ++i) v[i] += y[i];
-    R::store(x + (size_t)tok * C, lane, v);
+    if (write_x) R::store(x + (size_t)tok * C, lane, v);
   }
   R::norm(v, w, b, eps, lane, y);
   ActOut<C, XN>::st(xn, plane, (size_t)tok * C, lane, y);
 }
 
 template <int C, typename XN, typename YT>
-__global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const YT* __restrict__ yadd,
-                                                  const float* __restrict__ wa,
+__global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const YT* __restrict__ yadd0,
+                                                  const YT* __restrict__ yadd, const float* __restrict__ wa,
                                                   const float* __restrict__ ba, const float* __restrict__ pos,
                                                   const float* __restrict__ wb, const float* __restrict__ bb, float eps,
                                                   typename ActOut<C, XN>::ptr xn, size_t plane, int T, int F, int J) {
@@ -148,6 +150,11 @@ __global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const Y
   if (tok >= T) return;
   float v[R::NV], y[R::NV], z[R::NV];
   R::load(x + (size_t)tok * C, lane, v);
+  if (yadd0 != nullptr) {
+    R::load(yadd0 + (size_t)tok * C, lane, y);
+#pragma unroll
+    for (int i = 0; i < R::NV; ++i) v[i] += y[i];
+  }
   if (yadd != nullptr) {
     R::load(yadd + (size_t)tok * C, lane, y);
 #pragma unroll
@@ -203,8 +210,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
 }
 
 template <int C, typename YT>
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const YT* __restrict__ yadd,
-                                                   const float* __restrict__ wa,
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, const YT* __restrict__ yadd0,
+                                                   const YT* __restrict__ yadd, const float* __restrict__ wa,
                                                    const float* __restrict__ ba, float eps_a,
                                                    const float* __restrict__ wh, const float* __restrict__ bh,
                                                    float eps_h, const float* __restrict__ w, const float* __restrict__ b,
@@ -215,6 +222,11 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
   if (tok >= T) return;
   float v[R::NV], y[R::NV], z[R::NV];
   R::load(x + (size_t)tok * C, lane, v);
+  if (yadd0 != nullptr) {
+    R::load(yadd0 + (size_t)tok * C, lane, y);
+#pragma unroll
+    for (int i = 0; i < R::NV; ++i) v[i] += y[i];
+  }
   if (yadd != nullptr) {
     R::load(yadd + (size_t)tok * C, lane, y);
 #pragma unroll
@@ -299,34 +311,34 @@ int d3dp_launch_embed_ln(int act_bf16, const float* x2d, const float* x3d, const
   return 0;
 }
 
-int d3dp_launch_ln(int act_bf16, float* x, const void* yadd, const float* w, const float* b, float eps, void* xn, int T,
-                   int C, hipStream_t st) {
+int d3dp_launch_ln(int act_bf16, float* x, const void* yadd, int write_x, const float* w, const float* b, float eps,
+                   void* xn, int T, int C, hipStream_t st) {
   dim3 g((T + 3) / 4), blk(256);
   const size_t plane = (size_t)T * C;
   DISPATCH_C(C,
-    if (act_bf16 == 1) hipLaunchKernelGGL((ln_kernel<CC, bf16, bf16>), g, blk, 0, st, x, (const bf16*)yadd, w, b, eps, (bf16*)xn, plane, T);
-    else if (act_bf16 == 2) hipLaunchKernelGGL((ln_kernel<CC, b3, float>), g, blk, 0, st, x, (const float*)yadd, w, b, eps, (bf16*)xn, plane, T);
-    else hipLaunchKernelGGL((ln_kernel<CC, float, float>), g, blk, 0, st, x, (const float*)yadd, w, b, eps, (float*)xn, plane, T))
+    if (act_bf16 == 1) hipLaunchKernelGGL((ln_kernel<CC, bf16, bf16>), g, blk, 0, st, x, (const bf16*)yadd, w, b, eps, (bf16*)xn, plane, T, write_x);
+    else if (act_bf16 == 2) hipLaunchKernelGGL((ln_kernel<CC, b3, float>), g, blk, 0, st, x, (const float*)yadd, w, b, eps, (bf16*)xn, plane, T, write_x);
+    else hipLaunchKernelGGL((ln_kernel<CC, float, float>), g, blk, 0, st, x, (const float*)yadd, w, b, eps, (float*)xn, plane, T, write_x))
   return 0;
 }
 
-int d3dp_launch_ln2(int act_bf16, float* x, const void* yadd, const float* wa, const float* ba, const float* pos,
+int d3dp_launch_ln2(int act_bf16, float* x, const void* yadd0, const void* yadd, const float* wa, const float* ba, const float* pos,
                     const float* wb, const float* bb, float eps, void* xn, int T, int C, int F, int J, hipStream_t st) {
   dim3 g((T + 3) / 4), blk(256);
   const size_t plane = (size_t)T * C;
   DISPATCH_C(C,
-    if (act_bf16 == 1) hipLaunchKernelGGL((ln2_kernel<CC, bf16, bf16>), g, blk, 0, st, x, (const bf16*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, plane, T, F, J);
-    else if (act_bf16 == 2) hipLaunchKernelGGL((ln2_kernel<CC, b3, float>), g, blk, 0, st, x, (const float*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, plane, T, F, J);
-    else hipLaunchKernelGGL((ln2_kernel<CC, float, float>), g, blk, 0, st, x, (const float*)yadd, wa, ba, pos, wb, bb, eps, (float*)xn, plane, T, F, J))
+    if (act_bf16 == 1) hipLaunchKernelGGL((ln2_kernel<CC, bf16, bf16>), g, blk, 0, st, x, (const bf16*)yadd0, (const bf16*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, plane, T, F, J);
+    else if (act_bf16 == 2) hipLaunchKernelGGL((ln2_kernel<CC, b3, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, plane, T, F, J);
+    else hipLaunchKernelGGL((ln2_kernel<CC, float, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, pos, wb, bb, eps, (float*)xn, plane, T, F, J))
   return 0;
 }
 
-int d3dp_launch_head(int act_bf16, const float* x, const void* yadd, const float* wa, const float* ba, float eps_a, const float* wh,
+int d3dp_launch_head(int act_bf16, const float* x, const void* yadd0, const void* yadd, const float* wa, const float* ba, float eps_a, const float* wh,
                      const float* bh, float eps_h, const float* w, const float* b, float* out, int T, int C,
                      hipStream_t st) {
   dim3 g((T + 3) / 4), blk(256);
   DISPATCH_C(C,
-    if (act_bf16 == 1) hipLaunchKernelGGL((head_kernel<CC, bf16>), g, blk, 0, st, x, (const bf16*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T);
-    else hipLaunchKernelGGL((head_kernel<CC, float>), g, blk, 0, st, x, (const float*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T))
+    if (act_bf16 == 1) hipLaunchKernelGGL((head_kernel<CC, bf16>), g, blk, 0, st, x, (const bf16*)yadd0, (const bf16*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T);
+    else hipLaunchKernelGGL((head_kernel<CC, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T))
   return 0;
 }
