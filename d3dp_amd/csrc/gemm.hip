@@ -527,13 +527,13 @@ __device__ __forceinline__ float gelu_fast(float x) {
 }
 
 // Column permutation inside a wave's 64-wide output strip.  MFMA tile ni, operand row i (= LDS row ni*16 + i of
-// the wave's W strip) holds output column  sperm(ni, i); an output lane (fi, fg) then owns, for each of its 4 row
-// blocks, the columns  h*32 + fg*8 + [0..7], h = 0,1  -> two 16-byte (bf16) / four 16-byte (fp32) stores per row
-// block, 64 contiguous bytes per row per store instruction.  The loader applies the same map when it picks the
+// the wave's W strip) holds output column  sperm(ni, i); an output lane (fi, fg) then owns, for each of its row
+// blocks, the 16 columns  fg*16 + h*8 + [0..7], h = 0,1  -> two adjacent 16-byte bf16 stores; the four lane groups of a
+// row together write one complete 128-byte line when both halves are drained back to back.  The loader applies the same map when it picks the
 // W row for an LDS row, so the MFMA-side reads stay in natural (conflict-free) order.
 __device__ __forceinline__ int sperm(int q) {   // q = ni*16 + i in [0,64)
   const int ni = q >> 4, i = q & 15;
-  return (ni >> 1) * 32 + (i >> 2) * 8 + (ni & 1) * 4 + (i & 3);
+  return (i >> 2) * 16 + ni * 4 + (i & 3);      // lane group fg = i>>2 owns columns fg*16 .. fg*16+15 (ni-major)
 }
 
 // MI = 16-row MFMA blocks per compute wave: MI = 4 -> 8 compute waves (4 x 2, 64x64 each, two per SIMD);
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
   auto drain_one = [&](int u) {
     const int mi = u >> 1, h = u & 1;
     const int m = pm0 + wr * (MI * 16) + mi * 16 + fi;
-    const int n = pn0 + wc * 64 + h * 32 + fg * 8;
+    const int n = pn0 + wc * 64 + fg * 16 + h * 8;
     bf16x8 v = pend[0][0];
     if constexpr (EPI == EPI_GELU) {
 #pragma unroll
@@ -634,8 +634,9 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
 #pragma unroll
     for (int q = 0; q < NU - 1; ++q) pend[q >> 1][q & 1] = pend[(q + 1) >> 1][(q + 1) & 1];
   };
-  constexpr int UPS = (NU + NK - 1) / NK;                // units drained per draining k-step
-  constexpr int DEVERY = NK / NU > 0 ? NK / NU : 1;      // drain every DEVERY-th k-step
+  // both halves (h = 0,1) of a row block are drained in the same k-step: complete 128-byte lines per wave
+  constexpr int UPS = 2 * ((NU / 2 + NK - 1) / NK);      // units drained per draining k-step (even)
+  constexpr int DEVERY = NK / (NU / 2) > 0 ? NK / (NU / 2) : 1;   // drain every DEVERY-th k-step
   // one k-step: 16 ds_read_b128 + 32 MFMA (64 x 64 x 64 per wave)
   auto kstep = [&](int g) {
     if (!(dbg & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -674,12 +675,12 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
     if (!have_pend) {
 #pragma unroll 1
       for (int ks = 0; ks < NK; ++ks) kstep(g0 + ks);
-    } else if constexpr (NK >= NU && DEVERY > 1) {
-      int unit = 0;                                   // one unit every DEVERY k-steps (uniform scalar branch)
+    } else if constexpr (DEVERY > 1) {
+      int unit = 0;                                   // one row block every DEVERY k-steps (uniform scalar branch)
 #pragma unroll 1
       for (int ks = 0; ks < NK; ++ks) {
         kstep(g0 + ks);
-        if (ks % DEVERY == 0) drain_one(unit++);
+        if (ks % DEVERY == 0 && unit < NU) { drain_one(unit); drain_one(unit + 1); unit += 2; }
       }
     } else if constexpr (NK * UPS == NU) {
       int unit = 0;                                   // exactly UPS units behind every k-step, no branch
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int n = pn0 + wc * 64 + h * 32 + fg * 8;
+        const int n = pn0 + wc * 64 + fg * 16 + h * 8;
         const float4 b0 = *reinterpret_cast<const float4*>(sbias + n);
         const float4 b1 = *reinterpret_cast<const float4*>(sbias + n + 4);
         const f32x4 a0 = acc[mi][2 * h], a1 = acc[mi][2 * h + 1];

@@ -20,7 +20,7 @@ def main():
     a = ap.parse_args()
     lib = _lib.load()
     M = a.m
-    shapes = {"qkv": (1536, 512, 0), "proj": (512, 512, 16), "fc1": (1024, 512, 1), "fc2": (512, 1024, 16)}
+    shapes = {"qkv": (1536, 512, 0), "proj": (512, 512, 0), "fc1": (1024, 512, 1), "fc2": (512, 1024, 0)}   # bf16 outputs, as the denoiser launches them
     st = torch.cuda.current_stream().cuda_stream
     if a.x3:
         for name in a.shapes.split(","):
