@@ -17,6 +17,12 @@ MODE_EXACT, MODE_FAST, MODE_TRAIN = 0, 1, 2
 MODE_SPLIT3 = 2   # d3dp_op_linear only: split-bf16 operands
 EPI_BIAS, EPI_GELU, EPI_RESID = 0, 1, 2
 PROFILE_CLASSES = 12
+
+
+class AdamChunk(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int32),
+                ("pad", C.c_int32)]
+
 ABI_VERSION = 1
 
 
@@ -67,6 +73,16 @@ PROTOTYPES = {
     "d3dp_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.POINTER(Weights), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "d3dp_jpma": (C.c_int, [C.c_void_p] * 9 + [C.c_int32] * 6 + [C.c_void_p]),
+    "d3dp_clip_count": (C.c_int, [C.c_int32, C.c_int32]),
+    "d3dp_clip_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_void_p]),
+    "d3dp_clip_scatter": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]),
+    "d3dp_jpma_winners": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p]),
+    "d3dp_jpma_combine": (C.c_int, [C.c_void_p, C.c_int32, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "d3dp_batch_gather": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_void_p]),
+    "d3dp_adamw_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                  C.c_int64, C.c_void_p]),
+    "d3dp_procrustes": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p]),
     "d3dp_op_linear": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                  C.c_int32, C.c_int32, C.c_void_p]),
     "d3dp_op_attention": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,

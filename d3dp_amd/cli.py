@@ -1,4 +1,5 @@
-"""`main.py --evaluate`-compatible entrypoint of the hot path (reference main.py:596-794, README.md:39).
+"""`main.py`-compatible entrypoint: `--evaluate FILE` runs the hot path (reference main.py:596-794, README.md:39);
+without it the training loop runs (reference main.py:305-593; d3dp_amd/trainer.py).
 
 Keeps the reference's flag names for everything the path consumes (-c, --evaluate, -num_proposals,
 -sampling_timesteps, -b, -f, -cs, -dep, -scale, -timestep, -gpu, --nolog, --debug) and its control flow:
@@ -6,7 +7,8 @@ flipped 2D copy (main.py:646-648), clip chunking (267-299), -b batching (682-698
 trajectory add + reprojection (706-712), the four MPJPE aggregations (715-718), N-weighted accumulation (720-736)
 and the `step %d : Protocol #1 Error (MPJPE) ...` lines written to <checkpoint>/h36m_test_log_H%d_K%d.txt (745-774).
 
-Out of scope: the Human3.6M/3DHP dataset loaders, training loop, rendering and P-MPJPE (--p2).
+`--p2` adds the Procrustes-aligned Protocol #2 lines (main.py:726-729, 776-783) through the batched device kernel.
+Out of scope: the Human3.6M/3DHP dataset loaders and rendering.
 `--synthetic` replaces main.py:83-145 with seeded synthetic sequences; without it the script explains what is missing.
 Run under `python -m torch.distributed.run --nproc-per-node N main.py ...` to shard hypotheses over N GPUs.
 """
@@ -21,6 +23,7 @@ import numpy as np
 import torch
 
 from . import D3DP, jpma
+from .clips import clip_gather
 from .dist import all_gather_hypotheses, hypothesis_slice, init_from_env, rank_generator
 from .weights import H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, make_state_dict
 
@@ -43,6 +46,17 @@ def parse_args(argv=None):
     p.add_argument('-num_proposals', type=int, default=300)
     p.add_argument('--debug', action='store_true', default=False)
     p.add_argument('--p2', action='store_true', default=False)
+    # training (arguments.py:27-47, 68)
+    p.add_argument('-cf', '--checkpoint-frequency', default=20, type=int)
+    p.add_argument('-r', '--resume', default='', type=str, metavar='FILENAME')
+    p.add_argument('-s', '--stride', default=243, type=int)
+    p.add_argument('-e', '--epochs', default=400, type=int)
+    p.add_argument('-lr', '--learning-rate', default=0.00006, type=float)
+    p.add_argument('-lrd', '--lr-decay', default=0.993, type=float)
+    p.add_argument('--coverlr', action='store_true')
+    p.add_argument('-mloss', '--min_loss', default=100000, type=float)
+    p.add_argument('-no-da', '--no-data-augmentation', dest='data_augmentation', action='store_false')
+    p.add_argument('--no-eval', '--no_eval', dest='no_eval', action='store_true')
     # additions
     p.add_argument('--synthetic', action='store_true', help='seeded synthetic sequences instead of data/*.npz')
     p.add_argument('--synthetic-sequences', type=int, default=2)
@@ -94,21 +108,19 @@ def load_model(args, device, h_local):
 
 def evaluate(args, model, sequences, device, rank, world, gen):
     K = args.sampling_timesteps
-    sums = {k: torch.zeros(K, device=device) for k in ("J_Best", "P_Best", "P_Agg", "J_Agg")}
+    names = ("J_Best", "P_Best", "P_Agg", "J_Agg")
+    sums = {k: torch.zeros(K, device=device) for k in names}
+    sums_p2 = {k: torch.zeros(K, device=device) for k in names}
     N = 0
     F_ = args.number_of_frames
     kl, kr = H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT
     with torch.no_grad():
         for cam, batch, batch_2d in sequences:
-            inputs_2d = torch.from_numpy(batch_2d.astype('float32'))[None]
-            inputs_3d = torch.from_numpy(batch.astype('float32'))[None]
+            s2 = torch.from_numpy(batch_2d.astype('float32')).to(device)
+            s3 = torch.from_numpy(batch.astype('float32')).to(device)
             camt = torch.from_numpy(cam.astype('float32')).to(device)
-            flip = inputs_2d.clone()                       # main.py:646-648
-            flip[:, :, :, 0] *= -1
-            flip[:, :, kl + kr, :] = flip[:, :, kr + kl, :]
-            x2, x3 = jpma.eval_data_prepare(F_, inputs_2d, inputs_3d)
-            x2f, _ = jpma.eval_data_prepare(F_, flip, inputs_3d)
-            x2, x2f, x3 = x2.to(device), x2f.to(device), x3.to(device)
+            x2, x2f = clip_gather(s2, F_, kl, kr)          # main.py:646-648 (flip) + 267-299 (clips), one launch
+            x3, _ = clip_gather(s3, F_)
             traj = x3[:, :, :1].clone()
             x3[:, :, 0] = 0
             bs = args.batch_size
@@ -125,30 +137,25 @@ def evaluate(args, model, sequences, device, rank, world, gen):
                 w = a3.shape[0] * a3.shape[1]
                 for k in sums:
                     sums[k] += w * m[k]
+                if args.p2:                                                                          # main.py:724-729
+                    m2 = jpma.p_mpjpe_metrics(pred, a3, rp, a2)
+                    for k in sums_p2:
+                        sums_p2[k] += w * m2[k]
                 N += w
                 if args.debug:
                     break
             if args.debug:
                 break
-    return {k: (v / N) * 1000 for k, v in sums.items()}, N
+    out = {k: (v / N) * 1000 for k, v in sums.items()}
+    out_p2 = {k: (v / N) * 1000 for k, v in sums_p2.items()} if args.p2 else None
+    return out, out_p2, N
 
 
-def main(argv=None):
-    args = parse_args(argv)
-    rank, world, local = init_from_env()
-    if not torch.cuda.is_available():
-        raise SystemExit("main.py --evaluate needs an MI355X: libd3dp_hip has no CPU fallback")
-    if args.p2:
-        print("--p2 (P-MPJPE, numpy Procrustes) is outside this build's scope (SURVEY.md §2 row 3): ignored")
-    if not args.synthetic:
-        raise SystemExit("dataset loading (data/data_3d_h36m.npz, data_2d_*.npz) is out of scope for this build "
-                         "(SURVEY.md §2 rows 7-8); run with --synthetic")
-    torch.cuda.set_device(local if world > 1 else int(args.gpu.split(',')[0]))
-    device = torch.device('cuda', torch.cuda.current_device())
+def run_evaluate(args, rank, world, device):
     sl = hypothesis_slice(args.num_proposals, rank, world)
     model = load_model(args, device, sl.stop - sl.start)
     seqs = synthetic_sequences(args.synthetic_sequences, args.synthetic_frames, args.seed)
-    errs, N = evaluate(args, model, seqs, device, rank, world, rank_generator(args.seed, rank, device))
+    errs, errs_p2, N = evaluate(args, model, seqs, device, rank, world, rank_generator(args.seed, rank, device))
     if rank == 0:
         os.makedirs(args.checkpoint, exist_ok=True)
         log_path = os.path.join(args.checkpoint, 'h36m_test_log_H%d_K%d.txt' % (args.num_proposals, args.sampling_timesteps))
@@ -160,10 +167,55 @@ def main(argv=None):
                 for name in ("J_Best", "P_Best", "P_Agg", "J_Agg"):
                     print('step %d : Protocol #1 Error (MPJPE) %s:' % (ii, name), errs[name][ii].item(), 'mm')
                     f.write('step %d : Protocol #1 Error (MPJPE) %s: %f mm\n' % (ii, name, errs[name][ii].item()))
+            if errs_p2 is not None:                                                                  # main.py:776-783
+                for ii in range(args.sampling_timesteps):
+                    for name in ("J_Best", "P_Best", "P_Agg", "J_Agg"):
+                        print('step %d : Protocol #2 Error (MPJPE) %s:' % (ii, name), errs_p2[name][ii].item(), 'mm')
+                        f.write('step %d : Protocol #2 Error (MPJPE) %s: %f mm\n' % (ii, name, errs_p2[name][ii].item()))
             print('----------')
             f.write('----------\n')
         print(f'evaluated {N} frames; log appended to {log_path}')
     return 0
+
+
+def run_train(args, rank, world, device):
+    """main.py:305-593 on synthetic sequences: ChunkedBatcher (pools in HBM) -> D3DP(is_train=True) -> HipAdamW."""
+    from .data import ChunkedBatcher
+    from .trainer import fit
+    if world > 1:
+        raise SystemExit("training is single-GPU in this build (the reference's DataParallel replica split is not "
+                         "reproduced, SURVEY.md §8 E1); launch without torch.distributed.run")
+    kl, kr = H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT
+    train = synthetic_sequences(args.synthetic_sequences, args.synthetic_frames, args.seed)
+    valid = synthetic_sequences(max(1, args.synthetic_sequences // 2), args.synthetic_frames, args.seed + 1000)
+    model_train = D3DP(args, kl, kr, is_train=True).to(device)
+    model_eval = D3DP(args, kl, kr, is_train=False, numerics=args.numerics).to(device)
+    if not args.resume:
+        model_train.load_state_dict(make_state_dict(7, args.cs, args.dep, args.number_of_frames), strict=False)
+    n_params = sum(p.numel() for p in model_train.parameters())
+    print('INFO: Trainable parameter count:', n_params / 1000000, 'Million')
+    batcher = ChunkedBatcher(max(1, args.batch_size // args.stride), [c for c, _, _ in train], [g for _, g, _ in train],
+                             [k for _, _, k in train], args.number_of_frames, shuffle=True,
+                             augment=args.data_augmentation, kps_left=kl, kps_right=kr, joints_left=kl, joints_right=kr,
+                             device=device)
+    print('INFO: Training on {} frames'.format(sum(g.shape[0] for _, g, _ in train)))
+    hist = fit(args, model_train, model_eval, batcher, (lambda: valid) if not args.no_eval else None, device, kl, kr)
+    return 0 if hist["losses_3d_train"] else 1
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    rank, world, local = init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("main.py needs an MI355X: libd3dp_hip has no CPU fallback")
+    if not args.synthetic:
+        raise SystemExit("dataset loading (data/data_3d_h36m.npz, data_2d_*.npz) is out of scope for this build "
+                         "(SURVEY.md §2 rows 7-8); run with --synthetic")
+    torch.cuda.set_device(local if world > 1 else int(args.gpu.split(',')[0]))
+    device = torch.device('cuda', torch.cuda.current_device())
+    if args.evaluate:
+        return run_evaluate(args, rank, world, device)
+    return run_train(args, rank, world, device)        # like the reference: no --evaluate means train (main.py:305)
 
 
 if __name__ == '__main__':

@@ -51,6 +51,17 @@ int fail(int code, const char* fmt, ...) {
     if (r__ != 0) return fail(r__ == -1 ? D3DP_EINVAL : D3DP_ENOTSUP, "%s -> %d", #expr, r__); \
   } while (0)
 
+}  // namespace
+
+int d3dp_set_error(int code, const char* msg) { return fail(code, "%s", msg); }
+int d3dp_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(D3DP_EHIP, "%s: %s", what, hipGetErrorString(e));
+  return D3DP_OK;
+}
+
+namespace {
+
 enum ProfClass { P_QKV = 0, P_PROJ, P_FC1, P_FC2, P_ATTN_S, P_ATTN_T, P_LN, P_LN2, P_EMBED, P_HEAD, P_TIME, P_OTHER };
 const char* kClassNames[D3DP_PROFILE_CLASSES] = {"gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "attn_spatial",
                                                  "attn_temporal", "layernorm", "norm_pair", "embed_ln", "head",
@@ -426,8 +437,19 @@ int d3dp_jpma(const float* pred, const float* traj, const float* cam, const floa
   if (!pred || !traj || !cam || !gt2d || !agg || B < 1 || K < 1 || H < 1)
     return fail(D3DP_EINVAL, "d3dp_jpma: bad argument");
   if ((err_sel || err_min) && !gt3d) return fail(D3DP_EINVAL, "d3dp_jpma: error outputs need gt3d");
-  LAUNCH_TRY(d3dp_launch_jpma(pred, traj, cam, gt2d, gt3d, agg, sel, err_sel, err_min, B, K, H, F, J, zero_root,
-                              (hipStream_t)stream));
+  LAUNCH_TRY(d3dp_launch_jpma(pred, traj, cam, gt2d, gt3d, agg, sel, err_sel, err_min, nullptr, 0, B, K, H, F, J,
+                              zero_root, (hipStream_t)stream));
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
+int d3dp_jpma_winners(const float* pred, const float* traj, const float* cam, const float* gt2d, float* win,
+                      int32_t h_offset, int32_t B, int32_t K, int32_t H, int32_t F, int32_t J, int32_t zero_root,
+                      void* stream) {
+  if (!pred || !traj || !cam || !gt2d || !win || B < 1 || K < 1 || H < 1 || h_offset < 0)
+    return fail(D3DP_EINVAL, "d3dp_jpma_winners: bad argument");
+  LAUNCH_TRY(d3dp_launch_jpma(pred, traj, cam, gt2d, nullptr, nullptr, nullptr, nullptr, nullptr, win, h_offset, B, K, H,
+                              F, J, zero_root, (hipStream_t)stream));
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
 }

@@ -28,8 +28,8 @@ __global__ __launch_bounds__(256) void jpma_kernel(const float* __restrict__ pre
                                                    const float* __restrict__ cam, const float* __restrict__ gt2d,
                                                    const float* __restrict__ gt3d, float* __restrict__ agg,
                                                    int* __restrict__ sel, float* __restrict__ err_sel,
-                                                   float* __restrict__ err_min, int B, int K, int H, int F, int J,
-                                                   int zero_root) {
+                                                   float* __restrict__ err_min, float* __restrict__ win,
+                                                   int h_offset, int B, int K, int H, int F, int J, int zero_root) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t FJ = (size_t)F * J, total = (size_t)B * K * FJ;
   if (i >= total) return;
@@ -59,19 +59,23 @@ __global__ __launch_bounds__(256) void jpma_kernel(const float* __restrict__ pre
     min3 = fminf(min3, e3);
     if (e2 < best2) { best2 = e2; bh = h; bx = x[0]; by = x[1]; bz = x[2]; best3 = e3; }
   }
-  agg[i * 3] = bx; agg[i * 3 + 1] = by; agg[i * 3 + 2] = bz;
+  if (agg != nullptr) { agg[i * 3] = bx; agg[i * 3 + 1] = by; agg[i * 3 + 2] = bz; }
   if (sel != nullptr) sel[i] = bh;
   if (err_sel != nullptr) err_sel[i] = best3;     // J_Agg per-joint error (loss.py:70-72)
   if (err_min != nullptr) err_min[i] = min3;      // J_Best per-joint error (loss.py:38-41)
+  if (win != nullptr) {                           // this rank's winner for the reduced exchange
+    win[i * 5] = best2; win[i * 5 + 1] = bx; win[i * 5 + 2] = by; win[i * 5 + 3] = bz;
+    win[i * 5 + 4] = __int_as_float(h_offset + bh);
+  }
 }
 
 }  // namespace
 
 int d3dp_launch_jpma(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d,
-                     float* agg, int* sel, float* err_sel, float* err_min, int B, int K, int H, int F, int J,
-                     int zero_root, hipStream_t st) {
+                     float* agg, int* sel, float* err_sel, float* err_min, float* win, int h_offset, int B, int K,
+                     int H, int F, int J, int zero_root, hipStream_t st) {
   const size_t total = (size_t)B * K * F * J;
   hipLaunchKernelGGL(jpma_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pred, traj, cam, gt2d, gt3d,
-                     agg, sel, err_sel, err_min, B, K, H, F, J, zero_root);
+                     agg, sel, err_sel, err_min, win, h_offset, B, K, H, F, J, zero_root);
   return 0;
 }

@@ -63,8 +63,13 @@ int d3dp_launch_q_sample(const float* x0, const float* noise, const double* a, c
 
 // ---- jpma.hip ----------------------------------------------------------------------------------
 int d3dp_launch_jpma(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d,
-                     float* agg, int* sel, float* err_sel, float* err_min, int B, int K, int H, int F, int J,
-                     int zero_root, hipStream_t st);
+                     float* agg, int* sel, float* err_sel, float* err_min, float* win, int h_offset, int B, int K,
+                     int H, int F, int J, int zero_root, hipStream_t st);
+
+// ---- capi.hip helpers shared with caller.hip ---------------------------------------------------------------------
+int d3dp_set_error(int code, const char* msg);        // records the message for d3dp_last_error(), returns code
+int d3dp_check_launch(const char* what);              // hipGetLastError -> status
+extern "C" int d3dp_clip_count(int32_t n, int32_t F);
 
 // ---- train.hip (training step, fp32) -------------------------------------------------------------------------
 int d3dp_train_add_mask_ln(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* w,

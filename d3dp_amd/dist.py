@@ -72,3 +72,22 @@ def rank_generator(seed: int, rank: int, device) -> torch.Generator:
     g = torch.Generator(device=device)
     g.manual_seed(seed * 1000003 + rank)
     return g
+
+
+def jpma_sharded(preds_local: torch.Tensor, traj: torch.Tensor, cam: torch.Tensor, gt_2d: torch.Tensor,
+                 zero_root: bool = True, group=None):
+    """JPMA over hypotheses sharded across ranks with the REDUCED exchange of SURVEY.md §8 E1: every rank selects its
+    best hypothesis per (clip, step, frame, joint) locally, the ranks all-gather 5 floats per joint instead of
+    H_local poses, and each rank combines the winners.  Returns the same (aggregated poses (B,K,F,J,3), global
+    hypothesis index (B,K,F,J)) as JPMA over the all-gathered (B,K,H_total,F,J,3) tensor, with
+    H_local/ (5/3) = 12x less traffic at H_local = 20."""
+    from .jpma import jpma_combine, jpma_winners
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    Hl = preds_local.shape[2]
+    win = jpma_winners(preds_local, traj, cam, gt_2d, h_offset=rank * Hl, zero_root=zero_root)
+    if world == 1:
+        return jpma_combine(win[None])
+    gathered = torch.empty((world * win.shape[0],) + tuple(win.shape[1:]), dtype=win.dtype, device=win.device)
+    dist.all_gather_into_tensor(gathered, win.contiguous(), group=group)
+    return jpma_combine(gathered.view(world, *win.shape))

@@ -78,6 +78,13 @@ def jpma_metrics(pred: torch.Tensor, gt: torch.Tensor, reproj: torch.Tensor, gt_
     return {"J_Best": j_best, "P_Best": p_best, "P_Agg": p_agg, "J_Agg": j_agg}
 
 
+def mpjpe_diffusion(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+    """loss.py:78-107 ``mpjpe_diffusion``: per step, the best single hypothesis' mean error -> (K,)."""
+    K, H = pred.shape[1], pred.shape[2]
+    err = torch.norm(pred - gt[:, None, None], dim=-1)
+    return err.permute(1, 2, 0, 3, 4).reshape(K, H, -1).mean(-1).min(dim=1).values
+
+
 def jpma_hip(pred: torch.Tensor, traj: torch.Tensor, cam: torch.Tensor, gt_2d: torch.Tensor,
              gt_3d: torch.Tensor = None, zero_root: bool = True, want_errors: bool = False):
     """The fused HIP kernel (include/d3dp_hip.h: d3dp_jpma) for GPU tensors: returns the aggregated poses (B,K,F,J,3),
@@ -112,3 +119,89 @@ def jpma_aggregate(pred: torch.Tensor, reproj: torch.Tensor, gt_2d: torch.Tensor
     err2d = torch.norm(reproj - gt_2d[:, None, None], dim=-1)
     sel = err2d.min(dim=2, keepdim=True).indices
     return torch.gather(pred, 2, sel[..., None].expand(-1, -1, -1, -1, -1, 3))[:, :, 0]
+
+
+# ---- reduced hypothesis exchange --------------------------------------------------------------------
+def jpma_winners(pred: torch.Tensor, traj: torch.Tensor, cam: torch.Tensor, gt_2d: torch.Tensor, h_offset: int = 0,
+                 zero_root: bool = True) -> torch.Tensor:
+    """This rank's per-joint winner (B,K,F,J,5) = (2D reprojection error, x, y, z, int32 bits of the global hypothesis
+    index).  GPU tensors go through the fused HIP kernel (d3dp_jpma_winners); host tensors (the gloo tests) through the
+    torch statement of the same selection."""
+    B, K, H, Fr, J, _ = pred.shape
+    if pred.is_cuda:
+        from . import _lib
+        lib = _lib.load()
+        pred = pred.to(torch.float32).contiguous()
+        traj = traj.to(torch.float32).reshape(B, Fr, 3).contiguous()
+        cam = cam.to(device=pred.device, dtype=torch.float32).reshape(-1)[:9].contiguous()
+        gt_2d = gt_2d.to(torch.float32).contiguous()
+        win = torch.empty((B, K, Fr, J, 5), dtype=torch.float32, device=pred.device)
+        with torch.cuda.device(pred.device):
+            _lib.check(lib.d3dp_jpma_winners(pred.data_ptr(), traj.data_ptr(), cam.data_ptr(), gt_2d.data_ptr(),
+                                             win.data_ptr(), int(h_offset), B, K, H, Fr, J, int(zero_root),
+                                             _lib.current_stream()), "d3dp_jpma_winners")
+        return win
+    p = pred.clone().float()
+    if zero_root:
+        p[:, :, :, :, 0] = 0
+    err2d = torch.norm(reproject(p, traj.reshape(B, Fr, 1, 3).float(), cam.float()) - gt_2d[:, None, None].float(), dim=-1)
+    e, sel = err2d.min(dim=2, keepdim=True)
+    xyz = torch.gather(p, 2, sel[..., None].expand(-1, -1, -1, -1, -1, 3))[:, :, 0]
+    hbits = (sel[:, :, 0] + h_offset).to(torch.int32).view(torch.float32)
+    return torch.cat((e[:, :, 0, ..., None], xyz, hbits[..., None]), dim=-1).contiguous()
+
+
+def jpma_combine(win_all: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """win_all (R,B,K,F,J,5), rank-major -> aggregated poses (B,K,F,J,3) and the winning global hypothesis index
+    (B,K,F,J) int32: smallest 2D error per joint, lowest rank on ties (= lowest global h, what torch.min over the
+    gathered hypothesis axis returns, loss.py:67)."""
+    R = win_all.shape[0]
+    shp = win_all.shape[1:-1]
+    if win_all.is_cuda:
+        from . import _lib
+        lib = _lib.load()
+        w = win_all.to(torch.float32).contiguous()
+        n = w[0, ..., 0].numel()
+        agg = torch.empty(shp + (3,), dtype=torch.float32, device=w.device)
+        sel = torch.empty(shp, dtype=torch.int32, device=w.device)
+        with torch.cuda.device(w.device):
+            _lib.check(lib.d3dp_jpma_combine(w.data_ptr(), R, n, agg.data_ptr(), sel.data_ptr(), _lib.current_stream()),
+                       "d3dp_jpma_combine")
+        return agg, sel
+    r = win_all[..., 0].min(dim=0, keepdim=True).indices                   # first minimum = lowest rank
+    best = torch.gather(win_all, 0, r[..., None].expand(-1, *([-1] * len(shp)), 5))[0]
+    return best[..., 1:4].contiguous(), best[..., 4].contiguous().view(torch.int32)
+
+
+# ---- Protocol #2 (Procrustes-aligned) errors, SURVEY.md §8(f) row N4 --------------------------------------------------
+def procrustes_errors(pred: torch.Tensor, gt: torch.Tensor, want_aligned: bool = False):
+    """pred (B,K,H,F,J,3), gt (B,F,J,3) on the GPU -> per-joint error after the optimal similarity alignment of every
+    predicted pose to its target (B,K,H,F,J) (common/loss.py:190-247 for one pose; batched 3x3 SVD in one HIP launch,
+    d3dp_procrustes).  The reference runs this through numpy on the host for every batch (loss.py:263-264)."""
+    from . import _lib
+    if not pred.is_cuda:
+        raise _lib.D3DPHipError("procrustes_errors runs on the GPU (tensor on %s); there is no CPU fallback" % pred.device)
+    lib = _lib.load()
+    B, K, H, Fr, J, _ = pred.shape
+    p = pred.to(torch.float32).contiguous()
+    g = gt.to(torch.float32).contiguous()
+    err = torch.empty((B, K, H, Fr, J), dtype=torch.float32, device=p.device)
+    al = torch.empty_like(p) if want_aligned else None
+    with torch.cuda.device(p.device):
+        _lib.check(lib.d3dp_procrustes(p.data_ptr(), g.data_ptr(), err.data_ptr(), _lib.ptr(al), B, K * H, Fr, J,
+                                       _lib.current_stream()), "d3dp_procrustes")
+    return (err, al) if want_aligned else err
+
+
+def p_mpjpe_metrics(pred: torch.Tensor, gt: torch.Tensor, reproj: torch.Tensor, gt_2d: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """The four Protocol #2 errors main.py:726-729 logs per step (K,), in metres:
+    J_Best loss.py:p_mpjpe_diffusion_all_min, P_Best p_mpjpe_diffusion, P_Agg ..._all_min(mean_pos=True),
+    J_Agg p_mpjpe_diffusion_reproj."""
+    K, H = pred.shape[1], pred.shape[2]
+    err = procrustes_errors(pred, gt)                                                       # (B,K,H,F,J)
+    j_best = err.min(dim=2).values.permute(1, 0, 2, 3).reshape(K, -1).mean(-1)
+    p_best = err.permute(1, 2, 0, 3, 4).reshape(K, H, -1).mean(-1).min(dim=1).values
+    p_agg = procrustes_errors(pred.mean(dim=2, keepdim=True), gt)[:, :, 0].permute(1, 0, 2, 3).reshape(K, -1).mean(-1)
+    sel = torch.norm(reproj - gt_2d[:, None, None], dim=-1).min(dim=2, keepdim=True).indices
+    j_agg = torch.gather(err, 2, sel).permute(1, 2, 0, 3, 4).reshape(K, -1).mean(-1)
+    return {"J_Best": j_best, "P_Best": p_best, "P_Agg": p_agg, "J_Agg": j_agg}

@@ -162,6 +162,43 @@ int d3dp_train_backward(d3dp_ctx* ctx, const float* x2d, const float* x3d, const
                         const float* grad_out, const d3dp_weights* grads, int32_t B, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* ---- caller-side rows of SURVEY.md section 8(f) (d3dp_amd/csrc/caller.hip) ------------------------------------------
+ * N2 clip chunking: src (n,J,D) -> dst (n_clips,F,J,D), n_clips = d3dp_clip_count(n,F): consecutive clips, a trailing
+ * partial clip = the LAST F frames, n < F replicate-padded on the right (reference main.py:267-299,
+ * in_the_wild/utils.py:199-240).  dst_flip (optional): the flipped input main.py:646-648 builds (x negated, joints
+ * permuted by perm[J], perm[j] = source joint). */
+int d3dp_clip_count(int32_t n, int32_t F);
+int d3dp_clip_gather(const float* src, float* dst, float* dst_flip, const int32_t* perm, int32_t n, int32_t F, int32_t J,
+                     int32_t D, void* stream);
+/* de-chunking: pred (n_clips,K,H,F,J,D) -> out (K,H,n,J,D)  (in_the_wild/videopose_diffusion.py:150-164, including
+ * its n < F behaviour: the last n frames of the padded clip). */
+int d3dp_clip_scatter(const float* pred, float* out, int32_t n, int32_t K, int32_t H, int32_t F, int32_t J, int32_t D,
+                      void* stream);
+/* E1 reduced exchange: d3dp_jpma_winners writes this rank's per-joint winner win (B,K,F,J,5) =
+ * (2D error, x, y, z, bits of int32 global hypothesis index h_offset + h); after an all-gather over R ranks
+ * (rank-major) d3dp_jpma_combine picks the smallest 2D error per joint, lowest rank on ties (= lowest global h, the
+ * element torch.min returns in loss.py:67).  n = B*K*F*J. */
+int d3dp_jpma_winners(const float* pred, const float* traj, const float* cam, const float* gt2d, float* win,
+                      int32_t h_offset, int32_t B, int32_t K, int32_t H, int32_t F, int32_t J, int32_t zero_root,
+                      void* stream);
+int d3dp_jpma_combine(const float* win, int32_t R, size_t n, float* agg, int32_t* sel, void* stream);
+/* N3 training batch assembly from device-resident pools (common/generators.py:12-171 ChunkedGenerator_Seq):
+ * pool2d (N,J,2), pool3d (N,J,3) or NULL; table (nb,4) int32 = (first pool frame of the sequence, sequence length,
+ * chunk start frame (may be negative / run past the end: edge frames repeat), flip); perm2d/perm3d (J) = left/right
+ * swap for flipped items (x negated); zero_root: joint 0 of out3d written as 0 (main.py:365). */
+int d3dp_batch_gather(const float* pool2d, const float* pool3d, const int32_t* table, const int32_t* perm2d,
+                      const int32_t* perm3d, float* out2d, float* out3d, int32_t nb, int32_t F, int32_t J,
+                      int32_t zero_root, void* stream);
+/* AdamW (main.py:311: torch.optim.AdamW(lr, weight_decay=0.1)) over all parameter tensors in one launch.
+ * chunks: device array of d3dp_adam_chunk (one block each); step = 1-based step count of this update. */
+typedef struct d3dp_adam_chunk { float* p; const float* g; float* m; float* v; int32_t n; int32_t pad; } d3dp_adam_chunk;
+int d3dp_adamw_step(const void* chunks, int32_t n_chunks, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, int64_t step, void* stream);
+/* N4 Procrustes-aligned per-joint errors (common/loss.py:190-395 p_mpjpe*): pred (B,KH,F,J,3), target (B,F,J,3) ->
+ * err (B,KH,F,J) and (optional) the aligned poses. */
+int d3dp_procrustes(const float* pred, const float* target, float* err, float* aligned, int32_t B, int32_t KH, int32_t F,
+                    int32_t J, void* stream);
+
 /* ---- single operators (unit parity tests; same kernels the denoiser launches) ---------------------------- */
 /* out[M,N] = epi(A[M,K] W[N,K]^T + bias).  epi & 3: 0 bias, 1 bias+GELU(erf), 2 out(fp32) += result.
  * mode EXACT: everything fp32 (fp32 MFMA).  mode FAST: A, W bf16 (uint16 storage), fp32 accumulate; out is bf16

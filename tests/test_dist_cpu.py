@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from d3dp_amd import jpma
-from d3dp_amd.dist import all_gather_hypotheses, hypothesis_slice, shard_noise
+from d3dp_amd.dist import all_gather_hypotheses, hypothesis_slice, jpma_sharded, shard_noise
 
 
 def fake_sampler(x2d, noise):
@@ -40,6 +40,17 @@ def _worker(rank, world, port, out):
         agg = jpma.jpma_aggregate(gathered, rp, gt2)
         agg_ref = jpma.jpma_aggregate(full, full[..., :2] * 0.5, gt2)
         ok = ok and torch.equal(agg, agg_ref)
+        # reduced exchange: local winners -> all-gather of 5 floats per joint -> combine must pick
+        # the same hypothesis and pose as JPMA over the gathered stack (real projection, root zeroing, ties at joint 0)
+        cam = torch.tensor([2.29, 2.287, 0.0254, 0.0289, -0.2070, 0.2477, -0.0030, -0.0009, -0.0014])
+        traj = torch.randn(B, Fr, 1, 3, generator=torch.Generator().manual_seed(5)) * 0.1 + torch.tensor([0.0, 0.0, 4.0])
+        agg_r, sel_r = jpma_sharded(local, traj, cam, gt2)
+        z = full.clone()
+        z[:, :, :, :, 0] = 0
+        rp_full = jpma.reproject(z, traj, cam)
+        sel_ref = torch.norm(rp_full - gt2[:, None, None], dim=-1).min(dim=2).indices
+        ok = ok and torch.equal(agg_r, jpma.jpma_aggregate(z, rp_full, gt2)) and torch.equal(sel_r.long(), sel_ref)
+        ok = ok and bool((sel_r[..., 0] == 0).all())          # zeroed root: all hypotheses tie -> global h = 0
         out[rank] = bool(ok)
     finally:
         dist.destroy_process_group()

@@ -1,0 +1,291 @@
+"""GPU parity tests (-m gpu) of the caller-side kernels, through the C ABI, against
+the reference-generated fixtures g7-g10 and the CPU oracle (oracle/caller_oracle.py).
+
+Bars: bit-exact for the index/byte work (clips, batches, JPMA winners/combine); AdamW within 2 ulp-class of
+torch.optim.AdamW (fp32 divide/sqrt are correctly rounded on both sides, contraction differs); Procrustes errors
+within 1e-6 m (= 1e-3 mm, the north_star tolerance) of the reference's numpy-LAPACK result; the 8-iteration training
+loop within 1e-4 relative on every loss and 5e-6 on the final parameters."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from d3dp_amd import D3DP, _lib, jpma
+from d3dp_amd.clips import clip_count, clip_gather, clip_scatter
+from d3dp_amd.data import ChunkedBatcher
+from d3dp_amd.optim import HipAdamW
+from d3dp_amd.trainer import checkpoint_dict, fit, load_checkpoint
+from d3dp_amd.weights import H36M_JOINTS_LEFT as KL, H36M_JOINTS_RIGHT as KR, make_state_dict
+from oracle import caller_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def dataset(seed, lengths):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    p2 = [rng.uniform(-1, 1, (n, 17, 2)).astype(np.float32) for n in lengths]
+    p3 = [(rng.standard_normal((n, 17, 3)) * 0.3).astype(np.float32) for n in lengths]
+    cams = [rng.uniform(-1, 1, (9,)).astype(np.float32) for _ in lengths]
+    return cams, p3, p2
+
+
+# ---- N2 -----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [60, 54, 27, 20, 100])
+def test_clip_gather_matches_reference(golden_dir, n):
+    g = load(golden_dir, "g7_clips")
+    F = int(g["frames"])
+    s2 = torch.from_numpy(g[f"seq2d_{n}"]).cuda()
+    c2, c2f = clip_gather(s2, F, KL, KR)
+    assert np.array_equal(c2.cpu().numpy(), g[f"clips2d_{n}"])
+    assert np.array_equal(c2f.cpu().numpy(), co.clip_gather(co.flip_input(g[f"seq2d_{n}"], KL, KR), F))
+    c3, none = clip_gather(torch.from_numpy(g[f"seq3d_{n}"]).cuda()[None], F)
+    assert none is None and np.array_equal(c3.cpu().numpy(), g[f"clips3d_{n}"])
+
+
+@pytest.mark.parametrize("n,F", [(60, 27), (54, 27), (20, 27), (1000, 243), (243, 243), (100, 243)])
+def test_clip_scatter_matches_oracle_and_round_trips(n, F):
+    rng = np.random.default_rng(n + F)
+    nc, K, H = clip_count(n, F), 2, 3
+    pred = rng.standard_normal((nc, K, H, F, 17, 3)).astype(np.float32)
+    out = clip_scatter(torch.from_numpy(pred).cuda(), n).cpu().numpy()
+    assert np.array_equal(out, co.clip_scatter(pred, n))
+    if n >= F:
+        seq = torch.from_numpy(rng.standard_normal((n, 17, 3)).astype(np.float32)).cuda()
+        clips, _ = clip_gather(seq, F)
+        back = clip_scatter(clips[:, None, None].contiguous(), n)[0, 0]
+        assert torch.equal(back, seq)
+
+
+# ---- N3: batches ----------------------------------------------------------------------------------------------------------
+def test_batcher_matches_reference_generator(golden_dir):
+    g = load(golden_dir, "g8_batches")
+    lengths = [int(v) for v in g["lengths"]]
+    cams, p3, p2 = dataset(int(g["seed"]), lengths)
+    bt = ChunkedBatcher(4, cams, p3, p2, int(g["frames"]), shuffle=True, augment=True, kps_left=KL, kps_right=KR,
+                        joints_left=KL, joints_right=KR, device="cuda")
+    assert bt.batch_num() == int(g["num_batches"]) and bt.num_frames() == int(g["num_frames"])
+    k = 0
+    for _ in range(2):
+        for cam, b3, b2 in bt.next_epoch():
+            assert np.array_equal(b2.cpu().numpy(), g[f"b2_{k}"]) and np.array_equal(b3.cpu().numpy(), g[f"b3_{k}"]), k
+            assert np.array_equal(cam, g[f"cam_{k}"])
+            k += 1
+    assert k == int(g["n_batches_total"])
+    plain = ChunkedBatcher(3, None, p3, p2, int(g["frames"]), shuffle=False, augment=False, device="cuda", zero_root=True)
+    for j, (cam, b3, b2) in enumerate(plain.next_epoch()):
+        want3 = g[f"plain_b3_{j}"].copy()
+        want3[:, :, 0] = 0                                                   # main.py:365 folded into the gather
+        assert cam is None and np.array_equal(b2.cpu().numpy(), g[f"plain_b2_{j}"]) and np.array_equal(b3.cpu().numpy(), want3)
+    assert j + 1 == int(g["plain_batches"])
+
+
+# ---- E1: reduced exchange ---------------------------------------------------------------------------------------------
+def test_jpma_winners_combine_equals_full_jpma():
+    torch.manual_seed(4)
+    B, K, H, Fr, R = 3, 2, 12, 27, 4
+    pred = (torch.randn(B, K, H, Fr, 17, 3) * 0.3).cuda()
+    traj = (torch.randn(B, Fr, 1, 3) * 0.1 + torch.tensor([0.0, 0.0, 4.0])).cuda()
+    cam = torch.tensor([2.29, 2.287, 0.0254, 0.0289, -0.2070, 0.2477, -0.0030, -0.0009, -0.0014]).cuda()
+    gt2 = torch.rand(B, Fr, 17, 2).cuda() * 2 - 1
+    agg, sel = jpma.jpma_hip(pred, traj, cam, gt2, zero_root=True)
+    Hl = H // R
+    wins = torch.stack([jpma.jpma_winners(pred[:, :, r * Hl:(r + 1) * Hl].contiguous(), traj, cam, gt2, h_offset=r * Hl)
+                        for r in range(R)])
+    agg2, sel2 = jpma.jpma_combine(wins)
+    assert torch.equal(agg2, agg) and torch.equal(sel2, sel)
+    # host statement of the same two steps (what the gloo test runs): same selection up to last-ulp ties of the
+    # projection arithmetic (torch CPU vs the kernel's contraction)
+    wins_cpu = torch.stack([jpma.jpma_winners(pred[:, :, r * Hl:(r + 1) * Hl].cpu(), traj.cpu(), cam.cpu(), gt2.cpu(),
+                                              h_offset=r * Hl) for r in range(R)])
+    agg3, sel3 = jpma.jpma_combine(wins_cpu)
+    same = (sel3 == sel.cpu())
+    assert same.float().mean().item() > 0.999 and torch.equal(agg3[same], agg.cpu()[same])
+
+
+# ---- N4: Procrustes -----------------------------------------------------------------------------------------------------
+def _g5_tensors(golden_dir):
+    g5 = load(golden_dir, "g5_caller")
+    F = int(g5["frames"])
+    gt3 = np.stack([g5["seq3d"][s:s + F] for s in g5["starts"]]).copy()
+    gt2 = np.stack([g5["seq2d"][s:s + F] for s in g5["starts"]])
+    gt3[:, :, 0] = 0
+    pred = g5["pred"].copy()
+    pred[:, :, :, :, 0] = 0
+    return pred, gt3, g5["reproj"], gt2
+
+
+def test_pmpjpe_matches_reference(golden_dir):
+    g = load(golden_dir, "g9_pmpjpe")
+    pred, gt3, reproj, gt2 = _g5_tensors(golden_dir)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    m = jpma.p_mpjpe_metrics(t(pred), t(gt3), t(reproj), t(gt2))
+    for name, key in (("J_Best", "e_jbest"), ("P_Best", "e_pbest"), ("P_Agg", "e_pagg"), ("J_Agg", "e_jagg")):
+        d = np.abs(m[name].cpu().numpy() - g[key]).max()
+        assert d < 1e-6, (name, d)
+    refl = gt3.copy()
+    refl[..., 0] *= -1
+    e = jpma.procrustes_errors(t(pred), t(refl))
+    p_best = e.permute(1, 2, 0, 3, 4).reshape(pred.shape[1], pred.shape[2], -1).mean(-1).min(dim=1).values
+    assert np.abs(p_best.cpu().numpy() - g["e_pbest_reflected"]).max() < 1e-6
+
+
+def test_procrustes_per_joint_and_aligned_vs_oracle():
+    rng = np.random.default_rng(9)
+    B, K, H, Fr = 2, 2, 4, 50
+    gt = rng.standard_normal((B, Fr, 17, 3)).astype(np.float32) * 0.4
+    # predictions = random similarity transforms of the target + noise, some reflected, one exactly the target
+    pred = np.empty((B, K, H, Fr, 17, 3), np.float32)
+    for idx in np.ndindex(B, K, H, Fr):
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        pred[idx] = (gt[idx[0], idx[3]] @ q) * rng.uniform(0.5, 2) + rng.standard_normal(3) + rng.standard_normal((17, 3)) * 0.02
+    pred[0, 0, 0, 0] = gt[0, 0]
+    err, al = jpma.procrustes_errors(torch.from_numpy(pred).cuda(), torch.from_numpy(gt).cuda(), want_aligned=True)
+    want = co.procrustes_errors(pred.astype(np.float64), gt.astype(np.float64))
+    assert np.abs(err.cpu().numpy() - want).max() < 2e-6
+    assert err[0, 0, 0, 0].abs().max().item() < 1e-6
+    tgt = np.broadcast_to(gt[:, None, None], pred.shape)
+    assert np.abs(np.linalg.norm(al.cpu().numpy() - tgt, axis=-1) - err.cpu().numpy()).max() < 1e-6
+
+
+# ---- N3: AdamW ------------------------------------------------------------------------------------------------------------
+def test_hip_adamw_matches_torch_adamw_and_shares_state_dicts():
+    torch.manual_seed(0)
+    shapes = [(1536, 512), (512,), (1, 243, 512), (3, 512), (70001,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    hip_p = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref_p]
+    ref = torch.optim.AdamW(ref_p, lr=6e-5, weight_decay=0.1)
+    hip = HipAdamW(hip_p, lr=6e-5, weight_decay=0.1)
+    worst = 0.0
+    for step in range(6):
+        if step == 3:      # checkpoint interchange: torch's state into ours and back (main.py:337, 547)
+            hip.load_state_dict(ref.state_dict())
+            for a, b in zip(ref_p, hip_p):
+                b.data.copy_(a.data)
+            sd = hip.state_dict()
+            assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 3.0
+            torch.optim.AdamW([torch.nn.Parameter(p.detach().cpu().clone()) for p in hip_p], lr=1.0).load_state_dict(
+                {"state": {k: {kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in sd["state"].items()},
+                 "param_groups": sd["param_groups"]})
+        for a, b in zip(ref_p, hip_p):
+            gr = torch.randn(a.shape) * (10.0 ** (step % 3 - 2))
+            a.grad, b.grad = gr.clone(), gr.clone().cuda()
+        v0 = hip_p[0]._version
+        ref.step()
+        hip.step()
+        assert hip_p[0]._version > v0
+        for a, b in zip(ref_p, hip_p):
+            d = (a.detach() - b.detach().cpu()).abs().max().item()
+            worst = max(worst, d / max(1e-30, a.detach().abs().max().item()))
+        for g_ in ref.param_groups + hip.param_groups:
+            g_["lr"] *= 0.9
+    print(f"AdamW: worst |dp| / max|p| over 6 steps = {worst:.2e}")
+    assert worst < 1e-6
+    for a, b in zip(ref_p, hip_p):
+        sa, sb = ref.state[a], hip.state[b]
+        assert float(sa["step"]) == float(sb["step"]) == 6.0
+        assert torch.allclose(sa["exp_avg"], sb["exp_avg"].cpu(), rtol=1e-5, atol=1e-12)
+        assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"].cpu(), rtol=1e-5, atol=1e-20)
+
+
+# ---- N3: the loop ---------------------------------------------------------------------------------------------------------
+def _train_setup(g, tmp, epochs, resume=""):
+    cs, dep, Fr = int(g["cs"]), int(g["dep"]), int(g["frames"])
+    args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep,
+                           learning_rate=float(g["lr"]), lr_decay=float(g["lr_decay"]), epochs=epochs, checkpoint=str(tmp),
+                           checkpoint_frequency=1, resume=resume, coverlr=False, min_loss=100000, no_eval=True, debug=False)
+    lengths = [int(v) for v in g["lengths"]]
+    cams, p3, p2 = dataset(int(g["data_seed"]), lengths)
+    model = D3DP(args, KL, KR, is_train=True)
+    model.load_state_dict(make_state_dict(int(g["seed"]), cs, dep, Fr), strict=False)
+    model = model.cuda()
+    model.pose_estimator.drop_path_rate = 0.0            # the fixture ran with DropPath inactive
+    bt = ChunkedBatcher(4, cams, p3, p2, Fr, shuffle=True, augment=True, kps_left=KL, kps_right=KR, joints_left=KL,
+                        joints_right=KR, device="cuda")
+    return args, model, bt
+
+
+def test_training_loop_matches_reference(golden_dir, tmp_path):
+    g = load(golden_dir, "g10_train_loop")
+    args, model, bt = _train_setup(g, tmp_path, epochs=2)
+    n_it = len(g["losses"])
+    per_epoch = n_it // 2
+    it = {"i": 0}
+
+    def draws(epoch, iteration):
+        i = epoch * per_epoch + iteration
+        return dict(t=torch.from_numpy(g[f"t_{i}"])[:, None], noise=torch.from_numpy(g[f"noise_{i}"]))
+
+    hist = fit(args, model, None, bt, None, torch.device("cuda"), KL, KR, log=lambda s: None, forward_kwargs=draws)
+    losses = np.array(hist["iter_loss"])
+    rel = np.abs(losses - g["losses"]) / g["losses"]
+    print("training loop: loss rel err per iteration", rel)
+    assert losses.shape == g["losses"].shape and rel.max() < 1e-4
+    opt = hist["optimizer"]
+    assert abs(opt.param_groups[0]["lr"] - float(g["final_lr"])) < 1e-12
+    sd = model.state_dict()
+    worst = 0.0
+    for k in g.files:
+        if k.startswith("param::"):
+            worst = max(worst, np.abs(sd[k[len("param::"):]].cpu().numpy() - g[k]).max())
+    print(f"training loop: worst final-parameter deviation {worst:.2e}")
+    assert worst < 5e-6
+    st = opt.state_dict()["state"]
+    assert len(st) == int(g["n_state"]) and float(st[0]["step"]) == float(g["step0"])
+    v_sum = sum(float(v["exp_avg_sq"].double().sum()) for v in st.values())
+    m_sum = sum(float(v["exp_avg"].double().abs().sum()) for v in st.values())
+    assert abs(v_sum - float(g["exp_avg_sq_sum"])) / float(g["exp_avg_sq_sum"]) < 1e-3
+    assert abs(m_sum - float(g["exp_avg_abs_sum"])) / float(g["exp_avg_abs_sum"]) < 1e-3
+    # reference checkpoint layout (main.py:543-552)
+    ck = torch.load(os.path.join(tmp_path, "epoch_2.bin"), map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "lr", "random_state", "optimizer", "model_pos"} and ck["epoch"] == 2
+    assert all(k.startswith("module.") for k in ck["model_pos"]) and "module.pose_estimator.head.1.weight" in ck["model_pos"]
+    assert "module.sqrt_recipm1_alphas_cumprod" in ck["model_pos"] and isinstance(ck["random_state"], np.random.RandomState)
+
+
+def test_resume_continues_the_run(golden_dir, tmp_path):
+    """epoch 1 -> checkpoint -> resume into a zeroed model -> epoch 2 == the uninterrupted 2-epoch run (to the
+    run-to-run noise of the atomically accumulated weight gradients)."""
+    g = load(golden_dir, "g10_train_loop")
+    per_epoch = len(g["losses"]) // 2
+
+    def draws(epoch, iteration):
+        i = epoch * per_epoch + iteration
+        return dict(t=torch.from_numpy(g[f"t_{i}"])[:, None], noise=torch.from_numpy(g[f"noise_{i}"]))
+
+    a_args, a_model, a_bt = _train_setup(g, tmp_path / "a", epochs=2)
+    ha = fit(a_args, a_model, None, a_bt, None, torch.device("cuda"), KL, KR, log=lambda s: None, forward_kwargs=draws)
+    b_args, b_model, b_bt = _train_setup(g, tmp_path / "b", epochs=1)
+    fit(b_args, b_model, None, b_bt, None, torch.device("cuda"), KL, KR, log=lambda s: None, forward_kwargs=draws)
+    c_args, c_model, c_bt = _train_setup(g, tmp_path / "b", epochs=2, resume="epoch_1.bin")
+    with torch.no_grad():
+        for p in c_model.parameters():
+            p.zero_()                                   # everything must come from the checkpoint
+    hc = fit(c_args, c_model, None, c_bt, None, torch.device("cuda"), KL, KR, log=lambda s: None, forward_kwargs=draws)
+    assert np.allclose(hc["iter_loss"], ha["iter_loss"][per_epoch:], rtol=1e-5)
+    for (k, va), vc in zip(a_model.state_dict().items(), c_model.state_dict().values()):
+        assert torch.allclose(va, vc, rtol=1e-5, atol=1e-6), k
+    assert hc["lr"][-1] == ha["lr"][-1] and len(hc["iter_loss"]) == per_epoch
+
+
+def test_epoch_validation_and_best_checkpoint(golden_dir, tmp_path):
+    """main.py:416-472 + 555-568: per-epoch validation with the 1-hypothesis 1-step sampler, the reference's log line,
+    best_epoch.bin."""
+    g = load(golden_dir, "g10_train_loop")
+    args, model, bt = _train_setup(g, tmp_path, epochs=1)
+    args.no_eval, args.checkpoint_frequency = False, 20
+    ev = D3DP(args, KL, KR, is_train=False).cuda()
+    cams, p3, p2 = dataset(77, [60, 30])
+    lines = []
+    hist = fit(args, model, ev, bt, lambda: list(zip(cams, p3, p2)), torch.device("cuda"), KL, KR, log=lines.append)
+    assert len(hist["losses_3d_valid"]) == 1 and hist["losses_3d_valid"][0].shape == (1,)
+    assert any(l.startswith("[1] time ") and " 3d_pos_valid " in l for l in lines)
+    assert os.path.exists(os.path.join(tmp_path, "best_epoch.bin")) and not os.path.exists(os.path.join(tmp_path, "epoch_1.bin"))
+    assert open(os.path.join(tmp_path, "training_log.txt")).read().strip().endswith("best epoch")
+    ck = load_checkpoint(os.path.join(tmp_path, "best_epoch.bin"), ev)
+    assert ck["epoch"] == 1

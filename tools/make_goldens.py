@@ -301,9 +301,159 @@ def g5(D3DP):
          e_jagg=e_jagg.numpy())
 
 
+
+def _ref_function(path, name, extra_globals):
+    """Compile ONE function of a reference script that cannot be imported as a module (main.py executes dataset
+    loading on import) by lifting its FunctionDef node out of the parsed file, and return the live function.  This
+    runs the reference's own code object here; no reference text is stored anywhere."""
+    import ast
+    tree = ast.parse(open(os.path.join(REF, path)).read())
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    mod = ast.Module(body=[node], type_ignores=[])
+    ns = dict(extra_globals)
+    exec(compile(mod, os.path.join(REF, path), "exec"), ns)
+    return ns[name]
+
+
+def g7(D3DP):
+    """N2 clip chunking: main.py:267-299 eval_data_prepare on sequences of 60 (ragged), 54 (exact), 27, 20 (short)
+    frames at F=27."""
+    from einops import rearrange
+    fn = _ref_function("main.py", "eval_data_prepare", {"torch": torch, "rearrange": rearrange})
+    rng = np.random.Generator(np.random.PCG64(811))
+    arrs = {"frames": 27}
+    for n in (60, 54, 27, 20, 1, 100):
+        s2 = rng.uniform(-1, 1, (1, n, 17, 2)).astype(np.float32)
+        s3 = rng.standard_normal((1, n, 17, 3)).astype(np.float32)
+        if n == 1:      # torch.squeeze drops the frame axis of a 1-frame sequence in the reference: not a valid input
+            continue
+        c2, c3 = fn(27, torch.from_numpy(s2), torch.from_numpy(s3))
+        arrs[f"seq2d_{n}"], arrs[f"seq3d_{n}"] = s2[0], s3[0]
+        arrs[f"clips2d_{n}"], arrs[f"clips3d_{n}"] = c2.numpy(), c3.numpy()
+    save("g7_clips", **arrs)
+
+
+def _gen_dataset(seed, lengths):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    p2 = [rng.uniform(-1, 1, (n, 17, 2)).astype(np.float32) for n in lengths]
+    p3 = [(rng.standard_normal((n, 17, 3)) * 0.3).astype(np.float32) for n in lengths]
+    cams = [rng.uniform(-1, 1, (9,)).astype(np.float32) for _ in lengths]
+    return cams, p3, p2
+
+
+def g8(D3DP):
+    """N3 batches: common/generators.py ChunkedGenerator_Seq, F=27, batch 4, shuffle + flip augmentation, two epochs
+    (so the RandomState carries over), plus an unshuffled/unaugmented pass with cameras."""
+    from common.generators import ChunkedGenerator_Seq
+    lengths = [70, 27, 100, 20]
+    cams, p3, p2 = _gen_dataset(821, lengths)
+    kl, kr = H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT
+    gen = ChunkedGenerator_Seq(4, cams, p3, p2, 27, pad=0, causal_shift=0, shuffle=True, augment=True,
+                               kps_left=kl, kps_right=kr, joints_left=kl, joints_right=kr)
+    arrs = {"lengths": np.array(lengths), "frames": 27, "batch": 4, "seed": 821, "num_batches": gen.batch_num(),
+            "num_frames": gen.num_frames()}
+    k = 0
+    for ep in range(2):
+        for cam, b3, b2 in gen.next_epoch():
+            arrs[f"cam_{k}"], arrs[f"b3_{k}"], arrs[f"b2_{k}"] = cam.copy(), b3.astype(np.float32), b2.astype(np.float32)
+            k += 1
+    arrs["n_batches_total"] = k
+    gen2 = ChunkedGenerator_Seq(3, None, p3, p2, 27, shuffle=False, augment=False)
+    j = 0
+    for _, b3, b2 in gen2.next_epoch():
+        arrs[f"plain_b3_{j}"], arrs[f"plain_b2_{j}"] = b3.astype(np.float32), b2.astype(np.float32)
+        j += 1
+    arrs["plain_batches"] = j
+    save("g8_batches", **arrs)
+
+
+def g9(D3DP):
+    """N4 Protocol #2: common/loss.py p_mpjpe (one pose set) and the four *_diffusion variants main.py:726-729 logs,
+    on the g5 tensors."""
+    from common.camera import project_to_2d
+    from common.loss import (p_mpjpe, p_mpjpe_diffusion, p_mpjpe_diffusion_all_min, p_mpjpe_diffusion_reproj)
+    g5 = np.load(os.path.join(OUT, "g5_caller.npz"))
+    Fr = int(g5["frames"])
+    starts = g5["starts"]
+    inputs_3d = torch.from_numpy(np.stack([g5["seq3d"][s:s + Fr] for s in starts]))
+    inputs_2d = torch.from_numpy(np.stack([g5["seq2d"][s:s + Fr] for s in starts]))
+    inputs_3d[:, :, 0] = 0
+    pred = torch.from_numpy(g5["pred"]).clone()
+    pred[:, :, :, :, 0] = 0
+    reproj = torch.from_numpy(g5["reproj"])
+    with Draws():
+        e_jbest = p_mpjpe_diffusion_all_min(pred, inputs_3d)
+        e_pbest = p_mpjpe_diffusion(pred, inputs_3d)
+        e_pagg = p_mpjpe_diffusion_all_min(pred, inputs_3d, mean_pos=True)
+        e_jagg = p_mpjpe_diffusion_reproj(pred, inputs_3d, reproj, inputs_2d)
+    single = p_mpjpe(pred[:, 0, 0].reshape(-1, 17, 3).numpy(), inputs_3d.reshape(-1, 17, 3).numpy())
+    # a reflected target: exercises the det(R) < 0 branch (loss.py:218-222)
+    refl = inputs_3d.clone()
+    refl[..., 0] *= -1
+    e_refl = p_mpjpe_diffusion(pred, refl)
+    save("g9_pmpjpe", e_jbest=np.asarray(e_jbest), e_pbest=np.asarray(e_pbest), e_pagg=np.asarray(e_pagg),
+         e_jagg=np.asarray(e_jagg), single=np.float64(single), e_pbest_reflected=np.asarray(e_refl))
+
+
+def g10(D3DP):
+    """N3 training loop: reference model + ChunkedGenerator_Seq + optim.AdamW(weight_decay=0.1) + mpjpe +
+    backward(loss.detach()) + per-epoch lr decay (main.py:311-401, 519-522): cs=64, dep=2, F=27, batch 4, two epochs
+    of four iterations, DropPath inactive (recorded t / noise draws)."""
+    from common.generators import ChunkedGenerator_Seq
+    from common.loss import mpjpe
+    import torch.optim as optim
+    cs, dep, Fr, seed = 64, 2, 27, 17
+    lengths = [70, 27, 100]
+    cams, p3, p2 = _gen_dataset(831, lengths)
+    kl, kr = H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT
+    gen = ChunkedGenerator_Seq(4, cams, p3, p2, Fr, shuffle=True, augment=True, kps_left=kl, kps_right=kr,
+                               joints_left=kl, joints_right=kr)
+    m = build_ref(D3DP, Fr, cs, dep, seed, is_train=True)
+    m.train()
+    _DropPathStub.injected = None
+    lr, lr_decay = 1e-4, 0.9
+    opt = optim.AdamW(m.parameters(), lr=lr, weight_decay=0.1)
+    rng = np.random.Generator(np.random.PCG64(832))
+    arrs = dict(cs=cs, dep=dep, frames=Fr, seed=seed, lengths=np.array(lengths), data_seed=831, lr=lr, lr_decay=lr_decay)
+    losses, it = [], 0
+    for epoch in range(2):
+        for _, b3, b2 in gen.next_epoch():
+            inputs_3d = torch.from_numpy(b3.astype("float32"))
+            inputs_2d = torch.from_numpy(b2.astype("float32"))
+            inputs_3d[:, :, 0] = 0
+            B = inputs_3d.shape[0]
+            ts = [torch.tensor([int(rng.integers(0, 1000))], dtype=torch.long) for _ in range(B)]
+            ns = [torch.from_numpy(rng.standard_normal((Fr, 17, 3)).astype(np.float32)) for _ in range(B)]
+            arrs[f"t_{it}"] = np.array([int(v) for v in ts])
+            arrs[f"noise_{it}"] = np.stack([n.numpy() for n in ns])
+            opt.zero_grad()
+            with Draws(randn_list=list(ns), randint_list=list(ts)):
+                pred = m(inputs_2d, inputs_3d)
+            loss = mpjpe(pred, inputs_3d)
+            loss.backward(loss.clone().detach())
+            losses.append(loss.item())
+            opt.step()
+            it += 1
+        lr *= lr_decay
+        for g in opt.param_groups:
+            g["lr"] *= lr_decay
+    arrs["losses"] = np.array(losses, dtype=np.float64)
+    arrs["final_lr"] = np.float64(opt.param_groups[0]["lr"])
+    sd = m.state_dict()
+    for pn in ("pose_estimator.head.1.weight", "pose_estimator.STEblocks.0.attn.qkv.weight", "pose_estimator.TTEblocks.1.mlp.fc2.bias",
+               "pose_estimator.Temporal_pos_embed", "pose_estimator.Spatial_norm.weight", "pose_estimator.time_mlp.1.weight"):
+        arrs[f"param::{pn}"] = sd[pn].detach().numpy().copy()
+    st = opt.state_dict()["state"]
+    arrs["n_state"] = len(st)
+    arrs["step0"] = np.float64(float(st[0]["step"]))
+    arrs["exp_avg_sq_sum"] = np.float64(sum(float(v["exp_avg_sq"].double().sum()) for v in st.values()))
+    arrs["exp_avg_abs_sum"] = np.float64(sum(float(v["exp_avg"].double().abs().sum()) for v in st.values()))
+    save("g10_train_loop", **arrs)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g0,g1,g2,g3,g4,g5,g6")
+    ap.add_argument("--only", default="g0,g1,g2,g3,g4,g5,g6,g7,g8,g9,g10")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     D3DP = import_reference()
