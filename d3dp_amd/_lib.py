@@ -76,7 +76,8 @@ PROTOTYPES = {
     "d3dp_clip_count": (C.c_int, [C.c_int32, C.c_int32]),
     "d3dp_clip_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_void_p]),
-    "d3dp_clip_scatter": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]),
+    "d3dp_clip_scatter": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p]),
+    "d3dp_jpma_ex": (C.c_int, [C.c_void_p] * 11 + [C.c_int32] * 7 + [C.c_void_p]),
     "d3dp_jpma_winners": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 7 + [C.c_void_p]),
     "d3dp_jpma_combine": (C.c_int, [C.c_void_p, C.c_int32, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "d3dp_batch_gather": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 4 + [C.c_void_p]),

@@ -53,9 +53,10 @@ def clip_gather(seq: torch.Tensor, receptive_field: int, kps_left: Optional[Sequ
     return dst, flip
 
 
-def clip_scatter(pred: torch.Tensor, n_frames: int) -> torch.Tensor:
+def clip_scatter(pred: torch.Tensor, n_frames: int, last_wins: bool = False) -> torch.Tensor:
     """pred (n_clips,K,H,F,J,D) on the GPU -> (K,H,n_frames,J,D): the per-video prediction the reference assembles at
-    videopose_diffusion.py:150-164."""
+    videopose_diffusion.py:150-164; ``last_wins`` selects main_3dhp.py:327-330's variant, where the final clip
+    overwrites all of the last F frames."""
     if not pred.is_cuda:
         raise _lib.D3DPHipError("clip_scatter runs on the GPU (tensor on %s); there is no CPU fallback" % pred.device)
     lib = _lib.load()
@@ -64,6 +65,6 @@ def clip_scatter(pred: torch.Tensor, n_frames: int) -> torch.Tensor:
     src = pred.to(torch.float32).contiguous()
     out = torch.empty((K, H, n_frames, J, D), dtype=torch.float32, device=src.device)
     with torch.cuda.device(src.device):
-        _lib.check(lib.d3dp_clip_scatter(src.data_ptr(), out.data_ptr(), n_frames, K, H, Fr, J, D,
+        _lib.check(lib.d3dp_clip_scatter(src.data_ptr(), out.data_ptr(), n_frames, K, H, Fr, J, D, int(last_wins),
                                          _lib.current_stream()), "d3dp_clip_scatter")
     return out

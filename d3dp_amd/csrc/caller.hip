@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void clip_gather_kernel(const float* __restric
 // pred [n_clips, K, H, F, J, D] -> out [K, H, n, J, D]  (videopose_diffusion.py:150-164, including its behaviour for
 // n < F: the LAST n frames of the single padded clip are taken).
 __global__ __launch_bounds__(256) void clip_scatter_kernel(const float* __restrict__ pred, float* __restrict__ out,
-                                                           int n, int n_clips, int KH, int F, int JD) {
+                                                           int n, int n_clips, int KH, int F, int JD, int last_wins) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t total = (size_t)KH * n * JD;
   if (i >= total) return;
@@ -59,8 +59,11 @@ __global__ __launch_bounds__(256) void clip_scatter_kernel(const float* __restri
   const int fr = (int)(r % n), kh = (int)(r / n);
   int c, f;
   const int covered = (n_clips - 1) * F;         // frames owned by the leading full clips
-  if (fr < covered) { c = fr / F; f = fr % F; }
-  else { c = n_clips - 1; const int left = n - covered; f = F - left + (fr - covered); }
+  // last_wins: the final clip overwrites ALL of the last F frames (main_3dhp.py:327-330 pose_post_process) instead of
+  // only the frames no earlier clip produced
+  const int own = (last_wins && n >= F) ? n - F : covered;
+  if (fr < own) { c = fr / F; f = fr % F; }
+  else { c = n_clips - 1; f = F - (n - fr); }
   out[i] = pred[(((size_t)c * KH + kh) * F + f) * JD + e];
 }
 
@@ -252,13 +255,13 @@ int d3dp_clip_gather(const float* src, float* dst, float* dst_flip, const int32_
 }
 
 int d3dp_clip_scatter(const float* pred, float* out, int32_t n, int32_t K, int32_t H, int32_t F, int32_t J, int32_t D,
-                      void* stream) {
+                      int32_t last_wins, void* stream) {
   if (pred == nullptr || out == nullptr || n <= 0 || K <= 0 || H <= 0 || F <= 0 || J <= 0 || D <= 0)
     return d3dp_set_error(-1, "d3dp_clip_scatter: bad argument");
   const int n_clips = d3dp_clip_count(n, F);
   const size_t total = (size_t)K * H * n * J * D;
   hipLaunchKernelGGL(clip_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred,
-                     out, n, n_clips, K * H, F, J * D);
+                     out, n, n_clips, K * H, F, J * D, last_wins);
   return d3dp_check_launch("clip_scatter");
 }
 

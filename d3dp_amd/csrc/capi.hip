@@ -437,8 +437,20 @@ int d3dp_jpma(const float* pred, const float* traj, const float* cam, const floa
   if (!pred || !traj || !cam || !gt2d || !agg || B < 1 || K < 1 || H < 1)
     return fail(D3DP_EINVAL, "d3dp_jpma: bad argument");
   if ((err_sel || err_min) && !gt3d) return fail(D3DP_EINVAL, "d3dp_jpma: error outputs need gt3d");
-  LAUNCH_TRY(d3dp_launch_jpma(pred, traj, cam, gt2d, gt3d, agg, sel, err_sel, err_min, nullptr, 0, B, K, H, F, J,
-                              zero_root, (hipStream_t)stream));
+  LAUNCH_TRY(d3dp_launch_jpma(pred, traj, cam, gt2d, gt3d, agg, sel, err_sel, err_min, nullptr, nullptr, nullptr, 0, B,
+                              K, H, F, J, zero_root ? 0 : -1, 0, (hipStream_t)stream));
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
+int d3dp_jpma_ex(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d, float* agg,
+                 int32_t* sel, float* err_sel, float* err_min, float* jbest, float* mean, int32_t B, int32_t K, int32_t H,
+                 int32_t F, int32_t J, int32_t root_joint, int32_t linear_projection, void* stream) {
+  if (!pred || !traj || !cam || !gt2d || B < 1 || K < 1 || H < 1 || root_joint >= J)
+    return fail(D3DP_EINVAL, "d3dp_jpma_ex: bad argument");
+  if ((err_sel || err_min || jbest) && !gt3d) return fail(D3DP_EINVAL, "d3dp_jpma_ex: error / J-Best outputs need gt3d");
+  LAUNCH_TRY(d3dp_launch_jpma(pred, traj, cam, gt2d, gt3d, agg, sel, err_sel, err_min, nullptr, jbest, mean, 0, B, K, H,
+                              F, J, root_joint, linear_projection, (hipStream_t)stream));
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
 }
@@ -448,8 +460,8 @@ int d3dp_jpma_winners(const float* pred, const float* traj, const float* cam, co
                       void* stream) {
   if (!pred || !traj || !cam || !gt2d || !win || B < 1 || K < 1 || H < 1 || h_offset < 0)
     return fail(D3DP_EINVAL, "d3dp_jpma_winners: bad argument");
-  LAUNCH_TRY(d3dp_launch_jpma(pred, traj, cam, gt2d, nullptr, nullptr, nullptr, nullptr, nullptr, win, h_offset, B, K, H,
-                              F, J, zero_root, (hipStream_t)stream));
+  LAUNCH_TRY(d3dp_launch_jpma(pred, traj, cam, gt2d, nullptr, nullptr, nullptr, nullptr, nullptr, win, nullptr, nullptr,
+                              h_offset, B, K, H, F, J, zero_root ? 0 : -1, 0, (hipStream_t)stream));
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
 }

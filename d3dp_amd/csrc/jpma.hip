@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void jpma_kernel(const float* __restrict__ pre
                                                    const float* __restrict__ gt3d, float* __restrict__ agg,
                                                    int* __restrict__ sel, float* __restrict__ err_sel,
                                                    float* __restrict__ err_min, float* __restrict__ win,
-                                                   int h_offset, int B, int K, int H, int F, int J, int zero_root) {
+                                                   float* __restrict__ jbest, float* __restrict__ mean, int h_offset,
+                                                   int B, int K, int H, int F, int J, int root_joint, int linear) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t FJ = (size_t)F * J, total = (size_t)B * K * FJ;
   if (i >= total) return;
@@ -45,24 +46,33 @@ __global__ __launch_bounds__(256) void jpma_kernel(const float* __restrict__ pre
   if (gt3d != nullptr) { g3[0] = gt3d[(b * FJ + fj) * 3]; g3[1] = gt3d[(b * FJ + fj) * 3 + 1]; g3[2] = gt3d[(b * FJ + fj) * 3 + 2]; }
   const float* p = pred + (bk * H * FJ + fj) * 3;
   float best2 = INFINITY, bx = 0.f, by = 0.f, bz = 0.f, best3 = 0.f, min3 = INFINITY;
+  float mx = 0.f, my = 0.f, mz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;      // pose of the smallest 3D error; running sum
   int bh = 0;
   for (int h = 0; h < H; ++h, p += FJ * 3) {
     float x[3] = {p[0], p[1], p[2]};
-    if (zero_root && j == 0) { x[0] = 0.f; x[1] = 0.f; x[2] = 0.f; }       // main.py:700
+    if (j == root_joint) { x[0] = 0.f; x[1] = 0.f; x[2] = 0.f; }          // main.py:700 (joint 0), main_3dhp.py:777 (14)
     const float a[3] = {x[0] + tr[0], x[1] + tr[1], x[2] + tr[2]};        // main.py:706-707
     float u, v;
-    project(a, c, u, v);
+    if (linear) {                                                         // camera.py:62-83 project_to_2d_linear
+      u = c[0] * clamp1(a[0] / a[2]) + c[2];
+      v = c[1] * clamp1(a[1] / a[2]) + c[3];
+    } else {
+      project(a, c, u, v);
+    }
     const float du = u - g2u, dv = v - g2v;
     const float e2 = sqrtf(du * du + dv * dv);
     const float d0 = x[0] - g3[0], d1 = x[1] - g3[1], d2 = x[2] - g3[2];
     const float e3 = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
-    min3 = fminf(min3, e3);
+    if (e3 < min3) { min3 = e3; mx = x[0]; my = x[1]; mz = x[2]; }
+    sx += x[0]; sy += x[1]; sz += x[2];
     if (e2 < best2) { best2 = e2; bh = h; bx = x[0]; by = x[1]; bz = x[2]; best3 = e3; }
   }
   if (agg != nullptr) { agg[i * 3] = bx; agg[i * 3 + 1] = by; agg[i * 3 + 2] = bz; }
   if (sel != nullptr) sel[i] = bh;
   if (err_sel != nullptr) err_sel[i] = best3;     // J_Agg per-joint error (loss.py:70-72)
   if (err_min != nullptr) err_min[i] = min3;      // J_Best per-joint error (loss.py:38-41)
+  if (jbest != nullptr) { jbest[i * 3] = mx; jbest[i * 3 + 1] = my; jbest[i * 3 + 2] = mz; }   // main_3dhp.py:798-801
+  if (mean != nullptr) { mean[i * 3] = sx / H; mean[i * 3 + 1] = sy / H; mean[i * 3 + 2] = sz / H; }   // P-Agg pose
   if (win != nullptr) {                           // this rank's winner for the reduced exchange
     win[i * 5] = best2; win[i * 5 + 1] = bx; win[i * 5 + 2] = by; win[i * 5 + 3] = bz;
     win[i * 5 + 4] = __int_as_float(h_offset + bh);
@@ -72,10 +82,10 @@ __global__ __launch_bounds__(256) void jpma_kernel(const float* __restrict__ pre
 }  // namespace
 
 int d3dp_launch_jpma(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d,
-                     float* agg, int* sel, float* err_sel, float* err_min, float* win, int h_offset, int B, int K,
-                     int H, int F, int J, int zero_root, hipStream_t st) {
+                     float* agg, int* sel, float* err_sel, float* err_min, float* win, float* jbest, float* mean,
+                     int h_offset, int B, int K, int H, int F, int J, int root_joint, int linear, hipStream_t st) {
   const size_t total = (size_t)B * K * F * J;
   hipLaunchKernelGGL(jpma_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pred, traj, cam, gt2d, gt3d,
-                     agg, sel, err_sel, err_min, win, h_offset, B, K, H, F, J, zero_root);
+                     agg, sel, err_sel, err_min, win, jbest, mean, h_offset, B, K, H, F, J, root_joint, linear);
   return 0;
 }

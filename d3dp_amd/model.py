@@ -542,3 +542,23 @@ class D3DP(nn.Module):
         droppath = kw.pop("droppath", None)
         x_poses, _, t = self.prepare_targets(input_3d, **kw)
         return self.pose_estimator(input_2d, x_poses.float(), t.squeeze(-1), droppath=droppath)
+
+
+class D3DP3DHP(D3DP):
+    """Drop-in for the MPI-INF-3DHP variant (reference common/diffusionpose_3dhp.py): the same sampler and denoiser
+    working in metres internally, with millimetre poses at the boundary -- sampler outputs are multiplied by 1000
+    (:212, :256), training targets arrive in millimetres and are divided by 1000 (:280) and the training prediction
+    is returned in millimetres (:287)."""
+
+    MM = 1000.0
+
+    def ddim_sample_flip(self, *a, **k):
+        return super().ddim_sample_flip(*a, **k).mul_(self.MM)
+
+    def ddim_sample(self, *a, **k):
+        return [p * self.MM for p in super().ddim_sample(*a, **k)]
+
+    def forward(self, input_2d, input_3d, input_2d_flip=None, **kw):
+        if not self.is_train:
+            return super().forward(input_2d, input_3d, input_2d_flip=input_2d_flip, **kw)
+        return super().forward(input_2d, input_3d / self.MM, **kw) * self.MM

@@ -148,6 +148,14 @@ int d3dp_q_sample(const float* x0, const float* noise, const double* sqrt_ac, co
 int d3dp_jpma(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d, float* agg,
               int32_t* sel, float* err_sel, float* err_min, int32_t B, int32_t K, int32_t H, int32_t F, int32_t J,
               int32_t zero_root, void* stream);
+/* d3dp_jpma with the 3DHP evaluation's options and pose outputs (main_3dhp.py:777-835): root_joint = index of the joint
+ * written as 0 before use (0 for Human3.6M, 14 for 3DHP, -1 none); linear_projection = camera.py:62-83
+ * project_to_2d_linear (f * clamp(X/Z) + c) instead of the distortion model; jbest (B,K,F,J,3) = per joint the
+ * hypothesis closest to gt3d (J-Best pose), mean (B,K,F,J,3) = average over hypotheses (P-Agg pose).  Any output may be
+ * NULL. */
+int d3dp_jpma_ex(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d, float* agg,
+                 int32_t* sel, float* err_sel, float* err_min, float* jbest, float* mean, int32_t B, int32_t K, int32_t H,
+                 int32_t F, int32_t J, int32_t root_joint, int32_t linear_projection, void* stream);
 
 /* ---- training step (reference main.py:387-401 around diffusionpose.py:279-287 / mixste.py:215-225) ----------------
  * Context must be D3DP_MODE_TRAIN.  x3d (B,F,J,3) is the diffused pose from d3dp_q_sample, t (B) int64.
@@ -173,7 +181,7 @@ int d3dp_clip_gather(const float* src, float* dst, float* dst_flip, const int32_
 /* de-chunking: pred (n_clips,K,H,F,J,D) -> out (K,H,n,J,D)  (in_the_wild/videopose_diffusion.py:150-164, including
  * its n < F behaviour: the last n frames of the padded clip). */
 int d3dp_clip_scatter(const float* pred, float* out, int32_t n, int32_t K, int32_t H, int32_t F, int32_t J, int32_t D,
-                      void* stream);
+                      int32_t last_wins, void* stream);   /* last_wins: main_3dhp.py:327-330 (final clip owns the last F frames) */
 /* E1 reduced exchange: d3dp_jpma_winners writes this rank's per-joint winner win (B,K,F,J,5) =
  * (2D error, x, y, z, bits of int32 global hypothesis index h_offset + h); after an all-gather over R ranks
  * (rank-major) d3dp_jpma_combine picks the smallest 2D error per joint, lowest rank on ties (= lowest global h, the

@@ -177,3 +177,25 @@ def test_train_loop_oracle_matches_reference(golden_dir):
         if k.startswith("param::"):
             name = k[len("param::pose_estimator."):]
             assert np.allclose(ps[name].numpy(), g[k], rtol=0, atol=2e-6), name
+
+
+# ---- N4: 3DHP caller side -------------------------------------------------------------------------------------------------
+def test_3dhp_oracle_and_host_helpers_match_reference(golden_dir):
+    from d3dp_amd import eval3dhp as e3
+    g = load(golden_dir, "g11_3dhp")
+    pred, gt, valid = g["pred"], g["gt"], g["valid"]
+    # oracle
+    assert np.allclose(co.mpjpe_diffusion_3dhp(pred, gt, valid), g["e_pbest"], rtol=1e-6)
+    assert np.allclose(co.mpjpe_diffusion_3dhp(pred, gt, valid, mean_pos=True), g["e_pagg"], rtol=1e-6)
+    absol = pred + g["traj"][:, None, None]
+    assert np.allclose(co.project_linear(absol, g["cam1"]), g["reproj_linear"], rtol=1e-6, atol=1e-3)
+    assert np.allclose(co.image_coordinates(g["x2d"], 2048, 2048), g["target_pix"], rtol=1e-6)
+    assert np.array_equal(co.stitch_last_wins(pred[:, :, 0], int(g["n_frames"]), int(g["frames"])).transpose(3, 2, 1, 0), g["stitched"])
+    assert np.array_equal(co.cam_mm_to_pix([7.32506, 7.32506, -0.0322884, 0.0929296, 0, 0, 0, 0, 0], [2048, 2048, 10, 10]), g["cam1"])
+    # product host helpers (device-agnostic torch code paths; the kernels are covered by tests/test_hip_caller.py)
+    assert np.array_equal(e3.camera_for("TS1")[0].numpy(), g["cam1"]) and e3.camera_for("TS3")[2] is True
+    assert np.array_equal(e3.camera_for("TS5")[0].numpy(), g["cam2"]) and e3.camera_for("TS6")[2] is False
+    assert np.allclose(e3.image_coordinates(torch.from_numpy(g["x2d"]), 2048, 2048).numpy(), g["target_pix"], rtol=1e-6)
+    P, G, V = torch.from_numpy(pred), torch.from_numpy(gt), torch.from_numpy(valid) > 0.5
+    assert np.allclose(e3.mpjpe_diffusion_3dhp(P, G, V).numpy(), g["e_pbest"], rtol=1e-6)
+    assert np.allclose(e3.mpjpe_diffusion_3dhp(P, G, V, mean_pos=True).numpy(), g["e_pagg"], rtol=1e-6)

@@ -295,3 +295,98 @@ def test_epoch_validation_and_best_checkpoint(golden_dir, tmp_path):
     assert open(os.path.join(tmp_path, "training_log.txt")).read().strip().endswith("best epoch")
     ck = load_checkpoint(os.path.join(tmp_path, "best_epoch.bin"), ev)
     assert ck["epoch"] == 1
+
+
+# ---- N4: MPI-INF-3DHP variant -----------------------------------------------------------------------------------------------
+def test_3dhp_sampler_and_train_branch_match_reference(golden_dir):
+    """common/diffusionpose_3dhp.py: millimetre outputs (x1000) of the sampler and of the training branch (targets
+    /1000).  Exact numerics: <= 1e-3 mm mean per-joint error, the north_star tolerance."""
+    from d3dp_amd import D3DP3DHP
+    g = load(golden_dir, "g12_3dhp_sampler")
+    Fr, cs, dep = int(g["frames"]), int(g["cs"]), int(g["dep"])
+    jl, jr = [int(v) for v in g["joints_left"]], [int(v) for v in g["joints_right"]]
+    args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
+    out_ref = torch.from_numpy(g["out"])
+    B, K, H = out_ref.shape[:3]
+    m = D3DP3DHP(args, jl, jr, is_train=False, num_proposals=H, sampling_timesteps=K, numerics="exact")
+    m.load_state_dict(make_state_dict(int(g["seed"]), cs, dep, Fr), strict=False)
+    m = m.cuda().eval()
+    out = m(torch.from_numpy(g["x2d"]).cuda(), None, input_2d_flip=torch.from_numpy(g["x2d_flip"]).cuda(),
+            noise=[torch.from_numpy(n) for n in g["noise"]])
+    err_mm = torch.norm(out.cpu() - out_ref, dim=-1).mean().item()          # outputs are already millimetres
+    print(f"3DHP sampler vs reference: {err_mm:.2e} mm (|out| max {out_ref.abs().max().item():.0f} mm)")
+    assert out.shape == out_ref.shape and err_mm < 1e-3
+    mt = D3DP3DHP(args, jl, jr, is_train=True)
+    mt.load_state_dict(make_state_dict(int(g["seed"]), cs, dep, Fr), strict=False)
+    mt = mt.cuda().eval()                                                   # eval(): DropPath inactive like the fixture
+    with torch.no_grad():
+        tr = mt(torch.from_numpy(g["x2d"]).cuda(), torch.from_numpy(g["gt_mm"]).cuda(),
+                t=torch.from_numpy(g["t"])[:, None], noise=torch.from_numpy(g["train_noise"]))
+    err_tr = torch.norm(tr.cpu() - torch.from_numpy(g["train_out"]), dim=-1).mean().item()
+    print(f"3DHP train branch vs reference: {err_tr:.2e} mm")
+    assert err_tr < 1e-3
+
+
+def test_3dhp_aggregation_and_stitching(golden_dir, tmp_path):
+    from d3dp_amd import eval3dhp as e3
+    g = load(golden_dir, "g11_3dhp")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    pred, gt, traj = g["pred"], g["gt"], g["traj"]
+    cam1, linear = e3.camera_for("TS1")[0], True
+    tgt = g["target_pix"]
+    poses = e3.aggregate_poses(t(pred), t(gt), t(traj), cam1, t(tgt), linear)
+    want = co.aggregate_poses_3dhp(pred, gt, g["reproj_linear"], tgt)       # selection on the REFERENCE's reprojection
+    for k in ("P_Agg", "P_Best", "J_Best", "J_Agg"):
+        got = poses[k].cpu().numpy()
+        if k == "P_Agg":
+            assert np.abs(got - want[k]).max() < 1e-3                        # a mean of mm values: summation order
+        else:
+            same = np.all(got == want[k], axis=-1)
+            assert same.mean() > 0.999, (k, same.mean())                     # selections: exact up to last-ulp ties
+    # distortion-model camera (TS5/TS6) and a non-zero root index folded into the kernel
+    cam2 = e3.camera_for("TS5")[0]
+    p2 = pred.copy()
+    p2[:, :, :, :, 14] = 7.0
+    poses2 = e3.aggregate_poses(t(p2), t(gt), t(traj), cam2, t(tgt), False, root_joint=14)
+    want2 = co.aggregate_poses_3dhp(pred, gt, g["reproj_dist"], tgt)
+    assert np.all(poses2["J_Agg"].cpu().numpy() == want2["J_Agg"], axis=-1).mean() > 0.999
+    assert np.all(poses2["P_Best"].cpu().numpy() == want2["P_Best"])
+    # stitching: final clip owns the last F frames (main_3dhp.py:327-331), then the (3,17,n,K) export layout
+    n = int(g["n_frames"])
+    st = clip_scatter(t(pred[:, :, :1]), n, last_wins=True)[:, 0].cpu().numpy()
+    assert np.array_equal(st.transpose(3, 2, 1, 0), g["stitched"])
+    assert np.array_equal(st, co.stitch_last_wins(pred[:, :, 0], n, int(g["frames"])))
+    # valid-frame metrics on the device
+    V = t(g["valid"]) > 0.5
+    assert np.allclose(e3.mpjpe_diffusion_3dhp(t(pred), t(gt), V).cpu().numpy(), g["e_pbest"], rtol=1e-5)
+    assert np.allclose(e3.mpjpe_diffusion_3dhp(t(pred), t(gt), V, mean_pos=True).cpu().numpy(), g["e_pagg"], rtol=1e-5)
+
+
+def test_3dhp_evaluate_sequence_end_to_end(golden_dir, tmp_path):
+    """main_3dhp.py:711-912 on a synthetic 70-frame sequence: clips -> sampler (mm) -> poses/metrics -> stitched
+    (K,n,17,3) -> .mat files with the reference's (3,17,n,K) layout; cross-checked against the oracle on the same
+    sampler output."""
+    import scipy.io as scio
+    from d3dp_amd import D3DP3DHP, eval3dhp as e3
+    Fr, cs, dep, H, K, n = 27, 64, 2, 3, 2, 70
+    args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
+    m = D3DP3DHP(args, e3.KPS_LEFT_3DHP, e3.KPS_RIGHT_3DHP, is_train=False, num_proposals=H, sampling_timesteps=K)
+    m.load_state_dict(make_state_dict(23, cs, dep, Fr), strict=False)
+    m = m.cuda().eval()
+    rng = np.random.default_rng(5)
+    seq3 = (rng.standard_normal((n, 17, 3)) * 300).astype(np.float32)
+    seq3[:, 14] = np.array([0, 0, 4000.0]) + rng.standard_normal((n, 3)) * 50
+    seq2 = rng.uniform(-1, 1, (n, 17, 2)).astype(np.float32)
+    valid = (rng.uniform(size=n) < 0.8).astype(np.float32)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    sums, N, st = e3.evaluate_sequence(m, seq3, seq2, valid, "TS1", Fr, batch_clips=2, generator=gen)
+    assert N == 3 * Fr and st["all"].shape == (K, H, n, 17, 3) and all(st[k].shape == (K, n, 17, 3) for k in ("P_Agg", "J_Agg"))
+    assert torch.isfinite(sums["P_Best"]).all() and (sums["P_Agg"] > 0).all()
+    assert (st["all"][:, :, :, 14] == 0).all()
+    # P_Agg stitched == mean over hypotheses of the stitched stack; J_Agg picks existing hypotheses
+    assert torch.allclose(st["P_Agg"], st["all"].mean(dim=1), atol=1e-3)
+    d = (st["all"] - st["J_Agg"][:, None]).abs().sum(-1)                     # (K,H,n,17)
+    assert (d.min(dim=1).values == 0).all()
+    paths = e3.export_mat(str(tmp_path), {"TS1": st})
+    mat = scio.loadmat(paths["J_Agg"])
+    assert mat["TS1"].shape == (3, 17, n, K) and np.allclose(mat["TS1"], st["J_Agg"].cpu().numpy().transpose(3, 2, 1, 0))

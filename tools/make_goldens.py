@@ -451,9 +451,77 @@ def g10(D3DP):
     save("g10_train_loop", **arrs)
 
 
+
+def g11(D3DP):
+    """N4 3DHP caller side: common/loss.py mpjpe_diffusion_3dhp (valid-frame mask, both modes), camera.py
+    project_to_2d_linear / image_coordinates, and main_3dhp.py's cam_mm_to_pix + pose_post_process (lifted by AST),
+    on synthetic millimetre poses (3 clips of F=27 cut from a 60-frame sequence)."""
+    from common.camera import image_coordinates, project_to_2d, project_to_2d_linear
+    from common.loss import mpjpe_diffusion_3dhp
+    cam_mm_to_pix = _ref_function("main_3dhp.py", "cam_mm_to_pix", {})
+    pose_post_process = _ref_function("main_3dhp.py", "pose_post_process", {})
+    rng = np.random.Generator(np.random.PCG64(841))
+    B, K, H, Fr, N = 3, 2, 4, 27, 60
+    gt = (rng.standard_normal((B, Fr, 17, 3)) * 300).astype(np.float32)
+    traj = (rng.standard_normal((B, Fr, 1, 3)) * 100 + np.array([0, 0, 4000.0])).astype(np.float32)
+    gt[:, :, 14] = 0
+    pred = (gt[:, None, None] + rng.standard_normal((B, K, H, Fr, 17, 3)) * 40).astype(np.float32)
+    pred[:, :, :, :, 14] = 0
+    valid = (rng.uniform(size=(B, Fr, 1)) < 0.8).astype(np.float32)
+    x2d = rng.uniform(-1, 1, (B, Fr, 17, 2)).astype(np.float32)
+    cam1 = cam_mm_to_pix(torch.tensor([7.32506, 7.32506, -0.0322884, 0.0929296, 0, 0, 0, 0, 0]), [2048, 2048, 10, 10])
+    cam2 = cam_mm_to_pix(torch.tensor([8.770747185, 8.770747185, -0.104908645, 0.104899704, 0, 0, 0, 0, 0]),
+                         [1920, 1080, 10, 5.625])
+    P, G, V = torch.from_numpy(pred), torch.from_numpy(gt), torch.from_numpy(valid)
+    e_pbest = mpjpe_diffusion_3dhp(P, G, V.type(torch.bool))
+    e_pagg = mpjpe_diffusion_3dhp(P, G, V.type(torch.bool), mean_pos=True)
+    absol = (P + torch.from_numpy(traj)[:, None, None]).reshape(-1, 17, 3)
+    rp_lin = project_to_2d_linear(absol, cam1.unsqueeze(0).repeat(absol.shape[0], 1)).reshape(B, K, H, Fr, 17, 2)
+    rp_dist = project_to_2d(absol, cam2.unsqueeze(0).repeat(absol.shape[0], 1)).reshape(B, K, H, Fr, 17, 2)
+    tgt_pix = image_coordinates(x2d[..., :2], w=2048, h=2048)
+    # stitching: (n_clips, K, F, J, 3) -> (3, J, N, K)
+    sel = pred[:, :, 0]
+    stitched = pose_post_process(sel, {"TS1": np.zeros((K, N, 17, 3))}, "TS1", Fr)["TS1"]
+    save("g11_3dhp", pred=pred, gt=gt, traj=traj, valid=valid, x2d=x2d, cam1=cam1.numpy(), cam2=cam2.numpy(),
+         e_pbest=e_pbest.numpy(), e_pagg=e_pagg.numpy(), reproj_linear=rp_lin.numpy(), reproj_dist=rp_dist.numpy(),
+         target_pix=np.asarray(tgt_pix, dtype=np.float32), stitched=stitched.astype(np.float32), n_frames=N, frames=Fr)
+
+
+def g12(D3DP):
+    """N4 3DHP sampler: common/diffusionpose_3dhp.py D3DP, F=27, B=2, H=2, K=2, recorded noise -> millimetre output,
+    plus one training-branch forward (targets in millimetres)."""
+    from common.diffusionpose_3dhp import D3DP as D3DP_3DHP
+    Fr, cs, dep, seed, B, H, K = 27, 64, 2, 19, 2, 2, 2
+    jl, jr = [5, 6, 7, 11, 12, 13], [2, 3, 4, 8, 9, 10]
+    torch.manual_seed(0)
+    m = D3DP_3DHP(make_args(Fr, cs, dep), jl, jr, is_train=False, num_proposals=H, sampling_timesteps=K)
+    m.load_state_dict(make_state_dict(seed, cs, dep, Fr), strict=False)
+    m.eval()
+    x2d = torch.from_numpy(synthetic_inputs_2d(851, B, Fr))
+    x2f = x2d.clone()
+    x2f[..., 0] *= -1
+    x2f[:, :, jl + jr] = x2f[:, :, jr + jl]
+    noises = [torch.from_numpy(synthetic_noise(860 + i, (B, H, Fr, 17, 3))) for i in range(K)]
+    with Draws(randn_list=[n.clone() for n in noises]), torch.no_grad():
+        out = m(x2d, None, input_2d_flip=x2f)
+    mt = D3DP_3DHP(make_args(Fr, cs, dep), jl, jr, is_train=True)
+    mt.load_state_dict(make_state_dict(seed, cs, dep, Fr), strict=False)
+    mt.train()
+    _DropPathStub.injected = None
+    gt_mm = torch.from_numpy(synthetic_noise(870, (B, Fr, 17, 3))) * 300
+    ts = [torch.tensor([v], dtype=torch.long) for v in (17, 803)]
+    ns = [torch.from_numpy(synthetic_noise(880 + i, (Fr, 17, 3))) for i in range(B)]
+    with Draws(randn_list=[n.clone() for n in ns], randint_list=list(ts)), torch.no_grad():
+        tr = mt(x2d, gt_mm)
+    save("g12_3dhp_sampler", frames=Fr, cs=cs, dep=dep, seed=seed, x2d=x2d.numpy(), x2d_flip=x2f.numpy(),
+         noise=np.stack([n.numpy() for n in noises]), out=out.numpy(), gt_mm=gt_mm.numpy(),
+         t=np.array([int(v) for v in ts]), train_noise=np.stack([n.numpy() for n in ns]), train_out=tr.numpy(),
+         joints_left=np.array(jl), joints_right=np.array(jr))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g0,g1,g2,g3,g4,g5,g6,g7,g8,g9,g10")
+    ap.add_argument("--only", default="g0,g1,g2,g3,g4,g5,g6,g7,g8,g9,g10,g11,g12")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     D3DP = import_reference()
