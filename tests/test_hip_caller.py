@@ -390,3 +390,29 @@ def test_3dhp_evaluate_sequence_end_to_end(golden_dir, tmp_path):
     paths = e3.export_mat(str(tmp_path), {"TS1": st})
     mat = scio.loadmat(paths["J_Agg"])
     assert mat["TS1"].shape == (3, 17, n, K) and np.allclose(mat["TS1"], st["J_Agg"].cpu().numpy().transpose(3, 2, 1, 0))
+
+
+# ---- entrypoints ------------------------------------------------------------------------------------------------------------
+def test_cli_train_resume_evaluate_and_3dhp(tmp_path, capsys):
+    """`main.py` without --evaluate trains (reference main.py:305), writes reference-format checkpoints, resumes from
+    them, and `main.py --evaluate` / `main_3dhp.py --evaluate` read them back (Protocol #1 and #2 lines, .mat export)."""
+    from d3dp_amd import cli
+    ck = str(tmp_path)
+    common = ["--synthetic", "-c", ck, "-f", "27", "-cs", "64", "-dep", "2", "--synthetic-frames", "120"]
+    assert cli.main(common + ["-e", "2", "-b", "108", "-s", "27", "-cf", "1", "-lr", "0.0005"]) == 0
+    log = open(os.path.join(ck, "training_log.txt")).read().splitlines()
+    assert [l for l in log if l.startswith("[2] time ")] and os.path.exists(os.path.join(ck, "epoch_2.bin"))
+    first = float([l for l in log if l.startswith("[1] ")][0].split("3d_train ")[1].split()[0])
+    assert cli.main(common + ["-e", "3", "-b", "108", "-s", "27", "-cf", "1", "-r", "epoch_2.bin", "--no-eval"]) == 0
+    log = open(os.path.join(ck, "training_log.txt")).read().splitlines()
+    third = float([l for l in log if l.startswith("[3] ")][0].split("3d_train ")[1].split()[0])
+    print(f"cli training: epoch-1 loss {first:.2f} mm -> epoch-3 loss {third:.2f} mm")
+    assert third < first
+    assert cli.main(common + ["--evaluate", "epoch_3.bin", "-num_proposals", "4", "-sampling_timesteps", "2", "-b", "2", "--p2"]) == 0
+    txt = open(os.path.join(ck, "h36m_test_log_H4_K2.txt")).read()
+    assert "step 1 : Protocol #1 Error (MPJPE) J_Agg:" in txt and "step 1 : Protocol #2 Error (MPJPE) P_Best:" in txt
+    assert cli.main_3dhp(["--synthetic", "-c", ck, "-f", "27", "-cs", "64", "-dep", "2", "--synthetic-frames", "70",
+                          "--evaluate", "epoch_3.bin", "-num_proposals", "4", "-sampling_timesteps", "2"]) == 0
+    txt = open(os.path.join(ck, "3dhp_test_log_H4_K2.txt")).read()
+    assert "----TS2----" in txt and "step 1 : Protocol #1 Error (MPJPE) P_Agg:" in txt
+    assert os.path.exists(os.path.join(ck, "inference_data_J_Agg.mat"))
