@@ -122,19 +122,36 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(const float* __restri
 // exp_avg_sq by mul + addcmul; denom = sqrt(v)/sqrt(bc2) + eps; p += -step_size * m/denom).
 struct AdamChunk { float* p; const float* g; float* m; float* v; int n; int pad; };
 
+__device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, float decay, float w1, float beta2,
+                                          float w2, float bc2_sqrt, float eps, float neg_step_size) {
+  p = p * decay;
+  m = __fadd_rn(m, __fmul_rn(w1, __fsub_rn(g, m)));
+  v = __fmul_rn(v, beta2);
+  v = __fadd_rn(v, __fmul_rn(__fmul_rn(w2, g), g));
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
+  p = __fadd_rn(p, __fdiv_rn(__fmul_rn(neg_step_size, m), denom));
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict__ chunks, float decay, float w1,
                                                     float beta2, float w2, float bc2_sqrt, float eps,
                                                     float neg_step_size) {
   const AdamChunk c = chunks[blockIdx.x];
-  for (int i = threadIdx.x; i < c.n; i += 256) {
-    const float g = c.g[i];
-    float p = c.p[i] * decay;
-    float m = c.m[i];
-    m = __fadd_rn(m, __fmul_rn(w1, __fsub_rn(g, m)));
-    float v = __fmul_rn(c.v[i], beta2);
-    v = __fadd_rn(v, __fmul_rn(__fmul_rn(w2, g), g));
-    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
-    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(neg_step_size, m), denom));
+  // 16-byte path when the four pointers allow it (torch allocations are 512-byte aligned; chunk offsets are multiples
+  // of 32 K elements), scalar tail / fallback otherwise
+  const bool vec = ((((uintptr_t)c.p | (uintptr_t)c.g | (uintptr_t)c.m | (uintptr_t)c.v) & 15) == 0);
+  const int n4 = vec ? c.n / 4 : 0;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    float4 p = reinterpret_cast<float4*>(c.p)[i], m = reinterpret_cast<float4*>(c.m)[i], v = reinterpret_cast<float4*>(c.v)[i];
+    const float4 g = reinterpret_cast<const float4*>(c.g)[i];
+    adamw_one(p.x, g.x, m.x, v.x, decay, w1, beta2, w2, bc2_sqrt, eps, neg_step_size);
+    adamw_one(p.y, g.y, m.y, v.y, decay, w1, beta2, w2, bc2_sqrt, eps, neg_step_size);
+    adamw_one(p.z, g.z, m.z, v.z, decay, w1, beta2, w2, bc2_sqrt, eps, neg_step_size);
+    adamw_one(p.w, g.w, m.w, v.w, decay, w1, beta2, w2, bc2_sqrt, eps, neg_step_size);
+    reinterpret_cast<float4*>(c.p)[i] = p; reinterpret_cast<float4*>(c.m)[i] = m; reinterpret_cast<float4*>(c.v)[i] = v;
+  }
+  for (int i = n4 * 4 + threadIdx.x; i < c.n; i += 256) {
+    float p = c.p[i], m = c.m[i], v = c.v[i];
+    adamw_one(p, c.g[i], m, v, decay, w1, beta2, w2, bc2_sqrt, eps, neg_step_size);
     c.p[i] = p; c.m[i] = m; c.v[i] = v;
   }
 }

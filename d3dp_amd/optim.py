@@ -10,7 +10,6 @@ size, decay factor) are formed in double on the host and rounded once, as torch 
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import List
 
 import torch
@@ -33,7 +32,7 @@ class HipAdamW(torch.optim.Optimizer):
         sig = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
         hit = self._tables.get(gi)
         if hit is not None and hit[0] == sig:
-            return hit[1], hit[2]
+            return hit[1], hit[2], False
         rows = []
         for p in ps:
             st = self.state[p]
@@ -45,7 +44,7 @@ class HipAdamW(torch.optim.Optimizer):
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         dev = host.to(ps[0].device)
         self._tables[gi] = (sig, dev, len(rows))
-        return dev, len(rows)
+        return dev, len(rows), True
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -71,11 +70,11 @@ class HipAdamW(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            steps = {int(self.state[p]["step"].item()) for p in ps}
-            if len(steps) != 1:
-                raise _lib.D3DPHipError("HipAdamW: parameters of one group must share a step count")
-            step = steps.pop() + 1
-            table, n_chunks = self._table(gi, ps)
+            table, n_chunks, fresh = self._table(gi, ps)
+            if fresh:      # (re)validated whenever the table is rebuilt: new tensors, loaded state, new gradients
+                if len({int(self.state[p]["step"].item()) for p in ps}) != 1:
+                    raise _lib.D3DPHipError("HipAdamW: parameters of one group must share a step count")
+            step = int(self.state[ps[0]]["step"].item()) + 1
             b1, b2 = group["betas"]
             with torch.cuda.device(ps[0].device):
                 _lib.check(lib.d3dp_adamw_step(table.data_ptr(), n_chunks, float(group["lr"]), float(b1), float(b2),
