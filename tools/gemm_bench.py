@@ -17,6 +17,10 @@ def main():
     ap.add_argument("--tile", action="store_true", help="per-tile 128x128 kernel instead of the streaming one")
     ap.add_argument("--shapes", default="qkv,proj,fc1,fc2")
     ap.add_argument("--x3", action="store_true", help="EXACT-mode split-bf16 kernel (three planes per operand)")
+    ap.add_argument("--cache", default="hot", choices=["hot", "cold", "produced"],
+                    help="state of A before each timed launch: hot = same buffers back to back; cold = 1 GB written in "
+                         "between (evicts L2 + the 256 MB memory-side cache); produced = A rewritten front to back by a "
+                         "copy kernel (+ a 2x-sized unrelated read/write, like the row kernels in the denoiser)")
     a = ap.parse_args()
     lib = _lib.load()
     M = a.m
@@ -59,7 +63,15 @@ def main():
         for _ in range(3):
             _lib.check(lib.d3dp_op_linear(1, epi, A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, st))
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.iters)]
+        junk = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device="cuda") if a.cache == "cold" else None
+        src = A.clone() if a.cache == "produced" else None
+        side = torch.empty(M, K, dtype=torch.float32, device="cuda") if a.cache == "produced" else None
         for e0, e1 in evs:
+            if junk is not None:
+                junk.fill_(1.0)
+            if src is not None:
+                side.add_(1.0)
+                A.copy_(src)
             e0.record()
             _lib.check(lib.d3dp_op_linear(1, epi, A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, st))
             e1.record()
