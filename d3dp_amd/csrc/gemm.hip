@@ -296,7 +296,9 @@ int d3dp_launch_linear_f32_splitk(const float* A, const float* W, float* out, in
   if (K % XBK != 0 || N % 4 != 0 || M <= 0) return -1;
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
   const int nk = K / XBK;
-  int splits = (1024 + tm * tn - 1) / (tm * tn);                 // aim at >= 4 workgroups per CU
+  static int target = 0;                                          // workgroups aimed at: ~1 per CU measured best (88 ms/step vs 103 at 4 per CU: fewer fp32 atomics); env D3DP_SPLITK_TARGET for A/B
+  if (target == 0) { const char* e = getenv("D3DP_SPLITK_TARGET"); target = e ? atoi(e) : 256; if (target < 1) target = 256; }
+  int splits = (target + tm * tn - 1) / (tm * tn);
   if (splits > nk / 8) splits = nk / 8 > 0 ? nk / 8 : 1;
   const int per = (nk + splits - 1) / splits;
   hipLaunchKernelGGL((gemm_f32_kernel<EPI_ATOMIC>), dim3(tm * tn, (nk + per - 1) / per), dim3(256), 0, st, A, W, nullptr,

@@ -478,7 +478,7 @@ int d3dp_train_scale_mask(const float* in, const float* mask, int axis, int F, i
   return 0;
 }
 int d3dp_train_colsum(const float* in, float* out, int T, int C, hipStream_t st) {
-  hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, 64), dim3(256), 0, st, in, out, T, C);
+  hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, T < 512 ? T : 512), dim3(256), 0, st, in, out, T, C);
   return 0;
 }
 int d3dp_train_groupsum(const float* in, float* out, int T, int C, int mode, int F, int J, hipStream_t st) {
@@ -535,7 +535,7 @@ int d3dp_train_head_linear(const float* z, const float* w, const float* b, float
 }
 int d3dp_train_head_bwd(const float* g, const float* z, const float* w, float* dz, float* dW, float* db, int T, int C,
                         hipStream_t st) {
-  hipLaunchKernelGGL(head_bwd_kernel, dim3((C + 255) / 256, 1), dim3(256), 0, st, g, z, w, dz, dW, db, T, C);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3((C + 255) / 256, T < 512 ? T : 512), dim3(256), 0, st, g, z, w, dz, dW, db, T, C);
   return 0;
 }
 int d3dp_train_time_mlp_bwd(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2,
