@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 struct AttnStats { float m, l, D; };
 
 template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+__global__ __launch_bounds__(512) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                          const float* __restrict__ dout, float* __restrict__ dqkv,
                                                          AttnStats* __restrict__ stats, SeqMap map, int C, int heads) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -230,46 +230,94 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
     *reinterpret_cast<float4*>(Vs + j * LDR + c * 4) = *reinterpret_cast<const float4*>(src + C);
   }
   __syncthreads();
-  const int i = threadIdx.x;
-  if (i >= n) return;
-  const size_t tok = (size_t)(base + i * map.tok_stride);
+  // two threads (adjacent lanes) per query row, each owning half of the head dimension: q, dO, dQ halves stay in
+  // registers (96 instead of 192), partial dot products are combined with one lane exchange per key group
+  const int i = threadIdx.x >> 1, half = threadIdx.x & 1;
+  const bool live = i < n;
+  const int ii = live ? i : n - 1;
+  constexpr int HH = HD / 2;
+  const size_t tok = (size_t)(base + ii * map.tok_stride);
   const float scale = 1.0f / sqrtf((float)HD);
-  float q[HD], dO[HD], dq[HD];
+  float q[HH], dO[HH], dq[HH];
   float D = 0.f;
 #pragma unroll
-  for (int d = 0; d < HD; ++d) {
-    q[d] = qkv[tok * 3 * C + head * HD + d];
-    dO[d] = dout[tok * C + head * HD + d];
-    D = fmaf(dO[d], o[tok * C + head * HD + d], D);
+  for (int d = 0; d < HH; ++d) {
+    q[d] = qkv[tok * 3 * C + head * HD + half * HH + d];
+    dO[d] = dout[tok * C + head * HD + half * HH + d];
+    D = fmaf(dO[d], o[tok * C + head * HD + half * HH + d], D);
     dq[d] = 0.f;
   }
-  float m = -INFINITY;
-  for (int j = 0; j < n; ++j) {
-    float s = 0.f;
+  D += __shfl_xor(D, 1, 64);
+  const float* Kh = Ks + half * HH;
+  const float* Vh = Vs + half * HH;
+  // KB keys at a time: independent dot-product chains.  Pass A: row max and denominator (online recurrence).
+  constexpr int KB = 4;
+  float m = -INFINITY, l = 0.f;
+  for (int j0 = 0; j0 < n; j0 += KB) {
+    float sc[KB];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) s = fmaf(q[d], Ks[j * LDR + d], s);
-    m = fmaxf(m, s * scale);
-  }
-  float l = 0.f;
-  for (int j = 0; j < n; ++j) {
-    float s = 0.f;
+    for (int u = 0; u < KB; ++u) sc[u] = 0.f;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) s = fmaf(q[d], Ks[j * LDR + d], s);
-    l += expf(s * scale - m);
+    for (int c = 0; c < HH / 4; ++c) {
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const float4 kv = *reinterpret_cast<const float4*>(Kh + min(j0 + u, n - 1) * LDR + c * 4);
+        sc[u] = fmaf(q[c * 4], kv.x, sc[u]); sc[u] = fmaf(q[c * 4 + 1], kv.y, sc[u]);
+        sc[u] = fmaf(q[c * 4 + 2], kv.z, sc[u]); sc[u] = fmaf(q[c * 4 + 3], kv.w, sc[u]);
+      }
+    }
+    float gm = m;
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      sc[u] += __shfl_xor(sc[u], 1, 64);
+      sc[u] = (j0 + u < n) ? sc[u] * scale : -INFINITY;
+      gm = fmaxf(gm, sc[u]);
+    }
+    l *= expf(m - gm);
+#pragma unroll
+    for (int u = 0; u < KB; ++u) l += expf(sc[u] - gm);
+    m = gm;
   }
   const float inv = 1.0f / l;
-  for (int j = 0; j < n; ++j) {
-    float s = 0.f, dp = 0.f;
+  // Pass B: dS_ij = P_ij (dO_i . V_j - D_i) s ;  dQ_i += dS_ij K_j
+  for (int j0 = 0; j0 < n; j0 += KB) {
+    float sc[KB], dp[KB];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) { s = fmaf(q[d], Ks[j * LDR + d], s); dp = fmaf(dO[d], Vs[j * LDR + d], dp); }
-    const float p = expf(s * scale - m) * inv;
-    const float ds = p * (dp - D) * scale;
+    for (int u = 0; u < KB; ++u) { sc[u] = 0.f; dp[u] = 0.f; }
 #pragma unroll
-    for (int d = 0; d < HD; ++d) dq[d] = fmaf(ds, Ks[j * LDR + d], dq[d]);
+    for (int c = 0; c < HH / 4; ++c) {
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const int j = min(j0 + u, n - 1);
+        const float4 kv = *reinterpret_cast<const float4*>(Kh + j * LDR + c * 4);
+        const float4 vv = *reinterpret_cast<const float4*>(Vh + j * LDR + c * 4);
+        sc[u] = fmaf(q[c * 4], kv.x, sc[u]); sc[u] = fmaf(q[c * 4 + 1], kv.y, sc[u]);
+        sc[u] = fmaf(q[c * 4 + 2], kv.z, sc[u]); sc[u] = fmaf(q[c * 4 + 3], kv.w, sc[u]);
+        dp[u] = fmaf(dO[c * 4], vv.x, dp[u]); dp[u] = fmaf(dO[c * 4 + 1], vv.y, dp[u]);
+        dp[u] = fmaf(dO[c * 4 + 2], vv.z, dp[u]); dp[u] = fmaf(dO[c * 4 + 3], vv.w, dp[u]);
+      }
+    }
+    float ds[KB];
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      sc[u] += __shfl_xor(sc[u], 1, 64);
+      dp[u] += __shfl_xor(dp[u], 1, 64);
+      ds[u] = (j0 + u < n) ? expf(sc[u] * scale - m) * inv * (dp[u] - D) * scale : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < HH / 4; ++c) {
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const float4 kv = *reinterpret_cast<const float4*>(Kh + min(j0 + u, n - 1) * LDR + c * 4);
+        dq[c * 4] = fmaf(ds[u], kv.x, dq[c * 4]); dq[c * 4 + 1] = fmaf(ds[u], kv.y, dq[c * 4 + 1]);
+        dq[c * 4 + 2] = fmaf(ds[u], kv.z, dq[c * 4 + 2]); dq[c * 4 + 3] = fmaf(ds[u], kv.w, dq[c * 4 + 3]);
+      }
+    }
   }
+  if (!live) return;
 #pragma unroll
-  for (int d = 0; d < HD; ++d) dqkv[tok * 3 * C + head * HD + d] = dq[d];
-  stats[(size_t)blockIdx.x * n + i] = AttnStats{m, l, D};
+  for (int d = 0; d < HH; ++d) dqkv[tok * 3 * C + head * HD + half * HH + d] = dq[d];
+  if (half == 0) stats[(size_t)blockIdx.x * n + i] = AttnStats{m, l, D};
 }
 
 template <int HD>
@@ -294,32 +342,65 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const float* __restric
   }
   for (int i = threadIdx.x; i < n; i += blockDim.x) st[i] = stats[(size_t)blockIdx.x * n + i];
   __syncthreads();
-  // two threads per key: each owns half of the head dimension of dK_j and dV_j (register budget)
+  // two threads (adjacent lanes) per key, each owning half of the head dimension of k, v, dK_j, dV_j; partial dot
+  // products are combined with one lane exchange; KB queries at a time give independent FMA chains
   const int j = threadIdx.x >> 1, half = threadIdx.x & 1;
-  if (j >= n) return;
+  const bool live = j < n;
+  const int jj = live ? j : n - 1;
   constexpr int HH = HD / 2;
-  const size_t tok = (size_t)(base + j * map.tok_stride);
+  const size_t tok = (size_t)(base + jj * map.tok_stride);
   const float scale = 1.0f / sqrtf((float)HD);
-  float k[HD], v[HD], dk[HH], dv[HH];
+  float k[HH], v[HH], dk[HH], dv[HH];
 #pragma unroll
-  for (int d = 0; d < HD; ++d) {
-    k[d] = qkv[tok * 3 * C + C + head * HD + d];
-    v[d] = qkv[tok * 3 * C + 2 * C + head * HD + d];
+  for (int d = 0; d < HH; ++d) {
+    k[d] = qkv[tok * 3 * C + C + head * HD + half * HH + d];
+    v[d] = qkv[tok * 3 * C + 2 * C + head * HD + half * HH + d];
+    dk[d] = 0.f; dv[d] = 0.f;
   }
+  const float* Qh = Qs + half * HH;
+  const float* Oh = Os + half * HH;
+  constexpr int KB = 2;
+  for (int i0 = 0; i0 < n; i0 += KB) {
+    float sc[KB], dp[KB];
 #pragma unroll
-  for (int d = 0; d < HH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-  for (int i = 0; i < n; ++i) {
-    float s = 0.f, dp = 0.f;
+    for (int u = 0; u < KB; ++u) { sc[u] = 0.f; dp[u] = 0.f; }
 #pragma unroll
-    for (int d = 0; d < HD; ++d) { s = fmaf(Qs[i * LDR + d], k[d], s); dp = fmaf(Os[i * LDR + d], v[d], dp); }
-    const float p = expf(s * scale - st[i].m) / st[i].l;
-    const float ds = p * (dp - st[i].D) * scale;
+    for (int c = 0; c < HH / 4; ++c) {
 #pragma unroll
-    for (int d = 0; d < HH; ++d) {
-      dk[d] = fmaf(ds, Qs[i * LDR + half * HH + d], dk[d]);
-      dv[d] = fmaf(p, Os[i * LDR + half * HH + d], dv[d]);
+      for (int u = 0; u < KB; ++u) {
+        const int i = min(i0 + u, n - 1);
+        const float4 qv = *reinterpret_cast<const float4*>(Qh + i * LDR + c * 4);
+        const float4 ov = *reinterpret_cast<const float4*>(Oh + i * LDR + c * 4);
+        sc[u] = fmaf(qv.x, k[c * 4], sc[u]); sc[u] = fmaf(qv.y, k[c * 4 + 1], sc[u]);
+        sc[u] = fmaf(qv.z, k[c * 4 + 2], sc[u]); sc[u] = fmaf(qv.w, k[c * 4 + 3], sc[u]);
+        dp[u] = fmaf(ov.x, v[c * 4], dp[u]); dp[u] = fmaf(ov.y, v[c * 4 + 1], dp[u]);
+        dp[u] = fmaf(ov.z, v[c * 4 + 2], dp[u]); dp[u] = fmaf(ov.w, v[c * 4 + 3], dp[u]);
+      }
+    }
+    float pr[KB], ds[KB];
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      sc[u] += __shfl_xor(sc[u], 1, 64);
+      dp[u] += __shfl_xor(dp[u], 1, 64);
+      const AttnStats a = st[min(i0 + u, n - 1)];
+      pr[u] = (i0 + u < n) ? expf(sc[u] * scale - a.m) / a.l : 0.f;
+      ds[u] = pr[u] * (dp[u] - a.D) * scale;
+    }
+#pragma unroll
+    for (int c = 0; c < HH / 4; ++c) {
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const int i = min(i0 + u, n - 1);
+        const float4 qv = *reinterpret_cast<const float4*>(Qh + i * LDR + c * 4);
+        const float4 ov = *reinterpret_cast<const float4*>(Oh + i * LDR + c * 4);
+        dk[c * 4] = fmaf(ds[u], qv.x, dk[c * 4]); dk[c * 4 + 1] = fmaf(ds[u], qv.y, dk[c * 4 + 1]);
+        dk[c * 4 + 2] = fmaf(ds[u], qv.z, dk[c * 4 + 2]); dk[c * 4 + 3] = fmaf(ds[u], qv.w, dk[c * 4 + 3]);
+        dv[c * 4] = fmaf(pr[u], ov.x, dv[c * 4]); dv[c * 4 + 1] = fmaf(pr[u], ov.y, dv[c * 4 + 1]);
+        dv[c * 4 + 2] = fmaf(pr[u], ov.z, dv[c * 4 + 2]); dv[c * 4 + 3] = fmaf(pr[u], ov.w, dv[c * 4 + 3]);
+      }
     }
   }
+  if (!live) return;
 #pragma unroll
   for (int d = 0; d < HH; ++d) {
     dqkv[tok * 3 * C + C + head * HD + half * HH + d] = dk[d];
@@ -507,7 +588,7 @@ static int launch_attn_bwd(const float* qkv, const float* o, const float* dout, 
                             160 * 1024) != hipSuccess) return -3;
     attr = true;
   }
-  const int tq = n <= 64 ? 64 : 256, tkv = 2 * n <= 64 ? 64 : (2 * n <= 256 ? 256 : 512);
+  const int tkv = 2 * n <= 64 ? 64 : (2 * n <= 256 ? 256 : 512), tq = tkv;       // two threads per row in both passes
   hipLaunchKernelGGL((attn_bwd_q_kernel<HD>), dim3(n_seq * heads), dim3(tq), lds_q, st, qkv, o, dout, dqkv,
                      (AttnStats*)stats, map, C, heads);
   hipLaunchKernelGGL((attn_bwd_kv_kernel<HD>), dim3(n_seq * heads), dim3(tkv), lds_kv, st, qkv, dout, dqkv,
