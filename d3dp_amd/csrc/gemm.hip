@@ -541,7 +541,9 @@ __device__ __forceinline__ int sperm(int q) {   // q = ni*16 + i in [0,64)
 // MI = 16-row MFMA blocks per compute wave: MI = 4 -> 8 compute waves (4 x 2, 64x64 each, two per SIMD);
 // MI = 8 -> 4 compute waves (2 x 2, 128x64 each, ONE per SIMD next to one loader wave: no matrix-pipe / issue
 // contention between compute waves, 0.375 instead of 0.5 LDS fragment reads per MFMA).
-template <int EPI, typename OutT, int NK, int MI>
+// WIDE is a name tag only (same code): the qkv Linear (N = 3K) is instantiated as its own kernel symbol so that
+// rocprofv3 --stats reports it separately from the proj Linear, which shares EPI / OutT / NK with it.
+template <int EPI, typename OutT, int NK, int MI, int WIDE = 0>
 __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                                const float* __restrict__ bias, OutT* __restrict__ out,
                                                                int M, int N, int tiles_n, int total_tiles, int dbg) {
@@ -728,12 +730,17 @@ template <int EPI, typename OutT, int NK, int MI>
 int launch_stream_nk_mi(const void* A, const void* W, const float* bias, void* out, int M, int N, hipStream_t st) {
   const int tm = (M + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
   const int total = tm * tn;
-  auto kern = gemm_bf16_stream_kernel<EPI, OutT, NK, MI>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  void (*kern)(const bf16*, const bf16*, const float*, OutT*, int, int, int, int, int) =
+      gemm_bf16_stream_kernel<EPI, OutT, NK, MI, 0>;
+  if constexpr (EPI == EPI_BIAS && sizeof(OutT) == 2 && NK == 8) {
+    if (N == 3 * NK * SBK) kern = gemm_bf16_stream_kernel<EPI, OutT, NK, MI, 1>;
+  }
+  static bool attr_set[2] = {false, false};
+  const int which = (kern == gemm_bf16_stream_kernel<EPI, OutT, NK, MI, 0>) ? 0 : 1;
+  if (!attr_set[which]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             SLDS_BYTES) != hipSuccess) return -3;
-    attr_set = true;
+    attr_set[which] = true;
   }
   static int n_cu = 0;
   if (n_cu == 0) {
