@@ -416,3 +416,70 @@ def test_cli_train_resume_evaluate_and_3dhp(tmp_path, capsys):
     txt = open(os.path.join(ck, "3dhp_test_log_H4_K2.txt")).read()
     assert "----TS2----" in txt and "step 1 : Protocol #1 Error (MPJPE) P_Agg:" in txt
     assert os.path.exists(os.path.join(ck, "inference_data_J_Agg.mat"))
+
+
+# ---- serving flow -----------------------------------------------------------------------------------------------------------
+def test_predict_video_matches_step_by_step_composition():
+    """in_the_wild flow on a 70-frame 'video' at F=27 (3 clips, the last overlapping): the fused device path ==
+    the reference's steps done one at a time with the oracle's numpy pieces around the same sampler calls."""
+    from d3dp_amd import serve
+    Fr, cs, dep, H, K, n = 27, 64, 2, 2, 2, 70
+    args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
+    m = D3DP(args, KL, KR, is_train=False, num_proposals=H, sampling_timesteps=K)
+    m.load_state_dict(make_state_dict(29, cs, dep, Fr), strict=False)
+    m = m.cuda().eval()
+    rng = np.random.default_rng(11)
+    w, h = 1920, 1080
+    kp = np.stack([rng.uniform(0, w, (n, 17)), rng.uniform(0, h, (n, 17))], axis=-1).astype(np.float32)
+    noises = [[torch.from_numpy(rng.standard_normal((b, H, Fr, 17, 3)).astype(np.float32)) for _ in range(K)] for b in (2, 1)]
+    out = serve.predict_video(m, kp, w, h, batch_clips=2, noise=noises)
+    assert out.shape == (K, H, n, 17, 3) and bool((out[:, :, :, 0] == 0).all())
+    # step by step
+    norm = (kp.astype(np.float64) / w * 2 - np.array([1, h / w])).astype(np.float32)  # camera.py:7-11
+    c2 = co.clip_gather(norm, Fr)
+    c2f = co.clip_gather(co.flip_input(norm, serve.WILD_KPS_LEFT, serve.WILD_KPS_RIGHT), Fr)
+    parts = []
+    for bi, i in enumerate(range(0, c2.shape[0], 2)):
+        p = m(torch.from_numpy(c2[i:i + 2]).cuda(), None, input_2d_flip=torch.from_numpy(c2f[i:i + 2]).cuda(), noise=noises[bi])
+        p[:, :, :, :, 0] = 0
+        parts.append(p.cpu().numpy())
+    want = co.clip_scatter(np.concatenate(parts), n)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+# ---- full-size properties of the caller-side kernels (BASELINE configs[2] sizes) ----------------------------------------------
+def test_caller_kernels_full_size_properties():
+    torch.manual_seed(0)
+    B, K, H, Fr = 16, 10, 20, 243
+    gt = torch.randn(B, Fr, 17, 3, device="cuda") * 0.3
+    pred = gt[:, None, None] + torch.randn(B, K, H, Fr, 17, 3, device="cuda") * 0.05
+    traj = torch.randn(B, Fr, 1, 3, device="cuda") * 0.1 + torch.tensor([0.0, 0.0, 4.0], device="cuda")
+    cam = torch.tensor([2.29, 2.287, 0.0254, 0.0289, -0.2070, 0.2477, -0.0030, -0.0009, -0.0014], device="cuda")
+    gt2 = torch.rand(B, Fr, 17, 2, device="cuda") * 2 - 1
+    agg, sel, es, em = jpma.jpma_hip(pred, traj, cam, gt2, gt, zero_root=True, want_errors=True)
+    # the aggregate is, per joint, exactly the selected hypothesis; J_Best error <= J_Agg error; winners/combine agree
+    pz = pred.clone()
+    pz[:, :, :, :, 0] = 0
+    picked = torch.gather(pz, 2, sel.long()[:, :, None, :, :, None].expand(-1, -1, -1, -1, -1, 3))[:, :, 0]
+    assert torch.equal(picked, agg) and bool((em <= es + 1e-7).all()) and int(sel.max()) < H and int(sel.min()) >= 0
+    wins = torch.stack([jpma.jpma_winners(pred[:, :, r * 5:(r + 1) * 5].contiguous(), traj, cam, gt2, h_offset=r * 5) for r in range(4)])
+    agg2, sel2 = jpma.jpma_combine(wins)
+    assert torch.equal(agg2, agg) and torch.equal(sel2, sel)
+    # Procrustes: invariant under a similarity transform of the prediction; zero for an exact similarity copy of gt
+    e0 = jpma.procrustes_errors(pred[:2, :2], gt[:2])
+    rot = torch.linalg.qr(torch.randn(3, 3, device="cuda"))[0]
+    e1 = jpma.procrustes_errors((pred[:2, :2] @ rot) * 1.7 + torch.tensor([0.3, -0.2, 1.0], device="cuda"), gt[:2])
+    assert float((e0 - e1).abs().max()) < 2e-6
+    same = (gt[:2, None, None] @ rot * 0.6 + 0.1).expand(-1, 2, 3, -1, -1, -1)
+    assert float(jpma.procrustes_errors(same.contiguous(), gt[:2]).abs().max()) < 2e-6
+    # clips: a 100 k-frame sequence round-trips; the flipped copy is an involution of the plain clips
+    seq = torch.randn(100000, 17, 2, device="cuda")
+    c, cf = clip_gather(seq, Fr, KL, KR)
+    assert torch.equal(clip_scatter(c[:, None, None].contiguous(), seq.shape[0])[0, 0], seq)
+    back = cf.clone()
+    back[..., 0] *= -1
+    perm = torch.tensor(np.argsort(np.array([KL + KR, KR + KL])[1]), device="cuda")   # inverse of the swap = the swap itself
+    swap = list(range(17))
+    for a, b in zip(KL + KR, KR + KL):
+        swap[a] = b
+    assert torch.equal(back[:, :, swap], c)
