@@ -89,7 +89,6 @@ def jpma_hip(pred: torch.Tensor, traj: torch.Tensor, cam: torch.Tensor, gt_2d: t
              gt_3d: torch.Tensor = None, zero_root: bool = True, want_errors: bool = False):
     """The fused HIP kernel (include/d3dp_hip.h: d3dp_jpma) for GPU tensors: returns the aggregated poses (B,K,F,J,3),
     the selected hypothesis index (B,K,F,J) and, with ``want_errors``, the per-joint J_Agg / J_Best errors."""
-    import ctypes as C
     from . import _lib
     lib = _lib.load()
     assert pred.is_cuda, "jpma_hip needs GPU tensors (no CPU fallback); use jpma_aggregate for host tensors"

@@ -13,11 +13,11 @@ import numpy as np
 import pytest
 import torch
 
-from d3dp_amd import D3DP, _lib, jpma
+from d3dp_amd import D3DP, jpma
 from d3dp_amd.clips import clip_count, clip_gather, clip_scatter
 from d3dp_amd.data import ChunkedBatcher
 from d3dp_amd.optim import HipAdamW
-from d3dp_amd.trainer import checkpoint_dict, fit, load_checkpoint
+from d3dp_amd.trainer import fit, load_checkpoint
 from d3dp_amd.weights import H36M_JOINTS_LEFT as KL, H36M_JOINTS_RIGHT as KR, make_state_dict
 from oracle import caller_oracle as co
 
