@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from d3dp_amd import _lib  # noqa: E402
 
+if os.environ.get("D3DP_LIB"):          # A/B of differently compiled libraries
+    _lib.LIB_PATH = os.environ["D3DP_LIB"]
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -17,6 +20,7 @@ def main():
     ap.add_argument("--tile", action="store_true", help="per-tile 128x128 kernel instead of the streaming one")
     ap.add_argument("--shapes", default="qkv,proj,fc1,fc2")
     ap.add_argument("--x3", action="store_true", help="EXACT-mode split-bf16 kernel (three planes per operand)")
+    ap.add_argument("--check", action="store_true", help="compare each result with torch (fp32 matmul of the bf16 operands)")
     ap.add_argument("--cache", default="hot", choices=["hot", "cold", "produced"],
                     help="state of A before each timed launch: hot = same buffers back to back; cold = 1 GB written in "
                          "between (evicts L2 + the 256 MB memory-side cache); produced = A rewritten front to back by a "
@@ -76,6 +80,12 @@ def main():
             _lib.check(lib.d3dp_op_linear(1, epi, A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, st))
             e1.record()
         torch.cuda.synchronize()
+        if a.check:
+            ref = A.float() @ W.float().t() + b
+            if epi & 1:
+                ref = torch.nn.functional.gelu(ref)
+            err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
+            print(f"   check {name}: max |err| / max |ref| = {err:.2e}  ({'OK' if err < 1e-2 else 'MISMATCH'})")
         ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
         med = ts[len(ts) // 2]
         print(f"{name:5s} M={M} N={N} K={K} epi={epi:2d}: median {med * 1e3:8.1f} us  min {ts[0] * 1e3:8.1f} us  "
