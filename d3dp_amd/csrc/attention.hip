@@ -534,16 +534,25 @@ __global__ __launch_bounds__(256) void attn_spatial_bf16_kernel(const bf16* __re
   const bf16* qbase = qkv + (size_t)base * ld + (size_t)head * 64;
   char* KS = smem + wave * 8192;
   char* VS = KS + 4096;
+  // the query fragments of both 16-row tiles are requested BEFORE the K/V staging so that their HBM latency overlaps
+  // it (the kernel is latency/HBM-bound: one small problem per wave)
+  const int fi = lane & 15, fg = lane >> 4;
+  const int n_qt = (n + 15) >> 4;
+  bf16x8 qf[2][2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const bf16* qsrc = qbase + (size_t)min(qt * 16 + fi, n - 1) * ts * ld + fg * 8;
+    qf[qt][0] = *reinterpret_cast<const bf16x8*>(qsrc);
+    qf[qt][1] = *reinterpret_cast<const bf16x8*>(qsrc + 32);
+  }
   stage_kv<32, 64>(qbase + C, (size_t)ts * ld, n, KS, VS, lane, C);
   const FragBases fb = make_frag_bases(KS, VS, lane);
   // (wave-private LDS image: the LDS pipe executes one wave's accesses in order, no barrier needed)
-  const int fi = lane & 15, fg = lane >> 4;
-  const int n_qt = (n + 15) >> 4;
-  for (int qt = 0; qt < n_qt; ++qt) {
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    if (qt >= n_qt) break;
     const int q = qt * 16 + fi;
-    const bf16* qsrc = qbase + (size_t)min(q, n - 1) * ts * ld + fg * 8;
-    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(qsrc);
-    const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(qsrc + 32);
+    const bf16x8 q0 = qf[qt][0], q1 = qf[qt][1];
     f32x4 o[4];
     float denom;
     attn_tile<2>(fb, q0, q1, n, lane, o, denom);
