@@ -14,6 +14,10 @@
 
 namespace {
 
+#ifndef NT_STREAMS
+#define NT_STREAMS 1
+#endif
+
 // per-lane slice of a C-channel row: NV = C/64 values; for NV % 4 == 0 they are float4 groups at
 // element (g*64 + lane)*4, otherwise scalars at i*64 + lane.
 template <int C> struct Row {
@@ -45,6 +49,42 @@ template <int C> struct Row {
     } else {
 #pragma unroll
       for (int i = 0; i < NV; ++i) v[i] = (float)p[i * 64 + lane];
+    }
+  }
+  // streaming variants (nontemporal hint): for the fp32 residual stream and the branch outputs, which are read or
+  // written once here and not touched again until several kernels later -- they should not push the normalised
+  // activations (the next GEMM's A operand) out of L2 / the memory-side cache
+  static __device__ __forceinline__ void load_nt(const float* p, int lane, float* v) {
+    if constexpr (V4) {
+#pragma unroll
+      for (int g = 0; g < NV / 4; ++g) {
+        const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (g * 64 + lane) * 4));
+        v[g * 4] = a[0]; v[g * 4 + 1] = a[1]; v[g * 4 + 2] = a[2]; v[g * 4 + 3] = a[3];
+      }
+    } else {
+      load(p, lane, v);
+    }
+  }
+  static __device__ __forceinline__ void load_nt(const bf16* p, int lane, float* v) {
+    if constexpr (V4) {
+#pragma unroll
+      for (int g = 0; g < NV / 4; ++g) {
+        const bf16x4 a = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(p + (g * 64 + lane) * 4));
+        v[g * 4] = (float)a[0]; v[g * 4 + 1] = (float)a[1]; v[g * 4 + 2] = (float)a[2]; v[g * 4 + 3] = (float)a[3];
+      }
+    } else {
+      load(p, lane, v);
+    }
+  }
+  static __device__ __forceinline__ void store_nt(float* p, int lane, const float* v) {
+    if constexpr (V4) {
+#pragma unroll
+      for (int g = 0; g < NV / 4; ++g) {
+        const f32x4 a = {v[g * 4], v[g * 4 + 1], v[g * 4 + 2], v[g * 4 + 3]};
+        __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(p + (g * 64 + lane) * 4));
+      }
+    } else {
+      store(p, lane, v);
     }
   }
   static __device__ __forceinline__ void store(float* p, int lane, const float* v) {
@@ -127,9 +167,9 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const YT
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= T) return;
   float v[R::NV], y[R::NV];
-  R::load(x + (size_t)tok * C, lane, v);
+  if (NT_STREAMS) R::load_nt(x + (size_t)tok * C, lane, v); else R::load(x + (size_t)tok * C, lane, v);
   if (yadd != nullptr) {
-    R::load(yadd + (size_t)tok * C, lane, y);
+    if (NT_STREAMS) R::load_nt(yadd + (size_t)tok * C, lane, y); else R::load(yadd + (size_t)tok * C, lane, y);
 #pragma unroll
     for (int i = 0; i < R::NV; ++i) v[i] += y[i];
     if (write_x) R::store(x + (size_t)tok * C, lane, v);
@@ -149,14 +189,14 @@ __global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const Y
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= T) return;
   float v[R::NV], y[R::NV], z[R::NV];
-  R::load(x + (size_t)tok * C, lane, v);
+  if (NT_STREAMS) R::load_nt(x + (size_t)tok * C, lane, v); else R::load(x + (size_t)tok * C, lane, v);
   if (yadd0 != nullptr) {
-    R::load(yadd0 + (size_t)tok * C, lane, y);
+    if (NT_STREAMS) R::load_nt(yadd0 + (size_t)tok * C, lane, y); else R::load(yadd0 + (size_t)tok * C, lane, y);
 #pragma unroll
     for (int i = 0; i < R::NV; ++i) v[i] += y[i];
   }
   if (yadd != nullptr) {
-    R::load(yadd + (size_t)tok * C, lane, y);
+    if (NT_STREAMS) R::load_nt(yadd + (size_t)tok * C, lane, y); else R::load(yadd + (size_t)tok * C, lane, y);
 #pragma unroll
     for (int i = 0; i < R::NV; ++i) v[i] += y[i];
   }
@@ -168,7 +208,7 @@ __global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const Y
 #pragma unroll
     for (int i = 0; i < R::NV; ++i) y[i] += pv[i];
   }
-  R::store(x + (size_t)tok * C, lane, y);
+  if (NT_STREAMS) R::store_nt(x + (size_t)tok * C, lane, y); else R::store(x + (size_t)tok * C, lane, y);
   R::norm(y, wb, bb, eps, lane, z);
   ActOut<C, XN>::st(xn, plane, (size_t)tok * C, lane, z);
 }
