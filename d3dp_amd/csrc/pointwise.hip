@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
     a += temb[b * C + c];
     v[i] = a;
   }
-  R::store(x + (size_t)tl * C, lane, v);
+  if (NT_STREAMS) R::store_nt(x + (size_t)tl * C, lane, v); else R::store(x + (size_t)tl * C, lane, v);
   R::norm(v, lnw, lnb, eps, lane, y);
   ActOut<C, XN>::st(xn, plane, (size_t)tl * C, lane, y);
 }
@@ -261,14 +261,14 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= T) return;
   float v[R::NV], y[R::NV], z[R::NV];
-  R::load(x + (size_t)tok * C, lane, v);
+  if (NT_STREAMS) R::load_nt(x + (size_t)tok * C, lane, v); else R::load(x + (size_t)tok * C, lane, v);
   if (yadd0 != nullptr) {
-    R::load(yadd0 + (size_t)tok * C, lane, y);
+    if (NT_STREAMS) R::load_nt(yadd0 + (size_t)tok * C, lane, y); else R::load(yadd0 + (size_t)tok * C, lane, y);
 #pragma unroll
     for (int i = 0; i < R::NV; ++i) v[i] += y[i];
   }
   if (yadd != nullptr) {
-    R::load(yadd + (size_t)tok * C, lane, y);
+    if (NT_STREAMS) R::load_nt(yadd + (size_t)tok * C, lane, y); else R::load(yadd + (size_t)tok * C, lane, y);
 #pragma unroll
     for (int i = 0; i < R::NV; ++i) v[i] += y[i];
   }
