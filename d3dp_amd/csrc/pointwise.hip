@@ -17,6 +17,9 @@ namespace {
 #ifndef NT_STREAMS
 #define NT_STREAMS 1
 #endif
+#ifndef NT_Y
+#define NT_Y 1      // branch outputs (yadd) also nontemporal; 0: only the fp32 residual (A/B)
+#endif
 
 // per-lane slice of a C-channel row: NV = C/64 values; for NV % 4 == 0 they are float4 groups at
 // element (g*64 + lane)*4, otherwise scalars at i*64 + lane.
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, const YT
   float v[R::NV], y[R::NV];
   if (NT_STREAMS) R::load_nt(x + (size_t)tok * C, lane, v); else R::load(x + (size_t)tok * C, lane, v);
   if (yadd != nullptr) {
-    if (NT_STREAMS) R::load_nt(yadd + (size_t)tok * C, lane, y); else R::load(yadd + (size_t)tok * C, lane, y);
+    if (NT_STREAMS && NT_Y) R::load_nt(yadd + (size_t)tok * C, lane, y); else R::load(yadd + (size_t)tok * C, lane, y);
 #pragma unroll
     for (int i = 0; i < R::NV; ++i) v[i] += y[i];
     if (write_x) R::store(x + (size_t)tok * C, lane, v);
@@ -191,12 +194,12 @@ __global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const Y
   float v[R::NV], y[R::NV], z[R::NV];
   if (NT_STREAMS) R::load_nt(x + (size_t)tok * C, lane, v); else R::load(x + (size_t)tok * C, lane, v);
   if (yadd0 != nullptr) {
-    if (NT_STREAMS) R::load_nt(yadd0 + (size_t)tok * C, lane, y); else R::load(yadd0 + (size_t)tok * C, lane, y);
+    if (NT_STREAMS && NT_Y) R::load_nt(yadd0 + (size_t)tok * C, lane, y); else R::load(yadd0 + (size_t)tok * C, lane, y);
 #pragma unroll
     for (int i = 0; i < R::NV; ++i) v[i] += y[i];
   }
   if (yadd != nullptr) {
-    if (NT_STREAMS) R::load_nt(yadd + (size_t)tok * C, lane, y); else R::load(yadd + (size_t)tok * C, lane, y);
+    if (NT_STREAMS && NT_Y) R::load_nt(yadd + (size_t)tok * C, lane, y); else R::load(yadd + (size_t)tok * C, lane, y);
 #pragma unroll
     for (int i = 0; i < R::NV; ++i) v[i] += y[i];
   }
@@ -263,12 +266,12 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
   float v[R::NV], y[R::NV], z[R::NV];
   if (NT_STREAMS) R::load_nt(x + (size_t)tok * C, lane, v); else R::load(x + (size_t)tok * C, lane, v);
   if (yadd0 != nullptr) {
-    if (NT_STREAMS) R::load_nt(yadd0 + (size_t)tok * C, lane, y); else R::load(yadd0 + (size_t)tok * C, lane, y);
+    if (NT_STREAMS && NT_Y) R::load_nt(yadd0 + (size_t)tok * C, lane, y); else R::load(yadd0 + (size_t)tok * C, lane, y);
 #pragma unroll
     for (int i = 0; i < R::NV; ++i) v[i] += y[i];
   }
   if (yadd != nullptr) {
-    if (NT_STREAMS) R::load_nt(yadd + (size_t)tok * C, lane, y); else R::load(yadd + (size_t)tok * C, lane, y);
+    if (NT_STREAMS && NT_Y) R::load_nt(yadd + (size_t)tok * C, lane, y); else R::load(yadd + (size_t)tok * C, lane, y);
 #pragma unroll
     for (int i = 0; i < R::NV; ++i) v[i] += y[i];
   }
