@@ -1,0 +1,88 @@
+"""CPU tests of host-side logic that needs no GPU: the reference checkpoint layout, the entrypoints' flags, screen
+normalisation, clip bookkeeping.  (The kernels behind them are covered by tests/test_hip_caller.py, -m gpu.)"""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from d3dp_amd import D3DP, D3DP3DHP, _lib
+from d3dp_amd import cli, serve, trainer
+from d3dp_amd.clips import clip_count
+from d3dp_amd.data import ChunkLineage
+from d3dp_amd.weights import H36M_JOINTS_LEFT as KL, H36M_JOINTS_RIGHT as KR, make_state_dict
+
+
+def tiny_args(frames=9, cs=64, dep=2):
+    return SimpleNamespace(number_of_frames=frames, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
+
+
+def test_checkpoint_layout_round_trip(tmp_path):
+    """main.py:543-552 / 252-258, 335-343: {'epoch','lr','random_state','optimizer','model_pos'} with DataParallel-style
+    `module.` keys; written by trainer.checkpoint_dict, read back by trainer.load_checkpoint (and by a plain
+    load_state_dict after stripping the prefix, which is what the reference's DataParallel wrapper does)."""
+    m = D3DP(tiny_args(), KL, KR, is_train=True)
+    m.load_state_dict(make_state_dict(3, 64, 2, 9), strict=False)
+    opt = torch.optim.AdamW(m.parameters(), lr=6e-5, weight_decay=0.1)
+    for p in m.parameters():
+        p.grad = torch.full_like(p, 1e-3)
+    opt.step()
+    lin = ChunkLineage([40, 9], 4, 9, shuffle=True, augment=True)
+    lin.next_pairs()                                       # advance the RandomState like one epoch does
+    ck = trainer.checkpoint_dict(7, 5.5e-5, lin, opt, m)
+    assert set(ck) == {"epoch", "lr", "random_state", "optimizer", "model_pos"}
+    assert all(k.startswith("module.") for k in ck["model_pos"]) and len(ck["model_pos"]) == len(m.state_dict())
+    assert ck["model_pos"]["module.betas"].dtype == torch.float64
+    path = os.path.join(tmp_path, "epoch_7.bin")
+    torch.save(ck, path)
+    m2 = D3DP(tiny_args(), KL, KR, is_train=True)
+    opt2 = torch.optim.AdamW(m2.parameters(), lr=1.0, weight_decay=0.1)
+    lin2 = ChunkLineage([40, 9], 4, 9, shuffle=True, augment=True)
+    got = trainer.load_checkpoint(path, m2, opt2, lin2)
+    assert got["epoch"] == 7 and got["lr"] == 5.5e-5
+    for (k, a), b in zip(m.state_dict().items(), m2.state_dict().values()):
+        assert torch.equal(a, b), k
+    assert opt2.param_groups[0]["lr"] == 6e-5 and float(opt2.state[next(iter(m2.parameters()))]["step"]) == 1.0
+    # the restored RandomState continues the permutation stream exactly
+    assert np.array_equal(lin.next_pairs()[1], lin2.next_pairs()[1])
+    # an evaluation model (fewer buffers needed, different H/K) loads the same file non-strictly, as main.py:257 does
+    ev = D3DP(tiny_args(), KL, KR, is_train=False, num_proposals=3, sampling_timesteps=2)
+    ev.load_state_dict({k[len("module."):]: v for k, v in got["model_pos"].items()}, strict=False)
+
+
+def test_entrypoint_flags_follow_the_reference():
+    a = cli.parse_args(["--synthetic", "-c", "ck", "--evaluate", "best_epoch.bin", "-num_proposals", "20",
+                        "-sampling_timesteps", "10", "-b", "4", "-f", "243", "-cs", "512", "-dep", "8", "--p2"])
+    assert (a.evaluate, a.num_proposals, a.sampling_timesteps, a.batch_size, a.number_of_frames, a.p2) == \
+           ("best_epoch.bin", 20, 10, 4, 243, True) and a.test_time_augmentation is True
+    t = cli.parse_args(["--synthetic", "-e", "3", "-lr", "0.0001", "-lrd", "0.99", "-s", "243", "-b", "972", "-cf", "5",
+                        "-r", "epoch_2.bin", "--no-eval", "-no-da"])
+    assert (t.epochs, t.learning_rate, t.lr_decay, t.stride, t.batch_size, t.checkpoint_frequency, t.resume, t.no_eval,
+            t.data_augmentation, t.evaluate) == (3, 1e-4, 0.99, 243, 972, 5, "epoch_2.bin", True, False, "")
+    d = cli.parse_args([])                                  # reference defaults (arguments.py:27-47)
+    assert (d.epochs, d.learning_rate, d.lr_decay, d.checkpoint_frequency, d.stride) == (400, 6e-5, 0.993, 20, 243)
+
+
+def test_entrypoints_refuse_to_run_without_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(SystemExit):
+        cli.main(["--synthetic", "--evaluate", "x.bin"])
+    with pytest.raises(SystemExit):
+        cli.main_3dhp(["--synthetic", "--evaluate", "x.bin"])
+    m = D3DP(tiny_args(), KL, KR, is_train=False)
+    with pytest.raises(_lib.D3DPHipError):
+        serve.predict_video(m, np.zeros((5, 17, 2), np.float32), 100, 100)
+
+
+def test_3dhp_model_is_the_same_network_in_millimetres():
+    a, b = D3DP(tiny_args(), KL, KR, is_train=False), D3DP3DHP(tiny_args(), KL, KR, is_train=False)
+    assert list(a.state_dict()) == list(b.state_dict()) and D3DP3DHP.MM == 1000.0
+
+
+def test_normalisation_and_clip_counts():
+    x = torch.tensor([[0.0, 0.0], [1920.0, 1080.0], [960.0, 540.0]])
+    y = serve.normalize_screen_coordinates(x, 1920, 1080)                  # camera.py:7-11
+    assert torch.allclose(y, torch.tensor([[-1.0, -0.5625], [1.0, 0.5625], [0.0, 0.0]]))
+    assert [clip_count(n, 243) for n in (1, 242, 243, 244, 486, 487, 100000)] == [1, 1, 1, 2, 2, 3, 412]
