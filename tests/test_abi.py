@@ -106,3 +106,31 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_header_is_plain_c_and_links():
+    """include/d3dp_hip.h is the drop-in boundary: it must compile as C99 (no C++/torch types) and a C translation unit
+    that references every declared function must link against libd3dp_hip.so (no compute call is made)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "d3dp_hip.h")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    names = sorted(set(re.findall(r"^(?:int|const char\*)\s+(d3dp_[a-z0-9_]+)\s*\(", open(hdr).read(), flags=re.M)))
+    assert len(names) >= 30 and set(names) == set(_lib.PROTOTYPES), set(names) ^ set(_lib.PROTOTYPES)
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "link.c")
+        with open(src, "w") as f:
+            f.write('#include "d3dp_hip.h"\n#include <stdio.h>\nint main(void) {\n  void* p[] = {\n')
+            f.write("".join(f"    (void*){n},\n" for n in names))
+            f.write('  };\n  printf("%d %d\\n", (int)(sizeof p / sizeof p[0]), d3dp_abi_version());\n  return 0;\n}\n')
+        exe = os.path.join(td, "link")
+        libdir = os.path.dirname(_lib.LIB_PATH)
+        subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), src, "-o", exe, "-L", libdir, "-ld3dp_hip",
+                        "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined"], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
+        assert int(out[0]) == len(names) and int(out[1]) == _lib.ABI_VERSION
