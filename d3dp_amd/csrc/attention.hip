@@ -7,12 +7,12 @@
 //                               broadcast from LDS.  Used for EXACT mode (fp32 activations, both axes)
 //                               and for the spatial axis in FAST mode (bf16 activations; 0.4 % of FLOPs
 //                               and HBM-bound, so matrix cores would buy nothing).
-//   attn_temporal_bf16_kernel : FAST mode temporal axis on v_mfma_f32_16x16x32_bf16.  One workgroup per
-//                               (sequence, head); all of K (swizzled, row-major) and V^T live in LDS; each
-//                               wave owns 16-query tiles and keeps a whole score row-block in registers
-//                               (keys <= 256), so softmax is a plain two-pass fp32 softmax with wavefront
-//                               shuffles -- no online rescaling.  S^T = K Q^T is computed transposed so the
-//                               probabilities land directly in the A/B fragment layout of the P.V MFMA.
+//   attn_temporal2_bf16_kernel / attn_spatial_bf16_kernel : FAST mode on v_mfma_f32_16x16x32_bf16.  K and V rows
+//                               (swizzled, row-major) live in LDS; each wave owns 16-query tiles and keeps a whole
+//                               score row-block in registers (keys <= 256), so softmax is a plain two-pass fp32 softmax
+//                               with wavefront shuffles -- no online rescaling.  S^T = K Q^T is computed transposed so
+//                               the probabilities land directly in the A/B fragment layout of the P.V MFMA.
+//   attn_temporal_f32_kernel  : EXACT mode temporal axis on the fp32 matrix cores.
 #include <cstdlib>
 
 #include "common.h"
@@ -43,7 +43,7 @@ __device__ __forceinline__ void ld_vec(const T* p, float* v) {
 
 // OUT3: write the result as three split-bf16 planes (`plane` elements apart) instead of T -- the A operand
 // format of the bf16x3 EXACT-mode Linear.
-template <typename T, int HD, int TPP, bool OUT3>
+template <typename T, int HD, int TPP, int OUTS>   // OUTS: 0 = T out, 3 = three split-bf16 planes, 2 = two split-fp16 planes
 __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qkv, void* __restrict__ out_v, int n_prob,
                                                         SeqMap map, int C, int heads, size_t plane) {
   constexpr int PPB = 256 / TPP;
@@ -130,7 +130,21 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qk
     }
   }
   const float inv = 1.0f / l;
-  if constexpr (OUT3) {
+  if constexpr (OUTS == 2) {
+    f16* dst = reinterpret_cast<f16*>(out_v) + tok * C + head * HD;
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+      f16x4 p0, p1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f16 a0, a1;
+        split2h(o[c * 4 + e] * inv, a0, a1);
+        p0[e] = a0; p1[e] = a1;
+      }
+      *reinterpret_cast<f16x4*>(dst + c * 4) = p0;
+      *reinterpret_cast<f16x4*>(dst + plane + c * 4) = p1;
+    }
+  } else if constexpr (OUTS == 3) {
     bf16* dst = reinterpret_cast<bf16*>(out_v) + tok * C + head * HD;
 #pragma unroll
     for (int c = 0; c < HD / 4; ++c) {
@@ -158,14 +172,14 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qk
   }
 }
 
-template <typename T, int HD, int TPP, bool OUT3>
+template <typename T, int HD, int TPP, int OUTS>
 int launch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, hipStream_t st) {
   constexpr int PPB = 256 / TPP;
   constexpr int LDR = HD + Vec16<T>::N;
   const int n_prob = n_seq * heads;
   const size_t lds = (size_t)PPB * 2 * map.n_tok * LDR * sizeof(T);
   if (lds > 160 * 1024) return -2;
-  auto kern = attn_rows_kernel<T, HD, TPP, OUT3>;
+  auto kern = attn_rows_kernel<T, HD, TPP, OUTS>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -177,14 +191,14 @@ int launch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int he
   return 0;
 }
 
-template <typename T, bool OUT3>
+template <typename T, int OUTS>
 int dispatch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, hipStream_t st) {
   const int hd = C / heads;
   const bool small = map.n_tok <= 32;
   if (map.n_tok > 256) return -2;
 #define ROWS_CASE(HD_)                                                                                          \
-  case HD_: return small ? launch_rows<T, HD_, 32, OUT3>(qkv, out, n_seq, map, C, heads, plane, st)             \
-                         : launch_rows<T, HD_, 256, OUT3>(qkv, out, n_seq, map, C, heads, plane, st);
+  case HD_: return small ? launch_rows<T, HD_, 32, OUTS>(qkv, out, n_seq, map, C, heads, plane, st)             \
+                         : launch_rows<T, HD_, 256, OUTS>(qkv, out, n_seq, map, C, heads, plane, st);
   switch (hd) {
     ROWS_CASE(64) ROWS_CASE(32) ROWS_CASE(16) ROWS_CASE(8)
     default: return -2;
@@ -193,163 +207,7 @@ int dispatch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// FAST temporal attention on bf16 MFMA (head dim 64)
-// ------------------------------------------------------------------------------------------------
-template <int NKT>   // number of 16-key tiles (keys padded to 16*NKT <= 256)
-__global__ __launch_bounds__(256, 2) void attn_temporal_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                                 SeqMap map, int C, int heads) {
-  constexpr int NK = 16 * NKT;            // padded keys
-  constexpr int VSTR = (NK + 8) * 2;      // V^T row stride in bytes (16-B multiple, bank-spreading pad)
-  constexpr int KS_BYTES = NK * 128;
-  constexpr int ITER = (NK * 8 + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* KS = smem;                         // K rows, 128 B each, 16-B slots XOR-swizzled; first used as V staging
-  char* VT = smem + KS_BYTES;              // V^T: [64 d][NK keys] bf16
-
-  const int n = map.n_tok;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
-  const int base = seq_base(map, seq);
-  const int ts = map.tok_stride;
-  const size_t ld = (size_t)3 * C;
-  const bf16* qbase = qkv + (size_t)head * 64;
-
-  // ---- phase 1: V rows -> LDS staging (row-major), K rows -> registers -------------------------
-  float4 kreg[ITER];
-#pragma unroll
-  for (int i = 0; i < ITER; ++i) {
-    const int idx = tid + i * 256;
-    const int row = idx >> 3, slot = idx & 7;
-    float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
-    kreg[i] = vv;
-    if (idx < NK * 8 && row < n) {
-      const bf16* src = qbase + (size_t)(base + row * ts) * ld + slot * 8;
-      kreg[i] = *reinterpret_cast<const float4*>(src + C);
-      vv = *reinterpret_cast<const float4*>(src + 2 * C);
-    }
-    if (idx < NK * 8) *reinterpret_cast<float4*>(KS + row * 128 + slot * 16) = vv;
-  }
-  __syncthreads();
-  // ---- phase 2: transpose staging -> V^T ---------------------------------------------------------
-  for (int u = tid; u < 64 * (NK / 8); u += 256) {
-    const int d = u & 63, kg = u >> 6;
-    unsigned short e[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = *reinterpret_cast<const unsigned short*>(KS + (kg * 8 + j) * 128 + d * 2);
-    uint4 pk;
-    pk.x = e[0] | ((unsigned)e[1] << 16); pk.y = e[2] | ((unsigned)e[3] << 16);
-    pk.z = e[4] | ((unsigned)e[5] << 16); pk.w = e[6] | ((unsigned)e[7] << 16);
-    *reinterpret_cast<uint4*>(VT + d * VSTR + kg * 16) = pk;
-  }
-  __syncthreads();
-  // ---- phase 3: K registers -> swizzled LDS ------------------------------------------------------
-#pragma unroll
-  for (int i = 0; i < ITER; ++i) {
-    const int idx = tid + i * 256;
-    const int row = idx >> 3, slot = idx & 7;
-    if (idx < NK * 8) *reinterpret_cast<float4*>(KS + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = kreg[i];
-  }
-  __syncthreads();
-
-  const int fi = lane & 15, fg = lane >> 4;
-  const float cexp = 0.125f * 1.44269504088896340736f;   // hd^-0.5 * log2(e), hd = 64
-  const int n_qt = (n + 15) >> 4;
-  for (int qt = wave; qt < n_qt; qt += 4) {
-    const int q = qt * 16 + fi;
-    const int qc = min(q, n - 1);
-    const bf16* qsrc = qbase + (size_t)(base + qc * ts) * ld + fg * 8;
-    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(qsrc);
-    const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(qsrc + 32);
-
-    // S^T tile t: rows = keys 16t + 4*fg + r, column = query fi
-    f32x4 s[NKT];
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-      const int key = t * 16 + fi;
-      const int sw = (key >> 1) & 7;
-      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(KS + key * 128 + ((fg ^ sw) << 4));
-      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(KS + key * 128 + (((4 + fg) ^ sw) << 4));
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q0, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q1, a, 0, 0, 0);
-      s[t] = a;
-      if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the ds_read hoisting window (VGPR pressure)
-    }
-    // mask padded keys, row max
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-      if (16 * (t + 1) > n) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (16 * t + 4 * fg + r >= n) s[t][r] = -INFINITY;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mc = mx * cexp;
-    float sum = 0.f;
-    bf16x8 pf[NKT / 2];
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], cexp, -mc));
-        sum += p;
-        pf[t >> 1][(t & 1) * 4 + r] = (bf16)p;
-      }
-    }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-
-    // O^T[d][q] = sum_keys V^T[d][key] P^T[key][q]
-    f32x4 o[4];
-#pragma unroll
-    for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < NKT / 2; ++c) {
-#pragma unroll
-      for (int dn = 0; dn < 4; ++dn) {
-        const char* vrow = VT + (dn * 16 + fi) * VSTR + (32 * c + 4 * fg) * 2;
-        const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vrow);
-        const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vrow + 32);
-        const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[c], o[dn], 0, 0, 0);
-      }
-      if (c & 1) __builtin_amdgcn_sched_barrier(0);
-    }
-    if (q < n) {
-      const float inv = 1.0f / sum;
-      bf16* dst = out + (size_t)(base + q * ts) * C + head * 64 + fg * 4;
-#pragma unroll
-      for (int dn = 0; dn < 4; ++dn) {
-        bf16x4 r = {(bf16)(o[dn][0] * inv), (bf16)(o[dn][1] * inv), (bf16)(o[dn][2] * inv), (bf16)(o[dn][3] * inv)};
-        *reinterpret_cast<bf16x4*>(dst + dn * 16) = r;
-      }
-    }
-  }
-}
-
-template <int NKT>
-int launch_temporal(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st) {
-  constexpr int NK = 16 * NKT;
-  const size_t lds = (size_t)NK * 128 + (size_t)64 * (NK + 8) * 2;
-  auto kern = attn_temporal_bf16_kernel<NKT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) return -3;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(256), lds, st, (const bf16*)qkv, (bf16*)out, map, C, heads);
-  return 0;
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// FAST-mode attention, second generation (head dim 64): no transposes anywhere.
+// FAST-mode attention on bf16 MFMA (head dim 64): no transposes anywhere.
 //   K rows sit in LDS row-major (128 B per key) with the 16-byte-slot XOR swizzle ds_read_b128 wants;
 //   V rows sit row-major too, swizzled at 32-byte-chunk granularity, and are consumed with
 //   ds_read_b64_tr_b16: within each 16-lane group the instruction returns, to lane i, column i of the
@@ -577,7 +435,7 @@ __global__ __launch_bounds__(256) void attn_spatial_bf16_kernel(const bf16* __re
 // ------------------------------------------------------------------------------------------------
 constexpr int LDKF = 65, LDVF = 68;
 
-template <int NKT, bool OUT3>
+template <int NKT, int OUTS>
 __global__ __launch_bounds__(256, 1) void attn_temporal_f32_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
                                                                 SeqMap map, int C, int heads, size_t plane) {
   constexpr int NK = 16 * NKT;
@@ -672,7 +530,18 @@ __global__ __launch_bounds__(256, 1) void attn_temporal_f32_kernel(const float* 
 #pragma unroll
       for (int dn = 0; dn < 4; ++dn) {
         float r4[4] = {o[dn][0] * inv, o[dn][1] * inv, o[dn][2] * inv, o[dn][3] * inv};
-        if constexpr (OUT3) {
+        if constexpr (OUTS == 2) {
+          f16* dst = reinterpret_cast<f16*>(out_v) + off + dn * 16;
+          f16x4 p0, p1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            f16 a0, a1;
+            split2h(r4[e], a0, a1);
+            p0[e] = a0; p1[e] = a1;
+          }
+          *reinterpret_cast<f16x4*>(dst) = p0;
+          *reinterpret_cast<f16x4*>(dst + plane) = p1;
+        } else if constexpr (OUTS == 3) {
           bf16* dst = reinterpret_cast<bf16*>(out_v) + off + dn * 16;
           bf16x4 p0, p1, p2;
 #pragma unroll
@@ -692,11 +561,11 @@ __global__ __launch_bounds__(256, 1) void attn_temporal_f32_kernel(const float* 
   }
 }
 
-template <int NKT, bool OUT3>
+template <int NKT, int OUTS>
 int launch_temporal_f32(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, hipStream_t st) {
   constexpr int NK = 16 * NKT;
   const size_t lds = (size_t)(NK * LDKF + 3 + NK * LDVF) * 4 + 16;
-  auto kern = attn_temporal_f32_kernel<NKT, OUT3>;
+  auto kern = attn_temporal_f32_kernel<NKT, OUTS>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -724,41 +593,36 @@ int launch_temporal2(const void* qkv, void* out, int n_seq, SeqMap map, int C, i
 
 }  // namespace
 
-// act: 0 = fp32 in/out, 1 = bf16 in/out, 2 = fp32 in, split-bf16 planes out
+// act: 0 = fp32 in/out, 1 = bf16 in/out, 2 = fp32 in, split-bf16 planes out, 3 = fp32 in, split-fp16 planes out
 int d3dp_launch_attn_rows(int act, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st) {
   const size_t plane = (size_t)n_seq * map.n_tok * C;
-  if (act == 1) return dispatch_rows<bf16, false>(qkv, out, n_seq, map, C, heads, plane, st);
-  if (act == 2) return dispatch_rows<float, true>(qkv, out, n_seq, map, C, heads, plane, st);
-  return dispatch_rows<float, false>(qkv, out, n_seq, map, C, heads, plane, st);
+  if (act == 1) return dispatch_rows<bf16, 0>(qkv, out, n_seq, map, C, heads, plane, st);
+  if (act == 2) return dispatch_rows<float, 3>(qkv, out, n_seq, map, C, heads, plane, st);
+  if (act == 3) return dispatch_rows<float, 2>(qkv, out, n_seq, map, C, heads, plane, st);
+  return dispatch_rows<float, 0>(qkv, out, n_seq, map, C, heads, plane, st);
 }
 
 int d3dp_launch_attn_temporal_bf16(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
                                    hipStream_t st) {
   if (C / heads != 64 || map.n_tok > 256 || map.n_tok < 1) return -2;
   const int n = map.n_tok;
-  static int v1 = -1;
-  if (v1 < 0) { const char* e = getenv("D3DP_ATTN_V1"); v1 = (e && e[0] == '1') ? 1 : 0; }   // A/B: first-generation kernel
-  if (v1) {
-    if (n <= 32) return launch_temporal<2>(qkv, out, n_seq, map, C, heads, st);
-    if (n <= 64) return launch_temporal<4>(qkv, out, n_seq, map, C, heads, st);
-    if (n <= 128) return launch_temporal<8>(qkv, out, n_seq, map, C, heads, st);
-    return launch_temporal<16>(qkv, out, n_seq, map, C, heads, st);
-  }
   if (n <= 32) return launch_temporal2<2>(qkv, out, n_seq, map, C, heads, st);
   if (n <= 64) return launch_temporal2<4>(qkv, out, n_seq, map, C, heads, st);
   if (n <= 128) return launch_temporal2<8>(qkv, out, n_seq, map, C, heads, st);
   return launch_temporal2<16>(qkv, out, n_seq, map, C, heads, st);
 }
 
-// EXACT-mode temporal axis on the fp32 matrix cores (head dim 64); act 0 -> fp32 out, act 2 -> split-bf16 planes out
+// EXACT-mode temporal axis on the fp32 matrix cores (head dim 64); act 0 -> fp32 out, 2 -> split-bf16 planes out,
+// 3 -> split-fp16 planes out
 int d3dp_launch_attn_temporal_f32(int act, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
                                   hipStream_t st) {
-  if (C / heads != 64 || map.n_tok > 256 || map.n_tok < 1 || (act != 0 && act != 2)) return -2;
+  if (C / heads != 64 || map.n_tok > 256 || map.n_tok < 1 || (act != 0 && act != 2 && act != 3)) return -2;
   const size_t plane = (size_t)n_seq * map.n_tok * C;
   const int n = map.n_tok;
 #define TF32_CASE(NKT_)                                                                                       \
-  return act == 2 ? launch_temporal_f32<NKT_, true>(qkv, out, n_seq, map, C, heads, plane, st)                \
-                  : launch_temporal_f32<NKT_, false>(qkv, out, n_seq, map, C, heads, plane, st);
+  return act == 3 ? launch_temporal_f32<NKT_, 2>(qkv, out, n_seq, map, C, heads, plane, st)                   \
+       : act == 2 ? launch_temporal_f32<NKT_, 3>(qkv, out, n_seq, map, C, heads, plane, st)                   \
+                  : launch_temporal_f32<NKT_, 0>(qkv, out, n_seq, map, C, heads, plane, st);
   if (n <= 32) { TF32_CASE(2) }
   if (n <= 64) { TF32_CASE(4) }
   if (n <= 128) { TF32_CASE(8) }

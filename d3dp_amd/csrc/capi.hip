@@ -69,7 +69,8 @@ const char* kClassNames[D3DP_PROFILE_CLASSES] = {"gemm_qkv", "gemm_proj", "gemm_
 
 struct BlockDev {
   const float *n1w, *n1b, *n2w, *n2b, *qkv_b, *proj_b, *fc1_b, *fc2_b;
-  const void *qkv_w, *proj_w, *fc1_w, *fc2_w;   // bf16 (FAST), 3 bf16 planes (EXACT) or fp32 (EXACT, D3DP_EXACT_F32=1)
+  const void *qkv_w, *proj_w, *fc1_w, *fc2_w;   // bf16 (FAST); EXACT: 2 fp16 planes (default), 3 bf16 planes or fp32
+  float qkv_u = 1.f, proj_u = 1.f, fc1_u = 1.f, fc2_u = 1.f;   // EXACT f16x2: 2^-s of the per-matrix pre-scale 2^s
 };
 
 __global__ void to_bf16_kernel(const float* __restrict__ s, bf16* __restrict__ d, size_t n) {
@@ -107,18 +108,19 @@ struct d3dp_ctx {
   double total_ms[D3DP_PROFILE_CLASSES] = {0};
 
   bool fast() const { return cfg.mode == D3DP_MODE_FAST; }
-  // EXACT mode runs its Linears as split-bf16 (3 planes, 6 MFMA passes) unless env D3DP_EXACT_F32=1 selects the
-  // fp32-MFMA kernels (A/B and fallback).  Activations that feed a Linear are then three bf16 planes.
-  bool exact_f32 = false;
+  // EXACT mode runs its Linears on split-fp16 operands (2 planes, 3 fp16-MFMA passes, gemm_x2.hip); activations that
+  // feed a Linear are then two fp16 planes.  env D3DP_EXACT_IMPL=bf16x3 selects the round-1 six-pass split-bf16 kernels
+  // and =f32 the plain fp32-MFMA kernels (bitwise an fp32 fmaf chain) -- both kept as cross-checks.
+  int exact_impl = 0;   // 0 = f16x2, 1 = bf16x3, 2 = f32
   bool train() const { return cfg.mode == D3DP_MODE_TRAIN; }
-  bool x3() const { return !fast() && !exact_f32 && !train(); }
-  int act() const { return fast() ? 1 : (x3() ? 2 : 0); }            // code understood by the row-wise launchers
+  bool exact() const { return !fast() && !train(); }
+  bool x2() const { return exact() && exact_impl == 0; }
+  bool x3() const { return exact() && exact_impl == 1; }
+  int act() const { return fast() ? 1 : (x3() ? 2 : (x2() ? 3 : 0)); }   // code understood by the row-wise launchers
   size_t act_size() const { return fast() ? 2 : (x3() ? 6 : 4); }    // bytes per element of a Linear-input activation
-  size_t wide_size() const { return fast() ? 2 : 4; }                // bytes per element of bufB (qkv fp32 / hidden planes = 12C either way)
+  size_t wide_size() const { return fast() ? 2 : 4; }                // bytes per element of bufB (qkv fp32 = 12C; hidden planes <= 12C)
   size_t y_size() const { return fast() ? 2 : 4; }
   int chunk() const { return cfg.chunk_seqs > 0 ? cfg.chunk_seqs : 15; }
-  bool attn_rows_spatial = false;   // env D3DP_ATTN_V1=1: fp32-VALU row kernel for the spatial axis (A/B)
-  bool gemm_v1 = false;   // env D3DP_GEMM_V1=1: per-tile 128x128 kernel instead of the persistent streaming one (A/B)
 
   int flush_events() {
     for (size_t i = 0; i < used; ++i) {
@@ -160,13 +162,11 @@ struct Scope {
 };
 
 // out = epi(A W^T + bias).  out_f32: fp32 output even in FAST mode (the Linear outputs that feed a residual add).
-int linear(d3dp_ctx* c, int cls, int epi, int out_f32, const void* A, const void* W, const float* bias, void* out, int M,
-           int N, int K, hipStream_t st) {
+int linear(d3dp_ctx* c, int cls, int epi, int out_f32, const void* A, const void* W, float wu, const float* bias, void* out,
+           int M, int N, int K, hipStream_t st) {
   Scope s(c, cls, st);
-  if (c->fast()) {
-    if (c->gemm_v1) return d3dp_launch_linear_bf16(epi, out_f32, A, W, bias, out, M, N, K, st);
-    return d3dp_launch_linear_bf16_stream(epi, out_f32, A, W, bias, out, M, N, K, st);
-  }
+  if (c->fast()) return d3dp_launch_linear_bf16_stream(epi, out_f32, A, W, bias, out, M, N, K, st);
+  if (c->x2()) return d3dp_launch_linear_f16x2(epi, A, W, bias, wu, (float*)out, out, M, N, K, st);
   if (c->x3()) return d3dp_launch_linear_bf16x3(epi, A, W, bias, (float*)out, out, M, N, K, st);
   return d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, st);
 }
@@ -178,7 +178,7 @@ int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, hipSt
   const d3dp_cfg& g = c->cfg;
   Scope s(c, axis == 0 ? P_ATTN_S : P_ATTN_T, st);
   if (axis == 0) {
-    if (c->fast() && g.channels / g.heads == 64 && g.joints <= 32 && !c->attn_rows_spatial)
+    if (c->fast() && g.channels / g.heads == 64 && g.joints <= 32)
       return d3dp_launch_attn_spatial_bf16(qkv, out, n_bh * g.frames, spatial_map(g.frames, g.joints), g.channels,
                                            g.heads, st);
     return d3dp_launch_attn_rows(c->act(), qkv, out, n_bh * g.frames, spatial_map(g.frames, g.joints), g.channels,
@@ -187,7 +187,7 @@ int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, hipSt
   if (c->fast() && g.channels / g.heads == 64)
     return d3dp_launch_attn_temporal_bf16(qkv, out, n_bh * g.joints, temporal_map(g.frames, g.joints), g.channels,
                                           g.heads, st);
-  if (!c->fast() && g.channels / g.heads == 64 && !c->attn_rows_spatial)     // fp32 matrix cores (D3DP_ATTN_V1=1: row kernel)
+  if (c->exact() && g.channels / g.heads == 64)     // fp32 matrix cores
     return d3dp_launch_attn_temporal_f32(c->act(), qkv, out, n_bh * g.joints, temporal_map(g.frames, g.joints),
                                          g.channels, g.heads, st);
   return d3dp_launch_attn_rows(c->act(), qkv, out, n_bh * g.joints, temporal_map(g.frames, g.joints), g.channels,
@@ -203,15 +203,15 @@ int run_block(d3dp_ctx* c, const BlockDev& w, int axis, float* x, void* y1, void
               hipStream_t st) {
   const d3dp_cfg& g = c->cfg;
   const int Tc = n_bh * g.frames * g.joints, C = g.channels;
-  LAUNCH_TRY(linear(c, P_QKV, EPI_BIAS, 0, bufA, w.qkv_w, w.qkv_b, bufB, Tc, 3 * C, C, st));
+  LAUNCH_TRY(linear(c, P_QKV, EPI_BIAS, 0, bufA, w.qkv_w, w.qkv_u, w.qkv_b, bufB, Tc, 3 * C, C, st));
   LAUNCH_TRY(attention(c, axis, bufB, bufA, n_bh, st));
-  LAUNCH_TRY(linear(c, P_PROJ, EPI_BIAS, 0, bufA, w.proj_w, w.proj_b, y1, Tc, C, C, st));
+  LAUNCH_TRY(linear(c, P_PROJ, EPI_BIAS, 0, bufA, w.proj_w, w.proj_u, w.proj_b, y1, Tc, C, C, st));
   {
     Scope s(c, P_LN, st);      // xn = LN2(x + y1); x itself stays untouched (the caller's norm pair adds y1 and y)
     LAUNCH_TRY(d3dp_launch_ln(c->act(), x, y1, 0, w.n2w, w.n2b, g.eps_block, bufA, Tc, C, st));
   }
-  LAUNCH_TRY(linear(c, P_FC1, EPI_GELU, 0, bufA, w.fc1_w, w.fc1_b, bufB, Tc, g.hidden, C, st));
-  LAUNCH_TRY(linear(c, P_FC2, EPI_BIAS, 0, bufB, w.fc2_w, w.fc2_b, y, Tc, C, g.hidden, st));
+  LAUNCH_TRY(linear(c, P_FC1, EPI_GELU, 0, bufA, w.fc1_w, w.fc1_u, w.fc1_b, bufB, Tc, g.hidden, C, st));
+  LAUNCH_TRY(linear(c, P_FC2, EPI_BIAS, 0, bufB, w.fc2_w, w.fc2_u, w.fc2_b, y, Tc, C, g.hidden, st));
   return 0;
 }
 
@@ -244,12 +244,8 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
     return fail(D3DP_EHIP, "no HIP device visible: libd3dp_hip has no CPU fallback");
   d3dp_ctx* c = new d3dp_ctx();
   c->cfg = g;
-  const char* v1 = getenv("D3DP_GEMM_V1");
-  c->gemm_v1 = v1 && v1[0] == '1';
-  const char* xf = getenv("D3DP_EXACT_F32");
-  c->exact_f32 = xf && xf[0] == '1';
-  const char* a1 = getenv("D3DP_ATTN_V1");
-  c->attn_rows_spatial = a1 && a1[0] == '1';
+  const char* xf = getenv("D3DP_EXACT_IMPL");
+  c->exact_impl = (xf && !strcmp(xf, "bf16x3")) ? 1 : (xf && !strcmp(xf, "f32")) ? 2 : 0;
   HIP_TRY(hipGetDevice(&c->device));
   *out = c;
   return D3DP_OK;
@@ -309,9 +305,38 @@ int d3dp_set_weights(d3dp_ctx* c, const d3dp_weights* w, void* stream) {
     HIP_TRY(hipMalloc((void**)&c->arena, off));
     c->arena_bytes = off;
   }
-  for (auto& it : items) {
+  // EXACT f16x2: every weight matrix is multiplied by 2^s, s = 14 - exponent(max |w|), before the hi/lo split (max |w| 2^s
+  // in [2^13, 2^14): far from fp16 overflow, and the bulk of the matrix far above the subnormal range); the GEMM
+  // multiplies its result by 2^-s.
+  std::vector<float> unscale(items.size(), 1.f);
+  if (c->x2()) {
+    size_t n_mat = 0;
+    for (auto& it : items) n_mat += it.mat;
+    unsigned* dmax = nullptr;
+    HIP_TRY(hipMalloc((void**)&dmax, n_mat * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(dmax, 0, n_mat * sizeof(unsigned), st));
+    size_t k = 0;
+    for (auto& it : items)
+      if (it.mat) d3dp_launch_absmax((const float*)it.src, it.n, dmax + k++, st);
+    std::vector<float> hmax(n_mat);
+    HIP_TRY(hipMemcpyAsync(hmax.data(), dmax, n_mat * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipFree(dmax));
+    k = 0;
+    for (size_t i = 0; i < items.size(); ++i) {
+      if (!items[i].mat) continue;
+      const float mx = hmax[k++];
+      if (!(mx < INFINITY)) return fail(D3DP_EINVAL, "d3dp_set_weights: a weight matrix holds inf/nan");
+      int e = 0;
+      if (mx > 0.f) frexpf(mx, &e);                  // mx = f 2^e, f in [0.5, 1)
+      unscale[i] = ldexpf(1.f, e - 14);
+    }
+  }
+  for (size_t i = 0; i < items.size(); ++i) {
+    auto& it = items[i];
     if (it.mat && c->fast()) launch_to_bf16((const float*)it.src, c->arena + it.off, it.n, st);
     else if (it.mat && c->x3()) d3dp_launch_split3((const float*)it.src, c->arena + it.off, it.n, st);
+    else if (it.mat && c->x2()) d3dp_launch_split2((const float*)it.src, c->arena + it.off, it.n, 1.0f / unscale[i], st);
     else HIP_TRY(hipMemcpyAsync(c->arena + it.off, it.src, it.n * 4, hipMemcpyDeviceToDevice, st));
   }
   HIP_TRY(hipGetLastError());
@@ -326,7 +351,8 @@ int d3dp_set_weights(d3dp_ctx* c, const d3dp_weights* w, void* stream) {
   for (size_t k = 0; k < bis.size(); ++k) {
     const BI& bi = bis[k];
     BlockDev b{F32(bi.v[0]), F32(bi.v[1]), F32(bi.v[6]), F32(bi.v[7]), F32(bi.v[3]), F32(bi.v[5]), F32(bi.v[9]),
-               F32(bi.v[11]), ANY(bi.v[2]), ANY(bi.v[4]), ANY(bi.v[8]), ANY(bi.v[10])};
+               F32(bi.v[11]), ANY(bi.v[2]), ANY(bi.v[4]), ANY(bi.v[8]), ANY(bi.v[10]),
+               unscale[bi.v[2]], unscale[bi.v[4]], unscale[bi.v[8]], unscale[bi.v[10]]};
     (k < (size_t)g.depth ? c->ste : c->tte).push_back(b);
   }
   c->weights_set = true;
@@ -470,15 +496,18 @@ int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, cons
                    int32_t N, int32_t K, void* stream) {
   if (!A || !W || !bias || !out) return fail(D3DP_EINVAL, "d3dp_op_linear: null argument");
   if (mode == D3DP_MODE_FAST) {
-    // epi 0/1: the persistent streaming kernel the denoiser uses (epi | 16 selects its fp32-output form);
-    // epi 2 (in-place residual) and epi | 32: the per-tile 128x128 kernel.
+    // epi 0/1: the persistent streaming kernel the denoiser uses (epi | 16 selects its fp32-output form)
     const int e = epi & 3, f32 = (epi & 16) != 0;
-    if (e != EPI_RESID && !(epi & 32)) LAUNCH_TRY(d3dp_launch_linear_bf16_stream(e, f32, A, W, bias, out, M, N, K, (hipStream_t)stream));
-    else LAUNCH_TRY(d3dp_launch_linear_bf16(e, f32, A, W, bias, out, M, N, K, (hipStream_t)stream));
+    if (e == EPI_RESID || (epi & ~19)) return fail(D3DP_EINVAL, "d3dp_op_linear: FAST mode has epilogues 0, 1 and 0|16");
+    LAUNCH_TRY(d3dp_launch_linear_bf16_stream(e, f32, A, W, bias, out, M, N, K, (hipStream_t)stream));
   }
   else if (mode == 2) {
     // split-bf16: A, W are three bf16 planes each (d3dp_op_split3); epi 0 -> fp32 out, epi 1 -> three bf16 planes out
     LAUNCH_TRY(d3dp_launch_linear_bf16x3(epi, A, W, bias, (float*)out, out, M, N, K, (hipStream_t)stream));
+  }
+  else if (mode == 3) {
+    // split-fp16: A, W are two fp16 planes each (d3dp_op_split2); epi 0 -> fp32 out, epi 1 -> two fp16 planes out
+    LAUNCH_TRY(d3dp_launch_linear_f16x2(epi, A, W, bias, 1.0f, (float*)out, out, M, N, K, (hipStream_t)stream));
   }
   else LAUNCH_TRY(d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, (hipStream_t)stream));
   HIP_TRY(hipGetLastError());
@@ -488,6 +517,13 @@ int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, cons
 int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream) {
   if (!src || !dst) return fail(D3DP_EINVAL, "d3dp_op_split3: null argument");
   d3dp_launch_split3(src, dst, n, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
+int d3dp_op_split2(const float* src, void* dst, size_t n, float scale, void* stream) {
+  if (!src || !dst) return fail(D3DP_EINVAL, "d3dp_op_split2: null argument");
+  d3dp_launch_split2(src, dst, n, scale, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
 }

@@ -4,19 +4,22 @@
 // W is the nn.Linear weight as stored in the reference state_dict ([out, in], K contiguous), so both
 // MFMA operands are read along K and no transpose is ever materialised.
 //
-//   gemm_bf16_kernel : FAST mode.  bf16 operands, fp32 accumulate on v_mfma_f32_16x16x32_bf16.
-//                      128x128x64 block tile, 4 waves (2x2), 64x64 per wave = 4x4 MFMA tiles.
-//                      Tiles are DMA'd HBM->LDS with global_load_lds_dwordx4 (16 B/lane); the LDS image
-//                      is lane-linear, so the bank swizzle is applied on the per-lane SOURCE address
-//                      and again on the ds_read_b128 fragment address (same involution).
-//   gemm_f32_kernel  : EXACT mode.  fp32 operands on v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fmaf
-//                      chain over k).  128x128x16 block tile, 2x2 32x32 tiles per wave.
+//   gemm_bf16_stream_kernel : FAST mode (bottom of this file).  bf16 operands, fp32 accumulate on
+//                      v_mfma_f32_16x16x32_bf16; persistent 256x128x64 streaming kernel.  Tiles are DMA'd HBM->LDS with
+//                      global_load_lds_dwordx4 (16 B/lane); the LDS image is lane-linear, so the bank swizzle is applied
+//                      on the per-lane SOURCE address and again on the ds_read_b128 fragment address (same involution).
+//   gemm_f32_kernel  : TRAIN mode (and the EXACT cross-check D3DP_EXACT_IMPL=f32).  fp32 operands on
+//                      v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fmaf chain over k).  128x128x16 block tile, 2x2 32x32
+//                      tiles per wave.
+//   gemm_bf16x3_kernel : six-pass split-bf16 Linear (EXACT cross-check D3DP_EXACT_IMPL=bf16x3; the EXACT default is
+//                      the three-pass split-fp16 kernel in gemm_x2.hip).
 //
-// Both compute the TRANSPOSED product per wave (weight fragment as the MFMA A operand) so that each
-// lane ends up with 4 consecutive output columns of one row -> vector stores, bias as one float4.
+// All compute the TRANSPOSED product per wave (weight fragment as the MFMA A operand) so that each
+// lane ends up with consecutive output columns of one row -> vector stores, bias as one float4.
 //
-// Epilogues: EPI_BIAS (out = acc+b), EPI_GELU (out = gelu_erf(acc+b)), EPI_RESID (resid += acc+b, fp32).
+// Epilogues: EPI_BIAS (out = acc+b), EPI_GELU (out = gelu(acc+b)), EPI_RESID (resid += acc+b, fp32).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -51,103 +54,8 @@ __device__ __forceinline__ void epilogue4(const float* v, const float* __restric
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// FAST: bf16 MFMA
-// ------------------------------------------------------------------------------------------------
-constexpr int FBK = 64;                         // K per stage (128 B per tile row)
-constexpr int TILE_BYTES = BM * FBK * 2;        // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;     // A + W
-
 // physical 16-B slot of logical slot s in row `row` (8 slots per 128-B row)
 __device__ __forceinline__ int swz(int row, int s) { return s ^ ((row >> 1) & 7); }
-
-template <int EPI, typename OutT>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
-                                                        const float* __restrict__ bias, OutT* out, int M, int N,
-                                                        int K, int n_tiles_n) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
-
-  const int nblk = gridDim.x;
-  const int L = xcd_remap(blockIdx.x, nblk);
-  const int m0 = (L / n_tiles_n) * BM;
-  const int n0 = (L % n_tiles_n) * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-
-  // ---- per-lane DMA source pointers: wave w issues tile pieces j = 4w .. 4w+3 (8 rows each) ----
-  const bf16* srcA[4];
-  const bf16* srcW[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = (wave * 4 + q) * 8 + (lane >> 3);
-    const int s = swz(row, lane & 7);
-    const int ra = min(m0 + row, M - 1), rw = min(n0 + row, N - 1);
-    srcA[q] = A + (size_t)ra * K + s * 8;
-    srcW[q] = W + (size_t)rw * K + s * 8;
-  }
-  auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * STAGE_BYTES;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int piece = (wave * 4 + q) * 1024;
-      __builtin_amdgcn_global_load_lds(GPTR(srcA[q] + kt * FBK), LPTR(base + piece), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GPTR(srcW[q] + kt * FBK), LPTR(base + TILE_BYTES + piece), 16, 0, 0);
-    }
-  };
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = K / FBK;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const int fi = lane & 15, fg = lane >> 4;
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* sa = smem + cur * STAGE_BYTES;
-    const char* sw = sa + TILE_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[4], wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ra = wr * 64 + i * 16 + fi;
-        af[i] = *reinterpret_cast<const bf16x8*>(sa + ra * 128 + swz(ra, kk * 4 + fg) * 16);
-        const int rw = wc * 64 + i * 16 + fi;
-        wf[i] = *reinterpret_cast<const bf16x8*>(sw + rw * 128 + swz(rw, kk * 4 + fg) * 16);
-      }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  // ---- epilogue: lane holds out[m = .. + fi][n = .. + 4*fg .. +3] ----
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = m0 + wr * 64 + mi * 16 + fi;
-    if (m >= M) continue;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wc * 64 + ni * 16 + fg * 4;
-      if (n >= N) continue;
-      float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-      epilogue4<EPI, OutT>(v, bias, out, (size_t)m * N, n);
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // EXACT: fp32 MFMA
@@ -258,25 +166,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
-template <int EPI, typename OutT>
-static void launch_bf16(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
-                        hipStream_t st) {
-  const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OutT>), dim3(tm * tn), dim3(256), 0, st, (const bf16*)A, (const bf16*)W,
-                     bias, (OutT*)out, M, N, K, tn);
-}
-
-int d3dp_launch_linear_bf16(int epi, int out_f32, const void* A, const void* W, const float* bias, void* out, int M,
-                            int N, int K, hipStream_t st) {
-  if (K % FBK != 0 || N % 4 != 0 || M <= 0) return -1;
-  if (epi == EPI_RESID) launch_bf16<EPI_RESID, float>(A, W, bias, out, M, N, K, st);
-  else if (epi == EPI_GELU && !out_f32) launch_bf16<EPI_GELU, bf16>(A, W, bias, out, M, N, K, st);
-  else if (epi == EPI_BIAS && !out_f32) launch_bf16<EPI_BIAS, bf16>(A, W, bias, out, M, N, K, st);
-  else if (epi == EPI_BIAS && out_f32) launch_bf16<EPI_BIAS, float>(A, W, bias, out, M, N, K, st);
-  else return -1;
-  return 0;
-}
-
 int d3dp_launch_linear_f32(int epi, const float* A, const float* W, const float* bias, float* out, int M, int N,
                            int K, hipStream_t st) {
   if (K % XBK != 0 || N % 4 != 0 || M <= 0) return -1;
@@ -296,8 +185,7 @@ int d3dp_launch_linear_f32_splitk(const float* A, const float* W, float* out, in
   if (K % XBK != 0 || N % 4 != 0 || M <= 0) return -1;
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
   const int nk = K / XBK;
-  static int target = 0;                                          // workgroups aimed at: ~1 per CU measured best (88 ms/step vs 103 at 4 per CU: fewer fp32 atomics); env D3DP_SPLITK_TARGET for A/B
-  if (target == 0) { const char* e = getenv("D3DP_SPLITK_TARGET"); target = e ? atoi(e) : 256; if (target < 1) target = 256; }
+  const int target = 256;                                         // workgroups aimed at: ~1 per CU measured best (88 ms/step vs 103 at 4 per CU: fewer fp32 atomics)
   int splits = (target + tm * tn - 1) / (tm * tn);
   if (splits > nk / 8) splits = nk / 8 > 0 ? nk / 8 : 1;
   const int per = (nk + splits - 1) / splits;
@@ -330,8 +218,7 @@ __device__ __forceinline__ int swz3(int row, int s) { return s ^ (((row >> 3) & 
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16x3_kernel(const bf16* __restrict__ A3, const bf16* __restrict__ W3,
                                                           const float* __restrict__ bias, float* __restrict__ outf,
-                                                          bf16* __restrict__ out3, int M, int N, int K, int n_tiles_n,
-                                                          int dbg) {
+                                                          bf16* __restrict__ out3, int M, int N, int K, int n_tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (L / n_tiles_n) * TBM;
@@ -379,7 +266,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_kernel(const bf16* __restrict
   const int fi = lane & 15, fg = lane >> 4;
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk && !(dbg & 1)) stage(cur ^ 1, kt + 1);
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
     const char* sa = smem + cur * TSTAGE;
     const char* sw = sa + 3 * TA_PLANE;
     bf16x8 wf[4][3];
@@ -424,7 +311,6 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_kernel(const bf16* __restrict
     for (int ni = 0; ni < 4; ++ni) {
       const int n = n0 + wc * 64 + ni * 16 + fg * 4;
       if (n >= N) continue;
-      if (dbg & 2) continue;
       const float4 b = *reinterpret_cast<const float4*>(bias + n);
       float r[4] = {acc[mi][ni][0] + b.x, acc[mi][ni][1] + b.y, acc[mi][ni][2] + b.z, acc[mi][ni][3] + b.w};
       if constexpr (EPI == EPI_GELU) {
@@ -471,14 +357,12 @@ int d3dp_launch_linear_bf16x3(int epi, const void* A3, const void* W3, const flo
                             hipFuncAttributeMaxDynamicSharedMemorySize, TLDS) != hipSuccess) return -3;
     attr_set = true;
   }
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("D3DP_GEMM_DBG"); dbg = e ? atoi(e) : 0; }   // timing ablations only (results invalid)
   if (epi == EPI_BIAS)
     hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI_BIAS>), dim3(tm * tn), dim3(512), TLDS, st, (const bf16*)A3, (const bf16*)W3,
-                       bias, outf, (bf16*)out3, M, N, K, tn, dbg);
+                       bias, outf, (bf16*)out3, M, N, K, tn);
   else if (epi == EPI_GELU)
     hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI_GELU>), dim3(tm * tn), dim3(512), TLDS, st, (const bf16*)A3, (const bf16*)W3,
-                       bias, outf, (bf16*)out3, M, N, K, tn, dbg);
+                       bias, outf, (bf16*)out3, M, N, K, tn);
   else return -1;
   return 0;
 }
@@ -552,7 +436,7 @@ __device__ __forceinline__ int sperm(int q) {   // q = ni*16 + i in [0,64)
 template <int EPI, typename OutT, int NK, int MI, int WIDE = 0>
 __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                                const float* __restrict__ bias, OutT* __restrict__ out,
-                                                               int M, int N, int tiles_n, int total_tiles, int dbg) {
+                                                               int M, int N, int tiles_n, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sbias = reinterpret_cast<float*>(smem + SNSTAGE * SSTAGE);
   constexpr int K = NK * SBK;
@@ -595,14 +479,14 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
         __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(stage + SA_BYTES + (lw * 4 + i) * 1024), 16, 0, 0);
       }
     };
-    if (gtot > 0 && !(dbg & 1)) issue(0);
-    if (gtot > 1 && !(dbg & 1)) issue(1);
+    if (gtot > 0) issue(0);
+    if (gtot > 1) issue(1);
     for (int g = 0; g < gtot; ++g) {
       // 12 glds per loader wave per k-step (8 A + 4 W pieces): loads(g) landed, loads(g+1) stay in flight
       if (g + 1 < gtot) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (!(dbg & 8)) asm volatile("s_barrier" ::: "memory");
-      if (g + 2 < gtot && !(dbg & 1)) issue(g + 2);
+      asm volatile("s_barrier" ::: "memory");
+      if (g + 2 < gtot) issue(g + 2);
     }
     return;
   }
@@ -614,7 +498,11 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
   // Finished tile waiting to be stored: 8 units (mi, h) of 8 packed bf16 (acc + bias).  One unit is drained behind
   // the MFMAs of each k-step of the NEXT tile, so output traffic is a steady trickle instead of a per-tile burst in
   // which every CU of the (phase-locked) persistent grid hits the HBM write path at once.
-  bf16x8 pend[MI][2];
+  // (GELU form: the parked pre-activation is fp16, not bf16 -- 11 significand bits, so the rounding in front of the
+  //  nonlinearity is an eighth of the bf16 rounding behind it instead of a second rounding of the same size)
+  using pend_t = typename std::conditional<EPI == EPI_GELU, f16x8, bf16x8>::type;
+  using pelt_t = typename std::conditional<EPI == EPI_GELU, f16, bf16>::type;
+  pend_t pend[MI][2];
   int pm0 = 0, pn0 = 0;
   bool have_pend = false;
 
@@ -624,14 +512,17 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
     const int mi = u >> 1, h = u & 1;
     const int m = pm0 + wr * (MI * 16) + mi * 16 + fi;
     const int n = pn0 + wc * 64 + fg * 16 + h * 8;
-    bf16x8 v = pend[0][0];
+    bf16x8 v;
     if constexpr (EPI == EPI_GELU) {
+      const f16x8 pre = pend[0][0];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16)gelu_fast((float)v[e]);
+      for (int e = 0; e < 8; ++e) v[e] = (bf16)gelu_fast((float)pre[e]);
       // keep the activation OUT of the store's bounds branch (LLVM would sink it there, behind the MFMA block)
       asm volatile("" : "+v"(v));
+    } else {
+      v = pend[0][0];
     }
-    if (m < M && n < N && !(dbg & 2)) {
+    if (m < M && n < N) {
       if constexpr (sizeof(OutT) == 2) {
         *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(out) + (size_t)m * N + n) = v;
       } else {
@@ -649,7 +540,7 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
   constexpr int DEVERY = NK / (NU / 2) > 0 ? NK / (NU / 2) : 1;   // drain every DEVERY-th k-step
   // one k-step: 16 ds_read_b128 + 32 MFMA (64 x 64 x 64 per wave)
   auto kstep = [&](int g) {
-    if (!(dbg & 8)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const char* sa = smem + (g % SNSTAGE) * SSTAGE;
     const char* sw = sa + SA_BYTES;
 #pragma unroll
@@ -672,7 +563,7 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
     }
   };
-  if (!(dbg & 16)) __builtin_amdgcn_s_setprio(1);
+  __builtin_amdgcn_s_setprio(1);
   for (int ti = 0; ti < n_my; ++ti) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -721,8 +612,8 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
         const float4 b0 = *reinterpret_cast<const float4*>(sbias + n);
         const float4 b1 = *reinterpret_cast<const float4*>(sbias + n + 4);
         const f32x4 a0 = acc[mi][2 * h], a1 = acc[mi][2 * h + 1];
-        pend[mi][h] = (bf16x8){(bf16)(a0[0] + b0.x), (bf16)(a0[1] + b0.y), (bf16)(a0[2] + b0.z), (bf16)(a0[3] + b0.w),
-                               (bf16)(a1[0] + b1.x), (bf16)(a1[1] + b1.y), (bf16)(a1[2] + b1.z), (bf16)(a1[3] + b1.w)};
+        pend[mi][h] = (pend_t){(pelt_t)(a0[0] + b0.x), (pelt_t)(a0[1] + b0.y), (pelt_t)(a0[2] + b0.z), (pelt_t)(a0[3] + b0.w),
+                               (pelt_t)(a1[0] + b1.x), (pelt_t)(a1[1] + b1.y), (pelt_t)(a1[2] + b1.z), (pelt_t)(a1[3] + b1.w)};
       }
     have_pend = true;
   }
@@ -736,7 +627,7 @@ template <int EPI, typename OutT, int NK, int MI>
 int launch_stream_nk_mi(const void* A, const void* W, const float* bias, void* out, int M, int N, hipStream_t st) {
   const int tm = (M + SBM - 1) / SBM, tn = (N + SBN - 1) / SBN;
   const int total = tm * tn;
-  void (*kern)(const bf16*, const bf16*, const float*, OutT*, int, int, int, int, int) =
+  void (*kern)(const bf16*, const bf16*, const float*, OutT*, int, int, int, int) =
       gemm_bf16_stream_kernel<EPI, OutT, NK, MI, 0>;
   if constexpr (EPI == EPI_BIAS && sizeof(OutT) == 2 && NK == 8) {
     if (N == 3 * NK * SBK) kern = gemm_bf16_stream_kernel<EPI, OutT, NK, MI, 1>;
@@ -756,18 +647,15 @@ int launch_stream_nk_mi(const void* A, const void* W, const float* bias, void* o
     n_cu = prop.multiProcessorCount;
   }
   const int grid = total < n_cu ? total : n_cu;
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("D3DP_GEMM_DBG"); dbg = e ? atoi(e) : 0; }   // timing ablations only (results invalid)
   hipLaunchKernelGGL(kern, dim3(grid), dim3(MI == 4 ? 768 : 512), SLDS_BYTES, st, (const bf16*)A, (const bf16*)W, bias,
-                     (OutT*)out, M, N, tn, total, dbg);
+                     (OutT*)out, M, N, tn, total);
   return 0;
 }
 
 template <int EPI, typename OutT, int NK>
 int launch_stream_nk(const void* A, const void* W, const float* bias, void* out, int M, int N, hipStream_t st) {
-  static int mi = -1;
-  if (mi < 0) { const char* e = getenv("D3DP_GEMM_MI"); mi = (e && atoi(e) == 8) ? 8 : 4; }   // A/B of the wave layout
-  if (mi == 8) return launch_stream_nk_mi<EPI, OutT, NK, 8>(A, W, bias, out, M, N, st);
+  // MI = 8 (four compute waves of 128x64, one per SIMD) was measured: slower on qkv (a lone wave cannot hide its own
+  // ds_read latency), within noise elsewhere -- not instantiated.
   return launch_stream_nk_mi<EPI, OutT, NK, 4>(A, W, bias, out, M, N, st);
 }
 

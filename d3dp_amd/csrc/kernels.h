@@ -6,13 +6,16 @@
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_ATOMIC = 3 };
 
 // ---- gemm.hip ----------------------------------------------------------------------------------
-int d3dp_launch_linear_bf16(int epi, int out_f32, const void* A, const void* W, const float* bias, void* out, int M,
-                            int N, int K, hipStream_t st);
 int d3dp_launch_linear_bf16_stream(int epi, int out_f32, const void* A, const void* W, const float* bias, void* out,
                                    int M, int N, int K, hipStream_t st);
 int d3dp_launch_linear_bf16x3(int epi, const void* A3, const void* W3, const float* bias, float* outf, void* out3, int M,
                               int N, int K, hipStream_t st);
 void d3dp_launch_split3(const float* src, void* dst, size_t n, hipStream_t st);
+// ---- gemm_x2.hip (EXACT mode: split-fp16 operands, three fp16-MFMA passes) ------------------------
+int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const float* bias, float w_unscale, float* outf,
+                             void* out2, int M, int N, int K, hipStream_t st);
+void d3dp_launch_split2(const float* src, void* dst, size_t n, float scale, hipStream_t st);
+void d3dp_launch_absmax(const float* src, size_t n, unsigned* out, hipStream_t st);
 int d3dp_launch_linear_f32_splitk(const float* A, const float* W, float* out, int M, int N, int K, hipStream_t st);
 int d3dp_launch_linear_f32(int epi, const float* A, const float* W, const float* bias, float* out, int M, int N,
                            int K, hipStream_t st);

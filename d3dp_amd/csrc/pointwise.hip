@@ -125,6 +125,27 @@ template <int C> struct Row {
     store(p + plane, lane, a1);
     store(p + 2 * plane, lane, a2);
   }
+  // split-fp16 activation (common.h split2h): two planes `plane` elements apart
+  static __device__ __forceinline__ void store2h(f16* p, size_t plane, int lane, const float* v) {
+    if constexpr (V4) {
+#pragma unroll
+      for (int g = 0; g < NV / 4; ++g) {
+        f16x4 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f16 h, l; split2h(v[g * 4 + e], h, l); a[e] = h; b[e] = l; }
+        *reinterpret_cast<f16x4*>(p + (g * 64 + lane) * 4) = a;
+        *reinterpret_cast<f16x4*>(p + plane + (g * 64 + lane) * 4) = b;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        f16 h, l;
+        split2h(v[i], h, l);
+        p[i * 64 + lane] = h;
+        p[plane + i * 64 + lane] = l;
+      }
+    }
+  }
   // y = (v - mean) * rstd * w + b   (two-pass statistics, biased variance as torch LayerNorm)
   static __device__ __forceinline__ void norm(const float* v, const float* w, const float* b, float eps, int lane,
                                               float* y) {
@@ -158,6 +179,13 @@ template <int C> struct ActOut<C, b3> {
   using ptr = bf16*;
   static __device__ __forceinline__ void st(ptr base, size_t plane, size_t off, int lane, const float* v) {
     Row<C>::store3(base + off, plane, lane, v);
+  }
+};
+
+template <int C> struct ActOut<C, h2> {
+  using ptr = f16*;
+  static __device__ __forceinline__ void st(ptr base, size_t plane, size_t off, int lane, const float* v) {
+    Row<C>::store2h(base + off, plane, lane, v);
   }
 };
 
@@ -340,7 +368,8 @@ int d3dp_launch_time_mlp(const int64_t* t, const float* freq, const float* w1, c
   return 0;
 }
 
-// `act`: 0 = fp32 activations (y fp32), 1 = bf16 activations (y bf16), 2 = split-bf16 activation planes (y fp32)
+// `act`: 0 = fp32 activations (y fp32), 1 = bf16 activations (y bf16), 2 = split-bf16 activation planes (y fp32),
+//        3 = split-fp16 activation planes (y fp32)
 int d3dp_launch_embed_ln(int act_bf16, const float* x2d, const float* x3d, const float* temb, const float* ew,
                          const float* eb, const float* spos, const float* lnw, const float* lnb, float eps, float* x,
                          void* xn, int seq0, int n_seq, int H, int F, int J, int C, hipStream_t st) {
@@ -350,6 +379,7 @@ int d3dp_launch_embed_ln(int act_bf16, const float* x2d, const float* x3d, const
   DISPATCH_C(C,
     if (act_bf16 == 1) hipLaunchKernelGGL((embed_ln_kernel<CC, bf16>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, plane, seq0, n_seq, H, F, J);
     else if (act_bf16 == 2) hipLaunchKernelGGL((embed_ln_kernel<CC, b3>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, plane, seq0, n_seq, H, F, J);
+    else if (act_bf16 == 3) hipLaunchKernelGGL((embed_ln_kernel<CC, h2>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (f16*)xn, plane, seq0, n_seq, H, F, J);
     else hipLaunchKernelGGL((embed_ln_kernel<CC, float>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (float*)xn, plane, seq0, n_seq, H, F, J))
   return 0;
 }
@@ -361,6 +391,7 @@ int d3dp_launch_ln(int act_bf16, float* x, const void* yadd, int write_x, const 
   DISPATCH_C(C,
     if (act_bf16 == 1) hipLaunchKernelGGL((ln_kernel<CC, bf16, bf16>), g, blk, 0, st, x, (const bf16*)yadd, w, b, eps, (bf16*)xn, plane, T, write_x);
     else if (act_bf16 == 2) hipLaunchKernelGGL((ln_kernel<CC, b3, float>), g, blk, 0, st, x, (const float*)yadd, w, b, eps, (bf16*)xn, plane, T, write_x);
+    else if (act_bf16 == 3) hipLaunchKernelGGL((ln_kernel<CC, h2, float>), g, blk, 0, st, x, (const float*)yadd, w, b, eps, (f16*)xn, plane, T, write_x);
     else hipLaunchKernelGGL((ln_kernel<CC, float, float>), g, blk, 0, st, x, (const float*)yadd, w, b, eps, (float*)xn, plane, T, write_x))
   return 0;
 }
@@ -372,6 +403,7 @@ int d3dp_launch_ln2(int act_bf16, float* x, const void* yadd0, const void* yadd,
   DISPATCH_C(C,
     if (act_bf16 == 1) hipLaunchKernelGGL((ln2_kernel<CC, bf16, bf16>), g, blk, 0, st, x, (const bf16*)yadd0, (const bf16*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, plane, T, F, J);
     else if (act_bf16 == 2) hipLaunchKernelGGL((ln2_kernel<CC, b3, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, plane, T, F, J);
+    else if (act_bf16 == 3) hipLaunchKernelGGL((ln2_kernel<CC, h2, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, pos, wb, bb, eps, (f16*)xn, plane, T, F, J);
     else hipLaunchKernelGGL((ln2_kernel<CC, float, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, pos, wb, bb, eps, (float*)xn, plane, T, F, J))
   return 0;
 }

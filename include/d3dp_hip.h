@@ -43,8 +43,10 @@ enum {
 
 /* numerics mode of the denoiser */
 enum {
-  D3DP_MODE_EXACT = 0,   /* fp32-equivalent: split-bf16 (3 planes, 6 passes) MFMA Linears, fp32 everything else:
-                            <= 1e-3 mm vs the reference (env D3DP_EXACT_F32=1: plain fp32 MFMA Linears)       */
+  D3DP_MODE_EXACT = 0,   /* fp32-equivalent: Linears on split-fp16 operands (2 planes, 3 fp16-MFMA passes, fp32
+                            accumulate), fp32 everything else: <= 1e-3 mm vs the reference.  Linear inputs must stay
+                            below 65504 in magnitude.  (env D3DP_EXACT_IMPL=bf16x3 | f32: six-pass split-bf16 /
+                            plain fp32-MFMA Linears, kept as cross-checks)                                        */
   D3DP_MODE_FAST = 1,    /* bf16 activations/weights into v_mfma_f32_16x16x32_bf16, fp32 accumulate/LN/softmax */
   D3DP_MODE_TRAIN = 2,   /* fp32 weights/activations, fp32-MFMA Linears: required by d3dp_train_*; inference also works */
 };
@@ -209,9 +211,9 @@ int d3dp_procrustes(const float* pred, const float* target, float* err, float* a
 
 /* ---- single operators (unit parity tests; same kernels the denoiser launches) ---------------------------- */
 /* out[M,N] = epi(A[M,K] W[N,K]^T + bias).  epi & 3: 0 bias, 1 bias+GELU(erf), 2 out(fp32) += result.
- * mode EXACT: everything fp32 (fp32 MFMA).  mode FAST: A, W bf16 (uint16 storage), fp32 accumulate; out is bf16
- * unless (epi & 16) or epi == 2 (fp32).  FAST epi 0/1 run the persistent streaming kernel the denoiser uses;
- * (epi & 32) or epi == 2 select the per-tile 128x128 kernel instead. */
+ * mode EXACT: everything fp32 (fp32 MFMA; the EXACT denoiser itself runs mode 3 below).  mode FAST: A, W bf16 (uint16
+ * storage), fp32 accumulate, epi 0 or 1 only, out bf16 unless (epi & 16) (fp32): the persistent streaming kernel the
+ * denoiser uses. */
 int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, const float* bias, void* out, int32_t M,
                    int32_t N, int32_t K, void* stream);
 /* Multi-head attention over qkv[T,3C] -> out[T,C]; axis 0 = spatial (sequences of J joints), 1 = temporal
@@ -224,6 +226,10 @@ int d3dp_op_layernorm(int32_t out_bf16, const float* x, const float* w, const fl
 /* mode 2 of d3dp_op_linear: split-bf16.  A and W are three bf16 planes each (x = x0 + x1 + x2, made by
  * d3dp_op_split3: dst[0..n) | dst[n..2n) | dst[2n..3n)); epi 0 -> fp32 out, epi 1 -> GELU then three bf16 planes out. */
 int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream);
+/* mode 3 of d3dp_op_linear: split-fp16, the EXACT-mode Linear.  A and W are two fp16 planes each, made by
+ * d3dp_op_split2 from src * scale: dst[0..n) = hi = fp16(x), dst[n..2n) = fp16((x - hi) * 2048); epi 0 -> fp32 out,
+ * epi 1 -> GELU then two fp16 planes out. */
+int d3dp_op_split2(const float* src, void* dst, size_t n, float scale, void* stream);
 /* fp32 <-> bf16 conversion helper (round-to-nearest-even), n elements */
 int d3dp_op_to_bf16(const float* src, void* dst, size_t n, void* stream);
 

@@ -85,8 +85,51 @@ def time_mlp(p: Dict[str, Tensor], t: Tensor, cs: int, dtype) -> Tensor:
     return F.linear(e, p["time_mlp.3.weight"], p["time_mlp.3.bias"])
 
 
+# --------------------------------------------------------------------------------------
+# bf16 emulation of the library's FAST numerics mode (SURVEY.md §7 hard part 1(b), §8 C4): the SAME algorithm with a
+# bf16 rounding wherever the FAST kernels store or consume bf16 -- weights, Linear inputs (LayerNorm / attention /
+# GELU outputs), Linear outputs (q|k|v, the two branch outputs), the softmax probabilities entering P.V -- and the
+# kernels' polynomial GELU.  fp32 everywhere else (residual stream, LayerNorm statistics, softmax, accumulation).
+# It is the tight end-to-end gate of the FAST mode; the fp32 path above stays the parity target.
+# --------------------------------------------------------------------------------------
+def _r16(x: Tensor) -> Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def gelu_fast(x: Tensor) -> Tensor:
+    """d3dp_amd/csrc/gemm.hip gelu_fast: 0.5 x (1 + u P(u^2)), u = clamp(x, +-3.8) (odd minimax polynomial for erf)."""
+    u = x.clamp(-3.8, 3.8)
+    t = u * u
+    pl = t * 7.331557583256654e-08 + -4.5449246499629226e-06
+    for c in (0.0001213696159538813, -0.0018630953272804618, 0.018633270636200905, -0.13143958151340485,
+              0.7973535060882568):
+        pl = t * pl + c
+    h = 0.5 * x
+    return h * (u * pl) + h
+
+
+def attention_bf16(x: Tensor, p: Dict[str, Tensor], pre: str) -> Tensor:
+    S, N, C = x.shape
+    hd = C // NUM_HEADS
+    qkv = _r16(F.linear(_r16(x), _r16(p[pre + "attn.qkv.weight"]), p[pre + "attn.qkv.bias"]))
+    qkv = qkv.reshape(S, N, 3, NUM_HEADS, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    a = (q @ k.transpose(-2, -1)) * (hd ** -0.5)
+    e = torch.exp(a - a.amax(dim=-1, keepdim=True))           # kernel: exp2 of the scaled difference, fp32
+    o = (_r16(e) @ v) / e.sum(dim=-1, keepdim=True)             # bf16 probabilities into P.V, fp32 denominator
+    o = _r16(o).transpose(1, 2).reshape(S, N, C)
+    return _r16(F.linear(o, _r16(p[pre + "attn.proj.weight"]), p[pre + "attn.proj.bias"]))
+
+
+def mlp_bf16(x: Tensor, p: Dict[str, Tensor], pre: str) -> Tensor:
+    h = _r16(gelu_fast(F.linear(_r16(x), _r16(p[pre + "mlp.fc1.weight"]), p[pre + "mlp.fc1.bias"])))
+    return _r16(F.linear(h, _r16(p[pre + "mlp.fc2.weight"]), p[pre + "mlp.fc2.bias"]))
+
+
 def attention(x: Tensor, p: Dict[str, Tensor], pre: str) -> Tensor:
     """mixste.py:63-82 with comb=False: softmax(q k^T * hd^-0.5) v, then proj."""
+    if p.get("__emulate_bf16__") is not None:
+        return attention_bf16(x, p, pre)
     S, N, C = x.shape
     hd = C // NUM_HEADS
     qkv = F.linear(x, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"])
@@ -100,6 +143,8 @@ def attention(x: Tensor, p: Dict[str, Tensor], pre: str) -> Tensor:
 
 def mlp(x: Tensor, p: Dict[str, Tensor], pre: str) -> Tensor:
     """mixste.py:37-43."""
+    if p.get("__emulate_bf16__") is not None:
+        return mlp_bf16(x, p, pre)
     h = F.gelu(F.linear(x, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"]))
     return F.linear(h, p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
 
@@ -247,6 +292,13 @@ def prepare_targets(sched, targets: Tensor, ts: Tensor, noises: Tensor, scale: f
         x = torch.clamp(x, min=-1.1 * scale, max=1.1 * scale) / scale
         outs.append(x)
     return torch.stack(outs).float()
+
+
+def emulate_bf16(p: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """Copy of a parameter dict that makes every function above follow the FAST mode's bf16 roundings."""
+    q = dict(p)
+    q["__emulate_bf16__"] = torch.ones(())
+    return q
 
 
 def strip_prefix(sd: Dict[str, Tensor], prefix: str = "pose_estimator.", dtype=None) -> Dict[str, Tensor]:

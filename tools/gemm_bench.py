@@ -17,7 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--m", type=int, default=15 * 4131)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--tile", action="store_true", help="per-tile 128x128 kernel instead of the streaming one")
+    
     ap.add_argument("--shapes", default="qkv,proj,fc1,fc2")
     ap.add_argument("--x3", action="store_true", help="EXACT-mode split-bf16 kernel (three planes per operand)")
     ap.add_argument("--check", action="store_true", help="compare each result with torch (fp32 matmul of the bf16 operands)")
