@@ -58,6 +58,7 @@ PROTOTYPES = {
     "d3dp_create": (C.c_int, [C.POINTER(Cfg), C.POINTER(C.c_void_p)]),
     "d3dp_destroy": (C.c_int, [C.c_void_p]),
     "d3dp_set_weights": (C.c_int, [C.c_void_p, C.POINTER(Weights), C.c_void_p]),
+    "d3dp_set_weights_borrowed": (C.c_int, [C.c_void_p, C.POINTER(Weights)]),
     "d3dp_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "d3dp_denoise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                C.c_void_p, C.c_size_t, C.c_void_p]),

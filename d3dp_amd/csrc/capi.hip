@@ -359,6 +359,33 @@ int d3dp_set_weights(d3dp_ctx* c, const d3dp_weights* w, void* stream) {
   return D3DP_OK;
 }
 
+int d3dp_set_weights_borrowed(d3dp_ctx* c, const d3dp_weights* w) {
+  if (!c || !w || !w->ste || !w->tte) return fail(D3DP_EINVAL, "d3dp_set_weights_borrowed: null argument");
+  if (!c->train()) return fail(D3DP_ESTATE, "d3dp_set_weights_borrowed needs a D3DP_MODE_TRAIN context (fp32 weights)");
+  c->spos = w->spatial_pos; c->tpos = w->temporal_pos; c->ew = w->embed_w; c->eb = w->embed_b; c->freq = w->time_freq;
+  c->t1w = w->time1_w; c->t1b = w->time1_b; c->t3w = w->time3_w; c->t3b = w->time3_b;
+  c->snw = w->spatial_norm_w; c->snb = w->spatial_norm_b; c->tnw = w->temporal_norm_w; c->tnb = w->temporal_norm_b;
+  c->hnw = w->head_norm_w; c->hnb = w->head_norm_b; c->hw = w->head_w; c->hb = w->head_b;
+  const float* top[] = {c->spos, c->tpos, c->ew, c->eb, c->freq, c->t1w, c->t1b, c->t3w, c->t3b, c->snw, c->snb, c->tnw,
+                        c->tnb, c->hnw, c->hnb, c->hw, c->hb};
+  for (const float* p : top)
+    if (!p) return fail(D3DP_EINVAL, "d3dp_set_weights_borrowed: a weight pointer is null");
+  c->ste.clear(); c->tte.clear();
+  for (int kind = 0; kind < 2; ++kind)
+    for (int d = 0; d < c->cfg.depth; ++d) {
+      const d3dp_block_weights& b = (kind == 0 ? w->ste : w->tte)[d];
+      const void* all[] = {b.norm1_w, b.norm1_b, b.qkv_w, b.qkv_b, b.proj_w, b.proj_b, b.norm2_w, b.norm2_b, b.fc1_w,
+                           b.fc1_b, b.fc2_w, b.fc2_b};
+      for (const void* p : all)
+        if (!p) return fail(D3DP_EINVAL, "d3dp_set_weights_borrowed: a weight pointer is null");
+      BlockDev bd{b.norm1_w, b.norm1_b, b.norm2_w, b.norm2_b, b.qkv_b, b.proj_b, b.fc1_b, b.fc2_b, b.qkv_w, b.proj_w,
+                  b.fc1_w, b.fc2_w};
+      (kind == 0 ? c->ste : c->tte).push_back(bd);
+    }
+  c->weights_set = true;
+  return D3DP_OK;
+}
+
 int d3dp_workspace_bytes(const d3dp_ctx* c, int32_t B, int32_t H, size_t* bytes) {
   if (!c || !bytes || B < 1 || H < 1) return fail(D3DP_EINVAL, "d3dp_workspace_bytes: bad argument");
   const d3dp_cfg& g = c->cfg;

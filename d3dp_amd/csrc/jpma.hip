@@ -14,14 +14,27 @@ namespace {
 
 __device__ __forceinline__ float clamp1(float v) { return fminf(fmaxf(v, -1.f), 1.f); }
 
-// Human3.6M projection with radial + tangential distortion, camera.py:30-60 (same fp32 operation order)
+// The selection below is INDEX work: it must pick the hypothesis the reference picks, so every float operation is
+// written out in the reference's order with explicit single roundings (__fmul_rn / __fadd_rn are never contracted into
+// fma), and the two Euclidean norms follow torch.norm's CPU kernel, which accumulates squares with fma:
+// sqrt(fma(x1, x1, x0 * x0)) and sqrt(fma(x2, x2, fma(x1, x1, x0 * x0))).  Checked bit for bit against torch on the
+// host (200 k random points per expression) and, on the GPU, against fixtures g5 / g11 with exact equality.
+__device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float norm2(float a, float b) { return sqrtf(fmaf(b, b, mul(a, a))); }
+__device__ __forceinline__ float norm3(float a, float b, float c) { return sqrtf(fmaf(c, c, fmaf(b, b, mul(a, a)))); }
+
+// Human3.6M projection with radial + tangential distortion, camera.py:30-60 (same fp32 operation order:
+// r2 = sum(XX^2); radial = 1 + sum(k * (r2, r2^2, r2^3)); tan = sum(p * XX); f * (XX * (radial + tan) + p * r2) + c)
 __device__ __forceinline__ void project(const float* X, const float* cam, float& u, float& v) {
   const float xx = clamp1(X[0] / X[2]), yy = clamp1(X[1] / X[2]);
-  const float r2 = xx * xx + yy * yy;
-  const float radial = 1.f + (cam[4] * r2 + cam[5] * (r2 * r2) + cam[6] * (r2 * r2 * r2));
-  const float tan = cam[7] * xx + cam[8] * yy;
-  u = cam[0] * (xx * (radial + tan) + cam[7] * r2) + cam[2];
-  v = cam[1] * (yy * (radial + tan) + cam[8] * r2) + cam[3];
+  const float r2 = add(mul(xx, xx), mul(yy, yy));
+  const float r4 = mul(r2, r2), r6 = mul(r4, r2);
+  const float radial = add(1.f, add(add(mul(cam[4], r2), mul(cam[5], r4)), mul(cam[6], r6)));
+  const float tan = add(mul(cam[7], xx), mul(cam[8], yy));
+  const float rt = add(radial, tan);
+  u = add(mul(cam[0], add(mul(xx, rt), mul(cam[7], r2))), cam[2]);
+  v = add(mul(cam[1], add(mul(yy, rt), mul(cam[8], r2))), cam[3]);
 }
 
 __global__ __launch_bounds__(256) void jpma_kernel(const float* __restrict__ pred, const float* __restrict__ traj,
@@ -51,18 +64,16 @@ __global__ __launch_bounds__(256) void jpma_kernel(const float* __restrict__ pre
   for (int h = 0; h < H; ++h, p += FJ * 3) {
     float x[3] = {p[0], p[1], p[2]};
     if (j == root_joint) { x[0] = 0.f; x[1] = 0.f; x[2] = 0.f; }          // main.py:700 (joint 0), main_3dhp.py:777 (14)
-    const float a[3] = {x[0] + tr[0], x[1] + tr[1], x[2] + tr[2]};        // main.py:706-707
+    const float a[3] = {add(x[0], tr[0]), add(x[1], tr[1]), add(x[2], tr[2])};   // main.py:706-707
     float u, v;
     if (linear) {                                                         // camera.py:62-83 project_to_2d_linear
-      u = c[0] * clamp1(a[0] / a[2]) + c[2];
-      v = c[1] * clamp1(a[1] / a[2]) + c[3];
+      u = add(mul(c[0], clamp1(a[0] / a[2])), c[2]);
+      v = add(mul(c[1], clamp1(a[1] / a[2])), c[3]);
     } else {
       project(a, c, u, v);
     }
-    const float du = u - g2u, dv = v - g2v;
-    const float e2 = sqrtf(du * du + dv * dv);
-    const float d0 = x[0] - g3[0], d1 = x[1] - g3[1], d2 = x[2] - g3[2];
-    const float e3 = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    const float e2 = norm2(u - g2u, v - g2v);                             // loss.py:66 torch.norm
+    const float e3 = norm3(x[0] - g3[0], x[1] - g3[1], x[2] - g3[2]);     // loss.py:65
     if (e3 < min3) { min3 = e3; mx = x[0]; my = x[1]; mz = x[2]; }
     sx += x[0]; sy += x[1]; sz += x[2];
     if (e2 < best2) { best2 = e2; bh = h; bx = x[0]; by = x[1]; bz = x[2]; best3 = e3; }

@@ -47,17 +47,26 @@ def _resolve_mode(numerics: Optional[str]) -> int:
 
 class _TrainStep(torch.autograd.Function):
     """Autograd bridge for the training step: forward = d3dp_train_forward (activations stay in the library
-    workspace), backward = d3dp_train_backward, which fills one gradient buffer per parameter."""
+    workspace), backward = d3dp_train_backward, which fills one gradient buffer per parameter.
+
+    The activations live in ONE per-model workspace, so every forward stamps it with a generation number; a backward
+    whose forward is no longer the most recent one (gradient accumulation with deferred backwards, two losses from two
+    forwards, a validation forward in between) first re-runs its forward -- same inputs, same DropPath masks, hence the
+    same activations -- instead of differentiating through somebody else's."""
 
     @staticmethod
     def forward(ctx, net, x_2d, x_3d, t, masks, *params):
         ctx.net, ctx.masks = net, masks
         ctx.save_for_backward(x_2d, x_3d, t)
-        return net._train_forward(x_2d, x_3d, t, masks)
+        out = net._train_forward(x_2d, x_3d, t, masks)
+        ctx.gen = net._train_gen
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
         x_2d, x_3d, t = ctx.saved_tensors
+        if ctx.gen != ctx.net._train_gen:
+            ctx.net._train_forward(x_2d, x_3d, t, ctx.masks)
         grads = ctx.net._train_backward(x_2d, x_3d, t, ctx.masks, grad_out.contiguous())
         return (None, None, None, None, None) + tuple(grads)
 
@@ -124,6 +133,7 @@ class MixSTE2(nn.Module):
         self._weights_sig = None
         self._keep = None
         self._ws = None
+        self._train_gen = 0
 
     # -- library context ------------------------------------------------------------------------
     @property
@@ -159,13 +169,24 @@ class MixSTE2(nn.Module):
             with torch.cuda.device(device):
                 _lib.check(lib.d3dp_create(C.byref(cfg), C.byref(h)), "d3dp_create")
             self._ctx, self._ctx_device = h, device
-        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        # TRAIN mode reads the parameters' own storage (no packed copy): only a re-allocation changes anything.
+        # EXACT / FAST keep packed copies, refreshed when a parameter is replaced or modified through autograd-visible
+        # in-place ops; writes that bypass the version counter (p.data.mul_(), EMA code) need refresh_weights().
+        borrowed = self._mode == _lib.MODE_TRAIN and all(
+            p.device == device and p.dtype == torch.float32 and p.is_contiguous() for p in self.parameters())
+        sig = (borrowed,) + tuple((p.data_ptr(),) if borrowed else (p.data_ptr(), p._version) for p in self.parameters())
         if sig != self._weights_sig:
-            self._push_weights(device)
+            self._push_weights(device, borrowed)
             self._weights_sig = sig
         return self._ctx
 
-    def _push_weights(self, device):
+    def refresh_weights(self) -> None:
+        """Re-pack the library's weight copies on the next call.  Needed only after parameter writes that bypass
+        PyTorch's version counter (``p.data.copy_()``, ``p.data.mul_()``, weight averaging through ``.data``):
+        ``load_state_dict``, optimizer steps and ordinary in-place ops are picked up automatically."""
+        self._weights_sig = None
+
+    def _push_weights(self, device, borrowed=False):
         lib = _lib.load()
         keep: List[torch.Tensor] = []
 
@@ -185,6 +206,7 @@ class MixSTE2(nn.Module):
 
         half = self.embed_dim // 2
         freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))    # mixste.py:134-136, fp32 on host
+        freq_keep = freq = freq.to(device=device, dtype=torch.float32).contiguous()
         ste, tte = blocks(self.STEblocks), blocks(self.TTEblocks)
         w = _lib.Weights(dev(self.Spatial_pos_embed), dev(self.Temporal_pos_embed),
                          dev(self.Spatial_patch_to_embedding.weight), dev(self.Spatial_patch_to_embedding.bias),
@@ -195,8 +217,11 @@ class MixSTE2(nn.Module):
                          dev(self.head[0].weight), dev(self.head[0].bias), dev(self.head[1].weight),
                          dev(self.head[1].bias), ste, tte)
         with torch.cuda.device(device):
-            _lib.check(lib.d3dp_set_weights(self._ctx, C.byref(w), _lib.current_stream()), "d3dp_set_weights")
-        self._keep = None   # the library owns packed copies; originals may go
+            if borrowed:
+                _lib.check(lib.d3dp_set_weights_borrowed(self._ctx, C.byref(w)), "d3dp_set_weights_borrowed")
+            else:
+                _lib.check(lib.d3dp_set_weights(self._ctx, C.byref(w), _lib.current_stream()), "d3dp_set_weights")
+        self._keep = [freq_keep] if borrowed else None   # packed copies: originals may go; borrowed: keep the table
 
     def _workspace(self, ctx, B, H, device):
         n = C.c_size_t()
@@ -230,6 +255,10 @@ class MixSTE2(nn.Module):
         (d3dp_train_forward / d3dp_train_backward); DropPath is active in ``.train()`` mode like the reference
         (mixste.py:100,187) and ``droppath={'STEblocks.i': (m_attn, m_mlp), ...}`` injects recorded masks."""
         if x_3d.dim() == 4:
+            if self._mode != _lib.MODE_TRAIN and self.training and torch.is_grad_enabled():
+                raise RuntimeError("MixSTE2 train branch called with autograd enabled on a model in %r numerics: only "
+                                   "numerics='train' is differentiable (build the model with is_train=True, or wrap "
+                                   "inference in torch.no_grad() / call .eval())" % self.numerics)
             if self._mode == _lib.MODE_TRAIN and torch.is_grad_enabled():
                 masks = self._droppath_masks(x_3d.shape[0], x_3d.device, droppath)
                 return _TrainStep.apply(self, x_2d, x_3d, t, masks, *self.parameters())
@@ -280,6 +309,7 @@ class MixSTE2(nn.Module):
     def _train_forward(self, x_2d, x_3d, t, masks):
         ctx, B, dev, nbytes, x2, x3, tt = self._train_io(x_2d, x_3d, t)
         out = torch.empty_like(x3)
+        self._train_gen += 1
         with torch.cuda.device(dev):
             _lib.check(_lib.load().d3dp_train_forward(ctx, x2.data_ptr(), x3.data_ptr(), tt.data_ptr(), _lib.ptr(masks),
                                                       out.data_ptr(), B, self._train_ws.data_ptr(), nbytes,
@@ -377,7 +407,9 @@ class D3DP(nn.Module):
         self.register_buffer('posterior_mean_coef2',
                              (1. - alphas_cumprod_prev) * torch.sqrt(alphas) / (1. - alphas_cumprod))
 
-        numerics = numerics or getattr(args, "numerics", None) or ("train" if is_train else None)
+        # the train model is always differentiable ('train' numerics); args.numerics / D3DP_NUMERICS select the
+        # inference arithmetic of the evaluation models only (one argparse namespace builds all three, main.py:228-230)
+        numerics = "train" if is_train else (numerics or getattr(args, "numerics", None))
         self.pose_estimator = MixSTE2(num_frame=self.frames, num_joints=NUM_JOINTS, in_chans=2,
                                       embed_dim_ratio=args.cs, depth=args.dep, num_heads=8, mlp_ratio=2.,
                                       qkv_bias=True, qk_scale=None, drop_path_rate=0.1 if is_train else 0,

@@ -108,6 +108,9 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out);
 int d3dp_destroy(d3dp_ctx* ctx);
 /* Replaces: load_state_dict (main.py:257).  Converts/packs weights for cfg.mode (synchronises `stream`). */
 int d3dp_set_weights(d3dp_ctx* ctx, const d3dp_weights* w, void* stream);
+/* D3DP_MODE_TRAIN only: use the caller's fp32 device buffers in place (no packed copy, no launch, no synchronisation), so
+ * an optimizer step needs no re-push.  The buffers must stay allocated while the context uses them. */
+int d3dp_set_weights_borrowed(d3dp_ctx* ctx, const d3dp_weights* w);
 
 /* Scratch needed by d3dp_denoise for a (B, H) call. */
 int d3dp_workspace_bytes(const d3dp_ctx* ctx, int32_t B, int32_t H, size_t* bytes);
