@@ -3,17 +3,25 @@
 
 One "step" = one D3DP.forward (ddim_sample_flip: K DDIM steps x 2 flip-TTA denoiser passes) over one synthetic batch
 of B clips x H hypotheses at F=243, J=17.  N=1 workload = BASELINE.json configs[2] (B=16, H=20, K=10), the
-configuration the metric is quoted on.  With N>1 ranks every rank samples its own H=20 hypotheses of the same clips
-(weak scaling, no data-path collective during sampling) and one RCCL all-gather assembles (B,K,N*20,F,17,3) on every
-rank inside the timed region.  Inputs are resident in HBM before the timed region starts.
+configuration the metric is quoted on.
 
-Prints ONE JSON line on rank 0.
+The HEADLINE (`value`) is the parity-compliant numerics mode, `exact`: the mode that meets north_star's <= 1e-3 mm
+against the reference (Linears on split-fp16 operands, three fp16-MFMA passes, fp32 accumulate; fp32 elsewhere).  The
+single-pass bf16 mode (`fast`, millimetres away from the reference on random weights) is timed on the same workload
+and reported beside it as `fast_mode`, never as `value`.
+
+`python bench.py --gpus N` launches its own N ranks (re-executes itself under torch.distributed.run) when it is not
+already inside a torchrun job; every rank samples its own H=20 hypotheses of the same clips (weak scaling, no
+data-path collective during sampling) and one RCCL all-gather assembles (B,K,N*20,F,17,3) on every rank inside the
+timed region.  Inputs are resident in HBM before the timed region starts.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
 import sys
 import time
 from types import SimpleNamespace
@@ -22,11 +30,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-import torch  # noqa: E402
-
 F_, J_, C_, DEPTH = 243, 17, 512, 8
-PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md (2.5 PFLOP/s)
-PEAK_F32_TFLOPS = 157.3        # fp32 MFMA / vector peak
+PEAK_MFMA_TFLOPS = 2500.0      # dense bf16 / fp16 MFMA, MI355X_MICROARCH.md (2.5 PFLOP/s)
+EXACT_PASSES = 3               # fp16-MFMA products per algorithmic multiply-add in exact mode (hi.hi, hi.lo, lo.hi)
 
 
 def flops_per_denoiser_call(frames=F_, joints=J_, c=C_, depth=DEPTH):
@@ -37,21 +43,23 @@ def flops_per_denoiser_call(frames=F_, joints=J_, c=C_, depth=DEPTH):
     return tseq * (per_tok + attn + 2 * 5 * c + 2 * c * 3) + 2 * 2 * c * 2 * c
 
 
-def build_model(H, K, numerics, chunk_seqs):
+def build_model(H, K, numerics, chunk_seqs, frames=F_):
     from d3dp_amd import D3DP
     from d3dp_amd.weights import H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, make_state_dict
-    args = SimpleNamespace(number_of_frames=F_, test_time_augmentation=True, timestep=1000, scale=1.0, cs=C_,
+    args = SimpleNamespace(number_of_frames=frames, test_time_augmentation=True, timestep=1000, scale=1.0, cs=C_,
                            dep=DEPTH, chunk_seqs=chunk_seqs)
     m = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=False, num_proposals=H, sampling_timesteps=K,
              numerics=numerics)
-    m.load_state_dict(make_state_dict(7, C_, DEPTH, F_), strict=False)
+    m.load_state_dict(make_state_dict(7, C_, DEPTH, frames), strict=False)
     return m.cuda().eval()
 
 
-def cpu_baseline(budget_s=12.0):
+def cpu_baseline(budget_s=24.0):
     """The CPU oracle (a port of the reference path; the reference's own files cannot travel to the GPU box and
-    hard-code CUDA) timed on this host's cores: F=243, B=1, H=1, K=1 (= 2 denoiser calls), repeated for ~budget_s.
-    Extrapolated linearly in K to the K=10 unit of the metric."""
+    hard-code CUDA) timed on this host's cores on a BOUNDED sample of the workload: F=243, B=1, H=1, K=1 (= 2 denoiser
+    calls of the K=10 unit's 20).  The thread count is swept (oversubscribing a 128-thread host halves the rate) and the
+    best is reported with its count; the K=10 unit is K=1 x 10, stated as such."""
+    import torch
     from d3dp_amd.weights import H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, flip_2d, make_state_dict, synthetic_inputs_2d, synthetic_noise
     from oracle import d3dp_oracle as orc
     p = orc.strip_prefix(make_state_dict(7, C_, DEPTH, F_))
@@ -59,23 +67,41 @@ def cpu_baseline(budget_s=12.0):
     x2d = synthetic_inputs_2d(1234, 1, F_)
     nz = [torch.from_numpy(synthetic_noise(1, (1, 1, F_, J_, 3)))]
     a, b = torch.from_numpy(x2d), torch.from_numpy(flip_2d(x2d))
-    times = []
-    t_end = time.perf_counter() + budget_s
-    while not times or (time.perf_counter() < t_end and len(times) < 8):
+
+    def one():
         t0 = time.perf_counter()
         with torch.no_grad():
             orc.ddim_sample_flip(p, sched, a, b, 1, 1, DEPTH, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, nz)
-        times.append(time.perf_counter() - t0)
+        return time.perf_counter() - t0
+
+    ncpu = os.cpu_count() or 1
+    t_start = time.perf_counter()
+    old = torch.get_num_threads()
+    sweep = {}
+    one()                                                     # page in the weights / thread pool
+    for nt in [n for n in (8, 16, 32, 64, 128, 256) if n <= ncpu] or [ncpu]:
+        torch.set_num_threads(nt)
+        sweep[nt] = min(one(), one()) if time.perf_counter() - t_start < budget_s * 0.7 else one()
+        if time.perf_counter() - t_start > budget_s:
+            break
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    times = [sweep[best]]
+    while time.perf_counter() - t_start < budget_s and len(times) < 5:
+        times.append(one())
+    torch.set_num_threads(old)
     t_k1 = sorted(times)[len(times) // 2]
-    return {"value": 1.0 / (t_k1 * 10.0), "unit": "hypothesis-clips/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"oracle ddim_sample_flip F=243 B=1 H=1 K=1 (2 denoiser calls), median of {len(times)} runs = "
-                      f"{t_k1:.3f} s; x10 DDIM steps extrapolated linearly to the K=10 unit",
+    return {"value": 1.0 / (t_k1 * 10.0), "unit": "hypothesis-clips/s", "cores": best, "kind": "port",
+            "sample": f"oracle ddim_sample_flip F=243 B=1 H=1 K=1 (2 of the unit's 20 denoiser calls), median of "
+                      f"{len(times)} runs at the best thread count = {t_k1:.3f} s; x10 DDIM steps to the K=10 unit",
+            "host_cpus": ncpu, "thread_sweep_s": {str(k): round(v, 3) for k, v in sweep.items()},
             "gflops": 2 * flops_per_denoiser_call() / t_k1 / 1e9}
 
 
 def quick_parity():
-    """MPJPE (mm) of both numerics modes vs the CPU oracle on a small full-width problem (F=27,B=1,H=2,K=2)."""
+    """MPJPE (mm) of both numerics modes on a small full-width problem (F=27,B=1,H=2,K=2) against the fp32 CPU oracle
+    (the parity target) and, for fast mode, against the oracle's bf16-rounding emulation of the FAST kernels."""
+    import torch
     from d3dp_amd import D3DP
     from d3dp_amd.weights import H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, flip_2d, make_state_dict, synthetic_inputs_2d, synthetic_noise
     from oracle import d3dp_oracle as orc
@@ -84,8 +110,10 @@ def quick_parity():
     x2d = synthetic_inputs_2d(11, B, Fr)
     x2f = flip_2d(x2d)
     nz = [torch.from_numpy(synthetic_noise(20 + k, (B, H, Fr, J_, 3))) for k in range(K)]
-    ref = orc.ddim_sample_flip(orc.strip_prefix(sd), orc.cosine_schedule(1000), torch.from_numpy(x2d),
-                               torch.from_numpy(x2f), H, K, DEPTH, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, nz)
+    p = orc.strip_prefix(sd)
+    run = lambda q: orc.ddim_sample_flip(q, orc.cosine_schedule(1000), torch.from_numpy(x2d), torch.from_numpy(x2f), H, K,
+                                         DEPTH, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, nz)
+    ref, ref16 = run(p), run(orc.emulate_bf16(p))
     out = {}
     for numerics in ("exact", "fast"):
         args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=C_, dep=DEPTH)
@@ -93,14 +121,19 @@ def quick_parity():
                  numerics=numerics)
         m.load_state_dict(sd, strict=False)
         m = m.cuda().eval()
-        o = m(torch.from_numpy(x2d).cuda(), None, input_2d_flip=torch.from_numpy(x2f).cuda(), noise=nz)
-        out[numerics + "_mpjpe_mm"] = orc.mpjpe_mm(o.cpu(), ref)
+        o = m(torch.from_numpy(x2d).cuda(), None, input_2d_flip=torch.from_numpy(x2f).cuda(), noise=nz).cpu()
+        out[numerics + "_mpjpe_mm"] = orc.mpjpe_mm(o, ref)
+        if numerics == "fast":
+            out["fast_vs_bf16_oracle_mm"] = orc.mpjpe_mm(o, ref16)
     out["workload"] = "F=27 B=1 H=2 K=2 cs=512 dep=8, identical weights/inputs/noise, vs CPU oracle"
     out["tolerance_mm"] = 1e-3
+    out["exact_meets_tolerance"] = out["exact_mpjpe_mm"] <= 1e-3
+    out["fast_meets_tolerance"] = out["fast_mpjpe_mm"] <= 1e-3
     return out
 
 
 def timed_steps(model, x2d, x2f, steps, warmup, gen, gather):
+    import torch
     import torch.distributed as dist
     from d3dp_amd.dist import all_gather_hypotheses
 
@@ -127,6 +160,93 @@ def timed_steps(model, x2d, x2f, steps, warmup, gen, gather):
     return dt, out
 
 
+def shard_check(rank, world, numerics):
+    """N ranks, each sampling its slice of GLOBAL noise draws (dist.shard_noise), must reproduce the 1-rank run with
+    H_total = N * H_local hypotheses bit for bit (small problem: F=27, B=2, H_local=2, K=2; rank 0 runs the 1-rank form)."""
+    import torch
+    from d3dp_amd.dist import all_gather_hypotheses, shard_noise
+    from d3dp_amd.weights import flip_2d, synthetic_inputs_2d, synthetic_noise
+    Fr, B, Hl, K = 27, 2, 2, 2
+    x2d_np = synthetic_inputs_2d(77, B, Fr)
+    x2d, x2f = torch.from_numpy(x2d_np).cuda(), torch.from_numpy(flip_2d(x2d_np)).cuda()
+    noise = [torch.from_numpy(synthetic_noise(90 + k, (B, world * Hl, Fr, J_, 3))) for k in range(K)]
+    local = build_model(Hl, K, numerics, 0, frames=Fr)(x2d, None, input_2d_flip=x2f, noise=shard_noise(noise, rank, world))
+    got = all_gather_hypotheses(local)
+    ok = True
+    if rank == 0:
+        want = build_model(world * Hl, K, numerics, 0, frames=Fr)(x2d, None, input_2d_flip=x2f, noise=noise)
+        ok = bool(torch.equal(got, want))
+    return ok
+
+
+def roofline_from_profile(prof, numerics, B, H, K):
+    T_all = 2 * B * H * F_ * J_ * K                       # token-rows through each GEMM class over the step
+    gemm_flops = {"gemm_qkv": 2 * 3 * C_ * C_, "gemm_proj": 2 * C_ * C_, "gemm_fc1": 2 * 2 * C_ * C_, "gemm_fc2": 2 * 2 * C_ * C_}
+    dom = max(gemm_flops, key=lambda k: prof[k][1])
+    n, ms = prof[dom]
+    fl = gemm_flops[dom] * T_all * 2 * DEPTH              # 16 blocks
+    ach = fl / (ms * 1e-3) / 1e12
+    if numerics == "exact":
+        peak = PEAK_MFMA_TFLOPS / EXACT_PASSES
+        note = (f"peak = {PEAK_MFMA_TFLOPS:.0f} TFLOP/s dense fp16 MFMA / {EXACT_PASSES} MFMA passes per algorithmic product "
+                f"(split-fp16 operands); matrix-pipe work = {EXACT_PASSES} x achieved")
+    else:
+        peak, note = PEAK_MFMA_TFLOPS, "dense bf16 MFMA peak"
+    r = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+         "traffic": None, "launches": n, "avg_launch_ms": ms / max(n, 1), "algorithmic_gflop_per_launch": fl / max(n, 1) / 1e9,
+         "peak_note": note, "frac_of_raw_mfma_peak": ach * (EXACT_PASSES if numerics == "exact" else 1) / PEAK_MFMA_TFLOPS}
+    return r
+
+
+def lib_sha256():
+    from d3dp_amd import _lib
+    h = hashlib.sha256()
+    with open(_lib.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def attach_traffic(roof, numerics, chunk_seqs):
+    """HBM bytes per launch of the dominant kernel come from SEPARATE rocprofv3 --pmc passes (FETCH_SIZE doubled per
+    MI355X_MICROARCH.md, WRITE_SIZE) stored under profiles/ next to the hash of the library they were measured on: the
+    number is printed only when this run uses that very build."""
+    tpath = os.path.join(REPO, "profiles", "r02_gemm_traffic.json")
+    if not os.path.exists(tpath):
+        return
+    tj = json.load(open(tpath)).get(numerics, {}).get(roof["kernel"])
+    if not tj or chunk_seqs not in (0, 15):
+        return
+    if tj.get("lib_sha256") != lib_sha256():
+        roof["traffic_note"] = "profiles/r02_gemm_traffic.json was measured on a different build of libd3dp_hip.so: not reported"
+        return
+    roof["traffic"] = tj["hbm_bytes_per_launch"]
+    roof["traffic_note"] = (f"bytes/launch at M=61965 (15-sequence chunk), separate rocprofv3 --pmc passes of this build; "
+                            f"algorithmic bytes/launch {tj['algorithmic_bytes_per_launch']}; hardware MFMA busy "
+                            f"{tj.get('mfma_util_hw', float('nan')):.3f} of kernel cycles")
+
+
+def profile_step(model, x2d, x2f, gen):
+    pe = model.pose_estimator
+    pe.profile_enable(True)
+    model(x2d, None, input_2d_flip=x2f, generator=gen)
+    prof = pe.profile_read()
+    pe.profile_enable(False)
+    return prof
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` outside a torchrun job: become `python -m torch.distributed.run ... bench.py <same args>`."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,17 +255,22 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="clips per step (BASELINE config: 16)")
     ap.add_argument("--hyps", type=int, default=20, help="hypotheses per GPU (BASELINE config: 20)")
     ap.add_argument("--ksteps", type=int, default=10, help="DDIM sampling timesteps (BASELINE config: 10)")
-    ap.add_argument("--numerics", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--numerics", default="exact", choices=["exact", "fast"], help="mode timed as the headline")
     ap.add_argument("--chunk-seqs", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exact-leg", action="store_true")
+    ap.add_argument("--no-other-leg", action="store_true", help="skip timing the other numerics mode")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(a.gpus)
 
+    import torch
     from d3dp_amd.dist import init_from_env, rank_generator
     from d3dp_amd.weights import flip_2d, synthetic_inputs_2d
     rank, world, local = init_from_env()
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the job has WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     B, H, K = a.batch, a.hyps, a.ksteps
 
@@ -153,67 +278,82 @@ def main():
     x2d = torch.from_numpy(x2d_np).cuda()
     x2f = torch.from_numpy(flip_2d(x2d_np)).cuda()
     gen = rank_generator(1, rank, "cuda")
+    sharding_ok = shard_check(rank, world, a.numerics) if world > 1 else None
     model = build_model(H, K, a.numerics, a.chunk_seqs)
     dt, out = timed_steps(model, x2d, x2f, a.steps, a.warmup, gen, gather=world > 1)
     assert out.shape == (B, K, H * world, F_, J_, 3) and bool(torch.isfinite(out).all())
     units = B * H * world * a.steps
     value = units / dt
     flop_per_unit = 2 * K * flops_per_denoiser_call()
-    peak = PEAK_BF16_TFLOPS if a.numerics == "fast" else PEAK_F32_TFLOPS
+    peak = PEAK_MFMA_TFLOPS / (EXACT_PASSES if a.numerics == "exact" else 1)
+    dtypes = {"exact": "f16x2-split operands on fp16 MFMA, f32 accumulate (fp32-class: meets 1e-3 mm)",
+              "fast": "bf16 operands, f32 accumulate (does NOT meet 1e-3 mm)"}
 
     res = {
         "metric": "pose-hypotheses/sec (H x clips) at F=243, J=17, H=20, K=10",
         "value": value, "unit": "hypothesis-clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if a.numerics == "fast" else "f32", "data": "synthetic",
+        "dtype": dtypes[a.numerics], "data": "synthetic",
         "config": {"workload": f"BASELINE configs[2]: ddim_sample_flip F=243 J=17 B={B} H={H}/GPU K={K} flip-TTA, "
                                f"MixSTE2 cs=512 dep=8 (34.8M params, seed-generated), numerics={a.numerics}",
+                   "numerics": a.numerics, "parity_gate_mm": 1e-3 if a.numerics == "exact" else None,
                    "global_batch": B, "hypotheses_total": H * world, "parallelism": f"hshard{world}",
                    "frame_pose_hypotheses_per_sec": value * F_,
                    "algorithmic_tflop_per_step": flop_per_unit * B * H * world / 1e12,
                    "whole_path_tflops": value * flop_per_unit / 1e12,
-                   "whole_path_frac_of_mfma_peak": value * flop_per_unit / 1e12 / (peak * world)},
+                   "whole_path_frac_of_mfma_peak": value * flop_per_unit / 1e12 / (peak * world),
+                   "mfma_peak_used_tflops": peak},
     }
+    if world > 1:
+        import torch.distributed as dist
+        from d3dp_amd.dist import all_gather_hypotheses
+        local_preds = out[:, :, rank * H:(rank + 1) * H].contiguous()
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            all_gather_hypotheses(local_preds)
+        torch.cuda.synchronize()
+        ag_ms = (time.perf_counter() - t0) / 5 * 1e3
+        flag = torch.tensor([1 if sharding_ok else 0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        res["multi_gpu"] = {"backend": "nccl (RCCL)", "world_size": dist.get_world_size(),
+                            "all_gather_bytes_per_rank": local_preds.numel() * 4, "all_gather_ms": ag_ms,
+                            "all_gather_gbps_per_rank_out": local_preds.numel() * 4 * (world - 1) / (ag_ms * 1e-3) / 1e9,
+                            "sharded_equals_single_rank": bool(flag.item()),
+                            "shard_check": "F=27 B=2 H_local=2 K=2: N ranks on sliced global noise == 1 rank with H=2N, torch.equal"}
+        assert bool(flag.item()), "N-rank sampling does not reproduce the 1-rank run"
 
     if rank == 0 and not a.no_profile:
-        # per-kernel HIP-event timing (own stream = torch's current stream) over ONE extra untimed step
-        pe = model.pose_estimator
-        pe.profile_enable(True)
-        model(x2d, None, input_2d_flip=x2f, generator=gen)
-        prof = pe.profile_read()
-        pe.profile_enable(False)
+        # per-kernel HIP-event timing (on the launch stream = torch's current stream) over ONE extra untimed step
+        prof = profile_step(model, x2d, x2f, gen)
         total = sum(ms for _, ms in prof.values())
-        T_all = 2 * B * H * F_ * J_ * K                       # token-rows through each GEMM class over the step
-        gemm_flops = {"gemm_qkv": 2 * 3 * C_ * C_, "gemm_proj": 2 * C_ * C_, "gemm_fc1": 2 * 2 * C_ * C_, "gemm_fc2": 2 * 2 * C_ * C_}
-        dom = max(gemm_flops, key=lambda k: prof[k][1])
-        n, ms = prof[dom]
-        fl = gemm_flops[dom] * T_all * 2 * DEPTH              # 16 blocks
-        res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak,
-                           "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / peak, "traffic": None,
-                           "launches": n, "avg_launch_ms": ms / max(n, 1),
-                           "algorithmic_gflop_per_launch": fl / max(n, 1) / 1e9}
-        # HBM bytes per launch of the dominant kernel come from a SEPARATE rocprofv3 --pmc pass (FETCH_SIZE doubled per
-        # MI355X_MICROARCH.md, WRITE_SIZE), committed under profiles/; valid for the default 15-sequence chunk shape.
-        tpath = os.path.join(REPO, "profiles", "r01_gemm_traffic.json")
-        if dom == "gemm_qkv" and a.numerics == "fast" and a.chunk_seqs in (0, 15) and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            res["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
-            res["roofline"]["traffic_note"] = ("bytes/launch at M=61965 (15-sequence chunk), separate rocprofv3 --pmc pass; "
-                                               f"algorithmic bytes/launch {tj['algorithmic_bytes_per_launch']}; "
-                                               f"hardware MFMA busy {tj['mfma_util_hw']:.3f} of kernel cycles")
+        res["roofline"] = roofline_from_profile(prof, a.numerics, B, H, K)
+        attach_traffic(res["roofline"], a.numerics, a.chunk_seqs)
         res["kernel_time_share"] = {k: round(ms / total, 4) for k, (_, ms) in prof.items() if ms > 0}
         res["kernel_ms_per_step"] = {k: round(ms, 3) for k, (_, ms) in prof.items() if ms > 0}
 
     if rank == 0 and world == 1:
-        if not a.no_exact_leg and a.numerics == "fast":
-            Be = max(1, B // 8)
-            me = build_model(H, K, "exact", a.chunk_seqs)
-            dte, _ = timed_steps(me, x2d[:Be].contiguous(), x2f[:Be].contiguous(), 1, 1, gen, gather=False)
-            res["exact_mode"] = {"value": Be * H / dte, "unit": "hypothesis-clips/s", "dtype": "f32",
-                                 "workload": f"same path, numerics=exact (split-bf16 MFMA Linears, fp32 elsewhere), B={Be} H={H} K={K}, 1 step after 1 warmup",
-                                 "whole_path_tflops": Be * H / dte * flop_per_unit / 1e12}
-            del me
-        res["parity"] = quick_parity()
+        if not a.no_other_leg:
+            other = "fast" if a.numerics == "exact" else "exact"
+            del model
+            torch.cuda.empty_cache()
+            mo = build_model(H, K, other, a.chunk_seqs)
+            st, wu = max(1, min(a.steps, 5)), max(1, min(a.warmup, 2))
+            dto, _ = timed_steps(mo, x2d, x2f, st, wu, gen, gather=False)
+            vo = B * H * st / dto
+            leg = {"value": vo, "unit": "hypothesis-clips/s", "numerics": other, "dtype": dtypes[other], "steps": st,
+                   "warmup": wu, "ms_per_step": dto / st * 1e3,
+                   "workload": f"the same BASELINE configs[2] workload (B={B} H={H} K={K}) in numerics={other}",
+                   "whole_path_tflops": vo * flop_per_unit / 1e12}
+            if not a.no_profile:
+                po = profile_step(mo, x2d, x2f, gen)
+                leg["roofline"] = roofline_from_profile(po, other, B, H, K)
+                attach_traffic(leg["roofline"], other, a.chunk_seqs)
+                leg["kernel_ms_per_step"] = {k: round(ms, 3) for k, (_, ms) in po.items() if ms > 0}
+            res[other + "_mode"] = leg
+            del mo
+        if not a.no_parity:
+            res["parity"] = quick_parity()
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
     if rank == 0:

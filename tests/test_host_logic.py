@@ -86,3 +86,14 @@ def test_normalisation_and_clip_counts():
     y = serve.normalize_screen_coordinates(x, 1920, 1080)                  # camera.py:7-11
     assert torch.allclose(y, torch.tensor([[-1.0, -0.5625], [1.0, 0.5625], [0.0, 0.0]]))
     assert [clip_count(n, 243) for n in (1, 242, 243, 244, 486, 487, 100000)] == [1, 1, 1, 2, 2, 3, 412]
+
+
+def test_train_model_is_always_differentiable_numerics():
+    """One argparse namespace builds the train and the evaluation models (main.py:228-230): --numerics selects the
+    inference arithmetic only, the train model stays in 'train' numerics."""
+    from types import SimpleNamespace
+    from d3dp_amd import D3DP
+    args = SimpleNamespace(number_of_frames=9, test_time_augmentation=True, timestep=1000, scale=1.0, cs=64, dep=1,
+                           numerics="fast")
+    assert D3DP(args, [4, 5, 6], [1, 2, 3], is_train=True).pose_estimator.numerics == "train"
+    assert D3DP(args, [4, 5, 6], [1, 2, 3], is_train=False).pose_estimator.numerics == "fast"

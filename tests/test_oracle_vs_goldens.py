@@ -112,3 +112,21 @@ def test_fp32_floor_vs_fp64():
     o64 = orc.mixste_forward(p64, x2d.double(), x3d.double(), torch.tensor([999]), 8)
     d = orc.mpjpe_mm(o32, o64)
     assert 0 < d < 2e-3, d
+
+
+def test_g13_c2_full_size_slice(golden_dir):
+    """BASELINE configs[1] at full size (reference run, fixture g13): the oracle on ONE (clip, hypothesis) slice alone
+    reproduces that slice of the reference's batched run -- clips and hypotheses are independent given the 2D input
+    (mixste.py:227-230), which is also what the full-size GPU tests and the H-sharded multi-GPU path rely on."""
+    g = np.load(os.path.join(golden_dir, "g13_sampler_c2.npz"))
+    cs, dep, Fr, B, H, K = (int(g[k]) for k in ("cs", "dep", "frames", "B", "H", "K"))
+    b, h = 1, 2
+    x2d = synthetic_inputs_2d(int(g["x2d_seed"]), B, Fr)
+    noises = [torch.from_numpy(synthetic_noise(int(g["noise_seed"]) + k, (B, H, Fr, 17, 3)))[b:b + 1, h:h + 1] for k in range(K)]
+    p = orc.strip_prefix(make_state_dict(int(g["seed"]), cs, dep, Fr))
+    out = orc.ddim_sample_flip(p, orc.cosine_schedule(1000), torch.from_numpy(x2d[b:b + 1]), torch.from_numpy(flip_2d(x2d[b:b + 1])),
+                               1, K, dep, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, noises)
+    kept = torch.from_numpy(g["kept_frames"]).long()
+    err = orc.mpjpe_mm(out[0, :, 0][:, kept], torch.from_numpy(g["out_kept"][b, :, h]))
+    print(f"oracle slice (clip {b}, hypothesis {h}) vs reference full-size run: {err:.3e} mm")
+    assert err <= 1e-3

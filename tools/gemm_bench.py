@@ -19,7 +19,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     
     ap.add_argument("--shapes", default="qkv,proj,fc1,fc2")
-    ap.add_argument("--x3", action="store_true", help="EXACT-mode split-bf16 kernel (three planes per operand)")
+    ap.add_argument("--x3", action="store_true", help="six-pass split-bf16 kernel (three planes per operand)")
+    ap.add_argument("--x2", action="store_true", help="EXACT-mode split-fp16 kernel (two planes per operand, three passes)")
     ap.add_argument("--check", action="store_true", help="compare each result with torch (fp32 matmul of the bf16 operands)")
     ap.add_argument("--cache", default="hot", choices=["hot", "cold", "produced"],
                     help="state of A before each timed launch: hot = same buffers back to back; cold = 1 GB written in "
@@ -30,6 +31,41 @@ def main():
     M = a.m
     shapes = {"qkv": (1536, 512, 0), "proj": (512, 512, 0), "fc1": (1024, 512, 1), "fc2": (512, 1024, 0)}   # bf16 outputs, as the denoiser launches them
     st = torch.cuda.current_stream().cuda_stream
+    if a.x2:
+        for name in a.shapes.split(","):
+            N, K, epi = shapes[name]
+            A = torch.randn(M, K, device="cuda")
+            W = torch.randn(N, K, device="cuda") / K ** 0.5
+            A2 = torch.empty(2, M, K, dtype=torch.float16, device="cuda")
+            W2 = torch.empty(2, N, K, dtype=torch.float16, device="cuda")
+            _lib.check(lib.d3dp_op_split2(A.data_ptr(), A2.data_ptr(), M * K, 1.0, st))
+            _lib.check(lib.d3dp_op_split2(W.data_ptr(), W2.data_ptr(), N * K, 1.0, st))
+            b = torch.randn(N, device="cuda")
+            out = torch.empty(M * N, device="cuda", dtype=torch.float32)
+            ts = []
+            for i in range(a.iters + 3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.check(lib.d3dp_op_linear(3, epi, A2.data_ptr(), W2.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, st))
+                e1.record()
+                torch.cuda.synchronize()
+                if i >= 3:
+                    ts.append(e0.elapsed_time(e1))
+            ts.sort()
+            med = ts[len(ts) // 2]
+            if a.check:
+                ref = A.double() @ W.double().t() + b.double()
+                if epi:
+                    got = out.view(torch.float16)[:2 * M * N].view(2, M, N)
+                    got = got[0].double() + got[1].double() / 2048.0
+                    ref = torch.nn.functional.gelu(ref)
+                else:
+                    got = out.view(M, N).double()
+                print(f"   check {name}: mean |err| {(got - ref).abs().mean().item():.2e} (torch fp32 matmul: "
+                      f"{((A @ W.t() + b).double() - (A.double() @ W.double().t() + b.double())).abs().mean().item():.2e})")
+            print(f"x2 {name:5s} M={M} N={N} K={K}: median {med * 1e3:8.1f} us  min {ts[0] * 1e3:8.1f} us  "
+                  f"{2 * M * N * K / med / 1e9:7.1f} TFLOP/s effective ({3 * 2 * M * N * K / med / 1e9:7.1f} TFLOP/s of MFMA work)")
+        return
     if a.x3:
         for name in a.shapes.split(","):
             N, K, epi = shapes[name]
@@ -58,8 +94,6 @@ def main():
         return
     for name in a.shapes.split(","):
         N, K, epi = shapes[name]
-        if a.tile:
-            epi |= 32
         A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
         W = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
         b = torch.randn(N, device="cuda")

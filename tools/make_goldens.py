@@ -214,6 +214,20 @@ def g4(D3DP):
     save("g4_sampler_tiny_K10", cs=64, dep=2, frames=9, seed=11, B=3, H=4, K=10, x2d_seed=303, noise_seed=600, out=out)
 
 
+def g13(D3DP):
+    """BASELINE config 2 at FULL size through the reference: F=243, J=17, H=5, K=5, B=4, cs=512, dep=8 (200
+    (clip, hypothesis) denoiser passes of 295 GFLOP each: minutes on the host).  The (4,5,5,243,17,3) output is 5 MB, so
+    the fixture keeps every 10th frame in full plus, for every (clip, step, hypothesis), fp64 checksums over ALL frames:
+    sum, sum of squares and a position-weighted sum (catches permuted frames/joints)."""
+    B, H, K, Fr = 4, 5, 5, 243
+    out = run_sampler(D3DP, Fr, 512, 8, 7, B=B, H=H, K=K, x2d_seed=1301, noise_seed=1400)
+    o = out.astype(np.float64).reshape(B, K, H, -1)
+    w = np.cos(np.arange(o.shape[-1], dtype=np.float64) * 0.37) + 1.5
+    frames = np.arange(0, Fr, 10)
+    save("g13_sampler_c2", cs=512, dep=8, frames=Fr, seed=7, B=B, H=H, K=K, x2d_seed=1301, noise_seed=1400,
+         kept_frames=frames, out_kept=out[:, :, :, frames], sum=o.sum(-1), sumsq=(o * o).sum(-1), wsum=(o * w).sum(-1))
+
+
 def g6(D3DP):
     """Train step forward (+loss, grad norms): F=27, B=4, cs=64, dep=2; DropPath off and on."""
     sys.path.insert(0, REF)
@@ -521,7 +535,7 @@ def g12(D3DP):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g0,g1,g2,g3,g4,g5,g6,g7,g8,g9,g10,g11,g12")
+    ap.add_argument("--only", default="g0,g1,g2,g3,g4,g5,g6,g7,g8,g9,g10,g11,g12,g13")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     D3DP = import_reference()
