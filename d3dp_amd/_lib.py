@@ -15,7 +15,6 @@ LIB_PATH = os.path.join(_HERE, "lib", "libd3dp_hip.so")
 
 MODE_EXACT, MODE_FAST, MODE_TRAIN = 0, 1, 2
 MODE_SPLIT3 = 2   # d3dp_op_linear only: split-bf16 operands
-MODE_SPLIT2 = 3   # d3dp_op_linear only: split-fp16 operands (the EXACT-mode Linear)
 EPI_BIAS, EPI_GELU, EPI_RESID = 0, 1, 2
 PROFILE_CLASSES = 12
 
@@ -95,6 +94,8 @@ PROTOTYPES = {
     "d3dp_op_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "d3dp_op_split3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "d3dp_op_split2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p]),
+    "d3dp_op_linear_x2": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_void_p]),
     "d3dp_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "d3dp_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "d3dp_profile_class_name": (C.c_char_p, [C.c_int32]),

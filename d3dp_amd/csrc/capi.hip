@@ -166,7 +166,7 @@ int linear(d3dp_ctx* c, int cls, int epi, int out_f32, const void* A, const void
            int M, int N, int K, hipStream_t st) {
   Scope s(c, cls, st);
   if (c->fast()) return d3dp_launch_linear_bf16_stream(epi, out_f32, A, W, bias, out, M, N, K, st);
-  if (c->x2()) return d3dp_launch_linear_f16x2_stream(epi, A, W, bias, wu, (float*)out, out, M, N, K, st);
+  if (c->x2()) return d3dp_launch_linear_f16x2(epi, A, W, bias, wu * kActUnscale, (float*)out, out, M, N, K, st);
   if (c->x3()) return d3dp_launch_linear_bf16x3(epi, A, W, bias, (float*)out, out, M, N, K, st);
   return d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, st);
 }
@@ -532,13 +532,7 @@ int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, cons
     // split-bf16: A, W are three bf16 planes each (d3dp_op_split3); epi 0 -> fp32 out, epi 1 -> three bf16 planes out
     LAUNCH_TRY(d3dp_launch_linear_bf16x3(epi, A, W, bias, (float*)out, out, M, N, K, (hipStream_t)stream));
   }
-  else if (mode == 3) {
-    // split-fp16: A, W are two fp16 planes each (d3dp_op_split2); epi 0 -> fp32 out, epi 1 -> two fp16 planes out
-    LAUNCH_TRY(d3dp_launch_linear_f16x2_stream(epi, A, W, bias, 1.0f, (float*)out, out, M, N, K, (hipStream_t)stream));
-  }
-  else if (mode == 4) {   // the same Linear as a per-tile 128x128 kernel, two workgroups per CU (A/B of the structure)
-    LAUNCH_TRY(d3dp_launch_linear_f16x2(epi, A, W, bias, 1.0f, (float*)out, out, M, N, K, (hipStream_t)stream));
-  }
+
   else LAUNCH_TRY(d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, (hipStream_t)stream));
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
@@ -547,6 +541,14 @@ int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, cons
 int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream) {
   if (!src || !dst) return fail(D3DP_EINVAL, "d3dp_op_split3: null argument");
   d3dp_launch_split3(src, dst, n, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
+int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* bias, float w_scale, void* out, int32_t M,
+                      int32_t N, int32_t K, void* stream) {
+  if (!A2 || !W2 || !bias || !out || !(w_scale > 0.f)) return fail(D3DP_EINVAL, "d3dp_op_linear_x2: bad argument");
+  LAUNCH_TRY(d3dp_launch_linear_f16x2(epi, A2, W2, bias, kActUnscale / w_scale, (float*)out, out, M, N, K, (hipStream_t)stream));
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
 }

@@ -14,8 +14,6 @@ void d3dp_launch_split3(const float* src, void* dst, size_t n, hipStream_t st);
 // ---- gemm_x2.hip (EXACT mode: split-fp16 operands, three fp16-MFMA passes) ------------------------
 int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const float* bias, float w_unscale, float* outf,
                              void* out2, int M, int N, int K, hipStream_t st);
-int d3dp_launch_linear_f16x2_stream(int epi, const void* A2, const void* W2, const float* bias, float w_unscale,
-                                    float* outf, void* out2, int M, int N, int K, hipStream_t st);
 void d3dp_launch_split2(const float* src, void* dst, size_t n, float scale, hipStream_t st);
 void d3dp_launch_absmax(const float* src, size_t n, unsigned* out, hipStream_t st);
 int d3dp_launch_linear_f32_splitk(const float* A, const float* W, float* out, int M, int N, int K, hipStream_t st);

@@ -229,10 +229,13 @@ int d3dp_op_layernorm(int32_t out_bf16, const float* x, const float* w, const fl
 /* mode 2 of d3dp_op_linear: split-bf16.  A and W are three bf16 planes each (x = x0 + x1 + x2, made by
  * d3dp_op_split3: dst[0..n) | dst[n..2n) | dst[2n..3n)); epi 0 -> fp32 out, epi 1 -> GELU then three bf16 planes out. */
 int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream);
-/* mode 3 of d3dp_op_linear: split-fp16, the EXACT-mode Linear.  A and W are two fp16 planes each, made by
- * d3dp_op_split2 from src * scale: dst[0..n) = hi = fp16(x), dst[n..2n) = fp16((x - hi) * 2048); epi 0 -> fp32 out,
- * epi 1 -> GELU then two fp16 planes out. */
+/* The EXACT-mode Linear on split-fp16 operands.  A2 and W2 are two fp16 planes each, made by d3dp_op_split2 from
+ * y = src * scale: dst[0..n) = hi = fp16(y), dst[n..2n) = lo = fp16(y - hi).  A2 must be at scale 16 (the library's
+ * activation scale); W2 at any power-of-two `w_scale` (the denoiser picks it per matrix so that max |w| w_scale lies in
+ * [2^13, 2^14)).  epi 0 -> fp32 out, epi 1 -> GELU then two fp16 planes (scale 16) out. */
 int d3dp_op_split2(const float* src, void* dst, size_t n, float scale, void* stream);
+int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* bias, float w_scale, void* out, int32_t M,
+                      int32_t N, int32_t K, void* stream);
 /* fp32 <-> bf16 conversion helper (round-to-nearest-even), n elements */
 int d3dp_op_to_bf16(const float* src, void* dst, size_t n, void* stream);
 

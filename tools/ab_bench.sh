@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of two builds of libd3dp_hip on the same box: tools/ab_bench.sh <libA> <libB> [bench args...]; interleaved runs.
 A=$1; B=$2; shift 2
-for lib in "$A" "$B" "$A" "$B"; do
+for lib in "$A" "$B"; do
   python - "$lib" "$@" <<'PY'
 import json, runpy, sys, io, contextlib
 lib, args = sys.argv[1], sys.argv[2:]

@@ -21,7 +21,6 @@ def main():
     ap.add_argument("--shapes", default="qkv,proj,fc1,fc2")
     ap.add_argument("--x3", action="store_true", help="six-pass split-bf16 kernel (three planes per operand)")
     ap.add_argument("--x2", action="store_true", help="EXACT-mode split-fp16 kernel (two planes per operand, three passes)")
-    ap.add_argument("--x2-tile", action="store_true", help="with --x2: the per-tile 128x128 form instead of the persistent one")
     ap.add_argument("--check", action="store_true", help="compare each result with torch (fp32 matmul of the bf16 operands)")
     ap.add_argument("--cache", default="hot", choices=["hot", "cold", "produced"],
                     help="state of A before each timed launch: hot = same buffers back to back; cold = 1 GB written in "
@@ -39,15 +38,15 @@ def main():
             W = torch.randn(N, K, device="cuda") / K ** 0.5
             A2 = torch.empty(2, M, K, dtype=torch.float16, device="cuda")
             W2 = torch.empty(2, N, K, dtype=torch.float16, device="cuda")
-            _lib.check(lib.d3dp_op_split2(A.data_ptr(), A2.data_ptr(), M * K, 1.0, st))
-            _lib.check(lib.d3dp_op_split2(W.data_ptr(), W2.data_ptr(), N * K, 1.0, st))
+            _lib.check(lib.d3dp_op_split2(A.data_ptr(), A2.data_ptr(), M * K, 16.0, st))
+            _lib.check(lib.d3dp_op_split2(W.data_ptr(), W2.data_ptr(), N * K, 65536.0, st))
             b = torch.randn(N, device="cuda")
             out = torch.empty(M * N, device="cuda", dtype=torch.float32)
             ts = []
             for i in range(a.iters + 3):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                _lib.check(lib.d3dp_op_linear(4 if a.x2_tile else 3, epi, A2.data_ptr(), W2.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, st))
+                _lib.check(lib.d3dp_op_linear_x2(epi, A2.data_ptr(), W2.data_ptr(), b.data_ptr(), 65536.0, out.data_ptr(), M, N, K, st))
                 e1.record()
                 torch.cuda.synchronize()
                 if i >= 3:
@@ -58,7 +57,7 @@ def main():
                 ref = A.double() @ W.double().t() + b.double()
                 if epi:
                     got = out.view(torch.float16)[:2 * M * N].view(2, M, N)
-                    got = got[0].double() + got[1].double() / 2048.0
+                    got = (got[0].double() + got[1].double()) / 16.0
                     ref = torch.nn.functional.gelu(ref)
                 else:
                     got = out.view(M, N).double()

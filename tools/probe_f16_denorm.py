@@ -17,8 +17,8 @@ A2[0] = 3.0e-5            # fp16 subnormal (min normal 6.1e-5)
 W2[0] = 1.0
 b = torch.zeros(N, device="cuda")
 out = torch.empty(M, N, device="cuda")
-_lib.check(lib.d3dp_op_linear(3, 0, A2.data_ptr(), W2.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, st))
+_lib.check(lib.d3dp_op_linear_x2(0, A2.data_ptr(), W2.data_ptr(), b.data_ptr(), 1.0, out.data_ptr(), M, N, K, st))
 torch.cuda.synchronize()
-want = float(A2[0, 0, 0].float()) * K
+want = float(A2[0, 0, 0].float()) * K / 16.0          # the op divides by the activation scale
 print(f"subnormal A.hi x 1.0: got {out[0, 0].item():.6e}, exact {want:.6e} -> fp16 subnormal inputs are "
       f"{'PRESERVED' if abs(out[0, 0].item() - want) < 1e-9 else 'FLUSHED'} by the fp16 MFMA")
