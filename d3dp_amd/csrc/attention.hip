@@ -427,6 +427,239 @@ __global__ __launch_bounds__(256) void attn_spatial_bf16_kernel(const bf16* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// EXACT-mode attention on the fp16 matrix cores: split-fp16 operands, three MFMA passes per product (the scheme of the
+// EXACT Linear, gemm_x2.hip), same dataflow and LDS images as the bf16 kernels above with TWO planes per operand:
+//   K, V (fp32 in HBM, q|k|v from the qkv Linear) are split into hi/lo fp16 planes (x 16) while they are staged into
+//   LDS; the query fragments are split in registers; S^T = Kl.Qh + Kh.Ql + Kh.Qh (fp32 accumulate, scale 256 folded
+//   into the exponent constant); two-pass fp32 softmax over the whole score row in registers; the probabilities are
+//   split into fp16 pairs (x 1024) and O^T = Vl.Ph + Vh.Pl + Vh.Ph; the output leaves as fp32 or as the two fp16 planes
+//   the proj Linear consumes.  5.3x fewer matrix-pipe cycles than the fp32-MFMA kernel it replaces (16x16x4 f32: 32
+//   cycles for 2 Kflop; three 16x16x32 f16: 48 cycles for 16 Kflop).
+// ------------------------------------------------------------------------------------------------
+constexpr float kPScale = 1024.0f;
+
+__device__ __forceinline__ f16x8 as_f16x8(bf16x8 v) { return __builtin_bit_cast(f16x8, v); }
+
+// 8 consecutive fp32 -> one 16-byte slot of hi and one of lo (values x 16)
+__device__ __forceinline__ void split8(const float4 a, const float4 b, f16x8& hi, f16x8& lo) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { f16 h, l; split2h(v[e], h, l); hi[e] = h; lo[e] = l; }
+}
+
+// rows [0, n) of K and V (64 fp32 per row for this head) -> four swizzled LDS images (K hi, K lo, V hi, V lo, `plane`
+// bytes apart in that order); rows [n, NK) zeroed.
+template <int NK, int NTHREADS>
+__device__ __forceinline__ void stage_kv_x2(const float* __restrict__ kbase, size_t row_stride, int n, char* KH, int plane,
+                                            int tid, int C) {
+  for (int idx = tid; idx < NK * 8; idx += NTHREADS) {
+    const int row = idx >> 3, slot = idx & 7;
+    float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, v0 = k0, v1 = k0;
+    if (row < n) {
+      const float* src = kbase + (size_t)row * row_stride + slot * 8;
+      k0 = *reinterpret_cast<const float4*>(src); k1 = *reinterpret_cast<const float4*>(src + 4);
+      v0 = *reinterpret_cast<const float4*>(src + C); v1 = *reinterpret_cast<const float4*>(src + C + 4);
+    }
+    f16x8 kh, kl, vh, vl;
+    split8(k0, k1, kh, kl);
+    split8(v0, v1, vh, vl);
+    const int ko = row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
+    const int vo = row * 128 + ((slot ^ (((row >> 1) & 3) << 1)) << 4);
+    *reinterpret_cast<f16x8*>(KH + ko) = kh;
+    *reinterpret_cast<f16x8*>(KH + plane + ko) = kl;
+    *reinterpret_cast<f16x8*>(KH + 2 * plane + vo) = vh;
+    *reinterpret_cast<f16x8*>(KH + 3 * plane + vo) = vl;
+  }
+}
+
+template <int NKT, int C0>
+__device__ __forceinline__ void pv_chunks_x2(const FragBases& fb, int plane, const f16x8 (&ph)[NKT / 2],
+                                             const f16x8 (&pl)[NKT / 2], f32x4 (&o)[4]) {
+  if constexpr (C0 < NKT / 2) {
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) {
+      const f16x8 vh = as_f16x8(load_vt_frag<C0>(fb.v[dn]));
+      const f16x8 vl = as_f16x8(load_vt_frag<C0>(fb.v[dn] + plane));
+      o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[C0], o[dn], 0, 0, 0);
+      o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[C0], o[dn], 0, 0, 0);
+      o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[C0], o[dn], 0, 0, 0);
+    }
+    if (C0 & 1) __builtin_amdgcn_sched_barrier(0);
+    pv_chunks_x2<NKT, C0 + 1>(fb, plane, ph, pl, o);
+  }
+}
+
+// One 16-query tile against NKT 16-key tiles resident in LDS.  fb: fragment bases into the K hi / V hi images (the lo
+// images are `plane` bytes further).  qh/ql: the tile's query fragments (d 0..31, 32..63), values x 16.
+// Returns O^T accumulators scaled by 16 * 1024 and the softmax denominator of query (lane & 15).
+template <int NKT>
+__device__ __forceinline__ void attn_tile_x2(const FragBases& fb, int plane, const f16x8 (&qh)[2], const f16x8 (&ql)[2],
+                                             int n, int lane, f32x4 (&o)[4], float& denom) {
+  const int fg = lane >> 4;
+  const float cexp = 0.125f * 1.44269504088896340736f / (kActScale * kActScale);   // hd^-0.5 log2(e) / (16 * 16)
+  f32x4 s[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    const f16x8 k0h = *reinterpret_cast<const f16x8*>(fb.k0 + t * 2048);
+    const f16x8 k1h = *reinterpret_cast<const f16x8*>(fb.k1 + t * 2048);
+    const f16x8 k0l = *reinterpret_cast<const f16x8*>(fb.k0 + plane + t * 2048);
+    const f16x8 k1l = *reinterpret_cast<const f16x8*>(fb.k1 + plane + t * 2048);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0l, qh[0], a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1l, qh[1], a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, ql[0], a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, ql[1], a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, qh[0], a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, qh[1], a, 0, 0, 0);
+    s[t] = a;
+    if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // bound the ds_read hoisting window (VGPR pressure)
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    if (16 * (t + 1) > n) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * t + 4 * fg + r >= n) s[t][r] = -INFINITY;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+  f16x8 ph[NKT / 2], pl[NKT / 2];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = exp2f((s[t][r] - mx) * cexp);      // as the fp32-MFMA kernel: one rounding of the scaled argument
+      sum += p;
+      f16 h, l;
+      split2h_scaled(p * kPScale, h, l);
+      ph[t >> 1][(t & 1) * 4 + r] = h;
+      pl[t >> 1][(t & 1) * 4 + r] = l;
+    }
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  denom = sum;
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  pv_chunks_x2<NKT, 0>(fb, plane, ph, pl, o);
+}
+
+// this lane's query fragments (16 fp32 of row q: d = fg*8 .. +7 and 32 + fg*8 .. +7), split
+__device__ __forceinline__ void load_q_x2(const float* qrow, int fg, f16x8 (&qh)[2], f16x8 (&ql)[2]) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const float* p = qrow + half * 32 + fg * 8;
+    split8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), qh[half], ql[half]);
+  }
+}
+
+// O^T accumulators -> out row (fp32, or two fp16 planes `plane_elems` apart): lane holds channels dn*16 + 4 fg + (0..3)
+template <int OUTS>
+__device__ __forceinline__ void store_o_x2(const f32x4 (&o)[4], float inv, void* out_v, size_t off, size_t plane_elems) {
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) {
+    const float r4[4] = {o[dn][0] * inv, o[dn][1] * inv, o[dn][2] * inv, o[dn][3] * inv};
+    if constexpr (OUTS == 2) {
+      f16* dst = reinterpret_cast<f16*>(out_v) + off + dn * 16;
+      f16x4 p0, p1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { f16 a0, a1; split2h(r4[e], a0, a1); p0[e] = a0; p1[e] = a1; }
+      *reinterpret_cast<f16x4*>(dst) = p0;
+      *reinterpret_cast<f16x4*>(dst + plane_elems) = p1;
+    } else {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(out_v) + off + dn * 16) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+    }
+  }
+}
+
+template <int NKT, int OUTS>   // temporal axis: one workgroup per (sequence, head), 8 waves share the K/V images
+__global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
+                                                               SeqMap map, int C, int heads, size_t plane_elems) {
+  constexpr int NK = 16 * NKT;
+  constexpr int PLANE = NK * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = map.n_tok;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
+  const int base = seq_base(map, seq);
+  const int ts = map.tok_stride;
+  const size_t ld = (size_t)3 * C;
+  const float* qbase = qkv + (size_t)base * ld + (size_t)head * 64;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int n_qt = (n + 15) >> 4;
+  stage_kv_x2<NK, 512>(qbase + C, (size_t)ts * ld, n, smem, PLANE, tid, C);
+  FragBases fb = make_frag_bases(smem, smem + 2 * PLANE, lane);
+  __syncthreads();
+  const float inv_scale = 1.0f / (kActScale * kPScale);
+  for (int qt = wave; qt < n_qt; qt += 8) {
+    const int q = qt * 16 + fi;
+    f16x8 qh[2], ql[2];
+    load_q_x2(qbase + (size_t)min(q, n - 1) * ts * ld, fg, qh, ql);
+    f32x4 o[4];
+    float denom;
+    attn_tile_x2<NKT>(fb, PLANE, qh, ql, n, lane, o, denom);
+    if (q < n) store_o_x2<OUTS>(o, inv_scale / denom, out_v, (size_t)(base + q * ts) * C + head * 64 + fg * 4, plane_elems);
+  }
+}
+
+// spatial axis (<= 32 tokens per sequence): one WAVE per (sequence, head) with a private 16 KiB image (4 planes of
+// 32 rows); a 256-thread workgroup covers 4 heads of one sequence.
+template <int OUTS>
+__global__ __launch_bounds__(256) void attn_spatial_x2_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
+                                                              int n_prob, SeqMap map, int C, int heads, size_t plane_elems) {
+  constexpr int PLANE = 32 * 128;
+  __shared__ __attribute__((aligned(16))) char smem[4 * 4 * PLANE];
+  const int n = map.n_tok;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pid = blockIdx.x * 4 + wave;
+  if (pid >= n_prob) return;
+  const int seq = pid / heads, head = pid % heads;
+  const int base = seq_base(map, seq);
+  const int ts = map.tok_stride;
+  const size_t ld = (size_t)3 * C;
+  const float* qbase = qkv + (size_t)base * ld + (size_t)head * 64;
+  char* img = smem + wave * 4 * PLANE;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int n_qt = (n + 15) >> 4;
+  f16x8 qh[2][2], ql[2][2];                          // both query tiles requested before the K/V staging
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) load_q_x2(qbase + (size_t)min(qt * 16 + fi, n - 1) * ts * ld, fg, qh[qt], ql[qt]);
+  stage_kv_x2<32, 64>(qbase + C, (size_t)ts * ld, n, img, PLANE, lane, C);
+  const FragBases fb = make_frag_bases(img, img + 2 * PLANE, lane);
+  // (wave-private LDS image: the LDS pipe executes one wave's accesses in order, no barrier needed)
+  const float inv_scale = 1.0f / (kActScale * kPScale);
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    if (qt >= n_qt) break;
+    const int q = qt * 16 + fi;
+    f32x4 o[4];
+    float denom;
+    attn_tile_x2<2>(fb, PLANE, qh[qt], ql[qt], n, lane, o, denom);
+    if (q < n) store_o_x2<OUTS>(o, inv_scale / denom, out_v, (size_t)(base + q * ts) * C + head * 64 + fg * 4, plane_elems);
+  }
+}
+
+template <int NKT, int OUTS>
+int launch_temporal_x2(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, hipStream_t st) {
+  constexpr int NK = 16 * NKT;
+  const size_t lds = (size_t)NK * 128 * 4;
+  auto kern = attn_temporal_x2_kernel<NKT, OUTS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) return -3;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(512), lds, st, (const float*)qkv, out, map, C, heads, plane);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // EXACT-mode temporal attention on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: bitwise an fp32 fmaf chain).
 // Same dataflow as the bf16 kernel -- S^T = K Q^T so the probabilities are already the B operand of O^T = V^T P^T --
 // with fp32 K/V images in LDS (row strides 65 / 68 floats: conflict-free ds_read_b32 fragments), the whole score
@@ -628,6 +861,31 @@ int d3dp_launch_attn_temporal_f32(int act, const void* qkv, void* out, int n_seq
   if (n <= 128) { TF32_CASE(8) }
   TF32_CASE(16)
 #undef TF32_CASE
+}
+
+// EXACT-mode attention on the fp16 matrix cores (split-fp16 operands; head dim 64).  act 0 -> fp32 out, 3 -> two fp16
+// planes out (the EXACT Linear's operand format).  axis 0: <= 32 tokens per sequence; axis 1: <= 256.
+int d3dp_launch_attn_x2(int act, int axis, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
+                        hipStream_t st) {
+  if (C / heads != 64 || map.n_tok < 1 || (act != 0 && act != 3)) return -2;
+  const size_t plane = (size_t)n_seq * map.n_tok * C;
+  const int n = map.n_tok;
+  if (axis == 0) {
+    if (n > 32) return -2;
+    const int n_prob = n_seq * heads;
+    if (act == 3) hipLaunchKernelGGL((attn_spatial_x2_kernel<2>), dim3((n_prob + 3) / 4), dim3(256), 0, st, (const float*)qkv, out, n_prob, map, C, heads, plane);
+    else hipLaunchKernelGGL((attn_spatial_x2_kernel<0>), dim3((n_prob + 3) / 4), dim3(256), 0, st, (const float*)qkv, out, n_prob, map, C, heads, plane);
+    return 0;
+  }
+  if (n > 256) return -2;
+#define X2_CASE(NKT_)                                                                                         \
+  return act == 3 ? launch_temporal_x2<NKT_, 2>(qkv, out, n_seq, map, C, heads, plane, st)                    \
+                  : launch_temporal_x2<NKT_, 0>(qkv, out, n_seq, map, C, heads, plane, st);
+  if (n <= 32) { X2_CASE(2) }
+  if (n <= 64) { X2_CASE(4) }
+  if (n <= 128) { X2_CASE(8) }
+  X2_CASE(16)
+#undef X2_CASE
 }
 
 // spatial axis on MFMA (bf16, head dim 64, <= 32 tokens per sequence)

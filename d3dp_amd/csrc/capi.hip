@@ -177,6 +177,10 @@ SeqMap temporal_map(int F, int J) { return SeqMap{F, J, F * J, 1, J}; }
 int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, hipStream_t st) {
   const d3dp_cfg& g = c->cfg;
   Scope s(c, axis == 0 ? P_ATTN_S : P_ATTN_T, st);
+  if (c->x2() && g.channels / g.heads == 64 && (axis == 1 || g.joints <= 32))   // split-fp16 operands on the fp16 matrix cores
+    return d3dp_launch_attn_x2(3, axis, qkv, out, axis == 0 ? n_bh * g.frames : n_bh * g.joints,
+                               axis == 0 ? spatial_map(g.frames, g.joints) : temporal_map(g.frames, g.joints), g.channels,
+                               g.heads, st);
   if (axis == 0) {
     if (c->fast() && g.channels / g.heads == 64 && g.joints <= 32)
       return d3dp_launch_attn_spatial_bf16(qkv, out, n_bh * g.frames, spatial_map(g.frames, g.joints), g.channels,
@@ -565,7 +569,11 @@ int d3dp_op_attention(int32_t act_bf16, int32_t impl, int32_t axis, const void* 
   if (!qkv || !out || n_bh < 1) return fail(D3DP_EINVAL, "d3dp_op_attention: bad argument");
   hipStream_t st = (hipStream_t)stream;
   if (act_bf16 != 0 && act_bf16 != 1) return fail(D3DP_EINVAL, "act_bf16 must be 0 or 1");
-  if (axis == 0 && impl == 1) {
+  if (impl == 2) {       // EXACT mode: split-fp16 operands on the fp16 matrix cores, fp32 in / fp32 out
+    if (act_bf16) return fail(D3DP_EINVAL, "split-fp16 attention takes fp32 activations");
+    LAUNCH_TRY(d3dp_launch_attn_x2(0, axis, qkv, out, axis == 0 ? n_bh * F : n_bh * J, axis == 0 ? spatial_map(F, J) : temporal_map(F, J),
+                                   C, heads, st));
+  } else if (axis == 0 && impl == 1) {
     if (!act_bf16) return fail(D3DP_EINVAL, "MFMA spatial attention needs bf16 activations");
     LAUNCH_TRY(d3dp_launch_attn_spatial_bf16(qkv, out, n_bh * F, spatial_map(F, J), C, heads, st));
   } else if (axis == 0) LAUNCH_TRY(d3dp_launch_attn_rows(act_bf16, qkv, out, n_bh * F, spatial_map(F, J), C, heads, st));

@@ -32,6 +32,8 @@ int d3dp_launch_attn_temporal_bf16(const void* qkv, void* out, int n_seq, SeqMap
                                    hipStream_t st);
 int d3dp_launch_attn_temporal_f32(int act, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
                                   hipStream_t st);
+int d3dp_launch_attn_x2(int act, int axis, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
+                        hipStream_t st);
 int d3dp_launch_attn_spatial_bf16(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st);
 
 // ---- pointwise.hip -----------------------------------------------------------------------------

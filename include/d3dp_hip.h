@@ -220,8 +220,9 @@ int d3dp_procrustes(const float* pred, const float* target, float* err, float* a
 int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, const float* bias, void* out, int32_t M,
                    int32_t N, int32_t K, void* stream);
 /* Multi-head attention over qkv[T,3C] -> out[T,C]; axis 0 = spatial (sequences of J joints), 1 = temporal
- * (sequences of F frames); tokens ordered (seq_batch, f, n).  impl 0 = fp32-VALU row kernel (any activation type), 1 = matrix-core kernel (head dim 64): bf16 MFMA for bf16
- * activations (both axes), fp32 MFMA for fp32 activations (temporal axis). */
+ * (sequences of F frames); tokens ordered (seq_batch, f, n).  impl 0 = fp32-VALU row kernel (any activation type),
+ * 1 = matrix-core kernel (head dim 64): bf16 MFMA for bf16 activations (both axes), fp32 MFMA for fp32 activations
+ * (temporal axis), 2 = the EXACT-mode kernel: fp32 activations split into fp16 pairs on the fp16 matrix cores (both axes). */
 int d3dp_op_attention(int32_t act_bf16, int32_t impl, int32_t axis, const void* qkv, void* out, int32_t n_bh,
                       int32_t F, int32_t J, int32_t C, int32_t heads, void* stream);
 int d3dp_op_layernorm(int32_t out_bf16, const float* x, const float* w, const float* b, float eps, void* out,

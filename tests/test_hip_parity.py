@@ -184,6 +184,7 @@ def ref_attention(qkv, n_bh, F, J, C, heads, axis):
 @pytest.mark.parametrize("act,impl,axis,F,C", [
     ("f32", 0, 0, 27, 512), ("f32", 0, 1, 27, 512), ("f32", 0, 1, 243, 512), ("f32", 1, 1, 243, 512), ("f32", 1, 1, 27, 512),
     ("f32", 1, 1, 100, 512), ("f32", 0, 0, 9, 64), ("f32", 0, 1, 9, 64),
+    ("f32", 2, 0, 27, 512), ("f32", 2, 0, 243, 512), ("f32", 2, 1, 27, 512), ("f32", 2, 1, 243, 512), ("f32", 2, 1, 100, 512),
     ("bf16", 0, 0, 27, 512), ("bf16", 1, 0, 27, 512), ("bf16", 1, 0, 243, 512), ("bf16", 1, 1, 27, 512), ("bf16", 1, 1, 243, 512), ("bf16", 1, 1, 100, 512),
     ("bf16", 0, 1, 243, 512)])
 def test_attention(lib, act, impl, axis, F, C):
@@ -202,6 +203,11 @@ def test_attention(lib, act, impl, axis, F, C):
     assert torch.isfinite(got).all()
     atol = 2e-2 if bf else 2e-5
     assert torch.allclose(got, want, atol=atol, rtol=1e-2 if bf else 1e-4), (got - want).abs().max().item()
+    if not bf:
+        err = (got - want).abs().mean().item()
+        print(f"attention act={act} impl={impl} axis={axis} F={F}: mean |err| vs fp64 {err:.2e}")
+        if impl == 2:      # the EXACT-mode kernel (split-fp16 operands) must be fp32-class: compare with the fp32 kernels
+            assert err < 5e-7
 
 
 def test_attention_softmax_spike(lib):
@@ -211,7 +217,7 @@ def test_attention_softmax_spike(lib):
     qkv = torch.randn(n_bh * F * J, 3 * C, generator=g)
     qkv[100 * J + 3, :C] *= 30.0
     qkv[7 * J + 3, C:2 * C] = qkv[100 * J + 3, :C] / 30.0 * 4.0
-    for bf, impl in ((False, 0), (False, 1), (True, 1)):
+    for bf, impl in ((False, 0), (False, 1), (False, 2), (True, 1)):
         src = bf16_round(qkv) if bf else qkv
         want = ref_attention(src, n_bh, F, J, C, heads, 1)
         qd = (qkv.to(torch.bfloat16) if bf else qkv).cuda().contiguous()
