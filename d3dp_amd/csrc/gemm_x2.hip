@@ -34,6 +34,12 @@
 #include "common.h"
 #include "kernels.h"
 
+// Timing probes (results INVALID), compiled in only with -DD3DP_X2_PROBE=bits for tools/gemm_bench.py A/B builds; the
+// product library is built without it.  1: loaders issue no loads; 2: no fragment reads; 4: no output stores.
+#ifndef D3DP_X2_PROBE
+#define D3DP_X2_PROBE 0
+#endif
+
 namespace {
 
 constexpr int XBM = 256, XBN = 128, XBK = 32;
@@ -75,24 +81,40 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
     const int lr = lane >> 2, lps = lane & 3;
     const size_t planeA = (size_t)M * K, planeW = (size_t)N * K;
     int ti = 0, ks = 0, slot = 0;                      // (tile, k-step, ring slot) of the next slab to issue
+    const f16* pa[4];                                  // this lane's source rows of the current tile (k = 0, hi plane)
+    const f16* pw[2];
     auto issue = [&]() {
-      const int t = L + ti * G;
-      const int m0 = (t / tiles_n) * XBM, n0 = (t % tiles_n) * XBN;
-      char* base = smem + slot * XSTAGE;
+      if (ks == 0) {                                   // new tile: row pointers once per tile, not per k-step
+        const int t = L + ti * G;
+        const int m0 = (t / tiles_n) * XBM, n0 = (t % tiles_n) * XBN;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {                    // A row groups 4 lw .. 4 lw + 3 (16 rows each), both planes
-        const int rg = lw * 4 + i, row = rg * 16 + lr;
-        const f16* src = A2 + (size_t)min(m0 + row, M - 1) * K + ks * XBK + swz64(row, lps) * 8;
-        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(base + rg * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GPTR(src + planeA), LPTR(base + XA_PLANE + rg * 1024), 16, 0, 0);
+        for (int i = 0; i < 4; ++i) {                  // A row groups 4 lw .. 4 lw + 3 (16 rows each)
+          const int row = (lw * 4 + i) * 16 + lr;
+          pa[i] = A2 + (size_t)min(m0 + row, M - 1) * K + swz64(row, lps) * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                  // W row groups 2 lw, 2 lw + 1
+          const int row = (lw * 2 + i) * 16 + lr;                       // LDS row of the W slab
+          const int wrow = (row & 64) + colperm(row & 63);              // output column it carries
+          pw[i] = W2 + (size_t)min(n0 + wrow, N - 1) * K + swz64(row, lps) * 8;
+        }
+      }
+      char* base = smem + slot * XSTAGE;
+      const int ko = ks * XBK;
+#if D3DP_X2_PROBE & 1
+      if (ko >= 0) { if (++ks == NK) { ks = 0; ++ti; } slot = (slot == XNSTAGE - 1) ? 0 : slot + 1; return; }
+#endif
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rg = lw * 4 + i;
+        __builtin_amdgcn_global_load_lds(GPTR(pa[i] + ko), LPTR(base + rg * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GPTR(pa[i] + ko + planeA), LPTR(base + XA_PLANE + rg * 1024), 16, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {                    // W row groups 2 lw, 2 lw + 1, both planes
-        const int rg = lw * 2 + i, row = rg * 16 + lr;                  // LDS row of the W slab
-        const int wrow = (row & 64) + colperm(row & 63);                // output column it carries
-        const f16* src = W2 + (size_t)min(n0 + wrow, N - 1) * K + ks * XBK + swz64(row, lps) * 8;
-        __builtin_amdgcn_global_load_lds(GPTR(src), LPTR(base + 2 * XA_PLANE + rg * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GPTR(src + planeW), LPTR(base + 2 * XA_PLANE + XW_PLANE + rg * 1024), 16, 0, 0);
+      for (int i = 0; i < 2; ++i) {
+        const int rg = lw * 2 + i;
+        __builtin_amdgcn_global_load_lds(GPTR(pw[i] + ko), LPTR(base + 2 * XA_PLANE + rg * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GPTR(pw[i] + ko + planeW), LPTR(base + 2 * XA_PLANE + XW_PLANE + rg * 1024), 16, 0, 0);
       }
       if (++ks == NK) { ks = 0; ++ti; }
       slot = (slot == XNSTAGE - 1) ? 0 : slot + 1;
@@ -127,7 +149,11 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
 #pragma unroll 1
     for (int ks = 0; ks < NK; ++ks) {
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if D3DP_X2_PROBE & 2
+      const char* sb = smem;                           // (one fixed stage: reads hoisted out of the k-loop by the compiler)
+#else
       const char* sb = smem + slot * XSTAGE;
+#endif
       slot = (slot == XNSTAGE - 1) ? 0 : slot + 1;
       f16x8 wf[4][2];
 #pragma unroll
@@ -151,7 +177,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
     // ---- tile epilogue: lane holds out[m = pm0 + wr*64 + mi*16 + 4 fg + r][n = nb + ni], nb = tile column + wc*64 + 4 fi
     const int t = L + ti * G;
     const int pm0 = (t / tiles_n) * XBM + wr * 64 + 4 * fg, nb = (t % tiles_n) * XBN + wc * 64 + 4 * fi;
-    if (nb < N) {
+    if (nb < N && !(D3DP_X2_PROBE & 4)) {
       const float4 bz = *reinterpret_cast<const float4*>(sbias + nb);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
