@@ -40,6 +40,17 @@
 #define D3DP_X2_PROBE 0
 #endif
 
+// Output stores carry the nontemporal hint: the tile round's 4 MiB of output per XCD is not read again on that XCD
+// and otherwise pushes the weight matrix out of the 4 MiB L2 between rounds (FETCH_SIZE measurement in DESIGN.md).
+#ifndef D3DP_NT_OUT
+#define D3DP_NT_OUT 1
+#endif
+#if D3DP_NT_OUT
+#define OUT_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define OUT_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
 namespace {
 
 constexpr int XBM = 256, XBN = 128, XBK = 32;
@@ -57,7 +68,9 @@ __device__ __forceinline__ int swz64(int row, int s) { return s ^ (((row >> 3) &
 // W row carried by LDS row q of a 64-column strip: MFMA tile ni = q>>4, operand row i = q&15 -> output column 4 i + ni
 __device__ __forceinline__ int colperm(int q) { return (q & 15) * 4 + (q >> 4); }
 
-template <int EPI>
+// TAG is a name tag only (same code): the qkv Linear (N = 3K) is instantiated as its own kernel symbol so that
+// rocprofv3 --stats reports it separately from the proj Linear, which shares EPI with it.
+template <int EPI, int TAG>
 __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__ A2, const f16* __restrict__ W2,
                                                          const float* __restrict__ bias, float unscale,
                                                          float* __restrict__ outf, f16* __restrict__ out2, int M, int N,
@@ -196,11 +209,11 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
             }
             if (m < M) {
               f16* o = out2 + (size_t)m * N + nb;
-              *reinterpret_cast<f16x4*>(o) = ph;
-              *reinterpret_cast<f16x4*>(o + planeO) = pl;
+              OUT_STORE(reinterpret_cast<f16x4*>(o), ph);
+              OUT_STORE(reinterpret_cast<f16x4*>(o + planeO), pl);
             }
           } else {
-            if (m < M) *reinterpret_cast<float4*>(outf + (size_t)m * N + nb) = make_float4(v[0], v[1], v[2], v[3]);
+            if (m < M) OUT_STORE(reinterpret_cast<f32x4*>(outf + (size_t)m * N + nb), ((f32x4){v[0], v[1], v[2], v[3]}));
           }
         }
     }
@@ -239,9 +252,11 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x2_kernel<EPI_BIAS>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x2_kernel<EPI_BIAS, 0>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, XLDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x2_kernel<EPI_GELU>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x2_kernel<EPI_BIAS, 1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, XLDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x2_kernel<EPI_GELU, 0>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, XLDS) != hipSuccess) return -3;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -250,13 +265,11 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
     attr_set = true;
   }
   const int total = tm * tn, grid = total < n_cu ? total : n_cu;
-  if (epi == EPI_BIAS)
-    hipLaunchKernelGGL((gemm_f16x2_kernel<EPI_BIAS>), dim3(grid), dim3((XNCW + 4) * 64), XLDS, st, (const f16*)A2,
-                       (const f16*)W2, bias, unscale, outf, (f16*)out2, M, N, K, tn, total);
-  else if (epi == EPI_GELU)
-    hipLaunchKernelGGL((gemm_f16x2_kernel<EPI_GELU>), dim3(grid), dim3((XNCW + 4) * 64), XLDS, st, (const f16*)A2,
-                       (const f16*)W2, bias, unscale, outf, (f16*)out2, M, N, K, tn, total);
-  else return -1;
+  auto kern = epi == EPI_GELU ? gemm_f16x2_kernel<EPI_GELU, 0>
+                              : (N == 3 * K ? gemm_f16x2_kernel<EPI_BIAS, 1> : gemm_f16x2_kernel<EPI_BIAS, 0>);
+  if (epi != EPI_BIAS && epi != EPI_GELU) return -1;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3((XNCW + 4) * 64), XLDS, st, (const f16*)A2, (const f16*)W2, bias, unscale, outf,
+                     (f16*)out2, M, N, K, tn, total);
   return 0;
 }
 

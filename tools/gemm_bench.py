@@ -29,7 +29,8 @@ def main():
     a = ap.parse_args()
     lib = _lib.load()
     M = a.m
-    shapes = {"qkv": (1536, 512, 0), "proj": (512, 512, 0), "fc1": (1024, 512, 1), "fc2": (512, 1024, 0)}   # bf16 outputs, as the denoiser launches them
+    shapes = {"qkv": (1536, 512, 0), "proj": (512, 512, 0), "fc1": (1024, 512, 1), "fc2": (512, 1024, 0),   # bf16 outputs, as the denoiser launches them
+              "cal": (128, 512, 0)}   # ONE column tile: every A element is fetched exactly once (calibrates FETCH_SIZE)
     st = torch.cuda.current_stream().cuda_stream
     if a.x2:
         for name in a.shapes.split(","):
