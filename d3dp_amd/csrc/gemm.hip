@@ -418,14 +418,14 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return fmaf(h, e, h);                     // 0.5 x (1 + erf(x / sqrt 2))
 }
 
-// Column permutation inside a wave's 64-wide output strip.  MFMA tile ni, operand row i (= LDS row ni*16 + i of
-// the wave's W strip) holds output column  sperm(ni, i); an output lane (fi, fg) then owns, for each of its row
-// blocks, the 16 columns  fg*16 + h*8 + [0..7], h = 0,1  -> two adjacent 16-byte bf16 stores; the four lane groups of a
-// row together write one complete 128-byte line when both halves are drained back to back.  The loader applies the same map when it picks the
-// W row for an LDS row, so the MFMA-side reads stay in natural (conflict-free) order.
+// Column permutation inside a wave's 64-wide output strip.  The activation fragment is the MFMA A operand, so a lane
+// (fi, fg) holds C[row 4 fg + r][column fi] of each 16x16 tile; LDS row ni*16 + i of the wave's W strip carries output
+// column 4 i + ni, which makes the lane's four tiles ni four CONSECUTIVE columns: one 8-byte bf16 store per (mi, r) in
+// which the 16 lanes of a group cover one complete 128-byte line of ONE row (as in gemm_x2.hip, where the row-per-lane
+// store pattern this replaces was measured at 11-17 us of store tail per 256x128 tile).  The loader applies the same
+// map when it picks the W row for an LDS row, so the MFMA-side reads stay in natural (conflict-free) order.
 __device__ __forceinline__ int sperm(int q) {   // q = ni*16 + i in [0,64)
-  const int ni = q >> 4, i = q & 15;
-  return (i >> 2) * 16 + ni * 4 + (i & 3);      // lane group fg = i>>2 owns columns fg*16 .. fg*16+15 (ni-major)
+  return (q & 15) * 4 + (q >> 4);
 }
 
 // MI = 16-row MFMA blocks per compute wave: MI = 4 -> 8 compute waves (4 x 2, 64x64 each, two per SIMD);
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
   const int gtot = n_my * NK;
 
   constexpr int NCW = (SBM / (MI * 16)) * 2;          // compute waves
-  constexpr int NU = 2 * MI;                          // pending 8-column units per wave and tile
+  constexpr int NU = 4 * MI;                          // pending 4-column units (mi, r) per wave and tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -495,49 +495,45 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
   const int wr = wave >> 1, wc = wave & 1;
   const int fi = lane & 15, fg = lane >> 4;
   f32x4 acc[MI][4];
-  // Finished tile waiting to be stored: 8 units (mi, h) of 8 packed bf16 (acc + bias).  One unit is drained behind
-  // the MFMAs of each k-step of the NEXT tile, so output traffic is a steady trickle instead of a per-tile burst in
-  // which every CU of the (phase-locked) persistent grid hits the HBM write path at once.
+  // Finished tile waiting to be stored: 16 units (mi, r) of 4 packed bf16 (acc + bias) = 4 consecutive columns of one
+  // row.  Units are drained behind the MFMAs of the k-steps of the NEXT tile, so output traffic is a steady trickle
+  // instead of a per-tile burst in which every CU of the (phase-locked) persistent grid hits the HBM write path at once.
   // (GELU form: the parked pre-activation is fp16, not bf16 -- 11 significand bits, so the rounding in front of the
   //  nonlinearity is an eighth of the bf16 rounding behind it instead of a second rounding of the same size)
-  using pend_t = typename std::conditional<EPI == EPI_GELU, f16x8, bf16x8>::type;
+  using pend_t = typename std::conditional<EPI == EPI_GELU, f16x4, bf16x4>::type;
   using pelt_t = typename std::conditional<EPI == EPI_GELU, f16, bf16>::type;
-  pend_t pend[MI][2];
+  pend_t pend[NU];
   int pm0 = 0, pn0 = 0;
   bool have_pend = false;
 
-  // store the unit at the head of the pending queue (unit index u -> rows mi = u>>1, column half h = u&1), then
+  // store the unit at the head of the pending queue (unit index u -> row block mi = u>>2, row r = u&3), then
   // rotate the queue by one so the head index stays compile-time constant (no runtime-indexed register arrays)
   auto drain_one = [&](int u) {
-    const int mi = u >> 1, h = u & 1;
-    const int m = pm0 + wr * (MI * 16) + mi * 16 + fi;
-    const int n = pn0 + wc * 64 + fg * 16 + h * 8;
-    bf16x8 v;
+    const int m = pm0 + wr * (MI * 16) + (u >> 2) * 16 + 4 * fg + (u & 3);
+    const int n = pn0 + wc * 64 + 4 * fi;
+    bf16x4 v;
     if constexpr (EPI == EPI_GELU) {
-      const f16x8 pre = pend[0][0];
+      const f16x4 pre = pend[0];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16)gelu_fast((float)pre[e]);
+      for (int e = 0; e < 4; ++e) v[e] = (bf16)gelu_fast((float)pre[e]);
       // keep the activation OUT of the store's bounds branch (LLVM would sink it there, behind the MFMA block)
       asm volatile("" : "+v"(v));
     } else {
-      v = pend[0][0];
+      v = pend[0];
     }
     if (m < M && n < N) {
       if constexpr (sizeof(OutT) == 2) {
-        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(out) + (size_t)m * N + n) = v;
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(out) + (size_t)m * N + n) = v;
       } else {
-        float r[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = (float)v[e];
-        store8(reinterpret_cast<float*>(out) + (size_t)m * N + n, r);
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * N + n) =
+            make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
       }
     }
 #pragma unroll
-    for (int q = 0; q < NU - 1; ++q) pend[q >> 1][q & 1] = pend[(q + 1) >> 1][(q + 1) & 1];
+    for (int q = 0; q < NU - 1; ++q) pend[q] = pend[q + 1];
   };
-  // both halves (h = 0,1) of a row block are drained in the same k-step: complete 128-byte lines per wave
-  constexpr int UPS = 2 * ((NU / 2 + NK - 1) / NK);      // units drained per draining k-step (even)
-  constexpr int DEVERY = NK / (NU / 2) > 0 ? NK / (NU / 2) : 1;   // drain every DEVERY-th k-step
+  constexpr int UPS = (NU + NK - 1) / NK;                 // units drained per draining k-step
+  constexpr int DEVERY = NK / NU > 0 ? NK / NU : 1;       // drain every DEVERY-th k-step (K > 1024 only)
   // one k-step: 16 ds_read_b128 + 32 MFMA (64 x 64 x 64 per wave)
   auto kstep = [&](int g) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -560,7 +556,7 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], wf[ni], acc[mi][ni], 0, 0, 0);
     }
   };
   __builtin_amdgcn_s_setprio(1);
@@ -581,7 +577,7 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
 #pragma unroll 1
       for (int ks = 0; ks < NK; ++ks) {
         kstep(g0 + ks);
-        if (ks % DEVERY == 0 && unit < NU) { drain_one(unit); drain_one(unit + 1); unit += 2; }
+        if (ks % DEVERY == 0 && unit < NU) { drain_one(unit); unit += 1; }
       }
     } else if constexpr (NK * UPS == NU) {
       int unit = 0;                                   // exactly UPS units behind every k-step, no branch
@@ -604,17 +600,15 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
     const int t = L + ti * G;
     pm0 = (t / tiles_n) * SBM;
     pn0 = (t % tiles_n) * SBN;
+    {
+      const float4 b = *reinterpret_cast<const float4*>(sbias + pn0 + wc * 64 + 4 * fi);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int n = pn0 + wc * 64 + fg * 16 + h * 8;
-        const float4 b0 = *reinterpret_cast<const float4*>(sbias + n);
-        const float4 b1 = *reinterpret_cast<const float4*>(sbias + n + 4);
-        const f32x4 a0 = acc[mi][2 * h], a1 = acc[mi][2 * h + 1];
-        pend[mi][h] = (pend_t){(pelt_t)(a0[0] + b0.x), (pelt_t)(a0[1] + b0.y), (pelt_t)(a0[2] + b0.z), (pelt_t)(a0[3] + b0.w),
-                               (pelt_t)(a1[0] + b1.x), (pelt_t)(a1[1] + b1.y), (pelt_t)(a1[2] + b1.z), (pelt_t)(a1[3] + b1.w)};
-      }
+        for (int r = 0; r < 4; ++r)
+          pend[mi * 4 + r] = (pend_t){(pelt_t)(acc[mi][0][r] + b.x), (pelt_t)(acc[mi][1][r] + b.y),
+                                      (pelt_t)(acc[mi][2][r] + b.z), (pelt_t)(acc[mi][3][r] + b.w)};
+    }
     have_pend = true;
   }
   if (have_pend) {
@@ -676,7 +670,7 @@ int launch_stream(const void* A, const void* W, const float* bias, void* out, in
 // out[M,N] = epi(A W^T + bias); epi in {EPI_BIAS, EPI_GELU}; out bf16 or fp32.
 int d3dp_launch_linear_bf16_stream(int epi, int out_f32, const void* A, const void* W, const float* bias, void* out,
                                    int M, int N, int K, hipStream_t st) {
-  if (K % SBK != 0 || N % 8 != 0 || N > SBIAS_MAX || M <= 0) return -1;
+  if (K % SBK != 0 || N % 4 != 0 || N > SBIAS_MAX || M <= 0) return -1;
   if (epi == EPI_BIAS && out_f32) return launch_stream<EPI_BIAS, float>(A, W, bias, out, M, N, K, st);
   if (epi == EPI_BIAS && !out_f32) return launch_stream<EPI_BIAS, bf16>(A, W, bias, out, M, N, K, st);
   if (epi == EPI_GELU && !out_f32) return launch_stream<EPI_GELU, bf16>(A, W, bias, out, M, N, K, st);
