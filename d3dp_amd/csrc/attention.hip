@@ -577,8 +577,11 @@ __device__ __forceinline__ void store_o_x2(const f32x4 (&o)[4], float inv, void*
   }
 }
 
-template <int NKT, int OUTS>   // temporal axis: one workgroup per (sequence, head), 8 waves share the K/V images
-__global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
+// temporal axis: one workgroup per (sequence, head); NW waves share the K/V images (the four planes of 256 keys fill
+// 128 KiB of LDS, so only one workgroup fits a CU: 16 waves -- one 16-query tile each at F = 243 -- give the matrix
+// pipes and the softmax VALU work of different tiles something to overlap with)
+template <int NKT, int OUTS, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_temporal_x2_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
                                                                SeqMap map, int C, int heads, size_t plane_elems) {
   constexpr int NK = 16 * NKT;
   constexpr int PLANE = NK * 128;
@@ -592,11 +595,11 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
   const float* qbase = qkv + (size_t)base * ld + (size_t)head * 64;
   const int fi = lane & 15, fg = lane >> 4;
   const int n_qt = (n + 15) >> 4;
-  stage_kv_x2<NK, 512>(qbase + C, (size_t)ts * ld, n, smem, PLANE, tid, C);
+  stage_kv_x2<NK, NW * 64>(qbase + C, (size_t)ts * ld, n, smem, PLANE, tid, C);
   FragBases fb = make_frag_bases(smem, smem + 2 * PLANE, lane);
   __syncthreads();
   const float inv_scale = 1.0f / (kActScale * kPScale);
-  for (int qt = wave; qt < n_qt; qt += 8) {
+  for (int qt = wave; qt < n_qt; qt += NW) {
     const int q = qt * 16 + fi;
     f16x8 qh[2], ql[2];
     load_q_x2(qbase + (size_t)min(q, n - 1) * ts * ld, fg, qh, ql);
@@ -648,14 +651,15 @@ template <int NKT, int OUTS>
 int launch_temporal_x2(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, hipStream_t st) {
   constexpr int NK = 16 * NKT;
   const size_t lds = (size_t)NK * 128 * 4;
-  auto kern = attn_temporal_x2_kernel<NKT, OUTS>;
+  constexpr int NW = NKT > 8 ? 16 : 8;
+  auto kern = attn_temporal_x2_kernel<NKT, OUTS, NW>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) return -3;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(512), lds, st, (const float*)qkv, out, map, C, heads, plane);
+  hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(NW * 64), lds, st, (const float*)qkv, out, map, C, heads, plane);
   return 0;
 }
 
