@@ -224,9 +224,11 @@ def attach_traffic(roof, numerics, chunk_seqs):
         roof["traffic_note"] = "profiles/r02_gemm_traffic.json was measured on a different build of libd3dp_hip.so: not reported"
         return
     roof["traffic"] = tj["hbm_bytes_per_launch"]
-    roof["traffic_note"] = (f"bytes/launch at M=61965 (15-sequence chunk), separate rocprofv3 --pmc passes of this build; "
-                            f"algorithmic bytes/launch {tj['algorithmic_bytes_per_launch']}; hardware MFMA busy "
-                            f"{tj.get('mfma_util_hw', float('nan')):.3f} of kernel cycles")
+    roof["traffic_note"] = (f"HBM bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) at a mean of {tj.get('mean_rows_per_launch', 0):.0f} "
+                            f"rows per launch, separate rocprofv3 --pmc passes of this build inside the denoiser; algorithmic "
+                            f"bytes/launch {tj['algorithmic_bytes_per_launch']} (read amplification "
+                            f"{tj.get('read_amplification', float('nan')):.2f}x: the weight matrix is re-fetched by every XCD "
+                            f"every tile round); hardware MFMA busy {tj.get('mfma_util_hw', float('nan')):.3f} of kernel cycles")
 
 
 def profile_step(model, x2d, x2f, gen):
