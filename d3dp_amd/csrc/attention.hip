@@ -610,13 +610,17 @@ __global__ __launch_bounds__(NW * 64) void attn_temporal_x2_kernel(const float* 
   }
 }
 
-// spatial axis (<= 32 tokens per sequence): one WAVE per (sequence, head) with a private 16 KiB image (4 planes of
-// 32 rows); a 256-thread workgroup covers 4 heads of one sequence.
+// spatial axis (<= 32 tokens per sequence): one WAVE per (sequence, head).  The K fragments of its two 16-key tiles are
+// loaded straight from global memory into the MFMA operand layout (lane (key, g) <- 2 x 32 contiguous bytes of one K row,
+// exactly like a query fragment) and split in registers; only V goes through LDS (its fragments are transposed reads):
+// a private 8 KiB image (V hi, V lo: 32 rows x 128 B each), so a 256-thread workgroup needs 32 KiB and five of them fit a
+// CU -- this kernel is latency / HBM-bound (8 KB per token), and with K staged as well (16 KiB per wave, two workgroups
+// per CU) it ran at 3.8 TB/s.
 template <int OUTS>
 __global__ __launch_bounds__(256) void attn_spatial_x2_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
                                                               int n_prob, SeqMap map, int C, int heads, size_t plane_elems) {
   constexpr int PLANE = 32 * 128;
-  __shared__ __attribute__((aligned(16))) char smem[4 * 4 * PLANE];
+  __shared__ __attribute__((aligned(16))) char smem[4 * 2 * PLANE];
   const int n = map.n_tok;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pid = blockIdx.x * 4 + wave;
@@ -626,24 +630,79 @@ __global__ __launch_bounds__(256) void attn_spatial_x2_kernel(const float* __res
   const int ts = map.tok_stride;
   const size_t ld = (size_t)3 * C;
   const float* qbase = qkv + (size_t)base * ld + (size_t)head * 64;
-  char* img = smem + wave * 4 * PLANE;
+  char* img = smem + wave * 2 * PLANE;
   const int fi = lane & 15, fg = lane >> 4;
   const int n_qt = (n + 15) >> 4;
-  f16x8 qh[2][2], ql[2][2];                          // both query tiles requested before the K/V staging
+  // every global request of the problem is issued before anything is consumed: both query tiles, both key tiles, V
+  f16x8 qh[2][2], ql[2][2], kh[2][2], kl[2][2];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) load_q_x2(qbase + (size_t)min(qt * 16 + fi, n - 1) * ts * ld, fg, qh[qt], ql[qt]);
-  stage_kv_x2<32, 64>(qbase + C, (size_t)ts * ld, n, img, PLANE, lane, C);
-  const FragBases fb = make_frag_bases(img, img + 2 * PLANE, lane);
+  for (int t = 0; t < 2; ++t) {
+    const float* row = qbase + (size_t)min(t * 16 + fi, n - 1) * ts * ld;
+    load_q_x2(row, fg, qh[t], ql[t]);
+    load_q_x2(row + C, fg, kh[t], kl[t]);             // K row of the same token: same fragment shape
+  }
+  for (int idx = lane; idx < 32 * 8; idx += 64) {      // V rows -> hi / lo images (rows >= n zeroed)
+    const int row = idx >> 3, slot = idx & 7;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (row < n) {
+      const float* src = qbase + 2 * C + (size_t)row * ts * ld + slot * 8;
+      v0 = *reinterpret_cast<const float4*>(src); v1 = *reinterpret_cast<const float4*>(src + 4);
+    }
+    f16x8 vh, vl;
+    split8(v0, v1, vh, vl);
+    const int vo = row * 128 + ((slot ^ (((row >> 1) & 3) << 1)) << 4);
+    *reinterpret_cast<f16x8*>(img + vo) = vh;
+    *reinterpret_cast<f16x8*>(img + PLANE + vo) = vl;
+  }
+  const FragBases fb = make_frag_bases(img, img, lane);   // only the V bases are used
   // (wave-private LDS image: the LDS pipe executes one wave's accesses in order, no barrier needed)
   const float inv_scale = 1.0f / (kActScale * kPScale);
+  const float cexp = 0.125f * 1.44269504088896340736f / (kActScale * kActScale);
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     if (qt >= n_qt) break;
     const int q = qt * 16 + fi;
+    f32x4 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {                      // S^T tile t: keys 16 t + 4 fg + r, query fi
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[t][0], qh[qt][0], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[t][1], qh[qt][1], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[t][0], ql[qt][0], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[t][1], ql[qt][1], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[t][0], qh[qt][0], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[t][1], qh[qt][1], a, 0, 0, 0);
+      s[t] = a;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (16 * t + 4 * fg + r >= n) s[t][r] = -INFINITY;
+        mx = fmaxf(mx, s[t][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+    f16x8 ph[1], pl[1];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = exp2f((s[t][r] - mx) * cexp);
+        sum += p;
+        f16 h, l;
+        split2h_scaled(p * kPScale, h, l);
+        ph[0][t * 4 + r] = h; pl[0][t * 4 + r] = l;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
     f32x4 o[4];
-    float denom;
-    attn_tile_x2<2>(fb, PLANE, qh[qt], ql[qt], n, lane, o, denom);
-    if (q < n) store_o_x2<OUTS>(o, inv_scale / denom, out_v, (size_t)(base + q * ts) * C + head * 64 + fg * 4, plane_elems);
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    pv_chunks_x2<2, 0>(fb, PLANE, ph, pl, o);
+    if (q < n) store_o_x2<OUTS>(o, inv_scale / sum, out_v, (size_t)(base + q * ts) * C + head * 64 + fg * 4, plane_elems);
   }
 }
 
