@@ -644,3 +644,23 @@ def test_training_step_config5_vs_oracle_autograd():
             worst = (name, err)
         assert err < 5e-3, (name, err)
     print(f"config-5: worst relative gradient error over {len(po)} parameters: {worst[1]:.2e} ({worst[0]})")
+
+
+def test_bench_launches_its_own_ranks_when_two_gpus_are_visible():
+    """`python bench.py --gpus 2` outside a torchrun job re-executes itself as 2 RCCL ranks, checks that the 2-rank
+    run on sliced global noise reproduces the 1-rank H=2*H_local run bit for bit, and reports the world size and the
+    all-gather.  Needs two devices on the box: skipped on the 1-GPU test boxes."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs on the box")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--batch", "1", "--hyps", "2", "--ksteps", "1", "--no-cpu-baseline", "--no-parity", "--no-profile"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["multi_gpu"]["world_size"] == 2 and d["multi_gpu"]["sharded_equals_single_rank"]
+    assert d["config"]["hypotheses_total"] == 4

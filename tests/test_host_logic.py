@@ -97,3 +97,29 @@ def test_train_model_is_always_differentiable_numerics():
                            numerics="fast")
     assert D3DP(args, [4, 5, 6], [1, 2, 3], is_train=True).pose_estimator.numerics == "train"
     assert D3DP(args, [4, 5, 6], [1, 2, 3], is_train=False).pose_estimator.numerics == "fast"
+
+
+def test_bench_relaunches_itself_under_torchrun(monkeypatch):
+    """`python bench.py --gpus N` outside a torchrun job becomes `python -m torch.distributed.run --nproc-per-node N ...
+    bench.py <same args>` on 127.0.0.1 with a free port; inside a job whose WORLD_SIZE differs it refuses to run."""
+    import importlib.util
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_execv(exe, argv):
+        seen["exe"], seen["argv"] = exe, argv
+        raise SystemExit(0)
+
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit):
+        bench.main()
+    a = seen["argv"]
+    assert a[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=8" in a and "--nnodes=1" in a
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1" and int(a[a.index("--master-port") + 1]) > 0
+    assert a[-6:] == ["--gpus", "8", "--steps", "2", "--warmup", "1"] and a[-7].endswith("bench.py")

@@ -5,7 +5,10 @@ Every big nn.Linear of one denoiser call is replaced by an emulation of a multi-
 
   bf16x3  : x = x0 + x1 + x2 (bf16 planes), six leading plane pairs            (round-1 EXACT mode)
   f16x2   : x = hi + lo * 2^-11 (fp16 planes, lo pre-scaled by 2^11), passes hi.hi + (hi.lo + lo.hi) * 2^-11
+            (first round-2 form: cross terms in their own accumulator)
   f16x2+  : as f16x2 plus the lo.lo pass (four passes)
+  f16x2u  : THE SHIPPED FORM (gemm_x2.hip): activations x 16 and weights x 2^s (max |w| 2^s in [2^13, 2^14)) split into
+            hi = fp16(y), lo = fp16(y - hi) (unscaled), three passes hi.hi + hi.lo + lo.hi into ONE accumulator
 
 Accumulation is emulated two ways: `acc32` multiplies the planes with torch's fp32 matmul (products of two 11-bit
 significands are exact in fp32, accumulation rounds like an fp32 kernel), `acc64` accumulates in fp64 and rounds once
@@ -55,6 +58,12 @@ def split_f16x2(x):
     return hi, lo
 
 
+def split_f16x2u(y):
+    hi = y.to(torch.float16).float()
+    lo = (y - hi).to(torch.float16).float()
+    return hi, lo
+
+
 def mm(a, w, acc64):
     if acc64:
         return a.double() @ w.double().t()
@@ -71,6 +80,11 @@ def make_linear(kind, acc64):
             a0, a1, a2 = split_bf16x3(x)
             w0, w1, w2 = split_bf16x3(w)
             y = mm(a2, w0, acc64) + mm(a1, w1, acc64) + mm(a0, w2, acc64) + mm(a1, w0, acc64) + mm(a0, w1, acc64) + mm(a0, w0, acc64)
+        elif kind == 'f16x2u':
+            ws = 2.0 ** (13 - int(torch.floor(torch.log2(w.abs().max())).item()))
+            ah, al = split_f16x2u(x * 16.0)
+            wh, wl = split_f16x2u(w * ws)
+            y = (mm(ah, wl, acc64) + mm(al, wh, acc64) + mm(ah, wh, acc64)) / (16.0 * ws)
         else:
             ah, al = split_f16x2(x)
             wh, wl = split_f16x2(w)
@@ -85,7 +99,7 @@ def make_linear(kind, acc64):
     return lin
 
 
-for kind in ('bf16x3', 'f16x2', 'f16x2+'):
+for kind in ('bf16x3', 'f16x2', 'f16x2+', 'f16x2u'):
     for acc64 in (False, True):
         F.linear = make_linear(kind, acc64)
         try:
