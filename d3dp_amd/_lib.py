@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libd3dp_hip.so")
 
 MODE_EXACT, MODE_FAST, MODE_TRAIN = 0, 1, 2
 MODE_SPLIT3 = 2   # d3dp_op_linear only: split-bf16 operands
-EPI_BIAS, EPI_GELU, EPI_RESID = 0, 1, 2
+EPI_BIAS, EPI_GELU, EPI_RESID, EPI_QKV_PACK = 0, 1, 2, 4
 PROFILE_CLASSES = 12
 
 

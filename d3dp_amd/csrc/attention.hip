@@ -428,15 +428,17 @@ __global__ __launch_bounds__(256) void attn_spatial_bf16_kernel(const bf16* __re
 
 // ------------------------------------------------------------------------------------------------
 // EXACT-mode attention on the fp16 matrix cores: split-fp16 operands, three MFMA passes per product (the scheme of the
-// EXACT Linear, gemm_x2.hip), same dataflow and LDS images as the bf16 kernels above with TWO planes per operand:
-//   K, V (fp32 in HBM, q|k|v from the qkv Linear) are split into hi/lo fp16 planes (x 16) while they are staged into
-//   LDS; the query fragments are split in registers; S^T = Kl.Qh + Kh.Ql + Kh.Qh (fp32 accumulate, scale 256 folded
+// EXACT Linear, gemm_x2.hip), same dataflow and LDS images as the bf16 kernels above with TWO planes per operand.
+// Input: the PACKED qkv rows the qkv Linear writes in this mode (gemm_x2.hip, EPI_QKV_PACK), 12 C bytes per token:
+//     q fp32 [C] | k hi [C] | k lo [C] | v hi [C] | v lo [C]      (fp16 planes of the value x 16)
+// so K and V are already MFMA operands: the temporal kernel copies them HBM -> LDS with LDS-DMA (no registers, no VALU)
+// and the query fragments are split in registers.  S^T = Kl.Qh + Kh.Ql + Kh.Qh (fp32 accumulate, scale 256 folded
 //   into the exponent constant); two-pass fp32 softmax over the whole score row in registers; the probabilities are
 //   split into fp16 pairs (x 1024) and O^T = Vl.Ph + Vh.Pl + Vh.Ph; the output leaves as fp32 or as the two fp16 planes
 //   the proj Linear consumes.  5.3x fewer matrix-pipe cycles than the fp32-MFMA kernel it replaces (16x16x4 f32: 32
 //   cycles for 2 Kflop; three 16x16x32 f16: 48 cycles for 16 Kflop).
 // ------------------------------------------------------------------------------------------------
-constexpr float kPScale = 1024.0f;
+// (probabilities are split at scale 1024: the +10 in the exponent bias of the softmax below)
 
 __device__ __forceinline__ f16x8 as_f16x8(bf16x8 v) { return __builtin_bit_cast(f16x8, v); }
 
@@ -447,35 +449,11 @@ __device__ __forceinline__ void split8(const float4 a, const float4 b, f16x8& hi
   for (int e = 0; e < 8; ++e) { f16 h, l; split2h(v[e], h, l); hi[e] = h; lo[e] = l; }
 }
 
-// rows [0, n) of K and V (64 fp32 per row for this head) -> four swizzled LDS images (K hi, K lo, V hi, V lo, `plane`
-// bytes apart in that order); rows [n, NK) zeroed.
-template <int NK, int NTHREADS>
-__device__ __forceinline__ void stage_kv_x2(const float* __restrict__ kbase, size_t row_stride, int n, char* KH, int plane,
-                                            int tid, int C) {
-  for (int idx = tid; idx < NK * 8; idx += NTHREADS) {
-    const int row = idx >> 3, slot = idx & 7;
-    float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, v0 = k0, v1 = k0;
-    if (row < n) {
-      const float* src = kbase + (size_t)row * row_stride + slot * 8;
-      k0 = *reinterpret_cast<const float4*>(src); k1 = *reinterpret_cast<const float4*>(src + 4);
-      v0 = *reinterpret_cast<const float4*>(src + C); v1 = *reinterpret_cast<const float4*>(src + C + 4);
-    }
-    f16x8 kh, kl, vh, vl;
-    split8(k0, k1, kh, kl);
-    split8(v0, v1, vh, vl);
-    const int ko = row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
-    const int vo = row * 128 + ((slot ^ (((row >> 1) & 3) << 1)) << 4);
-    *reinterpret_cast<f16x8*>(KH + ko) = kh;
-    *reinterpret_cast<f16x8*>(KH + plane + ko) = kl;
-    *reinterpret_cast<f16x8*>(KH + 2 * plane + vo) = vh;
-    *reinterpret_cast<f16x8*>(KH + 3 * plane + vo) = vl;
-  }
-}
-
-template <int NKT, int C0>
+// key chunks [C0, C1) of O^T += V^T P^T (32 keys per chunk)
+template <int NKT, int C0, int C1 = NKT / 2, int WINDOW = 2>
 __device__ __forceinline__ void pv_chunks_x2(const FragBases& fb, int plane, const f16x8 (&ph)[NKT / 2],
                                              const f16x8 (&pl)[NKT / 2], f32x4 (&o)[4]) {
-  if constexpr (C0 < NKT / 2) {
+  if constexpr (C0 < C1) {
 #pragma unroll
     for (int dn = 0; dn < 4; ++dn) {
       const f16x8 vh = as_f16x8(load_vt_frag<C0>(fb.v[dn]));
@@ -484,17 +462,17 @@ __device__ __forceinline__ void pv_chunks_x2(const FragBases& fb, int plane, con
       o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[C0], o[dn], 0, 0, 0);
       o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[C0], o[dn], 0, 0, 0);
     }
-    if (C0 & 1) __builtin_amdgcn_sched_barrier(0);
-    pv_chunks_x2<NKT, C0 + 1>(fb, plane, ph, pl, o);
+    if ((C0 + 1) % WINDOW == 0) __builtin_amdgcn_sched_barrier(0);   // bound the ds_read hoisting window (VGPR pressure)
+    pv_chunks_x2<NKT, C0 + 1, C1, WINDOW>(fb, plane, ph, pl, o);
   }
 }
 
-// One 16-query tile against NKT 16-key tiles resident in LDS.  fb: fragment bases into the K hi / V hi images (the lo
-// images are `plane` bytes further).  qh/ql: the tile's query fragments (d 0..31, 32..63), values x 16.
-// Returns O^T accumulators scaled by 16 * 1024 and the softmax denominator of query (lane & 15).
+// Scores and softmax of one 16-query tile against NKT 16-key tiles resident in LDS.  fb: fragment bases into the K hi
+// image (the lo image is `plane` bytes further).  qh/ql: the tile's query fragments (d 0..31, 32..63), values x 16.
+// Returns the probabilities as split-fp16 B operands (x 1024) and 1024 x the softmax denominator of query (lane & 15).
 template <int NKT>
-__device__ __forceinline__ void attn_tile_x2(const FragBases& fb, int plane, const f16x8 (&qh)[2], const f16x8 (&ql)[2],
-                                             int n, int lane, f32x4 (&o)[4], float& denom) {
+__device__ __forceinline__ void attn_scores_x2(const FragBases& fb, int plane, const f16x8 (&qh)[2], const f16x8 (&ql)[2],
+                                               int n, int lane, f16x8 (&ph)[NKT / 2], f16x8 (&pl)[NKT / 2], float& denom) {
   const int fg = lane >> 4;
   const float cexp = 0.125f * 1.44269504088896340736f / (kActScale * kActScale);   // hd^-0.5 log2(e) / (16 * 16)
   f32x4 s[NKT];
@@ -514,39 +492,44 @@ __device__ __forceinline__ void attn_tile_x2(const FragBases& fb, int plane, con
     s[t] = a;
     if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // bound the ds_read hoisting window (VGPR pressure)
   }
-  float mx = -INFINITY;
+  // keys >= n are masked.  The usual case (n in the last key tile) touches that tile only; the per-element selects of
+  // the general form were a third of this kernel's VALU instructions.
+  if (n > 16 * (NKT - 1)) {
 #pragma unroll
-  for (int t = 0; t < NKT; ++t) {
-    if (16 * (t + 1) > n) {
+    for (int r = 0; r < 4; ++r)
+      if (16 * (NKT - 1) + 4 * fg + r >= n) s[NKT - 1][r] = -INFINITY;
+  } else {
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (16 * t + 4 * fg + r >= n) s[t][r] = -INFINITY;
-    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
-  }
   mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  // p * 1024 = exp2(s cexp - mx cexp + 10): one fma and the bare v_exp_f32 per element (arguments <= 10; a probability
+  // below 2^-126 becomes 0 instead of a denormal); the denominator is accumulated at the same scale.
+  const float nb = fmaf(-mx, cexp, 10.0f);
   float sum = 0.f;
-  f16x8 ph[NKT / 2], pl[NKT / 2];
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float p = exp2f((s[t][r] - mx) * cexp);      // as the fp32-MFMA kernel: one rounding of the scaled argument
-      sum += p;
-      f16 h, l;
-      split2h_scaled(p * kPScale, h, l);
+      const float y = __builtin_amdgcn_exp2f(fmaf(s[t][r], cexp, nb));
+      sum += y;
+      const f16 h = (f16)y;
       ph[t >> 1][(t & 1) * 4 + r] = h;
-      pl[t >> 1][(t & 1) * 4 + r] = l;
+      pl[t >> 1][(t & 1) * 4 + r] = (f16)fmaf(y, 1.0f, -(float)h);
     }
   }
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
-  denom = sum;
-#pragma unroll
-  for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  pv_chunks_x2<NKT, 0>(fb, plane, ph, pl, o);
+  denom = sum;                                         // = 1024 x the softmax denominator
 }
 
 // this lane's query fragments (16 fp32 of row q: d = fg*8 .. +7 and 32 + fg*8 .. +7), split
@@ -555,6 +538,15 @@ __device__ __forceinline__ void load_q_x2(const float* qrow, int fg, f16x8 (&qh)
   for (int half = 0; half < 2; ++half) {
     const float* p = qrow + half * 32 + fg * 8;
     split8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), qh[half], ql[half]);
+  }
+}
+
+// this lane's K fragments of key row `krow` (packed row: hi plane at krow, lo plane C halves further): already operands
+__device__ __forceinline__ void load_k_x2(const f16* krow, int C, int fg, f16x8 (&kh)[2], f16x8 (&kl)[2]) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    kh[half] = *reinterpret_cast<const f16x8*>(krow + half * 32 + fg * 8);
+    kl[half] = *reinterpret_cast<const f16x8*>(krow + C + half * 32 + fg * 8);
   }
 }
 
@@ -577,45 +569,172 @@ __device__ __forceinline__ void store_o_x2(const f32x4 (&o)[4], float inv, void*
   }
 }
 
-// temporal axis: one workgroup per (sequence, head); NW waves share the K/V images (the four planes of 256 keys fill
-// 128 KiB of LDS, so only one workgroup fits a CU: 16 waves -- one 16-query tile each at F = 243 -- give the matrix
-// pipes and the softmax VALU work of different tiles something to overlap with)
-template <int NKT, int OUTS, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_temporal_x2_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
-                                                               SeqMap map, int C, int heads, size_t plane_elems) {
+// One LDS-DMA wave-instruction: lane l's 16 bytes at `g` -> LDS bytes [lds + 16 l, +16) (`lds` wave-uniform).  Issued as
+// inline assembly on purpose: for the builtin the compiler (a) holds every later ds_read that might alias the destination
+// behind vmcnt(0) and (b) marks the instruction as a FLAT access of two address spaces, after which it stops counting
+// and turns EVERY vector-memory wait of the kernel into vmcnt(0) -- both would serialise the pipeline below, whose
+// ordering is carried by explicit counted waits and barriers instead.
+__device__ __forceinline__ void lds_dma16(const char* g, const char* lds) {
+  const unsigned la = (unsigned)(__UINTPTR_TYPE__)LPTR(lds);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory");   // (m0 is reserved: the compiler re-loads it before each of its own uses)
+}
+
+// 16-byte global load the compiler does not track (it would wait for it with counts that ignore the LDS-DMA operations
+// queued behind it, i.e. far too early): the caller waits with wait_vmcnt and then passes the registers through settle().
+__device__ __forceinline__ f32x4 gload16_untracked(const float* p) {
+  f32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ void settle(f32x4& r) { asm volatile("" : "+v"(r)); }
+
+// s_waitcnt vmcnt(v) with the other counters left alone (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8])
+template <int V>
+__device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt((V & 15) | (7 << 4) | (15 << 8) | ((V >> 4) << 14)); }
+
+// temporal axis: PERSISTENT workgroups (one per CU: the four planes of 256 keys fill 128 KiB of LDS), 8 waves, each wave
+// TPW = 1 or 2 16-query tiles of the current (sequence, head) problem (two waves per SIMD -> 256 registers per wave:
+// the score row, the probabilities of both tiles and the prefetched queries of the next problem all stay in registers).
+// K and V arrive by LDS-DMA straight from the packed qkv rows (8 rows x 128 B per wave-instruction, the image swizzle
+// applied on the global side) and are double-buffered in TIME, not in space:
+//     K(p+1) streams in while problem p multiplies P.V,   V(p+1) while problem p+1 computes its scores.
+//   top:  vmcnt(V pieces) -> K(p), q(p) landed        barrier 1     scores + softmax
+//         vmcnt(0)        -> V(p) landed              barrier 2     (every wave is done with the K image)  issue K(p+1)
+//         P.V (q(p+1) loads first), store O(p)        barrier 3     (every wave is done with the V image)  issue V(p+1)
+// The vmcnt(2 PER) at the top is exact: vector memory operations of a wave retire in order and the 2 PER youngest are
+// the V pieces.
+template <int NKT, int OUTS>
+__global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
+                                                               SeqMap map, int C, int heads, size_t plane_elems,
+                                                               int n_prob) {
+  constexpr int NW = 8;
+  constexpr int TPW = (NKT + NW - 1) / NW;             // query tiles per wave
   constexpr int NK = 16 * NKT;
   constexpr int PLANE = NK * 128;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PER = (2 * NKT + NW - 1) / NW;         // DMA pieces per wave and plane
+  __shared__ __attribute__((aligned(16))) char kimg[2 * PLANE];
+  __shared__ __attribute__((aligned(16))) char vimg[2 * PLANE];
   const int n = map.n_tok;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
-  const int base = seq_base(map, seq);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ts = map.tok_stride;
-  const size_t ld = (size_t)3 * C;
-  const float* qbase = qkv + (size_t)base * ld + (size_t)head * 64;
-  const int fi = lane & 15, fg = lane >> 4;
+  const size_t ldb = (size_t)12 * C;                   // bytes per packed token row
   const int n_qt = (n + 15) >> 4;
-  stage_kv_x2<NK, NW * 64>(qbase + C, (size_t)ts * ld, n, smem, PLANE, tid, C);
-  FragBases fb = make_frag_bases(smem, smem + 2 * PLANE, lane);
-  __syncthreads();
-  const float inv_scale = 1.0f / (kActScale * kPScale);
-  for (int qt = wave; qt < n_qt; qt += NW) {
-    const int q = qt * 16 + fi;
-    f16x8 qh[2], ql[2];
-    load_q_x2(qbase + (size_t)min(q, n - 1) * ts * ld, fg, qh, ql);
-    f32x4 o[4];
-    float denom;
-    attn_tile_x2<NKT>(fb, PLANE, qh, ql, n, lane, o, denom);
-    if (q < n) store_o_x2<OUTS>(o, inv_scale / denom, out_v, (size_t)(base + q * ts) * C + head * 64 + fg * 4, plane_elems);
+  const FragBases fb = make_frag_bases(kimg, vimg, lane);
+  const float inv_scale = 1.0f / kActScale;            // O^T is scaled by 16 x 1024, the denominator by 1024
+
+  // DMA piece `pc` of a plane = image rows 8 pc .. 8 pc + 7; a lane moves the 16-byte slot that belongs at position
+  // (lane & 7) of row 8 pc + (lane >> 3): K slot s sits at s ^ ((row >> 1) & 7), V slot s at s ^ (((row >> 1) & 3) << 1)
+  auto problem_row0 = [&](int p, int& head) -> const char* {
+    const int seq = p / heads;
+    head = p - seq * heads;
+    return reinterpret_cast<const char*>(qkv) + (size_t)seq_base(map, seq) * ldb;
+  };
+  // (per-lane source offsets are re-derived at every use from a copy of the lane id the compiler cannot see through:
+  // hoisted out of the problem loop they are ~40 live registers, which spills -- and scratch traffic shares vmcnt)
+  auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
+  auto issue_kv = [&](const char* row0, int head, int is_v) {
+    const int l = opaque(lane);
+    const char* g = row0 + (is_v ? 8 : 4) * C + head * 128;
+    char* img = is_v ? vimg : kimg;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int pc = min(wave + j * NW, 2 * NKT - 1);  // (surplus pieces repeat the last one: same bytes, same place)
+      const int row = pc * 8 + (l >> 3);
+      const int sw = is_v ? (((row >> 1) & 3) << 1) : ((row >> 1) & 7);
+      // rows >= n: a copy of the last row (finite values; their scores are masked, their probabilities are 0)
+      const char* gj = g + (unsigned)(min(row, n - 1) * ts) * (unsigned)ldb + (((l & 7) ^ sw) << 4);
+      lds_dma16(gj, img + pc * 1024);
+      lds_dma16(gj + 2 * C, img + PLANE + pc * 1024);
+    }
+  };
+  f32x4 qr[TPW][4];                                    // raw query fragments of the next problem
+  auto load_q_raw = [&](const char* row0, int head) {
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      const int qt = wave + u * NW;
+      if (qt < n_qt) {
+        const int l = opaque(lane);
+        const int q = qt * 16 + (l & 15);
+        const float* qrow = reinterpret_cast<const float*>(row0 + (size_t)min(q, n - 1) * ts * ldb) + head * 64 + (l >> 4) * 8;
+        qr[u][0] = gload16_untracked(qrow);
+        qr[u][1] = gload16_untracked(qrow + 4);
+        qr[u][2] = gload16_untracked(qrow + 32);
+        qr[u][3] = gload16_untracked(qrow + 36);
+      }
+    }
+  };
+
+  int p = blockIdx.x;
+  if (p >= n_prob) return;
+  // waves w and w + 4 share a SIMD and run the same phases between the same barriers: the static priority lets one of
+  // them take the matrix pipe first, after which its softmax (VALU) runs beside the other's MFMAs
+  if ((wave >> 2) & 1) __builtin_amdgcn_s_setprio(1);
+  int head;
+  const char* row0 = problem_row0(p, head);
+  issue_kv(row0, head, 0);
+  load_q_raw(row0, head);
+  issue_kv(row0, head, 1);
+  for (;;) {
+    wait_vmcnt<2 * PER>();
+    __builtin_amdgcn_s_barrier();                      // 1: the K image of problem p is complete
+    f16x8 ph[TPW][NKT / 2], pl[TPW][NKT / 2];
+    float denom[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      denom[u] = 1.f;
+      if (wave + u * NW < n_qt) {
+        f16x8 qh[2], ql[2];
+        float4 qf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          settle(qr[u][i]);                            // (after the counted wait above)
+          qf[i] = make_float4(qr[u][i][0], qr[u][i][1], qr[u][i][2], qr[u][i][3]);
+        }
+        split8(qf[0], qf[1], qh[0], ql[0]);
+        split8(qf[2], qf[3], qh[1], ql[1]);
+        attn_scores_x2<NKT>(fb, PLANE, qh, ql, n, lane, ph[u], pl[u], denom[u]);
+      }
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                      // 2: V image complete; nobody reads the K image any more
+    const int pn = p + gridDim.x;
+    const bool has_next = pn < n_prob;
+    int head_n = 0;
+    const char* row0_n = row0;
+    if (has_next) {
+      row0_n = problem_row0(pn, head_n);
+      issue_kv(row0_n, head_n, 0);
+      load_q_raw(row0_n, head_n);
+    }
+    const int tok0 = seq_base(map, p / heads);
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      const int qt = wave + u * NW;
+      if (qt < n_qt) {
+        f32x4 o[4];
+#pragma unroll
+        for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        pv_chunks_x2<NKT, 0>(fb, PLANE, ph[u], pl[u], o);
+        const int l = opaque(lane);
+        const int q = qt * 16 + (l & 15);
+        if (q < n)
+          store_o_x2<OUTS>(o, inv_scale / denom[u], out_v, (size_t)(tok0 + q * ts) * C + head * 64 + (l >> 4) * 4, plane_elems);
+      }
+    }
+    if (!has_next) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // 3: nobody reads the V image any more
+    issue_kv(row0_n, head_n, 1);
+    p = pn; row0 = row0_n; head = head_n;
   }
 }
 
 // spatial axis (<= 32 tokens per sequence): one WAVE per (sequence, head).  The K fragments of its two 16-key tiles are
-// loaded straight from global memory into the MFMA operand layout (lane (key, g) <- 2 x 32 contiguous bytes of one K row,
-// exactly like a query fragment) and split in registers; only V goes through LDS (its fragments are transposed reads):
-// a private 8 KiB image (V hi, V lo: 32 rows x 128 B each), so a 256-thread workgroup needs 32 KiB and five of them fit a
-// CU -- this kernel is latency / HBM-bound (8 KB per token), and with K staged as well (16 KiB per wave, two workgroups
-// per CU) it ran at 3.8 TB/s.
+// loaded straight from the packed rows into the MFMA operand layout (lane (key, g) <- 2 x 16 contiguous bytes of each K
+// plane); only V goes through LDS (its fragments are transposed reads): a private 8 KiB image (V hi, V lo: 32 rows x
+// 128 B each), so a 256-thread workgroup needs 32 KiB and five of them fit a CU -- this kernel is latency / HBM-bound
+// (8 KB per token), and with K staged as well (16 KiB per wave, two workgroups per CU) it ran at 3.8 TB/s.
 template <int OUTS>
 __global__ __launch_bounds__(256) void attn_spatial_x2_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
                                                               int n_prob, SeqMap map, int C, int heads, size_t plane_elems) {
@@ -628,8 +747,8 @@ __global__ __launch_bounds__(256) void attn_spatial_x2_kernel(const float* __res
   const int seq = pid / heads, head = pid % heads;
   const int base = seq_base(map, seq);
   const int ts = map.tok_stride;
-  const size_t ld = (size_t)3 * C;
-  const float* qbase = qkv + (size_t)base * ld + (size_t)head * 64;
+  const size_t ldb = (size_t)12 * C;                   // bytes per packed token row: q fp32 | k hi | k lo | v hi | v lo
+  const char* rows = reinterpret_cast<const char*>(qkv) + (size_t)base * ldb;
   char* img = smem + wave * 2 * PLANE;
   const int fi = lane & 15, fg = lane >> 4;
   const int n_qt = (n + 15) >> 4;
@@ -637,26 +756,25 @@ __global__ __launch_bounds__(256) void attn_spatial_x2_kernel(const float* __res
   f16x8 qh[2][2], ql[2][2], kh[2][2], kl[2][2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const float* row = qbase + (size_t)min(t * 16 + fi, n - 1) * ts * ld;
-    load_q_x2(row, fg, qh[t], ql[t]);
-    load_q_x2(row + C, fg, kh[t], kl[t]);             // K row of the same token: same fragment shape
+    const char* row = rows + (size_t)min(t * 16 + fi, n - 1) * ts * ldb;
+    load_q_x2(reinterpret_cast<const float*>(row) + head * 64, fg, qh[t], ql[t]);
+    load_k_x2(reinterpret_cast<const f16*>(row + 4 * C) + head * 64, C, fg, kh[t], kl[t]);
   }
   for (int idx = lane; idx < 32 * 8; idx += 64) {      // V rows -> hi / lo images (rows >= n zeroed)
     const int row = idx >> 3, slot = idx & 7;
-    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    f16x8 vh = {}, vl = {};
     if (row < n) {
-      const float* src = qbase + 2 * C + (size_t)row * ts * ld + slot * 8;
-      v0 = *reinterpret_cast<const float4*>(src); v1 = *reinterpret_cast<const float4*>(src + 4);
+      const f16* src = reinterpret_cast<const f16*>(rows + (size_t)row * ts * ldb + 8 * C) + head * 64 + slot * 8;
+      vh = *reinterpret_cast<const f16x8*>(src);
+      vl = *reinterpret_cast<const f16x8*>(src + C);
     }
-    f16x8 vh, vl;
-    split8(v0, v1, vh, vl);
     const int vo = row * 128 + ((slot ^ (((row >> 1) & 3) << 1)) << 4);
     *reinterpret_cast<f16x8*>(img + vo) = vh;
     *reinterpret_cast<f16x8*>(img + PLANE + vo) = vl;
   }
   const FragBases fb = make_frag_bases(img, img, lane);   // only the V bases are used
   // (wave-private LDS image: the LDS pipe executes one wave's accesses in order, no barrier needed)
-  const float inv_scale = 1.0f / (kActScale * kPScale);
+  const float inv_scale = 1.0f / kActScale;            // O^T is scaled by 16 x 1024, `sum` by 1024
   const float cexp = 0.125f * 1.44269504088896340736f / (kActScale * kActScale);
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -684,17 +802,18 @@ __global__ __launch_bounds__(256) void attn_spatial_x2_kernel(const float* __res
       }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float nb = fmaf(-mx, cexp, 10.0f);          // p * 1024 = exp2(s cexp - mx cexp + 10), as attn_scores_x2
     float sum = 0.f;
     f16x8 ph[1], pl[1];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = exp2f((s[t][r] - mx) * cexp);
-        sum += p;
-        f16 h, l;
-        split2h_scaled(p * kPScale, h, l);
-        ph[0][t * 4 + r] = h; pl[0][t * 4 + r] = l;
+        const float y = __builtin_amdgcn_exp2f(fmaf(s[t][r], cexp, nb));
+        sum += y;
+        const f16 h = (f16)y;
+        ph[0][t * 4 + r] = h;
+        pl[0][t * 4 + r] = (f16)fmaf(y, 1.0f, -(float)h);
       }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
@@ -706,19 +825,45 @@ __global__ __launch_bounds__(256) void attn_spatial_x2_kernel(const float* __res
   }
 }
 
+// fp32 qkv rows [T, 3C] -> the packed rows of the split-fp16 attention kernels (what the qkv Linear writes directly with
+// EPI_QKV_PACK); used by d3dp_op_attention, whose C-ABI input is the plain fp32 layout.
+__global__ void qkv_pack_x2_kernel(const float* __restrict__ src, char* __restrict__ dst, size_t T, int C) {
+  const size_t total = T * (size_t)(3 * C / 4);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t t = i / (3 * C / 4);
+    const int c = (int)(i - t * (3 * C / 4)) * 4, region = c / C, cn = c - region * C;
+    const float4 v = *reinterpret_cast<const float4*>(src + t * 3 * C + c);
+    char* row = dst + t * 12 * C;
+    if (region == 0) {
+      *reinterpret_cast<float4*>(row + cn * 4) = v;
+    } else {
+      const float a[4] = {v.x, v.y, v.z, v.w};
+      f16x4 ph, pl;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { f16 h, l; split2h(a[e], h, l); ph[e] = h; pl[e] = l; }
+      *reinterpret_cast<f16x4*>(row + region * 4 * C + cn * 2) = ph;
+      *reinterpret_cast<f16x4*>(row + region * 4 * C + 2 * C + cn * 2) = pl;
+    }
+  }
+}
+
 template <int NKT, int OUTS>
 int launch_temporal_x2(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, hipStream_t st) {
   constexpr int NK = 16 * NKT;
-  const size_t lds = (size_t)NK * 128 * 4;
-  constexpr int NW = NKT > 8 ? 16 : 8;
-  auto kern = attn_temporal_x2_kernel<NKT, OUTS, NW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) return -3;
-    attr_set = true;
+  const size_t lds = (size_t)NK * 128 * 4;             // static LDS of the kernel (K and V images, two planes each)
+  constexpr int NW = 8;
+  auto kern = attn_temporal_x2_kernel<NKT, OUTS>;
+  static int n_wg = 0;
+  if (!n_wg) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -3;
+    const int per_cu = (int)((160 * 1024) / lds) < 2048 / (NW * 64) ? (int)((160 * 1024) / lds) : 2048 / (NW * 64);
+    n_wg = prop.multiProcessorCount * per_cu;          // persistent: as many workgroups as fit the chip
   }
-  hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(NW * 64), lds, st, (const float*)qkv, out, map, C, heads, plane);
+  const int n_prob = n_seq * heads;
+  hipLaunchKernelGGL(kern, dim3(n_prob < n_wg ? n_prob : n_wg), dim3(NW * 64), 0, st, (const float*)qkv, out, map, C,
+                     heads, plane, n_prob);
   return 0;
 }
 
@@ -926,8 +1071,15 @@ int d3dp_launch_attn_temporal_f32(int act, const void* qkv, void* out, int n_seq
 #undef TF32_CASE
 }
 
-// EXACT-mode attention on the fp16 matrix cores (split-fp16 operands; head dim 64).  act 0 -> fp32 out, 3 -> two fp16
-// planes out (the EXACT Linear's operand format).  axis 0: <= 32 tokens per sequence; axis 1: <= 256.
+// EXACT-mode attention on the fp16 matrix cores (split-fp16 operands; head dim 64) over PACKED qkv rows (see above).
+// act 0 -> fp32 out, 3 -> two fp16 planes out (the EXACT Linear's operand format).  axis 0: <= 32 tokens per sequence;
+// axis 1: <= 256.
+void d3dp_launch_qkv_pack_x2(const float* src, void* dst, size_t T, int C, hipStream_t st) {
+  const size_t total = T * (size_t)(3 * C / 4);
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(qkv_pack_x2_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, (char*)dst, T, C);
+}
+
 int d3dp_launch_attn_x2(int act, int axis, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
                         hipStream_t st) {
   if (C / heads != 64 || map.n_tok < 1 || (act != 0 && act != 3)) return -2;

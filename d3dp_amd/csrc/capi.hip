@@ -115,6 +115,7 @@ struct d3dp_ctx {
   bool train() const { return cfg.mode == D3DP_MODE_TRAIN; }
   bool exact() const { return !fast() && !train(); }
   bool x2() const { return exact() && exact_impl == 0; }
+  bool x2_attn() const { return x2() && cfg.channels / cfg.heads == 64; }   // split-fp16 attention kernels (head dim 64)
   bool x3() const { return exact() && exact_impl == 1; }
   int act() const { return fast() ? 1 : (x3() ? 2 : (x2() ? 3 : 0)); }   // code understood by the row-wise launchers
   size_t act_size() const { return fast() ? 2 : (x3() ? 6 : 4); }    // bytes per element of a Linear-input activation
@@ -168,7 +169,11 @@ int linear(d3dp_ctx* c, int cls, int epi, int out_f32, const void* A, const void
            int M, int N, int K, hipStream_t st) {
   Scope s(c, cls, st);
   if (c->fast()) return d3dp_launch_linear_bf16_stream(epi, out_f32, A, W, bias, out, M, N, K, st);
-  if (c->x2()) return d3dp_launch_linear_f16x2(epi, A, W, bias, wu * kActUnscale, (float*)out, out, M, N, K, st);
+  if (c->x2()) {
+    // the qkv Linear writes the packed rows of the split-fp16 attention kernels (K and V already as fp16 planes)
+    if (cls == P_QKV && c->x2_attn()) epi = EPI_QKV_PACK;
+    return d3dp_launch_linear_f16x2(epi, A, W, bias, wu * kActUnscale, (float*)out, out, M, N, K, st);
+  }
   if (c->x3()) return d3dp_launch_linear_bf16x3(epi, A, W, bias, (float*)out, out, M, N, K, st);
   return d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, st);
 }
@@ -179,7 +184,7 @@ SeqMap temporal_map(int F, int J) { return SeqMap{F, J, F * J, 1, J}; }
 int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, hipStream_t st) {
   const d3dp_cfg& g = c->cfg;
   Scope s(c, axis == 0 ? P_ATTN_S : P_ATTN_T, st);
-  if (c->x2() && g.channels / g.heads == 64 && (axis == 1 || g.joints <= 32))   // split-fp16 operands on the fp16 matrix cores
+  if (c->x2_attn())                                    // split-fp16 operands on the fp16 matrix cores; packed qkv rows
     return d3dp_launch_attn_x2(3, axis, qkv, out, axis == 0 ? n_bh * g.frames : n_bh * g.joints,
                                axis == 0 ? spatial_map(g.frames, g.joints) : temporal_map(g.frames, g.joints), g.channels,
                                g.heads, st);
@@ -573,8 +578,15 @@ int d3dp_op_attention(int32_t act_bf16, int32_t impl, int32_t axis, const void* 
   if (act_bf16 != 0 && act_bf16 != 1) return fail(D3DP_EINVAL, "act_bf16 must be 0 or 1");
   if (impl == 2) {       // EXACT mode: split-fp16 operands on the fp16 matrix cores, fp32 in / fp32 out
     if (act_bf16) return fail(D3DP_EINVAL, "split-fp16 attention takes fp32 activations");
-    LAUNCH_TRY(d3dp_launch_attn_x2(0, axis, qkv, out, axis == 0 ? n_bh * F : n_bh * J, axis == 0 ? spatial_map(F, J) : temporal_map(F, J),
-                                   C, heads, st));
+    // the kernels read the packed rows the EXACT qkv Linear writes: repack the fp32 rows into a stream-ordered temporary
+    void* packed = nullptr;
+    const size_t T = (size_t)n_bh * F * J;
+    HIP_TRY(hipMallocAsync(&packed, T * 12 * (size_t)C, st));
+    d3dp_launch_qkv_pack_x2((const float*)qkv, packed, T, C, st);
+    const int rc = d3dp_launch_attn_x2(0, axis, packed, out, axis == 0 ? n_bh * F : n_bh * J,
+                                       axis == 0 ? spatial_map(F, J) : temporal_map(F, J), C, heads, st);
+    HIP_TRY(hipFreeAsync(packed, st));
+    LAUNCH_TRY(rc);
   } else if (axis == 0 && impl == 1) {
     if (!act_bf16) return fail(D3DP_EINVAL, "MFMA spatial attention needs bf16 activations");
     LAUNCH_TRY(d3dp_launch_attn_spatial_bf16(qkv, out, n_bh * F, spatial_map(F, J), C, heads, st));

@@ -31,17 +31,30 @@
 //   EPI_GELU -> gelu_erf(.) re-split into two fp16 planes (the fc2 operand)
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
 // Timing probes (results INVALID), compiled in only with -DD3DP_X2_PROBE=bits for tools/gemm_bench.py A/B builds; the
-// product library is built without it.  1: loaders issue no loads; 2: no fragment reads; 4: no output stores.
+// product library is built without it.  1: loaders issue no loads; 2: fragments read from one fixed stage (hoisted out of
+// the k-loop); 4: no output stores (the epilogue sits behind a condition that is false at run time, so the accumulators
+// and with them the MFMAs stay live -- compiling the epilogue out removes every MFMA); 8: no MFMAs (fragment reads kept
+// live); 16: odd workgroups start half a tile late (D3DP_X2_STAGGER s_sleep(127) periods).
 #ifndef D3DP_X2_PROBE
 #define D3DP_X2_PROBE 0
 #endif
 
 // Output stores carry the nontemporal hint: the tile round's 4 MiB of output per XCD is not read again on that XCD
 // and otherwise pushes the weight matrix out of the 4 MiB L2 between rounds (FETCH_SIZE measurement in DESIGN.md).
+#if D3DP_X2_PROBE & 32                                  // 32: no k-step barriers (with 1|4: the loop without its synchronisation)
+#define X2_BARRIER() asm volatile("" ::: "memory")
+#else
+#define X2_BARRIER() asm volatile("s_barrier" ::: "memory")
+#endif
+#ifndef D3DP_X2_LAG
+#define D3DP_X2_LAG 1
+#endif
 #ifndef D3DP_NT_OUT
 #define D3DP_NT_OUT 1
 #endif
@@ -68,8 +81,23 @@ __device__ __forceinline__ int swz64(int row, int s) { return s ^ (((row >> 3) &
 // W row carried by LDS row q of a 64-column strip: MFMA tile ni = q>>4, operand row i = q&15 -> output column 4 i + ni
 __device__ __forceinline__ int colperm(int q) { return (q & 15) * 4 + (q >> 4); }
 
-// TAG is a name tag only (same code): the qkv Linear (N = 3K) is instantiated as its own kernel symbol so that
-// rocprofv3 --stats reports it separately from the proj Linear, which shares EPI with it.
+// Two fp16 planes of a 4-column group per lane -> ONE 16-byte store per lane: lanes 2j / 2j+1 hold neighbouring column
+// groups of the same row; the even lane collects both hi halves (8 columns of the hi plane), the odd lane both lo halves.
+// `dst`: where this lane's 16 bytes go (even lanes: own columns in the hi plane; odd lanes: the even neighbour's columns
+// in the lo plane).
+__device__ __forceinline__ void store_planes_paired(char* dst, f16x4 ph, f16x4 pl, bool odd, bool live) {
+  const uint2 h = __builtin_bit_cast(uint2, ph), l = __builtin_bit_cast(uint2, pl);
+  const uint2 send = odd ? h : l;
+  uint2 recv;                                          // quad_perm [1,0,3,2]: the value of lane ^ 1
+  recv.x = __builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xF, 0xF, false);
+  recv.y = __builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xF, 0xF, false);
+  using u32x4 = unsigned __attribute__((ext_vector_type(4)));
+  const u32x4 out = odd ? (u32x4){recv.x, recv.y, l.x, l.y} : (u32x4){h.x, h.y, recv.x, recv.y};
+  if (live) OUT_STORE(reinterpret_cast<u32x4*>(dst), out);
+}
+
+// TAG 1: the qkv Linear feeding the split-fp16 attention kernels -- packed output rows (see the epilogue); as its own
+// kernel symbol rocprofv3 --stats also reports it separately from the proj Linear, which shares EPI with it.
 template <int EPI, int TAG>
 __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__ A2, const f16* __restrict__ W2,
                                                          const float* __restrict__ bias, float unscale,
@@ -92,6 +120,9 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
     // ------------------------------------------------------------------ loader waves
     const int lw = wave - XNCW;
     const int lr = lane >> 2, lps = lane & 3;
+#ifdef D3DP_X2_LPRIO
+    __builtin_amdgcn_s_setprio(D3DP_X2_LPRIO);
+#endif
     const size_t planeA = (size_t)M * K, planeW = (size_t)N * K;
     int ti = 0, ks = 0, slot = 0;                      // (tile, k-step, ring slot) of the next slab to issue
     const f16* pa[4];                                  // this lane's source rows of the current tile (k = 0, hi plane)
@@ -138,7 +169,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
       // 12 glds per loader wave per k-step: loads(g) landed, loads(g+1) stay in flight
       if (g + 1 < gtot) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");
+      X2_BARRIER();
       if (g + 2 < gtot) issue();                       // into the slot of k-step g-1: every wave has passed barrier g
     }
     return;
@@ -153,15 +184,80 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
   const size_t planeO = (size_t)M * N;
   f32x4 acc[4][4];
   __builtin_amdgcn_s_setprio(1);
+#if D3DP_X2_PROBE & 16
+  if (L & 1)
+    for (int i = 0; i < D3DP_X2_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   int slot = 0;
   for (int ti = 0; ti < n_my; ++ti) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if D3DP_X2_LAG
+    // The last two products of row block 3 (al.wh, ah.wh: 8 MFMAs) are issued AFTER the next k-step's barrier, behind
+    // that step's first fragment reads: they cover the LDS latency that otherwise idles the matrix pipe after every
+    // barrier release (all waves of the workgroup read at once).  Their operands stay in 24 registers across the
+    // barrier; the k-loop is unrolled by two so that the two fragment sets swap roles without register copies.
+    f16x8 wfa[4][2], wfb[4][2], taa[2], tab[2];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) wfb[ni][0] = (f16x8){};
+    tab[0] = tab[1] = (f16x8){};
+    auto kstep = [&](f16x8 (&wf)[4][2], f16x8 (&ta)[2], const f16x8 (&pw)[4][2], const f16x8 (&pa)[2]) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): this wave has read everything it wanted from the old slot
+      X2_BARRIER();
+      __builtin_amdgcn_sched_barrier(0);
+      const char* sb = smem + slot * XSTAGE;
+      slot = (slot == XNSTAGE - 1) ? 0 : slot + 1;
+      f16x8 ah[2], al[2];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          wf[ni][pl] = *reinterpret_cast<const f16x8*>(sb + offW + pl * XW_PLANE + ni * 1024);
+      ah[0] = *reinterpret_cast<const f16x8*>(sb + offA);
+      al[0] = *reinterpret_cast<const f16x8*>(sb + offA + XA_PLANE);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[3][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[1], pw[ni][0], acc[3][ni], 0, 0, 0);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[3][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[0], pw[ni][0], acc[3][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < 3; ++mi) {
+        const int b = mi & 1;
+        if (mi < 2) {                                  // next row block's fragments while this one multiplies
+          ah[b ^ 1] = *reinterpret_cast<const f16x8*>(sb + offA + (mi + 1) * 1024);
+          al[b ^ 1] = *reinterpret_cast<const f16x8*>(sb + offA + XA_PLANE + (mi + 1) * 1024);
+        } else {
+          ta[0] = *reinterpret_cast<const f16x8*>(sb + offA + 3 * 1024);
+          ta[1] = *reinterpret_cast<const f16x8*>(sb + offA + XA_PLANE + 3 * 1024);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], wf[ni][1], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[b], wf[ni][0], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], wf[ni][0], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[3][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[0], wf[ni][1], acc[3][ni], 0, 0, 0);
+    };
+#pragma unroll 1
+    for (int ks = 0; ks < NK; ks += 2) {               // NK is even (K % 64 == 0, checked by the launcher)
+      kstep(wfa, taa, wfb, tab);
+      kstep(wfb, tab, wfa, taa);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[3][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tab[1], wfb[ni][0], acc[3][ni], 0, 0, 0);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[3][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tab[0], wfb[ni][0], acc[3][ni], 0, 0, 0);
+#else
 #pragma unroll 1
     for (int ks = 0; ks < NK; ++ks) {
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      X2_BARRIER();
 #if D3DP_X2_PROBE & 2
       const char* sb = smem;                           // (one fixed stage: reads hoisted out of the k-loop by the compiler)
 #else
@@ -179,43 +275,85 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
         const f16x8 ah = *reinterpret_cast<const f16x8*>(sb + offA + mi * 1024);
         const f16x8 al = *reinterpret_cast<const f16x8*>(sb + offA + XA_PLANE + mi * 1024);
         // small terms first; the three products of one output tile are 4 MFMAs apart (no back-to-back dependency)
+#if D3DP_X2_PROBE & 8
+        asm volatile("" :: "v"(ah), "v"(al));
+        if (mi == 3)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) asm volatile("" :: "v"(wf[ni][0]), "v"(wf[ni][1]));
+#else
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wf[ni][1], acc[mi][ni], 0, 0, 0);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wf[ni][0], acc[mi][ni], 0, 0, 0);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wf[ni][0], acc[mi][ni], 0, 0, 0);
+#endif
       }
     }
-    // ---- tile epilogue: lane holds out[m = pm0 + wr*64 + mi*16 + 4 fg + r][n = nb + ni], nb = tile column + wc*64 + 4 fi
+#endif
+    // ---- tile epilogue: lane holds out[m = pm0 + mi*16 + r][n = nb + ni], pm0 = tile row + wr*64 + 4 fg, nb = tile column
+    // + wc*64 + 4 fi.  Every store address is  uniform base + 32-bit lane offset  (the launcher refuses outputs of 4 GiB or
+    // more), advanced row by row: per-row 64-bit address arithmetic was most of the epilogue's VALU work, and it runs
+    // with the matrix pipes idle.
     const int t = L + ti * G;
     const int pm0 = (t / tiles_n) * XBM + wr * 64 + 4 * fg, nb = (t % tiles_n) * XBN + wc * 64 + 4 * fi;
-    if (nb < N && !(D3DP_X2_PROBE & 4)) {
+    if (nb < N && (!(D3DP_X2_PROBE & 4) || unscale == -12345.f)) {
       const float4 bz = *reinterpret_cast<const float4*>(sbias + nb);
+      const bool odd = fi & 1;
+      unsigned off, pitch;
+      bool planes;                                     // split the values and store fp16 planes (else fp32)
+      char* base = reinterpret_cast<char*>(outf);
+      if constexpr (EPI == EPI_GELU) {
+        base = reinterpret_cast<char*>(out2);
+        pitch = N * 2; planes = true;
+        off = nb * 2 + (odd ? (unsigned)planeO * 2 - 8 : 0);
+      } else if constexpr (TAG == 1) {
+        // packed qkv row (12 C bytes, C = N / 3): q fp32 | k hi | k lo | v hi | v lo (fp16 planes x 16) -- the
+        // K / V operand images of the split-fp16 attention kernels, which copy them into LDS without touching them
+        const int C = N / 3, region = nb / C, cn = nb - region * C;      // a wave's 64 columns lie in one region
+        pitch = N * 4; planes = region != 0;
+        off = planes ? region * 4 * C + cn * 2 + (odd ? 2 * C - 8 : 0) : cn * 4;
+      } else {
+        pitch = N * 4; planes = false;
+        off = nb * 4;
+      }
+      off += (unsigned)pm0 * pitch;
+      const int rows = M - pm0;                        // row k = mi*16 + r of this lane exists iff k < rows
+      auto value = [&](int mi, int r, int e) {
+        return fmaf(acc[mi][e][r], unscale, e == 0 ? bz.x : e == 1 ? bz.y : e == 2 ? bz.z : bz.w);
+      };
+      auto store_rows = [&](auto planes_c, auto checked_c) {
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = pm0 + mi * 16 + r;
-          const float v[4] = {fmaf(acc[mi][0][r], unscale, bz.x), fmaf(acc[mi][1][r], unscale, bz.y),
-                              fmaf(acc[mi][2][r], unscale, bz.z), fmaf(acc[mi][3][r], unscale, bz.w)};
-          if constexpr (EPI == EPI_GELU) {
-            f16x4 ph, pl;
+          for (int r = 0; r < 4; ++r) {
+            const int k = mi * 16 + r;
+            const bool live = !decltype(checked_c)::value || k < rows;
+            char* dst = base + (off + (unsigned)k * pitch);
+            if constexpr (decltype(planes_c)::value) {
+              f16x4 ph, pl;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              f16 a, b;
-              split2h(gelu_erf(v[e]), a, b);
-              ph[e] = a; pl[e] = b;
+              for (int e = 0; e < 4; ++e) {
+                f16 h, l;
+                float v = value(mi, r, e);
+                if constexpr (EPI == EPI_GELU) v = gelu_erf_rational(v);
+                split2h(v, h, l);
+                ph[e] = h; pl[e] = l;
+              }
+              store_planes_paired(dst, ph, pl, odd, live);
+            } else {
+              if (live) OUT_STORE(reinterpret_cast<f32x4*>(dst), ((f32x4){value(mi, r, 0), value(mi, r, 1), value(mi, r, 2), value(mi, r, 3)}));
             }
-            if (m < M) {
-              f16* o = out2 + (size_t)m * N + nb;
-              OUT_STORE(reinterpret_cast<f16x4*>(o), ph);
-              OUT_STORE(reinterpret_cast<f16x4*>(o + planeO), pl);
-            }
-          } else {
-            if (m < M) OUT_STORE(reinterpret_cast<f32x4*>(outf + (size_t)m * N + nb), ((f32x4){v[0], v[1], v[2], v[3]}));
           }
-        }
+      };
+      using T_ = std::true_type; using F_ = std::false_type;
+      if (rows >= 64) {                                // (all but the last row of tiles)
+        if (planes) { if constexpr (EPI == EPI_GELU || TAG == 1) store_rows(T_{}, F_{}); }
+        else { if constexpr (EPI != EPI_GELU) store_rows(F_{}, F_{}); }
+      } else {
+        if (planes) { if constexpr (EPI == EPI_GELU || TAG == 1) store_rows(T_{}, T_{}); }
+        else { if constexpr (EPI != EPI_GELU) store_rows(F_{}, T_{}); }
+      }
     }
   }
 }
@@ -243,11 +381,13 @@ __global__ void absmax_kernel(const float* __restrict__ s, size_t n, unsigned* _
 
 }  // namespace
 
-// out = epi((A W^T) unscale + bias) with A2/W2 split-fp16 planes; EPI_BIAS: fp32 `outf`; EPI_GELU: two fp16 planes `out2`.
+// out = epi((A W^T) unscale + bias) with A2/W2 split-fp16 planes; EPI_BIAS: fp32 `outf`; EPI_GELU: two fp16 planes `out2`;
+// EPI_QKV_PACK (N = 3 C, C % 64 == 0): `outf` rows of 12 C bytes = q fp32 | k hi | k lo | v hi | v lo (fp16 x 16).
 // `unscale` = 1 / (scale of the A planes * scale of the W planes).
 int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const float* bias, float unscale, float* outf,
                              void* out2, int M, int N, int K, hipStream_t st) {
   if (K % XBK != 0 || N % 4 != 0 || N > XBIAS_MAX || M <= 0) return -1;
+  if ((size_t)M * N * 4 >= ((size_t)1 << 32)) return -1;   // 32-bit byte offsets in the epilogue
   const int tm = (M + XBM - 1) / XBM, tn = (N + XBN - 1) / XBN;
   static bool attr_set = false;
   static int n_cu = 0;
@@ -265,9 +405,11 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
     attr_set = true;
   }
   const int total = tm * tn, grid = total < n_cu ? total : n_cu;
+  if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_QKV_PACK) return -1;
+  if (epi == EPI_QKV_PACK && (N % 3 != 0 || (N / 3) % 64 != 0)) return -1;
+  if (epi == EPI_GELU && N % 8 != 0) return -1;        // plane stores are paired across two 4-column groups
   auto kern = epi == EPI_GELU ? gemm_f16x2_kernel<EPI_GELU, 0>
-                              : (N == 3 * K ? gemm_f16x2_kernel<EPI_BIAS, 1> : gemm_f16x2_kernel<EPI_BIAS, 0>);
-  if (epi != EPI_BIAS && epi != EPI_GELU) return -1;
+                              : (epi == EPI_QKV_PACK ? gemm_f16x2_kernel<EPI_BIAS, 1> : gemm_f16x2_kernel<EPI_BIAS, 0>);
   hipLaunchKernelGGL(kern, dim3(grid), dim3((XNCW + 4) * 64), XLDS, st, (const f16*)A2, (const f16*)W2, bias, unscale, outf,
                      (f16*)out2, M, N, K, tn, total);
   return 0;

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_ATOMIC = 3 };
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_ATOMIC = 3, EPI_QKV_PACK = 4 };
 
 // ---- gemm.hip ----------------------------------------------------------------------------------
 int d3dp_launch_linear_bf16_stream(int epi, int out_f32, const void* A, const void* W, const float* bias, void* out,
@@ -32,8 +32,11 @@ int d3dp_launch_attn_temporal_bf16(const void* qkv, void* out, int n_seq, SeqMap
                                    hipStream_t st);
 int d3dp_launch_attn_temporal_f32(int act, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
                                   hipStream_t st);
+// split-fp16 attention: `qkv` = PACKED rows of 12 C bytes (q fp32 | k hi | k lo | v hi | v lo), written by the qkv Linear
+// with EPI_QKV_PACK or from fp32 rows by d3dp_launch_qkv_pack_x2
 int d3dp_launch_attn_x2(int act, int axis, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
                         hipStream_t st);
+void d3dp_launch_qkv_pack_x2(const float* src, void* dst, size_t T, int C, hipStream_t st);
 int d3dp_launch_attn_spatial_bf16(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st);
 
 // ---- pointwise.hip -----------------------------------------------------------------------------

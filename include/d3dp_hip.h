@@ -222,7 +222,9 @@ int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, cons
 /* Multi-head attention over qkv[T,3C] -> out[T,C]; axis 0 = spatial (sequences of J joints), 1 = temporal
  * (sequences of F frames); tokens ordered (seq_batch, f, n).  impl 0 = fp32-VALU row kernel (any activation type),
  * 1 = matrix-core kernel (head dim 64): bf16 MFMA for bf16 activations (both axes), fp32 MFMA for fp32 activations
- * (temporal axis), 2 = the EXACT-mode kernel: fp32 activations split into fp16 pairs on the fp16 matrix cores (both axes). */
+ * (temporal axis), 2 = the EXACT-mode kernels: split-fp16 operands on the fp16 matrix cores (both axes; head dim 64).  Inside
+ * the denoiser those read the packed rows of its qkv Linear (d3dp_op_linear_x2, epi 4); this entry point takes plain fp32
+ * rows and repacks them into a stream-ordered temporary (hipMallocAsync) first. */
 int d3dp_op_attention(int32_t act_bf16, int32_t impl, int32_t axis, const void* qkv, void* out, int32_t n_bh,
                       int32_t F, int32_t J, int32_t C, int32_t heads, void* stream);
 int d3dp_op_layernorm(int32_t out_bf16, const float* x, const float* w, const float* b, float eps, void* out,
@@ -233,7 +235,9 @@ int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream);
 /* The EXACT-mode Linear on split-fp16 operands.  A2 and W2 are two fp16 planes each, made by d3dp_op_split2 from
  * y = src * scale: dst[0..n) = hi = fp16(y), dst[n..2n) = lo = fp16(y - hi).  A2 must be at scale 16 (the library's
  * activation scale); W2 at any power-of-two `w_scale` (the denoiser picks it per matrix so that max |w| w_scale lies in
- * [2^13, 2^14)).  epi 0 -> fp32 out, epi 1 -> GELU then two fp16 planes (scale 16) out. */
+ * [2^13, 2^14)).  epi 0 -> fp32 out, epi 1 -> GELU then two fp16 planes (scale 16) out, epi 4 (N = 3 C, C % 64 == 0; the
+ * qkv Linear of the EXACT denoiser) -> packed rows of 12 C bytes: q fp32 [C] | k hi | k lo | v hi | v lo (fp16 [C] each,
+ * scale 16), the operand format of the split-fp16 attention kernels. */
 int d3dp_op_split2(const float* src, void* dst, size_t n, float scale, void* stream);
 int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* bias, float w_scale, void* out, int32_t M,
                       int32_t N, int32_t K, void* stream);

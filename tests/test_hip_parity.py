@@ -166,6 +166,37 @@ def test_linear_split_f16_is_fp32_class(lib, M, N, K):
         assert abs(out[0, 0].item() - float(Az[0, 0, 0].float()) * K / 16.0) < 1e-9
 
 
+
+@pytest.mark.parametrize("M,C", [(4131, 512), (700, 128), (129, 64)])
+def test_qkv_linear_packed_epilogue_is_the_split_of_the_plain_one(lib, M, C):
+    """EPI_QKV_PACK (what the EXACT denoiser's qkv Linear writes): rows of 12 C bytes, q fp32 | k hi | k lo | v hi | v lo
+    with hi = fp16(16 x), lo = fp16(16 x - hi) -- bit for bit the split of the fp32 result of the plain epilogue."""
+    N, K = 3 * C, C
+    g = torch.Generator().manual_seed(M + C)
+    A = (torch.randn(M, K, generator=g) * 2).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    A2 = torch.empty(2, M, K, dtype=torch.float16, device="cuda")
+    W2 = torch.empty(2, N, K, dtype=torch.float16, device="cuda")
+    w_scale = 2.0 ** (13 - int(np.floor(np.log2(W.abs().max().item()))))
+    _lib.check(lib.d3dp_op_split2(A.data_ptr(), A2.data_ptr(), M * K, 16.0, stream()))
+    _lib.check(lib.d3dp_op_split2(W.data_ptr(), W2.data_ptr(), N * K, w_scale, stream()))
+    plain = torch.empty(M, N, device="cuda")
+    _lib.check(lib.d3dp_op_linear_x2(_lib.EPI_BIAS, A2.data_ptr(), W2.data_ptr(), bias.data_ptr(), w_scale,
+                                     plain.data_ptr(), M, N, K, stream()))
+    packed = torch.full((M, N), float("nan"), device="cuda")
+    _lib.check(lib.d3dp_op_linear_x2(_lib.EPI_QKV_PACK, A2.data_ptr(), W2.data_ptr(), bias.data_ptr(), w_scale,
+                                     packed.data_ptr(), M, N, K, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(packed[:, :C], plain[:, :C])                      # q: fp32, untouched
+    planes = packed[:, C:].contiguous().view(torch.float16).view(M, 4, C)   # k hi | k lo | v hi | v lo
+    for i, col0 in ((0, C), (2, 2 * C)):
+        y = plain[:, col0:col0 + C] * 16.0
+        hi = y.half()
+        lo = (y - hi.float()).half()
+        assert torch.equal(planes[:, i], hi) and torch.equal(planes[:, i + 1], lo)
+
+
 def ref_attention(qkv, n_bh, F, J, C, heads, axis):
     """fp64 reference on the (n_bh, F, J, 3C) layout."""
     hd = C // heads

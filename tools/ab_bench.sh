@@ -1,7 +1,9 @@
 #!/bin/bash
-# A/B of two builds of libd3dp_hip on the same box: tools/ab_bench.sh <libA> <libB> [bench args...]; interleaved runs.
-A=$1; B=$2; shift 2
-for lib in "$A" "$B"; do
+# A/B of builds of libd3dp_hip on the same box: tools/ab_bench.sh <libA> <libB> [bench args...], or LIBS="a b c ..."
+# tools/ab_bench.sh [bench args...]; "default" = the in-tree library.
+if [ -n "$LIBS" ]; then set -- $LIBS -- "$@"; else A=$1; B=$2; shift 2; set -- "$A" "$B" -- "$@"; fi
+L=(); while [ "$1" != "--" ]; do L+=("$1"); shift; done; shift
+for lib in "${L[@]}"; do
   python - "$lib" "$@" <<'PY'
 import json, runpy, sys, io, contextlib
 lib, args = sys.argv[1], sys.argv[2:]
