@@ -56,6 +56,33 @@ __device__ __forceinline__ float gelu_erf_rational(float x) {
   return fmaf(hx, e, hx);
 }
 
+// two elements at a time on the packed fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32): the same arithmetic per
+// element, half the instructions for the polynomials -- for epilogues, where no MFMA is in flight to be disturbed by them
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf_rational2(f32x2 x) {
+  const f32x2 zs = x * 0.70710678118654752440f;
+  const f32x2 z = {__builtin_amdgcn_fmed3f(zs.x, -4.0f, 4.0f), __builtin_amdgcn_fmed3f(zs.y, -4.0f, 4.0f)};
+  const f32x2 z2 = z * z;
+  auto c = [](float v) { return (f32x2){v, v}; };
+  f32x2 p = c(-2.72614225801306e-10f);
+  p = __builtin_elementwise_fma(p, z2, c(2.77068142495902e-08f));
+  p = __builtin_elementwise_fma(p, z2, c(-2.10102402082508e-06f));
+  p = __builtin_elementwise_fma(p, z2, c(-5.69250639462346e-05f));
+  p = __builtin_elementwise_fma(p, z2, c(-7.34990630326855e-04f));
+  p = __builtin_elementwise_fma(p, z2, c(-2.95459980854025e-03f));
+  p = __builtin_elementwise_fma(p, z2, c(-1.60960333262415e-02f)) * z;
+  f32x2 q = c(-1.45660718464996e-05f);
+  q = __builtin_elementwise_fma(q, z2, c(-2.13374055278905e-04f));
+  q = __builtin_elementwise_fma(q, z2, c(-1.68282697438203e-03f));
+  q = __builtin_elementwise_fma(q, z2, c(-7.37332916720468e-03f));
+  q = __builtin_elementwise_fma(q, z2, c(-1.42647390514189e-02f));
+  const f32x2 r = {__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
+  f32x2 e = p * r;
+  e = __builtin_elementwise_fma(__builtin_elementwise_fma(-q, e, p), r, e);
+  const f32x2 hx = x * 0.5f;
+  return __builtin_elementwise_fma(hx, e, hx);
+}
+
 // XCD-aware bijective remap of a 1-D grid: blocks that are consecutive in the LOGICAL order land on
 // the same XCD (hardware places block b on XCD b % 8), so neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -27,8 +27,12 @@
 // 256 contiguous bytes of ONE row -- every store instruction writes whole 128-byte lines.  (First version: transposed
 // product, 16 columns per lane, each store instruction touching 64 different lines with 16 bytes: the tile-end store
 // tail cost 11-17 us per 256x128 tile against 18-22 us for its 16 k-steps, fitted over the four Linear shapes.)
-//   EPI_BIAS -> fp32 out (feeds attention / the residual-adding row kernels)
-//   EPI_GELU -> gelu_erf(.) re-split into two fp16 planes (the fc2 operand)
+//   EPI_BIAS     -> fp32 out (feeds the residual-adding row kernels)
+//   EPI_GELU     -> GELU (rational erf, common.h) re-split into two fp16 planes (the fc2 operand)
+//   EPI_QKV_PACK -> q fp32, k and v as fp16 planes: the packed rows the split-fp16 attention kernels read (attention.hip)
+// Plane outputs leave as ONE 16-byte store per lane too (neighbouring lanes swap halves, store_planes_paired).
+// Timing probes of this kernel (loads / stores / MFMAs / barriers compiled out one at a time) and what they say about
+// the clock the chip sustains under this instruction mix: profiles/r02_gemm_probes.md.
 #include <cstdlib>
 
 #include <type_traits>
@@ -51,6 +55,11 @@
 #define X2_BARRIER() asm volatile("" ::: "memory")
 #else
 #define X2_BARRIER() asm volatile("s_barrier" ::: "memory")
+#endif
+// GELU of the fc1 epilogue two elements at a time on v_pk_fma_f32 (the epilogue runs with no MFMA in flight): -45 ms
+// of the 1387 ms fc1 class per step
+#ifndef D3DP_X2_PKGELU
+#define D3DP_X2_PKGELU 1
 #endif
 #ifndef D3DP_X2_LAG
 #define D3DP_X2_LAG 1
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
     // barrier; the k-loop is unrolled by two so that the two fragment sets swap roles without register copies.
     f16x8 wfa[4][2], wfb[4][2], taa[2], tab[2];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) wfb[ni][0] = (f16x8){};
+    for (int ni = 0; ni < 4; ++ni) wfb[ni][0] = wfb[ni][1] = (f16x8){};
     tab[0] = tab[1] = (f16x8){};
     auto kstep = [&](f16x8 (&wf)[4][2], f16x8 (&ta)[2], const f16x8 (&pw)[4][2], const f16x8 (&pa)[2]) {
       __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): this wave has read everything it wanted from the old slot
@@ -222,6 +231,10 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
       for (int ni = 0; ni < 4; ++ni) acc[3][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[1], pw[ni][0], acc[3][ni], 0, 0, 0);
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[3][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[0], pw[ni][0], acc[3][ni], 0, 0, 0);
+#if D3DP_X2_LAG >= 2                                   // probe: all twelve MFMAs of row block 3 lag (16 more registers)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[3][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[0], pw[ni][1], acc[3][ni], 0, 0, 0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mi = 0; mi < 3; ++mi) {
@@ -241,8 +254,10 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], wf[ni][0], acc[mi][ni], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+#if D3DP_X2_LAG < 2
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[3][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[0], wf[ni][1], acc[3][ni], 0, 0, 0);
+#endif
     };
 #pragma unroll 1
     for (int ks = 0; ks < NK; ks += 2) {               // NK is even (K % 64 == 0, checked by the launcher)
@@ -253,6 +268,10 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
     for (int ni = 0; ni < 4; ++ni) acc[3][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tab[1], wfb[ni][0], acc[3][ni], 0, 0, 0);
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[3][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tab[0], wfb[ni][0], acc[3][ni], 0, 0, 0);
+#if D3DP_X2_LAG >= 2
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[3][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tab[0], wfb[ni][1], acc[3][ni], 0, 0, 0);
+#endif
 #else
 #pragma unroll 1
     for (int ks = 0; ks < NK; ++ks) {
@@ -332,12 +351,20 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
             char* dst = base + (off + (unsigned)k * pitch);
             if constexpr (decltype(planes_c)::value) {
               f16x4 ph, pl;
+              float v[4] = {value(mi, r, 0), value(mi, r, 1), value(mi, r, 2), value(mi, r, 3)};
+              if constexpr (EPI == EPI_GELU) {
+#if D3DP_X2_PKGELU
+                const f32x2 g0 = gelu_erf_rational2((f32x2){v[0], v[1]}), g1 = gelu_erf_rational2((f32x2){v[2], v[3]});
+                v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
+#else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf_rational(v[e]);
+#endif
+              }
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 f16 h, l;
-                float v = value(mi, r, e);
-                if constexpr (EPI == EPI_GELU) v = gelu_erf_rational(v);
-                split2h(v, h, l);
+                split2h(v[e], h, l);
                 ph[e] = h; pl[e] = l;
               }
               store_planes_paired(dst, ph, pl, odd, live);

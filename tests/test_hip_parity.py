@@ -215,6 +215,9 @@ def ref_attention(qkv, n_bh, F, J, C, heads, axis):
     ("f32", 0, 0, 27, 512), ("f32", 0, 1, 27, 512), ("f32", 0, 1, 243, 512), ("f32", 1, 1, 243, 512), ("f32", 1, 1, 27, 512),
     ("f32", 1, 1, 100, 512), ("f32", 0, 0, 9, 64), ("f32", 0, 1, 9, 64),
     ("f32", 2, 0, 27, 512), ("f32", 2, 0, 243, 512), ("f32", 2, 1, 27, 512), ("f32", 2, 1, 243, 512), ("f32", 2, 1, 100, 512),
+    # the persistent LDS-DMA kernel's masking paths: keys end inside the last tile (49, 243), whole tiles masked (9, 33,
+    # 130), nothing masked (256)
+    ("f32", 2, 1, 9, 512), ("f32", 2, 1, 33, 512), ("f32", 2, 1, 49, 512), ("f32", 2, 1, 130, 512), ("f32", 2, 1, 256, 512),
     ("bf16", 0, 0, 27, 512), ("bf16", 1, 0, 27, 512), ("bf16", 1, 0, 243, 512), ("bf16", 1, 1, 27, 512), ("bf16", 1, 1, 243, 512), ("bf16", 1, 1, 100, 512),
     ("bf16", 0, 1, 243, 512)])
 def test_attention(lib, act, impl, axis, F, C):
@@ -238,6 +241,22 @@ def test_attention(lib, act, impl, axis, F, C):
         print(f"attention act={act} impl={impl} axis={axis} F={F}: mean |err| vs fp64 {err:.2e}")
         if impl == 2:      # the EXACT-mode kernel (split-fp16 operands) must be fp32-class: compare with the fp32 kernels
             assert err < 5e-7
+
+
+def test_attention_split_f16_many_problems_per_workgroup(lib):
+    """The EXACT temporal kernel is persistent: with more (sequence, head) problems than resident workgroups every
+    workgroup loops, K(p+1) and V(p+1) streaming into the LDS images problem p is still being read from."""
+    n_bh, F, J, C, heads = 24, 27, 17, 512, 8          # 3264 problems
+    g = torch.Generator().manual_seed(99)
+    qkv = torch.randn(n_bh * F * J, 3 * C, generator=g)
+    want = ref_attention(qkv, n_bh, F, J, C, heads, 1)
+    qd = qkv.cuda().contiguous()
+    out = torch.full((n_bh * F * J, C), float("nan"), device="cuda")
+    _lib.check(lib.d3dp_op_attention(0, 2, 1, qd.data_ptr(), out.data_ptr(), n_bh, F, J, C, heads, stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().double()
+    assert torch.allclose(got, want, atol=2e-5, rtol=1e-4), (got - want).abs().max().item()
+    assert (got - want).abs().mean().item() < 5e-7
 
 
 def test_attention_softmax_spike(lib):
