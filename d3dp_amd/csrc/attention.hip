@@ -449,52 +449,118 @@ __device__ __forceinline__ void split8(const float4 a, const float4 b, f16x8& hi
   for (int e = 0; e < 8; ++e) { f16 h, l; split2h(v[e], h, l); hi[e] = h; lo[e] = l; }
 }
 
-// key chunks [C0, C1) of O^T += V^T P^T (32 keys per chunk)
-template <int NKT, int C0, int C1 = NKT / 2, int WINDOW = 2>
+// key chunks [C0, C1) of O^T += V^T P^T (32 keys per chunk).  Software-pipelined by hand: the fragments of chunk c+1 are
+// read before the MFMAs of chunk c, and the twelve MFMAs of a chunk go pass by pass over the four channel tiles, so that
+// two MFMAs on the same accumulator are four apart (issued back to back each waits out the previous one's latency:
+// with two waves per SIMD the kernel spent 39 % of its wave cycles in such issue stalls).
+template <int C0>
+__device__ __forceinline__ void load_v_frags_x2(const FragBases& fb, int plane, f16x8 (&vh)[4], f16x8 (&vl)[4]) {
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) {
+    vh[dn] = as_f16x8(load_vt_frag<C0>(fb.v[dn]));
+    vl[dn] = as_f16x8(load_vt_frag<C0>(fb.v[dn] + plane));
+  }
+}
+template <int NKT, int C0, int C1 = NKT / 2>
+__device__ __forceinline__ void pv_chunks_x2_rec(const FragBases& fb, int plane, const f16x8 (&ph)[NKT / 2],
+                                                 const f16x8 (&pl)[NKT / 2], f32x4 (&o)[4], const f16x8 (&vh)[4],
+                                                 const f16x8 (&vl)[4]) {
+  f16x8 nh[4], nl[4];
+  if constexpr (C0 + 1 < C1) load_v_frags_x2<C0 + 1>(fb, plane, nh, nl);
+  __builtin_amdgcn_sched_barrier(0);                   // (the reads stay in front of the MFMAs that cover their latency)
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[dn], ph[C0], o[dn], 0, 0, 0);
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dn], pl[C0], o[dn], 0, 0, 0);
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dn], ph[C0], o[dn], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (C0 + 1 < C1) pv_chunks_x2_rec<NKT, C0 + 1, C1>(fb, plane, ph, pl, o, nh, nl);
+}
+template <int NKT, int C0, int C1 = NKT / 2>
 __device__ __forceinline__ void pv_chunks_x2(const FragBases& fb, int plane, const f16x8 (&ph)[NKT / 2],
                                              const f16x8 (&pl)[NKT / 2], f32x4 (&o)[4]) {
   if constexpr (C0 < C1) {
+    f16x8 vh[4], vl[4];
+    load_v_frags_x2<C0>(fb, plane, vh, vl);
+    pv_chunks_x2_rec<NKT, C0, C1>(fb, plane, ph, pl, o, vh, vl);
+  }
+}
+
+// the same product one channel tile after the other (8 fragment registers live instead of 32: the spatial kernel, whose
+// occupancy -- five waves per SIMD at <= 96 registers -- matters more to it than MFMA issue order)
+template <int C0>
+__device__ __forceinline__ void pv_chunk_x2_seq(const FragBases& fb, int plane, const f16x8& ph, const f16x8& pl, f32x4 (&o)[4]) {
 #pragma unroll
-    for (int dn = 0; dn < 4; ++dn) {
-      const f16x8 vh = as_f16x8(load_vt_frag<C0>(fb.v[dn]));
-      const f16x8 vl = as_f16x8(load_vt_frag<C0>(fb.v[dn] + plane));
-      o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[C0], o[dn], 0, 0, 0);
-      o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[C0], o[dn], 0, 0, 0);
-      o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[C0], o[dn], 0, 0, 0);
-    }
-    if ((C0 + 1) % WINDOW == 0) __builtin_amdgcn_sched_barrier(0);   // bound the ds_read hoisting window (VGPR pressure)
-    pv_chunks_x2<NKT, C0 + 1, C1, WINDOW>(fb, plane, ph, pl, o);
+  for (int dn = 0; dn < 4; ++dn) {
+    const f16x8 vh = as_f16x8(load_vt_frag<C0>(fb.v[dn]));
+    const f16x8 vl = as_f16x8(load_vt_frag<C0>(fb.v[dn] + plane));
+    o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, o[dn], 0, 0, 0);
+    o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, o[dn], 0, 0, 0);
+    o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, o[dn], 0, 0, 0);
   }
 }
 
 // Scores and softmax of one 16-query tile against NKT 16-key tiles resident in LDS.  fb: fragment bases into the K hi
 // image (the lo image is `plane` bytes further).  qh/ql: the tile's query fragments (d 0..31, 32..63), values x 16.
 // Returns the probabilities as split-fp16 B operands (x 1024) and 1024 x the softmax denominator of query (lane & 15).
-template <int NKT>
+template <int NKT, bool MASK_ANY_TILE>
 __device__ __forceinline__ void attn_scores_x2(const FragBases& fb, int plane, const f16x8 (&qh)[2], const f16x8 (&ql)[2],
                                                int n, int lane, f16x8 (&ph)[NKT / 2], f16x8 (&pl)[NKT / 2], float& denom) {
   const int fg = lane >> 4;
   const float cexp = 0.125f * 1.44269504088896340736f / (kActScale * kActScale);   // hd^-0.5 log2(e) / (16 * 16)
+  // S^T, two key tiles at a time with their MFMAs interleaved (two independent accumulator chains) and the fragments
+  // of the next pair already on their way from LDS (see pv_chunks_x2)
   f32x4 s[NKT];
+  auto read_k = [&](int t, f16x8 (&k)[4]) {
+    k[0] = *reinterpret_cast<const f16x8*>(fb.k0 + plane + t * 2048);   // lo, d 0..31
+    k[1] = *reinterpret_cast<const f16x8*>(fb.k1 + plane + t * 2048);   // lo, d 32..63
+    k[2] = *reinterpret_cast<const f16x8*>(fb.k0 + t * 2048);           // hi
+    k[3] = *reinterpret_cast<const f16x8*>(fb.k1 + t * 2048);
+  };
+  // PF = 1: the lo-plane fragments of the NEXT pair are read before this pair's MFMAs (16 registers; prefetching all
+  // four fragments per tile does not fit the 256 registers of the two-tile temporal kernel)
+  f16x8 kc[2][4], kn[2][2];
+  read_k(0, kc[0]);
+  read_k(1, kc[1]);
 #pragma unroll
-  for (int t = 0; t < NKT; ++t) {
-    const f16x8 k0h = *reinterpret_cast<const f16x8*>(fb.k0 + t * 2048);
-    const f16x8 k1h = *reinterpret_cast<const f16x8*>(fb.k1 + t * 2048);
-    const f16x8 k0l = *reinterpret_cast<const f16x8*>(fb.k0 + plane + t * 2048);
-    const f16x8 k1l = *reinterpret_cast<const f16x8*>(fb.k1 + plane + t * 2048);
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0l, qh[0], a, 0, 0, 0);
-    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1l, qh[1], a, 0, 0, 0);
-    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, ql[0], a, 0, 0, 0);
-    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, ql[1], a, 0, 0, 0);
-    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0h, qh[0], a, 0, 0, 0);
-    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1h, qh[1], a, 0, 0, 0);
-    s[t] = a;
-    if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // bound the ds_read hoisting window (VGPR pressure)
+  for (int t = 0; t < NKT; t += 2) {
+    if (t + 2 < NKT) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        kn[j][0] = *reinterpret_cast<const f16x8*>(fb.k0 + plane + (t + 2 + j) * 2048);
+        kn[j][1] = *reinterpret_cast<const f16x8*>(fb.k1 + plane + (t + 2 + j) * 2048);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                 // (the reads stay in front of the MFMAs that cover their latency)
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][0], qh[0], a, 0, 0, 0);
+    b = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][0], qh[0], b, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][1], qh[1], a, 0, 0, 0);
+    b = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][1], qh[1], b, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][2], ql[0], a, 0, 0, 0);
+    b = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][2], ql[0], b, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][3], ql[1], a, 0, 0, 0);
+    b = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][3], ql[1], b, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][2], qh[0], a, 0, 0, 0);
+    b = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][2], qh[0], b, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][3], qh[1], a, 0, 0, 0);
+    b = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][3], qh[1], b, 0, 0, 0);
+    s[t] = a; s[t + 1] = b;
+    if (t + 2 < NKT) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        kc[j][0] = kn[j][0]; kc[j][1] = kn[j][1];
+        kc[j][2] = *reinterpret_cast<const f16x8*>(fb.k0 + (t + 2 + j) * 2048);
+        kc[j][3] = *reinterpret_cast<const f16x8*>(fb.k1 + (t + 2 + j) * 2048);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
-  // keys >= n are masked.  The usual case (n in the last key tile) touches that tile only; the per-element selects of
-  // the general form were a third of this kernel's VALU instructions.
-  if (n > 16 * (NKT - 1)) {
+  // keys >= n are masked.  The usual case (n in the last key tile: MASK_ANY_TILE = false, chosen by the launcher) touches
+  // that tile only; the per-element selects of the general form were a third of this kernel's VALU instructions, and
+  // their 64 loop-invariant lane masks cost registers.
+  if constexpr (!MASK_ANY_TILE) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (16 * (NKT - 1) + 4 * fg + r >= n) s[NKT - 1][r] = -INFINITY;
@@ -515,18 +581,19 @@ __device__ __forceinline__ void attn_scores_x2(const FragBases& fb, int plane, c
   // p * 1024 = exp2(s cexp - mx cexp + 10): one fma and the bare v_exp_f32 per element (arguments <= 10; a probability
   // below 2^-126 becomes 0 instead of a denormal); the denominator is accumulated at the same scale.
   const float nb = fmaf(-mx, cexp, 10.0f);
-  float sum = 0.f;
+  float sum4[2] = {0.f, 0.f};                          // two independent chains
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float y = __builtin_amdgcn_exp2f(fmaf(s[t][r], cexp, nb));
-      sum += y;
+      sum4[r & 1] += y;
       const f16 h = (f16)y;
       ph[t >> 1][(t & 1) * 4 + r] = h;
       pl[t >> 1][(t & 1) * 4 + r] = (f16)fmaf(y, 1.0f, -(float)h);
     }
   }
+  float sum = sum4[0] + sum4[1];
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
   denom = sum;                                         // = 1024 x the softmax denominator
@@ -600,10 +667,10 @@ __device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt((V & 1
 //     K(p+1) streams in while problem p multiplies P.V,   V(p+1) while problem p+1 computes its scores.
 //   top:  vmcnt(V pieces) -> K(p), q(p) landed        barrier 1     scores + softmax
 //         vmcnt(0)        -> V(p) landed              barrier 2     (every wave is done with the K image)  issue K(p+1)
-//         P.V (q(p+1) loads first), store O(p)        barrier 3     (every wave is done with the V image)  issue V(p+1)
+//         P.V (q(p+1) requested on the way), store O  barrier 3     (every wave is done with the V image)  issue V(p+1)
 // The vmcnt(2 PER) at the top is exact: vector memory operations of a wave retire in order and the 2 PER youngest are
 // the V pieces.
-template <int NKT, int OUTS>
+template <int NKT, int OUTS, bool MASK_ANY_TILE>
 __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
                                                                SeqMap map, int C, int heads, size_t plane_elems,
                                                                int n_prob) {
@@ -620,7 +687,6 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
   const int ts = map.tok_stride;
   const size_t ldb = (size_t)12 * C;                   // bytes per packed token row
   const int n_qt = (n + 15) >> 4;
-  const FragBases fb = make_frag_bases(kimg, vimg, lane);
   const float inv_scale = 1.0f / kActScale;            // O^T is scaled by 16 x 1024, the denominator by 1024
 
   // DMA piece `pc` of a plane = image rows 8 pc .. 8 pc + 7; a lane moves the 16-byte slot that belongs at position
@@ -668,7 +734,8 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
   int p = blockIdx.x;
   if (p >= n_prob) return;
   // waves w and w + 4 share a SIMD and run the same phases between the same barriers: the static priority lets one of
-  // them take the matrix pipe first, after which its softmax (VALU) runs beside the other's MFMAs
+  // them take the matrix pipe first, after which its softmax (VALU) runs beside the other's MFMAs (measured: 563 vs
+  // 568 ms per step without it -- within noise; starting odd workgroups half a problem late changed nothing either)
   if ((wave >> 2) & 1) __builtin_amdgcn_s_setprio(1);
   int head;
   const char* row0 = problem_row0(p, head);
@@ -680,6 +747,8 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
     __builtin_amdgcn_s_barrier();                      // 1: the K image of problem p is complete
     f16x8 ph[TPW][NKT / 2], pl[TPW][NKT / 2];
     float denom[TPW];
+    // (fragment bases re-derived per phase from the opaque lane id: the four V bases are not live during the scores)
+    const FragBases fbk = make_frag_bases(kimg, vimg, opaque(lane));
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
       denom[u] = 1.f;
@@ -693,7 +762,7 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
         }
         split8(qf[0], qf[1], qh[0], ql[0]);
         split8(qf[2], qf[3], qh[1], ql[1]);
-        attn_scores_x2<NKT>(fb, PLANE, qh, ql, n, lane, ph[u], pl[u], denom[u]);
+        attn_scores_x2<NKT, MASK_ANY_TILE>(fbk, PLANE, qh, ql, n, lane, ph[u], pl[u], denom[u]);
       }
     }
     wait_vmcnt<0>();
@@ -705,11 +774,14 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
     if (has_next) {
       row0_n = problem_row0(pn, head_n);
       issue_kv(row0_n, head_n, 0);
-      load_q_raw(row0_n, head_n);
     }
     const int tok0 = seq_base(map, p / heads);
+    const FragBases fb = make_frag_bases(kimg, vimg, opaque(lane));
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
+      // the next problem's queries: requested before the LAST tile's P.V (with two tiles the probabilities of both are
+      // live during the first one's, and 32 more registers there would spill)
+      if (u == TPW - 1 && has_next) load_q_raw(row0_n, head_n);
       const int qt = wave + u * NW;
       if (qt < n_qt) {
         f32x4 o[4];
@@ -820,7 +892,7 @@ __global__ __launch_bounds__(256) void attn_spatial_x2_kernel(const float* __res
     f32x4 o[4];
 #pragma unroll
     for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    pv_chunks_x2<2, 0>(fb, PLANE, ph, pl, o);
+    pv_chunk_x2_seq<0>(fb, PLANE, ph[0], pl[0], o);
     if (q < n) store_o_x2<OUTS>(o, inv_scale / sum, out_v, (size_t)(base + q * ts) * C + head * 64 + fg * 4, plane_elems);
   }
 }
@@ -852,7 +924,8 @@ int launch_temporal_x2(const void* qkv, void* out, int n_seq, SeqMap map, int C,
   constexpr int NK = 16 * NKT;
   const size_t lds = (size_t)NK * 128 * 4;             // static LDS of the kernel (K and V images, two planes each)
   constexpr int NW = 8;
-  auto kern = attn_temporal_x2_kernel<NKT, OUTS>;
+  // (n inside the last key tile -- F = 243, 27 -- needs masking in that tile only)
+  auto kern = map.n_tok > 16 * (NKT - 1) ? attn_temporal_x2_kernel<NKT, OUTS, false> : attn_temporal_x2_kernel<NKT, OUTS, true>;
   static int n_wg = 0;
   if (!n_wg) {
     int dev = 0;

@@ -5,7 +5,6 @@ R=$PWD
 python -m pytest tests -m gpu -q --durations=5 2>&1 | tail -12 > gpurun_out/final/tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final/smoke.log 2>&1
 python bench.py --steps 5 --warmup 2 > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
-python tools/cpu_c2.py 16 > gpurun_out/final/cpu_c2.json 2> /dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/final/stats -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity > $R/gpurun_out/final/bench_prof.json 2> /dev/null
 for mode in exact fast; do
@@ -21,4 +20,4 @@ db=$(find gpurun_out/final/stats -name "*.db" | head -1); [ -n "$db" ] && python
 for d in gpurun_out/final/pmc_*/; do f=$(find $d -name "*counter_collection.csv" | head -1); echo "== $d"; [ -n "$f" ] && python tools/pmc_summary.py $f gemm | grep -v "^$"; done > gpurun_out/final/pmc.log 2>&1
 sha256sum d3dp_amd/lib/libd3dp_hip.so > gpurun_out/final/lib.sha256
 find gpurun_out/final -name "*.csv" -size +10M -delete; rm -rf gpurun_out/final/stats
-cat gpurun_out/final/cpu_c2.json; tail -6 gpurun_out/final/tests.log; tail -2 gpurun_out/final/smoke.log; head -c 600 gpurun_out/final/bench.json; echo; cat gpurun_out/final/pmc.log | grep -E "==|FETCH|WRITE|MFMA|GRBM"
+tail -6 gpurun_out/final/tests.log; tail -2 gpurun_out/final/smoke.log; head -c 600 gpurun_out/final/bench.json; echo; cat gpurun_out/final/pmc.log | grep -E "==|FETCH|WRITE|MFMA|GRBM"
