@@ -32,6 +32,7 @@ if REPO not in sys.path:
 
 F_, J_, C_, DEPTH = 243, 17, 512, 8
 PEAK_MFMA_TFLOPS = 2500.0      # dense bf16 / fp16 MFMA, MI355X_MICROARCH.md (2.5 PFLOP/s)
+MFMA_STREAM_PFLOPS = 1.57   # measured ceiling of the EXACT Linear's MFMA stream alone (profiles/r02_gemm_probes.md)
 EXACT_PASSES = 3               # fp16-MFMA products per algorithmic multiply-add in exact mode (hi.hi, hi.lo, lo.hi)
 
 
@@ -192,12 +193,16 @@ def roofline_from_profile(prof, numerics, B, H, K):
     if numerics == "exact":
         peak = PEAK_MFMA_TFLOPS / EXACT_PASSES
         note = (f"peak = {PEAK_MFMA_TFLOPS:.0f} TFLOP/s dense fp16 MFMA / {EXACT_PASSES} MFMA passes per algorithmic product "
-                f"(split-fp16 operands); matrix-pipe work = {EXACT_PASSES} x achieved")
+                f"(split-fp16 operands); matrix-pipe work = {EXACT_PASSES} x achieved.  Under this instruction stream the "
+                f"chip clocks at 1.7-1.9 GHz, not 2.4: the kernel's bare MFMA stream (no loads, LDS reads, stores or "
+                f"barriers) measured {MFMA_STREAM_PFLOPS} PFLOP/s of matrix work (profiles/r02_gemm_probes.md)")
     else:
         peak, note = PEAK_MFMA_TFLOPS, "dense bf16 MFMA peak"
     r = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
          "traffic": None, "launches": n, "avg_launch_ms": ms / max(n, 1), "algorithmic_gflop_per_launch": fl / max(n, 1) / 1e9,
          "peak_note": note, "frac_of_raw_mfma_peak": ach * (EXACT_PASSES if numerics == "exact" else 1) / PEAK_MFMA_TFLOPS}
+    if numerics == "exact":
+        r["frac_of_measured_mfma_stream"] = ach * EXACT_PASSES / (MFMA_STREAM_PFLOPS * 1e3)
     return r
 
 
