@@ -123,3 +123,58 @@ def test_bench_relaunches_itself_under_torchrun(monkeypatch):
     assert a[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=8" in a and "--nnodes=1" in a
     assert a[a.index("--master-addr") + 1] == "127.0.0.1" and int(a[a.index("--master-port") + 1]) > 0
     assert a[-6:] == ["--gpus", "8", "--steps", "2", "--warmup", "1"] and a[-7].endswith("bench.py")
+
+
+def test_bench_reports_counter_traffic_only_for_the_build_it_was_measured_on(monkeypatch):
+    """roofline.traffic comes from separate rocprofv3 --pmc passes stored in profiles/ next to the sha256 of the library
+    they were measured on ('refuse to print it when it differs')."""
+    import json
+    import bench
+    tj = json.load(open(os.path.join(os.path.dirname(bench.__file__), "profiles", "r02_gemm_traffic.json")))
+    sha = tj["exact"]["gemm_qkv"]["lib_sha256"]
+    roof = {"kernel": "gemm_qkv", "traffic": None}
+    monkeypatch.setattr(bench, "lib_sha256", lambda: sha)
+    bench.attach_traffic(roof, "exact", 0)
+    assert roof["traffic"] == tj["exact"]["gemm_qkv"]["hbm_bytes_per_launch"] > tj["exact"]["gemm_qkv"]["algorithmic_bytes_per_launch"]
+    roof = {"kernel": "gemm_qkv", "traffic": None}
+    monkeypatch.setattr(bench, "lib_sha256", lambda: "0" * 64)
+    bench.attach_traffic(roof, "exact", 0)
+    assert roof["traffic"] is None and "different build" in roof["traffic_note"]
+
+
+def test_rational_erf_of_the_exact_fc1_epilogue_is_fp32_class():
+    """common.h gelu_erf_rational (one rational x P(x^2)/Q(x^2) instead of libm's erff), restated in numpy with the same
+    coefficients and fma order: against fp64 its GELU is as accurate as torch's own fp32 GELU on N(0,1) inputs."""
+    import re
+    import numpy as np
+    from scipy.special import erf
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "d3dp_amd", "csrc", "common.h")).read()
+    body = src[src.index("float gelu_erf_rational(float x)"):src.index("typedef float f32x2")]
+    coef = [np.float32(c) for c in re.findall(r"(-?\d\.\d+e-\d+)f", body)]
+    assert len(coef) == 12
+    A, B = coef[:7], coef[7:]
+
+    def fma(x, y, z):
+        return (x.astype(np.float64) * y.astype(np.float64) + z.astype(np.float64)).astype(np.float32)
+
+    def gelu(x):
+        z = np.clip(x * np.float32(0.70710678118654752440), np.float32(-4), np.float32(4))
+        z2 = z * z
+        p = np.full_like(x, A[0])
+        for c in A[1:]:
+            p = fma(p, z2, np.full_like(x, c))
+        p = p * z
+        q = np.full_like(x, B[0])
+        for c in B[1:]:
+            q = fma(q, z2, np.full_like(x, c))
+        e = (p / q).astype(np.float32)
+        hx = np.float32(0.5) * x
+        return fma(hx, e, hx)
+
+    x = np.random.default_rng(0).standard_normal(400000).astype(np.float32)
+    truth = 0.5 * x.astype(np.float64) * (1 + erf(x.astype(np.float64) / np.sqrt(2)))
+    err = np.abs(gelu(x).astype(np.float64) - truth)
+    terr = np.abs(torch.nn.functional.gelu(torch.from_numpy(x)).numpy().astype(np.float64) - truth)
+    assert err.mean() < 1.5 * terr.mean() and err.max() < 1.5e-6, (err.mean(), terr.mean(), err.max())
+    big = np.array([-30.0, -6.0, -4.0, 4.0, 6.0, 30.0], dtype=np.float32)      # beyond the clamp: erf = -1 / +1
+    assert np.allclose(gelu(big), [0, 0, -1.3e-4, 4.0, 6.0, 30.0], atol=2e-4)
