@@ -116,6 +116,9 @@ struct d3dp_ctx {
   bool exact() const { return !fast() && !train(); }
   bool x2() const { return exact() && exact_impl == 0; }
   bool x2_attn() const { return x2() && cfg.channels / cfg.heads == 64; }   // split-fp16 attention kernels (head dim 64)
+  // proj / fc2 add into the residual stream in their epilogue (x += ...), so the row kernels read x alone
+  bool fold_resid() const { return x2() && fold; }
+  bool fold = true;
   bool x3() const { return exact() && exact_impl == 1; }
   int act() const { return fast() ? 1 : (x3() ? 2 : (x2() ? 3 : 0)); }   // code understood by the row-wise launchers
   size_t act_size() const { return fast() ? 2 : (x3() ? 6 : 4); }    // bytes per element of a Linear-input activation
@@ -216,13 +219,14 @@ int run_block(d3dp_ctx* c, const BlockDev& w, int axis, float* x, void* y1, void
   const int Tc = n_bh * g.frames * g.joints, C = g.channels;
   LAUNCH_TRY(linear(c, P_QKV, EPI_BIAS, 0, bufA, w.qkv_w, w.qkv_u, w.qkv_b, bufB, Tc, 3 * C, C, st));
   LAUNCH_TRY(attention(c, axis, bufB, bufA, n_bh, st));
-  LAUNCH_TRY(linear(c, P_PROJ, EPI_BIAS, 0, bufA, w.proj_w, w.proj_u, w.proj_b, y1, Tc, C, C, st));
+  const bool fold = c->fold_resid();   // EXACT split-fp16 Linears: x += proj / fc2 inside their epilogues
+  LAUNCH_TRY(linear(c, P_PROJ, fold ? EPI_RESID : EPI_BIAS, 0, bufA, w.proj_w, w.proj_u, w.proj_b, fold ? (void*)x : y1, Tc, C, C, st));
   {
     Scope s(c, P_LN, st);      // xn = LN2(x + y1); x itself stays untouched (the caller's norm pair adds y1 and y)
-    LAUNCH_TRY(d3dp_launch_ln(c->act(), x, y1, 0, w.n2w, w.n2b, g.eps_block, bufA, Tc, C, st));
+    LAUNCH_TRY(d3dp_launch_ln(c->act(), x, fold ? nullptr : y1, 0, w.n2w, w.n2b, g.eps_block, bufA, Tc, C, st));
   }
   LAUNCH_TRY(linear(c, P_FC1, EPI_GELU, 0, bufA, w.fc1_w, w.fc1_u, w.fc1_b, bufB, Tc, g.hidden, C, st));
-  LAUNCH_TRY(linear(c, P_FC2, EPI_BIAS, 0, bufB, w.fc2_w, w.fc2_u, w.fc2_b, y, Tc, C, g.hidden, st));
+  LAUNCH_TRY(linear(c, P_FC2, fold ? EPI_RESID : EPI_BIAS, 0, bufB, w.fc2_w, w.fc2_u, w.fc2_b, fold ? (void*)x : y, Tc, C, g.hidden, st));
   return 0;
 }
 
@@ -257,6 +261,8 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->cfg = g;
   const char* xf = getenv("D3DP_EXACT_IMPL");
   c->exact_impl = (xf && !strcmp(xf, "bf16x3")) ? 1 : (xf && !strcmp(xf, "f32")) ? 2 : 0;
+  const char* nf = getenv("D3DP_NO_FOLD");               // (A/B switch while the folded epilogue is being evaluated)
+  c->fold = !(nf && nf[0] == '1');
   HIP_TRY(hipGetDevice(&c->device));
   *out = c;
   return D3DP_OK;
@@ -441,25 +447,26 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
       LAUNCH_TRY(d3dp_launch_embed_ln(c->act(), x2d, x_t, temb, c->ew, c->eb, c->spos, c->ste[0].n1w, c->ste[0].n1b,
                                       g.eps_block, x, bufA, seq0, n, H, F, J, C, st));
     }
+    const bool fold = c->fold_resid();
     for (int d = 0; d < g.depth; ++d) {
       int r = run_block(c, c->ste[d], 0, x, y1, y, bufA, bufB, n, st);
       if (r) return r;
       {
         Scope s(c, P_LN2, st);   // x += fc2 out; Spatial_norm (+ Temporal_pos after block 0); TTE block d's norm1
-        LAUNCH_TRY(d3dp_launch_ln2(c->act(), x, y1, y, c->snw, c->snb, d == 0 ? c->tpos : nullptr, c->tte[d].n1w,
+        LAUNCH_TRY(d3dp_launch_ln2(c->act(), x, fold ? nullptr : y1, fold ? nullptr : y, c->snw, c->snb, d == 0 ? c->tpos : nullptr, c->tte[d].n1w,
                                    c->tte[d].n1b, g.eps_block, bufA, Tc, C, F, J, st));
       }
       r = run_block(c, c->tte[d], 1, x, y1, y, bufA, bufB, n, st);
       if (r) return r;
       if (d + 1 < g.depth) {
         Scope s(c, P_LN2, st);   // x += fc2 out; Temporal_norm; STE block d+1's norm1
-        LAUNCH_TRY(d3dp_launch_ln2(c->act(), x, y1, y, c->tnw, c->tnb, nullptr, c->ste[d + 1].n1w, c->ste[d + 1].n1b,
+        LAUNCH_TRY(d3dp_launch_ln2(c->act(), x, fold ? nullptr : y1, fold ? nullptr : y, c->tnw, c->tnb, nullptr, c->ste[d + 1].n1w, c->ste[d + 1].n1b,
                                    g.eps_block, bufA, Tc, C, F, J, st));
       }
     }
     {
       Scope s(c, P_HEAD, st);    // x += fc2 out; Temporal_norm; head LayerNorm; Linear(C,3)
-      LAUNCH_TRY(d3dp_launch_head(c->fast() ? 1 : 0, x, y1, y, c->tnw, c->tnb, g.eps_block, c->hnw, c->hnb, g.eps_head, c->hw, c->hb,
+      LAUNCH_TRY(d3dp_launch_head(c->fast() ? 1 : 0, x, fold ? nullptr : y1, fold ? nullptr : y, c->tnw, c->tnb, g.eps_block, c->hnw, c->hnb, g.eps_head, c->hw, c->hb,
                                   out + (size_t)seq0 * FJ * 3, Tc, C, st));
     }
   }

@@ -30,6 +30,7 @@
 //   EPI_BIAS     -> fp32 out (feeds the residual-adding row kernels)
 //   EPI_GELU     -> GELU (rational erf, common.h) re-split into two fp16 planes (the fc2 operand)
 //   EPI_QKV_PACK -> q fp32, k and v as fp16 planes: the packed rows the split-fp16 attention kernels read (attention.hip)
+//   EPI_RESID    -> x += A W^T + b in place on the fp32 residual stream (proj, fc2: mixste.py:113-115)
 // Plane outputs leave as ONE 16-byte store per lane too (neighbouring lanes swap halves, store_planes_paired).
 // Timing probes of this kernel (loads / stores / MFMAs / barriers compiled out one at a time) and what they say about
 // the clock the chip sustains under this instruction mix: profiles/r02_gemm_probes.md.
@@ -368,10 +369,33 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
                 ph[e] = h; pl[e] = l;
               }
               store_planes_paired(dst, ph, pl, odd, live);
-            } else {
+            } else if constexpr (EPI != EPI_RESID) {
               if (live) OUT_STORE(reinterpret_cast<f32x4*>(dst), ((f32x4){value(mi, r, 0), value(mi, r, 1), value(mi, r, 2), value(mi, r, 3)}));
             }
           }
+        if constexpr (EPI == EPI_RESID && !decltype(planes_c)::value) {
+          // x += A W^T + b in place (the residual stream): all sixteen reads of the tile in flight before the first add
+          f32x4 res[4][4];
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int k = mi * 16 + r;
+              const bool live = !decltype(checked_c)::value || k < rows;
+              res[mi][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+              if (live) res[mi][r] = *reinterpret_cast<const f32x4*>(base + (off + (unsigned)k * pitch));
+            }
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int k = mi * 16 + r;
+              const bool live = !decltype(checked_c)::value || k < rows;
+              const f32x4 v = {res[mi][r][0] + value(mi, r, 0), res[mi][r][1] + value(mi, r, 1),
+                               res[mi][r][2] + value(mi, r, 2), res[mi][r][3] + value(mi, r, 3)};
+              if (live) *reinterpret_cast<f32x4*>(base + (off + (unsigned)k * pitch)) = v;   // (re-read by the next row kernel: no nt hint)
+            }
+        }
       };
       using T_ = std::true_type; using F_ = std::false_type;
       if (rows >= 64) {                                // (all but the last row of tiles)
@@ -409,7 +433,8 @@ __global__ void absmax_kernel(const float* __restrict__ s, size_t n, unsigned* _
 }  // namespace
 
 // out = epi((A W^T) unscale + bias) with A2/W2 split-fp16 planes; EPI_BIAS: fp32 `outf`; EPI_GELU: two fp16 planes `out2`;
-// EPI_QKV_PACK (N = 3 C, C % 64 == 0): `outf` rows of 12 C bytes = q fp32 | k hi | k lo | v hi | v lo (fp16 x 16).
+// EPI_QKV_PACK (N = 3 C, C % 64 == 0): `outf` rows of 12 C bytes = q fp32 | k hi | k lo | v hi | v lo (fp16 x 16);
+// EPI_RESID: `outf` [M, N] fp32 is read and written (outf += ...).
 // `unscale` = 1 / (scale of the A planes * scale of the W planes).
 int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const float* bias, float unscale, float* outf,
                              void* out2, int M, int N, int K, hipStream_t st) {
@@ -424,6 +449,8 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x2_kernel<EPI_BIAS, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, XLDS) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x2_kernel<EPI_GELU, 0>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, XLDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x2_kernel<EPI_RESID, 0>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, XLDS) != hipSuccess) return -3;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -432,11 +459,12 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
     attr_set = true;
   }
   const int total = tm * tn, grid = total < n_cu ? total : n_cu;
-  if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_QKV_PACK) return -1;
+  if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_QKV_PACK && epi != EPI_RESID) return -1;
   if (epi == EPI_QKV_PACK && (N % 3 != 0 || (N / 3) % 64 != 0)) return -1;
   if (epi == EPI_GELU && N % 8 != 0) return -1;        // plane stores are paired across two 4-column groups
   auto kern = epi == EPI_GELU ? gemm_f16x2_kernel<EPI_GELU, 0>
-                              : (epi == EPI_QKV_PACK ? gemm_f16x2_kernel<EPI_BIAS, 1> : gemm_f16x2_kernel<EPI_BIAS, 0>);
+              : epi == EPI_RESID ? gemm_f16x2_kernel<EPI_RESID, 0>
+                                 : (epi == EPI_QKV_PACK ? gemm_f16x2_kernel<EPI_BIAS, 1> : gemm_f16x2_kernel<EPI_BIAS, 0>);
   hipLaunchKernelGGL(kern, dim3(grid), dim3((XNCW + 4) * 64), XLDS, st, (const f16*)A2, (const f16*)W2, bias, unscale, outf,
                      (f16*)out2, M, N, K, tn, total);
   return 0;

@@ -167,6 +167,31 @@ def test_linear_split_f16_is_fp32_class(lib, M, N, K):
 
 
 
+
+@pytest.mark.parametrize("M,N,K", [(4131, 512, 512), (1000, 512, 1024), (129, 192, 64)])
+def test_linear_split_f16_residual_epilogue_adds_in_place(lib, M, N, K):
+    """EPI_RESID (proj and fc2 of the EXACT denoiser): x += A W^T + b on the fp32 residual stream, bit for bit the plain
+    epilogue's result added to x in fp32 (what the row kernels did before the add moved into the Linear)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 2).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    x = torch.randn(M, N, generator=g).cuda()
+    A2 = torch.empty(2, M, K, dtype=torch.float16, device="cuda")
+    W2 = torch.empty(2, N, K, dtype=torch.float16, device="cuda")
+    w_scale = 2.0 ** (13 - int(np.floor(np.log2(W.abs().max().item()))))
+    _lib.check(lib.d3dp_op_split2(A.data_ptr(), A2.data_ptr(), M * K, 16.0, stream()))
+    _lib.check(lib.d3dp_op_split2(W.data_ptr(), W2.data_ptr(), N * K, w_scale, stream()))
+    plain = torch.empty(M, N, device="cuda")
+    _lib.check(lib.d3dp_op_linear_x2(_lib.EPI_BIAS, A2.data_ptr(), W2.data_ptr(), bias.data_ptr(), w_scale,
+                                     plain.data_ptr(), M, N, K, stream()))
+    acc = x.clone()
+    _lib.check(lib.d3dp_op_linear_x2(_lib.EPI_RESID, A2.data_ptr(), W2.data_ptr(), bias.data_ptr(), w_scale,
+                                     acc.data_ptr(), M, N, K, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(acc, x + plain)
+
+
 @pytest.mark.parametrize("M,C", [(4131, 512), (700, 128), (129, 64)])
 def test_qkv_linear_packed_epilogue_is_the_split_of_the_plain_one(lib, M, C):
     """EPI_QKV_PACK (what the EXACT denoiser's qkv Linear writes): rows of 12 C bytes, q fp32 | k hi | k lo | v hi | v lo

@@ -61,7 +61,7 @@ hdr = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup
        "# in FAST numerics (the secondary leg).  gemm_f16x2_kernel<0,1> = the EXACT qkv Linear (own symbol); bench.py's",
        f"# roofline.avg_launch_ms (HIP events on the launch stream) in the un-profiled run of the same build: {d['roofline']['avg_launch_ms'] * 1e3:.1f} us"
        + (f", in this profiled run: {prof['roofline']['avg_launch_ms'] * 1e3:.1f} us." if prof else "."),
-       "# <0,0> = proj and fc2 (EXACT), <1,0> = fc1 + GELU (EXACT); gemm_bf16_stream_kernel<...> = the FAST Linears.", ""]
+       "# <2,0> = proj and fc2 (EXACT: x += ... in place), <1,0> = fc1 + GELU (EXACT); gemm_bf16_stream_kernel<...> = the FAST Linears.", ""]
 open(os.path.join(P, "r02_bench_c3_kernel_stats.md"), "w").write("\n".join(hdr) + open(os.path.join(F, "kernel_stats.md")).read())
 print("value", d["value"], "fast", d["fast_mode"]["value"], "sha", sha[:12])
 print(json.dumps(t["exact"]["gemm_qkv"], indent=1))
