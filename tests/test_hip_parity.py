@@ -597,6 +597,20 @@ def test_exact_mode_cross_check_implementations(golden_dir, monkeypatch, impl):
     assert e <= EXACT_TOL_MM
 
 
+def test_exact_residual_adds_inside_the_linears_change_no_bit(golden_dir, monkeypatch):
+    """EXACT mode adds proj / fc2 into the residual stream inside the Linear epilogues; env D3DP_NO_FOLD=1 keeps the earlier
+    dataflow (separate y1 / y buffers, added by the row kernels).  Same fp32 additions in the same order: bit-identical."""
+    g = load_g(golden_dir, "g3_denoiser_F27")
+    x2d = torch.from_numpy(synthetic_inputs_2d(int(g["x2d_seed"]), 1, 27)).cuda()
+    x3d = torch.from_numpy(synthetic_noise(int(g["x3d_seed"]), (1, 1, 27, 17, 3))).cuda()
+    t = torch.tensor([499], device="cuda")
+    folded = make_model(27, 512, 8, 1, 1, "exact", int(g["seed"])).pose_estimator(x2d, x3d, t).clone()
+    monkeypatch.setenv("D3DP_NO_FOLD", "1")
+    plain = make_model(27, 512, 8, 1, 1, "exact", int(g["seed"])).pose_estimator(x2d, x3d, t)
+    assert torch.equal(folded, plain)
+    assert orc.mpjpe_mm(folded.cpu(), torch.from_numpy(g["out_t499"])) <= EXACT_TOL_MM
+
+
 def test_deferred_backward_recomputes_its_own_forward(golden_dir):
     """Two forwards before the first backward share one activation workspace: the first backward must differentiate
     through ITS forward (it re-runs it), as plain autograd does in the reference."""
