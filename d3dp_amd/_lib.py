@@ -11,7 +11,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libd3dp_hip.so")
+# D3DP_LIB=path: load another build of the library (A/B runs of differently compiled kernels; test-only)
+LIB_PATH = os.environ.get("D3DP_LIB") or os.path.join(_HERE, "lib", "libd3dp_hip.so")
 
 MODE_EXACT, MODE_FAST, MODE_TRAIN = 0, 1, 2
 MODE_SPLIT3 = 2   # d3dp_op_linear only: split-bf16 operands

@@ -35,7 +35,8 @@
 // Timing probes of this kernel (loads / stores / MFMAs / barriers compiled out one at a time) and what they say about
 // the clock the chip sustains under this instruction mix: profiles/r02_gemm_probes.md.
 #include <cstdlib>
-
+#include <cstring>
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -65,6 +66,23 @@
 #ifndef D3DP_X2_LAG
 #define D3DP_X2_LAG 1
 #endif
+#ifndef D3DP_X2_SBEND
+#define D3DP_X2_SBEND 0
+#endif
+// L2 prefetch distance in k-steps (even; 0 = off): the compute waves touch, D k-steps ahead of the loaders, every
+// 128-byte line of the A and W slabs (and, PFR, of the residual tile the EPI_RESID epilogue will read) with a 4-byte
+// LDS-DMA into a junk area -- no register destination, nothing ever waits for it.  The LDS ring bounds the bytes a CU
+// has in flight at two 48 KiB slabs (1.6 us at the rate it consumes them), less than the latency of a line that comes
+// from HBM or the memory-side cache; with the touch ahead of it the loaders' own LDS-DMA finds the line in the XCD's L2.
+#ifndef D3DP_X2_PFD
+#define D3DP_X2_PFD 0
+#endif
+#ifndef D3DP_X2_PFW
+#define D3DP_X2_PFW 1
+#endif
+#ifndef D3DP_X2_PFR
+#define D3DP_X2_PFR 1
+#endif
 #ifndef D3DP_NT_OUT
 #define D3DP_NT_OUT 1
 #endif
@@ -82,7 +100,8 @@ constexpr int XW_PLANE = XBN * XBK * 2;              //  8 KiB
 constexpr int XSTAGE = 2 * XA_PLANE + 2 * XW_PLANE;  // 48 KiB
 constexpr int XNSTAGE = 3;
 constexpr int XBIAS_MAX = 2048;                      // floats of bias kept in LDS
-constexpr int XLDS = XNSTAGE * XSTAGE + XBIAS_MAX * 4;   // 152 KiB
+constexpr int XJUNK = XNSTAGE * XSTAGE + XBIAS_MAX * 4;  // 256 bytes nobody reads: destination of the L2 prefetch touches
+constexpr int XLDS = XJUNK + 256;                        // 152.25 KiB
 constexpr int XNCW = 8;                              // compute waves (4 x 2); waves 8..11 are loaders
 
 // 64-byte rows (4 slots of 16 B): XOR bit 1 of the slot with bit 3 of the row -> conflict-free ds_read_b128 fragments
@@ -90,6 +109,28 @@ __device__ __forceinline__ int swz64(int row, int s) { return s ^ (((row >> 3) &
 
 // W row carried by LDS row q of a 64-column strip: MFMA tile ni = q>>4, operand row i = q&15 -> output column 4 i + ni
 __device__ __forceinline__ int colperm(int q) { return (q & 15) * 4 + (q >> 4); }
+
+// ---- SH = 1: the same kernel on v_mfma_f32_32x32x16_f16 (half the MFMA instructions and half the operand-register
+// reads per FLOP; the guide's micro-benchmark ceiling for fp16 is 2178 TFLOP/s on 32x32 against 1955 on 16x16).  Each
+// compute wave owns 32 rows x all 128 columns of the tile (4 accumulator tiles of 32x32 = the same 64 registers): a lane
+// holds C[row (reg&3) + 8 (reg>>2) + 4 (lane>>5)][column lane&31] of each tile, and the loader permutes the W rows of the
+// 128-column slab (LDS row ni*32 + i carries column 4 i + ni), so the lane's four tiles are again four CONSECUTIVE
+// columns: the epilogue's 16-byte stores are those of the 16x16 form, with 32 lanes covering 512 contiguous bytes of a row.
+// A 32-row fragment is read by the four 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the
+// same + 32): rows r, r+4, r+8, ... share a bank group, so the 16-byte slot is XORed with h(r>>2), h(q) = (q ^ q>>1) & 3,
+// which is injective on {0,3,5,6} and on {1,2,4,7} -- the row quads each lane group touches: conflict-free.
+__device__ __forceinline__ int h32(int row) { const int q = (row & 31) >> 2; return (q ^ (q >> 1)) & 3; }
+__device__ __forceinline__ int swz32(int row, int s) { return s ^ h32(row); }
+__device__ __forceinline__ int colperm32(int q) { return (q & 31) * 4 + (q >> 5); }
+typedef float f32x16_ __attribute__((ext_vector_type(16)));
+
+// One 4-byte LDS-DMA per lane from base + voff into the junk area at LDS byte address `junk` (wave-uniform): brings the
+// lane's 128-byte line into the L2.  M0 is saved and restored inside the statement (the compiler does not model it).
+__device__ __forceinline__ void touch_line(const void* base, unsigned voff, unsigned junk) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(junk) : "memory");
+}
 
 // Two fp16 planes of a 4-column group per lane -> ONE 16-byte store per lane: lanes 2j / 2j+1 hold neighbouring column
 // groups of the same row; the even lane collects both hi halves (8 columns of the hi plane), the odd lane both lo halves.
@@ -108,7 +149,7 @@ __device__ __forceinline__ void store_planes_paired(char* dst, f16x4 ph, f16x4 p
 
 // TAG 1: the qkv Linear feeding the split-fp16 attention kernels -- packed output rows (see the epilogue); as its own
 // kernel symbol rocprofv3 --stats also reports it separately from the proj Linear, which shares EPI with it.
-template <int EPI, int TAG>
+template <int EPI, int TAG, int SH>
 __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__ A2, const f16* __restrict__ W2,
                                                          const float* __restrict__ bias, float unscale,
                                                          float* __restrict__ outf, f16* __restrict__ out2, int M, int N,
@@ -144,13 +185,13 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                  // A row groups 4 lw .. 4 lw + 3 (16 rows each)
           const int row = (lw * 4 + i) * 16 + lr;
-          pa[i] = A2 + (size_t)min(m0 + row, M - 1) * K + swz64(row, lps) * 8;
+          pa[i] = A2 + (size_t)min(m0 + row, M - 1) * K + (SH ? swz32(row, lps) : swz64(row, lps)) * 8;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {                  // W row groups 2 lw, 2 lw + 1
           const int row = (lw * 2 + i) * 16 + lr;                       // LDS row of the W slab
-          const int wrow = (row & 64) + colperm(row & 63);              // output column it carries
-          pw[i] = W2 + (size_t)min(n0 + wrow, N - 1) * K + swz64(row, lps) * 8;
+          const int wrow = SH ? colperm32(row) : (row & 64) + colperm(row & 63);   // output column it carries
+          pw[i] = W2 + (size_t)min(n0 + wrow, N - 1) * K + (SH ? swz32(row, lps) : swz64(row, lps)) * 8;
         }
       }
       char* base = smem + slot * XSTAGE;
@@ -187,12 +228,13 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
 
   // -------------------------------------------------------------------- compute waves
   const int wr = wave >> 1, wc = wave & 1;
-  const int fi = lane & 15, fg = lane >> 4;
-  // per-lane fragment offsets inside a stage (the swizzle depends on the lane only: rows advance in multiples of 16)
-  const int offA = (wr * 64 + fi) * 64 + swz64(fi, fg) * 16;
-  const int offW = 2 * XA_PLANE + (wc * 64 + fi) * 64 + swz64(fi, fg) * 16;
+  const int fi = SH ? (lane & 31) : (lane & 15), fg = SH ? (lane >> 5) : (lane >> 4);
+  // per-lane fragment offsets inside a stage (the swizzle depends on the lane only: rows advance in multiples of 16 / 32)
+  const int offA = SH ? (wave * 32 + fi) * 64 + swz32(fi, fg) * 16 : (wr * 64 + fi) * 64 + swz64(fi, fg) * 16;
+  const int offW = 2 * XA_PLANE + (SH ? fi * 64 + swz32(fi, fg) * 16 : (wc * 64 + fi) * 64 + swz64(fi, fg) * 16);
   const size_t planeO = (size_t)M * N;
-  f32x4 acc[4][4];
+  f32x4 acc[4][4];                                     // SH = 0: [row block mi][column tile ni][r]
+  f32x16_ acc32[4];                                    // SH = 1: [column tile ni][reg]
   __builtin_amdgcn_s_setprio(1);
 #if D3DP_X2_PROBE & 16
   if (L & 1)
@@ -200,10 +242,115 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
 #endif
   int slot = 0;
   for (int ti = 0; ti < n_my; ++ti) {
+   if constexpr (SH == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc32[i][j] = 0.f;
+    // One k-step = two k-halves of 16 (slots 2 s + fg of the 64-byte rows: the second half's offset is the first's ^ 32).
+    // Per half and column tile three products into one accumulator, same-accumulator MFMAs four instructions apart.  The
+    // last product of a k-step (ah . wh of its second half: 4 MFMAs) is issued after the NEXT k-step's barrier, behind that
+    // step's first fragment reads, where it covers the LDS latency every wave meets at once; its operands (20 registers)
+    // alternate between two sets as the loop is unrolled by two.
+    f16x8 lwa[4], lwb[4], laa, lab;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) lwb[ni] = (f16x8){};
+    lab = (f16x8){};
+    const int offA1 = offA ^ 32, offW1 = offW ^ 32;
+    auto kstep32 = [&](f16x8 (&lw)[4], f16x8& la, const f16x8 (&pw)[4], const f16x8& pa) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0)
+      X2_BARRIER();
+      __builtin_amdgcn_sched_barrier(0);
+      const char* sb = smem + slot * XSTAGE;
+      slot = (slot == XNSTAGE - 1) ? 0 : slot + 1;
+      f16x8 wh[4], wl[4], wl1[4];
+      const f16x8 ah = *reinterpret_cast<const f16x8*>(sb + offA);
+      const f16x8 al = *reinterpret_cast<const f16x8*>(sb + offA + XA_PLANE);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        wl[ni] = *reinterpret_cast<const f16x8*>(sb + offW + XW_PLANE + ni * 2048);
+        wh[ni] = *reinterpret_cast<const f16x8*>(sb + offW + ni * 2048);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#if !(D3DP_X2_PROBE & 8)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc32[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, pw[ni], acc32[ni], 0, 0, 0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      la = *reinterpret_cast<const f16x8*>(sb + offA1);
+      const f16x8 al1 = *reinterpret_cast<const f16x8*>(sb + offA1 + XA_PLANE);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        wl1[ni] = *reinterpret_cast<const f16x8*>(sb + offW1 + XW_PLANE + ni * 2048);
+        lw[ni] = *reinterpret_cast<const f16x8*>(sb + offW1 + ni * 2048);
+      }
+#if D3DP_X2_PROBE & 8
+      asm volatile("" :: "v"(ah), "v"(al), "v"(la), "v"(al1));
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) asm volatile("" :: "v"(wh[ni]), "v"(wl[ni]), "v"(wl1[ni]), "v"(lw[ni]));
+#else
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc32[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[ni], acc32[ni], 0, 0, 0);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc32[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[ni], acc32[ni], 0, 0, 0);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc32[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[ni], acc32[ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc32[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(la, wl1[ni], acc32[ni], 0, 0, 0);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc32[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, lw[ni], acc32[ni], 0, 0, 0);
+#endif
+#if D3DP_X2_SBEND
+      __builtin_amdgcn_sched_barrier(0);               // (A/B: keep the k-step's products above the next barrier)
+#endif
+    };
+#pragma unroll 1
+    for (int ks = 0; ks < NK; ks += 2) {               // NK is even (K % 64 == 0, checked by the launcher)
+      kstep32(lwa, laa, lwb, lab);
+      kstep32(lwb, lab, lwa, laa);
+    }
+#if !(D3DP_X2_PROBE & 8)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc32[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lab, lwb[ni], acc32[ni], 0, 0, 0);
+#endif
+   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if D3DP_X2_PFD
+    // ---- L2 prefetch touches (see D3DP_X2_PFD): byte offsets of this lane's lines in the current and the next tile
+    const int L512 = wave * 64 + lane;
+    unsigned pfa0, pfw0, pfda = 0, pfdw = 0, pfr = 0;   // (pfd*: next tile's offset minus this tile's, modulo 2^32)
+    int pf_lim = NK;                                   // prefetch only k-steps below this (no next tile: none beyond NK)
+    {
+      const int t0 = L + ti * G, m0 = (t0 / tiles_n) * XBM, n0 = (t0 % tiles_n) * XBN;
+      const int prow = L512 & 255, ppl = L512 >> 8, wrow_ = L512 & 127, wpl = (L512 >> 7) & 1;
+      pfa0 = (unsigned)((ppl * M + min(m0 + prow, M - 1)) * K) * 2u;
+      pfw0 = (unsigned)((wpl * N + min(n0 + wrow_, N - 1)) * K) * 2u;
+      if (ti + 1 < n_my) {
+        const int t1 = t0 + G, m1 = (t1 / tiles_n) * XBM, n1 = (t1 % tiles_n) * XBN;
+        pfda = (unsigned)((ppl * M + min(m1 + prow, M - 1)) * K) * 2u - pfa0 - (unsigned)K * 2u;
+        pfdw = (unsigned)((wpl * N + min(n1 + wrow_, N - 1)) * K) * 2u - pfw0 - (unsigned)K * 2u;
+        pf_lim = 2 * NK;
+      }
+      if constexpr (EPI == EPI_RESID)   // residual tile: 256 rows x 512 bytes = 1024 lines, two per lane (L512, L512 + 512)
+        pfr = (unsigned)(min(m0 + (L512 >> 2), M - 1) * N + min(n0 + (L512 & 3) * 32, N - 4)) * 4u;
+    }
+    const unsigned junk = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem + XJUNK));
+#define X2_PREFETCH(ks)                                                                                       \
+    do {             /* after the barrier of even k-step ks: the lines of k-steps ks+D, ks+D+1 (next tile past NK) */ \
+      const int kk_ = (ks) + D3DP_X2_PFD;                                                                      \
+      if (kk_ < pf_lim) {                                                                                      \
+        const unsigned wrap_ = kk_ >= NK ? 1u : 0u;                                                            \
+        touch_line(A2, pfa0 + wrap_ * pfda + (unsigned)kk_ * (XBK * 2), junk);                                 \
+        if (D3DP_X2_PFW && wave < 4) touch_line(W2, pfw0 + wrap_ * pfdw + (unsigned)kk_ * (XBK * 2), junk);     \
+      }                                                                                                        \
+      if constexpr (EPI == EPI_RESID && D3DP_X2_PFR)                                                           \
+        if ((ks) == NK - 8 || (ks) == NK - 6) touch_line(outf, pfr + ((ks) == NK - 6 ? 128u * N * 4u : 0u), junk); \
+    } while (0)
+#endif
 #if D3DP_X2_LAG
     // The last two products of row block 3 (al.wh, ah.wh: 8 MFMAs) are issued AFTER the next k-step's barrier, behind
     // that step's first fragment reads: they cover the LDS latency that otherwise idles the matrix pipe after every
@@ -213,7 +360,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) wfb[ni][0] = wfb[ni][1] = (f16x8){};
     tab[0] = tab[1] = (f16x8){};
-    auto kstep = [&](f16x8 (&wf)[4][2], f16x8 (&ta)[2], const f16x8 (&pw)[4][2], const f16x8 (&pa)[2]) {
+    auto kstep = [&](f16x8 (&wf)[4][2], f16x8 (&ta)[2], const f16x8 (&pw)[4][2], const f16x8 (&pa)[2], int pfks) {
       __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): this wave has read everything it wanted from the old slot
       X2_BARRIER();
       __builtin_amdgcn_sched_barrier(0);
@@ -237,6 +384,10 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
       for (int ni = 0; ni < 4; ++ni) acc[3][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[0], pw[ni][1], acc[3][ni], 0, 0, 0);
 #endif
       __builtin_amdgcn_sched_barrier(0);
+#if D3DP_X2_PFD
+      if (pfks >= 0) X2_PREFETCH(pfks);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int mi = 0; mi < 3; ++mi) {
         const int b = mi & 1;
@@ -262,8 +413,8 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
     };
 #pragma unroll 1
     for (int ks = 0; ks < NK; ks += 2) {               // NK is even (K % 64 == 0, checked by the launcher)
-      kstep(wfa, taa, wfb, tab);
-      kstep(wfb, tab, wfa, taa);
+      kstep(wfa, taa, wfb, tab, ks);
+      kstep(wfb, tab, wfa, taa, -1);
     }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[3][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tab[1], wfb[ni][0], acc[3][ni], 0, 0, 0);
@@ -311,12 +462,15 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
       }
     }
 #endif
-    // ---- tile epilogue: lane holds out[m = pm0 + mi*16 + r][n = nb + ni], pm0 = tile row + wr*64 + 4 fg, nb = tile column
-    // + wc*64 + 4 fi.  Every store address is  uniform base + 32-bit lane offset  (the launcher refuses outputs of 4 GiB or
-    // more), advanced row by row: per-row 64-bit address arithmetic was most of the epilogue's VALU work, and it runs
-    // with the matrix pipes idle.
+   }
+    // ---- tile epilogue: lane holds out[m = pm0 + rowk(q)][n = nb + ni] for its 16 row slots q.  SH = 0: q = mi*4 + r,
+    // rowk = mi*16 + r, pm0 = tile row + wr*64 + 4 fg, nb = tile column + wc*64 + 4 fi; SH = 1: q = reg, rowk = (reg&3) +
+    // 8 (reg>>2), pm0 = tile row + wave*32 + 4 fg, nb = tile column + 4 fi.  Every store address is  uniform base + 32-bit
+    // lane offset  (the launcher refuses outputs of 4 GiB or more), advanced row by row: per-row 64-bit address arithmetic
+    // was most of the epilogue's VALU work, and it runs with the matrix pipes idle.
     const int t = L + ti * G;
-    const int pm0 = (t / tiles_n) * XBM + wr * 64 + 4 * fg, nb = (t % tiles_n) * XBN + wc * 64 + 4 * fi;
+    const int pm0 = (t / tiles_n) * XBM + (SH ? wave * 32 : wr * 64) + 4 * fg;
+    const int nb = (t % tiles_n) * XBN + (SH ? 0 : wc * 64) + 4 * fi;
     if (nb < N && (!(D3DP_X2_PROBE & 4) || unscale == -12345.f)) {
       const float4 bz = *reinterpret_cast<const float4*>(sbias + nb);
       const bool odd = fi & 1;
@@ -338,16 +492,18 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
         off = nb * 4;
       }
       off += (unsigned)pm0 * pitch;
-      const int rows = M - pm0;                        // row k = mi*16 + r of this lane exists iff k < rows
+      const int rows = M - pm0;                        // row slot q of this lane exists iff rowk(q) < rows
       auto value = [&](int mi, int r, int e) {
-        return fmaf(acc[mi][e][r], unscale, e == 0 ? bz.x : e == 1 ? bz.y : e == 2 ? bz.z : bz.w);
+        const float a = SH ? acc32[e][mi * 4 + r] : acc[mi][e][r];
+        return fmaf(a, unscale, e == 0 ? bz.x : e == 1 ? bz.y : e == 2 ? bz.z : bz.w);
       };
+      auto rowk = [&](int mi, int r) { return SH ? r + 8 * mi : mi * 16 + r; };
       auto store_rows = [&](auto planes_c, auto checked_c) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int k = mi * 16 + r;
+            const int k = rowk(mi, r);
             const bool live = !decltype(checked_c)::value || k < rows;
             char* dst = base + (off + (unsigned)k * pitch);
             if constexpr (decltype(planes_c)::value) {
@@ -380,7 +536,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
           for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int k = mi * 16 + r;
+              const int k = rowk(mi, r);
               const bool live = !decltype(checked_c)::value || k < rows;
               res[mi][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
               if (live) res[mi][r] = *reinterpret_cast<const f32x4*>(base + (off + (unsigned)k * pitch));
@@ -389,7 +545,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
           for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int k = mi * 16 + r;
+              const int k = rowk(mi, r);
               const bool live = !decltype(checked_c)::value || k < rows;
               const f32x4 v = {res[mi][r][0] + value(mi, r, 0), res[mi][r][1] + value(mi, r, 1),
                                res[mi][r][2] + value(mi, r, 2), res[mi][r][3] + value(mi, r, 3)};
@@ -398,7 +554,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
         }
       };
       using T_ = std::true_type; using F_ = std::false_type;
-      if (rows >= 64) {                                // (all but the last row of tiles)
+      if (rows >= (SH ? 32 : 64)) {                    // (all but the last row of tiles)
         if (planes) { if constexpr (EPI == EPI_GELU || TAG == 1) store_rows(T_{}, F_{}); }
         else { if constexpr (EPI != EPI_GELU) store_rows(F_{}, F_{}); }
       } else {
@@ -407,6 +563,9 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
       }
     }
   }
+#if D3DP_X2_PFD
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no touch may still be writing LDS when the workgroup's LDS is released
+#endif
 }
 
 // dst[0][i] = hi, dst[1][i] = lo of src[i] * scale
@@ -436,35 +595,49 @@ __global__ void absmax_kernel(const float* __restrict__ s, size_t n, unsigned* _
 // EPI_QKV_PACK (N = 3 C, C % 64 == 0): `outf` rows of 12 C bytes = q fp32 | k hi | k lo | v hi | v lo (fp16 x 16);
 // EPI_RESID: `outf` [M, N] fp32 is read and written (outf += ...).
 // `unscale` = 1 / (scale of the A planes * scale of the W planes).
+// K must be a multiple of 64: the k-loop is unrolled by two k-steps of 32 (the lagged products alternate between two
+// register sets), and the loader / compute waves count barriers per k-step.
+// env D3DP_X2_SHAPE=32 selects the v_mfma_f32_32x32x16_f16 form of the kernel (measured 11 % slower on the whole step,
+// profiles/r03_gemm_mfma_shape.md; kept as a tested cross-check).
 int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const float* bias, float unscale, float* outf,
                              void* out2, int M, int N, int K, hipStream_t st) {
-  if (K % XBK != 0 || N % 4 != 0 || N > XBIAS_MAX || M <= 0) return -1;
+  if (K % (2 * XBK) != 0 || N % 4 != 0 || N > XBIAS_MAX || M <= 0) return -1;
   if ((size_t)M * N * 4 >= ((size_t)1 << 32)) return -1;   // 32-bit byte offsets in the epilogue
-  const int tm = (M + XBM - 1) / XBM, tn = (N + XBN - 1) / XBN;
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x2_kernel<EPI_BIAS, 0>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, XLDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x2_kernel<EPI_BIAS, 1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, XLDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x2_kernel<EPI_GELU, 0>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, XLDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x2_kernel<EPI_RESID, 0>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, XLDS) != hipSuccess) return -3;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -3;
-    n_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
-  const int total = tm * tn, grid = total < n_cu ? total : n_cu;
   if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_QKV_PACK && epi != EPI_RESID) return -1;
   if (epi == EPI_QKV_PACK && (N % 3 != 0 || (N / 3) % 64 != 0)) return -1;
   if (epi == EPI_GELU && N % 8 != 0) return -1;        // plane stores are paired across two 4-column groups
-  auto kern = epi == EPI_GELU ? gemm_f16x2_kernel<EPI_GELU, 0>
-              : epi == EPI_RESID ? gemm_f16x2_kernel<EPI_RESID, 0>
-                                 : (epi == EPI_QKV_PACK ? gemm_f16x2_kernel<EPI_BIAS, 1> : gemm_f16x2_kernel<EPI_BIAS, 0>);
+  const int tm = (M + XBM - 1) / XBM, tn = (N + XBN - 1) / XBN;
+  using KernT = void (*)(const f16*, const f16*, const float*, float, float*, f16*, int, int, int, int, int);
+  static const KernT kerns[2][4] = {
+      {gemm_f16x2_kernel<EPI_BIAS, 0, 0>, gemm_f16x2_kernel<EPI_BIAS, 1, 0>, gemm_f16x2_kernel<EPI_GELU, 0, 0>,
+       gemm_f16x2_kernel<EPI_RESID, 0, 0>},
+      {gemm_f16x2_kernel<EPI_BIAS, 0, 1>, gemm_f16x2_kernel<EPI_BIAS, 1, 1>, gemm_f16x2_kernel<EPI_GELU, 0, 1>,
+       gemm_f16x2_kernel<EPI_RESID, 0, 1>}};
+  // per DEVICE: the 152 KiB dynamic-LDS opt-in of every instantiation and the CU count (one process may drive several
+  // devices: nn.DataParallel callers)
+  constexpr int kMaxDev = 64;
+  static std::mutex mu;
+  static int n_cu[kMaxDev] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return -3;
+  int cus;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (n_cu[dev] == 0) {
+      for (int sh = 0; sh < 2; ++sh)
+        for (int k = 0; k < 4; ++k)
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[sh][k]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  XLDS) != hipSuccess) return -3;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return -3;
+      n_cu[dev] = prop.multiProcessorCount;
+    }
+    cus = n_cu[dev];
+  }
+  const char* she = getenv("D3DP_X2_SHAPE");           // read per launch: tests flip it inside one process
+  const int shape = (she && !strcmp(she, "32")) ? 1 : 0;
+  const int total = tm * tn, grid = total < cus ? total : cus;
+  const KernT kern = kerns[shape][epi == EPI_GELU ? 2 : epi == EPI_RESID ? 3 : epi == EPI_QKV_PACK ? 1 : 0];
   hipLaunchKernelGGL(kern, dim3(grid), dim3((XNCW + 4) * 64), XLDS, st, (const f16*)A2, (const f16*)W2, bias, unscale, outf,
                      (f16*)out2, M, N, K, tn, total);
   return 0;

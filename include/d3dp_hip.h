@@ -239,7 +239,13 @@ int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream);
  * activation scale); W2 at any power-of-two `w_scale` (the denoiser picks it per matrix so that max |w| w_scale lies in
  * [2^13, 2^14)).  epi 0 -> fp32 out, epi 1 -> GELU then two fp16 planes (scale 16) out, epi 4 (N = 3 C, C % 64 == 0; the
  * qkv Linear of the EXACT denoiser) -> packed rows of 12 C bytes: q fp32 [C] | k hi | k lo | v hi | v lo (fp16 [C] each,
- * scale 16), the operand format of the split-fp16 attention kernels. */
+ * scale 16), the operand format of the split-fp16 attention kernels; epi 2 -> out[M,N] fp32 is read and written
+ * (out += A W^T + b: the residual-adding form of proj and fc2).
+ * Constraints (D3DP_EINVAL otherwise): K % 64 == 0 (the k-loop runs two 32-deep k-steps per iteration), N % 4 == 0
+ * (N % 8 for epi 1), N <= 2048, M * N * 4 < 2^32.  Every operand value must stay below 65504 / scale in magnitude
+ * (activations: |x| < 4094): d3dp_op_split2 saturates the hi plane at the fp16 maximum instead of producing inf.
+ * Test-only environment switches read by the library: D3DP_X2_SHAPE=32 (the 32x32x16 MFMA form of this kernel),
+ * D3DP_EXACT_IMPL=bf16x3|f32 and D3DP_NO_FOLD=1 (cross-check implementations of EXACT mode, read in d3dp_create). */
 int d3dp_op_split2(const float* src, void* dst, size_t n, float scale, void* stream);
 int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* bias, float w_scale, void* out, int32_t M,
                       int32_t N, int32_t K, void* stream);

@@ -168,6 +168,60 @@ def test_linear_split_f16_is_fp32_class(lib, M, N, K):
 
 
 
+@pytest.mark.parametrize("M,N,K", [(4131, 1536, 512), (1000, 512, 1024), (129, 192, 64), (66000, 512, 512)])
+def test_linear_split_f16_mfma_32x32x16_form(lib, monkeypatch, M, N, K):
+    """D3DP_X2_SHAPE=32: the same Linear on v_mfma_f32_32x32x16_f16 (another fragment layout, LDS swizzle, W-row
+    permutation and accumulator-to-row map; measured slower, profiles/r03_gemm_mfma_shape.md, kept as a cross-check).
+    Same fp32-class gate, and the packed / GELU / residual epilogues must agree with the default form to rounding of the
+    summation order."""
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    A = (torch.randn(M, K, generator=g) * 2).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    want = A.double() @ W.double().t() + bias.double()
+    f32_err = ((A @ W.t() + bias).double() - want).abs().mean().item()
+    A2 = torch.empty(2, M, K, dtype=torch.float16, device="cuda")
+    W2 = torch.empty(2, N, K, dtype=torch.float16, device="cuda")
+    w_scale = 2.0 ** (13 - int(np.floor(np.log2(W.abs().max().item()))))
+    _lib.check(lib.d3dp_op_split2(A.data_ptr(), A2.data_ptr(), M * K, 16.0, stream()))
+    _lib.check(lib.d3dp_op_split2(W.data_ptr(), W2.data_ptr(), N * K, w_scale, stream()))
+    res = {}
+    for shape in ("16", "32"):
+        monkeypatch.setenv("D3DP_X2_SHAPE", shape)
+        outs = []
+        for epi in (_lib.EPI_BIAS, _lib.EPI_GELU, _lib.EPI_RESID) + ((_lib.EPI_QKV_PACK,) if N % 192 == 0 else ()):
+            out = torch.ones(M, N, device="cuda")
+            _lib.check(lib.d3dp_op_linear_x2(epi, A2.data_ptr(), W2.data_ptr(), bias.data_ptr(), w_scale, out.data_ptr(),
+                                             M, N, K, stream()))
+            outs.append(out)
+        torch.cuda.synchronize()
+        res[shape] = outs
+    err = (res["32"][0].double() - want).abs().mean().item()
+    print(f"32x32x16 form M={M} N={N} K={K}: mean |err| {err:.3e} (torch fp32 matmul {f32_err:.3e})")
+    assert err <= 3.0 * f32_err
+    assert torch.allclose(res["32"][0], res["16"][0], atol=2e-5, rtol=2e-5)
+    assert torch.allclose(res["32"][2], res["16"][2], atol=2e-5, rtol=2e-5)           # x += ...
+    h16, h32 = (r[1].view(torch.float16)[:, :].reshape(-1)[:2 * M * N].view(2, M, N) for r in (res["16"], res["32"]))
+    assert torch.allclose((h32[0].double() + h32[1].double()) / 16, (h16[0].double() + h16[1].double()) / 16, atol=2e-5, rtol=2e-5)
+    if N % 192 == 0:
+        C = N // 3
+        assert torch.allclose(res["32"][3][:, :C], res["16"][3][:, :C], atol=2e-5, rtol=2e-5)
+        p16, p32 = (r[3][:, C:].contiguous().view(torch.float16).view(M, 4, C).double() for r in (res["16"], res["32"]))
+        for i in (0, 2):
+            assert torch.allclose((p32[:, i] + p32[:, i + 1]) / 16, (p16[:, i] + p16[:, i + 1]) / 16, atol=2e-5, rtol=2e-5)
+
+
+def test_linear_split_f16_rejects_k_not_multiple_of_64(lib):
+    """The k-loop runs two k-steps of 32 per iteration: K = 96 must be refused, not mis-computed."""
+    M, N, K = 300, 128, 96
+    A2 = torch.zeros(2, M, K, dtype=torch.float16, device="cuda")
+    W2 = torch.zeros(2, N, K, dtype=torch.float16, device="cuda")
+    out = torch.zeros(M, N, device="cuda")
+    rc = lib.d3dp_op_linear_x2(_lib.EPI_BIAS, A2.data_ptr(), W2.data_ptr(), torch.zeros(N, device="cuda").data_ptr(), 1.0,
+                               out.data_ptr(), M, N, K, stream())
+    assert rc != 0 and b"d3dp_launch_linear_f16x2" in lib.d3dp_last_error()
+
+
 @pytest.mark.parametrize("M,N,K", [(4131, 512, 512), (1000, 512, 1024), (129, 192, 64)])
 def test_linear_split_f16_residual_epilogue_adds_in_place(lib, M, N, K):
     """EPI_RESID (proj and fc2 of the EXACT denoiser): x += A W^T + b on the fp32 residual stream, bit for bit the plain

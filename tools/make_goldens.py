@@ -228,6 +228,39 @@ def g13(D3DP):
          kept_frames=frames, out_kept=out[:, :, :, frames], sum=o.sum(-1), sumsq=(o * o).sum(-1), wsum=(o * w).sum(-1))
 
 
+def g14(D3DP):
+    """BASELINE config 3 -- the benchmarked workload -- at FULL size through the reference: F=243, J=17, H=20, K=10,
+    B=16, cs=512, dep=8 (6400 (clip, hypothesis) denoiser passes of 295 GFLOP each: about an hour and a half on 8 host
+    cores, run clip by clip -- clips are independent given their 2D input, mixste.py:227-230 -- and resumable through
+    /tmp/g14_clip*.npy).  The (16,10,20,243,17,3) output is 159 MB, so the fixture keeps, for EVERY (clip, step,
+    hypothesis), fp64 checksums over all frames: sum, sum of squares and four Gaussian random projections (weights from
+    PCG64(1414), regenerated by the test).  E[(w . e)^2] = |e|^2 for such weights, so the projections measure the RMS
+    error of every slice, not only its mean: tests/test_hip_parity.py::test_c3_full_size_all_slices_vs_reference_fixture."""
+    B, H, K, Fr = 16, 20, 10, 243
+    x2d = synthetic_inputs_2d(1234, B, Fr)
+    noises = [synthetic_noise(2000 + k, (B, H, Fr, 17, 3)) for k in range(K)]
+    m = build_ref(D3DP, Fr, 512, 8, 7, H=H, K=K)
+    n = H and Fr * 17 * 3
+    w = np.random.Generator(np.random.PCG64(1414)).standard_normal(size=(4, n))
+    sums, sqs, projs = np.zeros((B, K, H)), np.zeros((B, K, H)), np.zeros((B, K, H, 4))
+    for b in range(B):
+        tmp = f"/tmp/g14_clip{b}.npy"
+        if os.path.exists(tmp):
+            out = np.load(tmp)
+        else:
+            xb = x2d[b:b + 1]
+            with Draws(randn_list=[torch.from_numpy(nz[b:b + 1]) for nz in noises]) as d:
+                with torch.no_grad():
+                    out = m(torch.from_numpy(xb), None, input_2d_flip=torch.from_numpy(flip_2d(xb))).numpy()
+                assert d.n_randn == K and not d.randn_list
+            np.save(tmp, out)
+            print(f"  clip {b} done", flush=True)
+        o = out.astype(np.float64).reshape(K, H, n)
+        sums[b], sqs[b], projs[b] = o.sum(-1), (o * o).sum(-1), o @ w.T
+    save("g14_sampler_c3", cs=512, dep=8, frames=Fr, seed=7, B=B, H=H, K=K, x2d_seed=1234, noise_seed=2000,
+         proj_seed=1414, sum=sums, sumsq=sqs, proj=projs)
+
+
 def g6(D3DP):
     """Train step forward (+loss, grad norms): F=27, B=4, cs=64, dep=2; DropPath off and on."""
     sys.path.insert(0, REF)
