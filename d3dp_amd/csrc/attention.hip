@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qk
   }
   const float inv = 1.0f / l;
   if constexpr (OUTS == 2) {
-    f16* dst = reinterpret_cast<f16*>(out_v) + tok * C + head * HD;
+    f16* dst = reinterpret_cast<f16*>(out_v) + (size_t)tok * (2 * C);   // h2i row (common.h)
 #pragma unroll
     for (int c = 0; c < HD / 4; ++c) {
       f16x4 p0, p1;
@@ -141,8 +141,9 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qk
         split2h(o[c * 4 + e] * inv, a0, a1);
         p0[e] = a0; p1[e] = a1;
       }
-      *reinterpret_cast<f16x4*>(dst + c * 4) = p0;
-      *reinterpret_cast<f16x4*>(dst + plane + c * 4) = p1;
+      const int hc = h2i_col(head * HD + c * 4);
+      *reinterpret_cast<f16x4*>(dst + hc) = p0;
+      *reinterpret_cast<f16x4*>(dst + hc + kH2iLo) = p1;
     }
   } else if constexpr (OUTS == 3) {
     bf16* dst = reinterpret_cast<bf16*>(out_v) + tok * C + head * HD;
@@ -617,21 +618,22 @@ __device__ __forceinline__ void load_k_x2(const f16* krow, int C, int fg, f16x8 
   }
 }
 
-// O^T accumulators -> out row (fp32, or two fp16 planes `plane_elems` apart): lane holds channels dn*16 + 4 fg + (0..3)
+// O^T accumulators -> out row `tok` (fp32 [T][C], or the h2i layout of the proj Linear's operand, common.h): lane holds
+// channels col + dn*16 + (0..3), col = head*64 + 4 fg
 template <int OUTS>
-__device__ __forceinline__ void store_o_x2(const f32x4 (&o)[4], float inv, void* out_v, size_t off, size_t plane_elems) {
+__device__ __forceinline__ void store_o_x2(const f32x4 (&o)[4], float inv, void* out_v, size_t tok, int C, int col) {
 #pragma unroll
   for (int dn = 0; dn < 4; ++dn) {
     const float r4[4] = {o[dn][0] * inv, o[dn][1] * inv, o[dn][2] * inv, o[dn][3] * inv};
     if constexpr (OUTS == 2) {
-      f16* dst = reinterpret_cast<f16*>(out_v) + off + dn * 16;
+      f16* dst = reinterpret_cast<f16*>(out_v) + tok * (2 * C) + h2i_col(col + dn * 16);
       f16x4 p0, p1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { f16 a0, a1; split2h(r4[e], a0, a1); p0[e] = a0; p1[e] = a1; }
       *reinterpret_cast<f16x4*>(dst) = p0;
-      *reinterpret_cast<f16x4*>(dst + plane_elems) = p1;
+      *reinterpret_cast<f16x4*>(dst + kH2iLo) = p1;
     } else {
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(out_v) + off + dn * 16) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(out_v) + tok * C + col + dn * 16) = make_float4(r4[0], r4[1], r4[2], r4[3]);
     }
   }
 }
@@ -791,7 +793,7 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
         const int l = opaque(lane);
         const int q = qt * 16 + (l & 15);
         if (q < n)
-          store_o_x2<OUTS>(o, inv_scale / denom[u], out_v, (size_t)(tok0 + q * ts) * C + head * 64 + (l >> 4) * 4, plane_elems);
+          store_o_x2<OUTS>(o, inv_scale / denom[u], out_v, (size_t)(tok0 + q * ts), C, head * 64 + (l >> 4) * 4);
       }
     }
     if (!has_next) break;
@@ -893,7 +895,7 @@ __global__ __launch_bounds__(256) void attn_spatial_x2_kernel(const float* __res
 #pragma unroll
     for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
     pv_chunk_x2_seq<0>(fb, PLANE, ph[0], pl[0], o);
-    if (q < n) store_o_x2<OUTS>(o, inv_scale / sum, out_v, (size_t)(base + q * ts) * C + head * 64 + fg * 4, plane_elems);
+    if (q < n) store_o_x2<OUTS>(o, inv_scale / sum, out_v, (size_t)(base + q * ts), C, head * 64 + fg * 4);
   }
 }
 
@@ -1044,8 +1046,8 @@ __global__ __launch_bounds__(256, 1) void attn_temporal_f32_kernel(const float* 
 #pragma unroll
       for (int dn = 0; dn < 4; ++dn) {
         float r4[4] = {o[dn][0] * inv, o[dn][1] * inv, o[dn][2] * inv, o[dn][3] * inv};
-        if constexpr (OUTS == 2) {
-          f16* dst = reinterpret_cast<f16*>(out_v) + off + dn * 16;
+        if constexpr (OUTS == 2) {                      // h2i row (common.h)
+          f16* dst = reinterpret_cast<f16*>(out_v) + (size_t)(base + q * ts) * (2 * C) + h2i_col(head * 64 + fg * 4 + dn * 16);
           f16x4 p0, p1;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -1054,7 +1056,7 @@ __global__ __launch_bounds__(256, 1) void attn_temporal_f32_kernel(const float* 
             p0[e] = a0; p1[e] = a1;
           }
           *reinterpret_cast<f16x4*>(dst) = p0;
-          *reinterpret_cast<f16x4*>(dst + plane) = p1;
+          *reinterpret_cast<f16x4*>(dst + kH2iLo) = p1;
         } else if constexpr (OUTS == 3) {
           bf16* dst = reinterpret_cast<bf16*>(out_v) + off + dn * 16;
           bf16x4 p0, p1, p2;

@@ -154,6 +154,14 @@ typedef _Float16 f16;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float kActScale = 16.0f, kActUnscale = 1.0f / 16.0f;
+// HBM layout of a split-fp16 matrix [R][K] ("h2i": hi / lo interleaved per 128-byte line): row r = 2 K fp16 = K/32 blocks
+// of 64 fp16, block kb = [hi of columns 32 kb .. 32 kb + 31 | lo of the same columns].  One 32-deep k-step of one row --
+// both values of every element -- is ONE 128-byte line, which is what the Linear kernel's LDS-DMA loaders want
+// (gemm_x2.hip: 8 whole lines per 1 KiB piece instead of 16 half lines).  h2i_col(c) = offset of column c's hi value
+// inside its row; the lo value sits kH2iLo elements further.  A group of 4 (8) columns aligned to 4 (8) stays inside
+// one block: 8 (16) contiguous bytes per plane.
+__device__ __forceinline__ int h2i_col(int c) { return ((c >> 5) << 6) | (c & 31); }
+constexpr int kH2iLo = 32;
 __device__ __forceinline__ void split2h_scaled(float y, f16& hi, f16& lo) {   // y = x 2^s already
   hi = (f16)y;
   lo = (f16)(y - (float)hi);

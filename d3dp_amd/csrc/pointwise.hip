@@ -125,24 +125,35 @@ template <int C> struct Row {
     store(p + plane, lane, a1);
     store(p + 2 * plane, lane, a2);
   }
-  // split-fp16 activation (common.h split2h): two planes `plane` elements apart
-  static __device__ __forceinline__ void store2h(f16* p, size_t plane, int lane, const float* v) {
+  // split-fp16 activation (common.h split2h) in the h2i layout: `p` = start of the token's row of 2 C fp16.  Lanes 2j and
+  // 2j+1 hold neighbouring 4-column groups: the even lane collects both hi halves (8 columns = 16 bytes of the hi slot),
+  // the odd lane both lo halves -- one 16-byte store per lane and group, a wave-instruction writes 1 KiB of whole lines.
+  static __device__ __forceinline__ void store2h(f16* p, size_t, int lane, const float* v) {
     if constexpr (V4) {
+      const bool odd = lane & 1;
 #pragma unroll
       for (int g = 0; g < NV / 4; ++g) {
         f16x4 a, b;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { f16 h, l; split2h(v[g * 4 + e], h, l); a[e] = h; b[e] = l; }
-        *reinterpret_cast<f16x4*>(p + (g * 64 + lane) * 4) = a;
-        *reinterpret_cast<f16x4*>(p + plane + (g * 64 + lane) * 4) = b;
+        const uint2 h = __builtin_bit_cast(uint2, a), l = __builtin_bit_cast(uint2, b);
+        const uint2 send = odd ? h : l;
+        uint2 recv;                                    // quad_perm [1,0,3,2]: the value of lane ^ 1
+        recv.x = __builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xF, 0xF, false);
+        recv.y = __builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xF, 0xF, false);
+        using u32x4 = unsigned __attribute__((ext_vector_type(4)));
+        const u32x4 out = odd ? (u32x4){recv.x, recv.y, l.x, l.y} : (u32x4){h.x, h.y, recv.x, recv.y};
+        const int c0 = (g * 64 + (lane & ~1)) * 4;     // first of the pair's 8 columns
+        *reinterpret_cast<u32x4*>(p + h2i_col(c0) + (odd ? kH2iLo : 0)) = out;
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         f16 h, l;
         split2h(v[i], h, l);
-        p[i * 64 + lane] = h;
-        p[plane + i * 64 + lane] = l;
+        const int c = i * 64 + lane;
+        p[h2i_col(c)] = h;
+        p[h2i_col(c) + kH2iLo] = l;
       }
     }
   }
@@ -185,7 +196,7 @@ template <int C> struct ActOut<C, b3> {
 template <int C> struct ActOut<C, h2> {
   using ptr = f16*;
   static __device__ __forceinline__ void st(ptr base, size_t plane, size_t off, int lane, const float* v) {
-    Row<C>::store2h(base + off, plane, lane, v);
+    Row<C>::store2h(base + 2 * off, plane, lane, v);   // off = token * C; an h2i row is 2 C fp16
   }
 };
 

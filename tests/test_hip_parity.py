@@ -54,6 +54,13 @@ def test_native_library_is_loaded(lib):
     assert "libd3dp_hip.so" in maps
 
 
+def h2i_planes(buf, R, K):
+    """(hi, lo) [R, K] views of a split-fp16 matrix in the library's line-interleaved "h2i" layout (common.h): a row is K/32
+    blocks of 64 fp16, block kb = [hi of columns 32 kb .. 32 kb + 31 | lo of the same columns]."""
+    v = buf.reshape(-1)[:2 * R * K].view(R, K // 32, 2, 32)
+    return v[:, :, 0].reshape(R, K), v[:, :, 1].reshape(R, K)
+
+
 # ------------------------------------------------------------------------------------------------ single ops
 @pytest.mark.parametrize("mode", ["exact", "fast"])
 @pytest.mark.parametrize("M,N,K", [(4131, 1536, 512), (300, 512, 1024), (17, 1024, 512), (1000, 64, 128),
@@ -138,7 +145,9 @@ def test_linear_split_f16_is_fp32_class(lib, M, N, K):
     _lib.check(lib.d3dp_op_split2(Ad.data_ptr(), A2.data_ptr(), M * K, 16.0, stream()))    # activation scale
     w_scale = 2.0 ** (13 - int(np.floor(np.log2(W.abs().max().item()))))    # max |w| w_scale in [2^13, 2^14), as capi.hip
     _lib.check(lib.d3dp_op_split2(Wd.data_ptr(), W2.data_ptr(), N * K, w_scale, stream()))
-    rec = (A2[0].double() + A2[1].double()) / 16.0
+    a_hi, a_lo = h2i_planes(A2, M, K)
+    assert torch.equal(a_hi, (Ad * 16.0).half()) and torch.equal(a_lo, (Ad * 16.0 - a_hi.float()).half())   # layout + split
+    rec = (a_hi.double() + a_lo.double()) / 16.0
     rel = ((rec.cpu() - A.double()).abs() / A.double().abs().clamp_min(1e-30))
     assert rel[A.abs() > 2.0 ** -7].max().item() <= 2.0 ** -21     # 22-bit representation wherever lo is a normal fp16
     assert (rec.cpu() - A.double()).abs()[A.abs() <= 2.0 ** -7].max().item() <= 2.0 ** -28   # absolute below that
@@ -153,62 +162,21 @@ def test_linear_split_f16_is_fp32_class(lib, M, N, K):
     out2 = torch.empty(2, M, N, dtype=torch.float16, device="cuda")
     _lib.check(lib.d3dp_op_linear_x2(_lib.EPI_GELU, A2.data_ptr(), W2.data_ptr(), bd.data_ptr(), w_scale,
                                      out2.data_ptr(), M, N, K, stream()))
-    got = ((out2[0].double() + out2[1].double()) / 16.0).cpu()
+    g_hi, g_lo = h2i_planes(out2, M, N)
+    assert torch.equal(g_lo, ((g_hi.float() + g_lo.float()) - g_hi.float()).half())   # a proper (hi, lo) pair
+    got = ((g_hi.double() + g_lo.double()) / 16.0).cpu()
     assert torch.allclose(got, torch.nn.functional.gelu(want), atol=2e-5, rtol=2e-5)
     # the tail of the range relies on the fp16 matrix cores NOT flushing subnormal inputs: hand-made planes
     if (M, N, K) == (129, 192, 64):
         Az = torch.zeros(2, M, K, dtype=torch.float16, device="cuda")
         Wz = torch.zeros(2, N, K, dtype=torch.float16, device="cuda")
-        Az[0] = 3.0e-5                                     # fp16 subnormal (smallest normal 6.1e-5)
-        Wz[0] = 1.0
+        h2i_planes(Az, M, K)[0].fill_(3.0e-5)              # hi values: fp16 subnormal (smallest normal 6.1e-5)
+        h2i_planes(Wz, N, K)[0].fill_(1.0)
         _lib.check(lib.d3dp_op_linear_x2(_lib.EPI_BIAS, Az.data_ptr(), Wz.data_ptr(), torch.zeros(N, device="cuda").data_ptr(),
                                          1.0, out.data_ptr(), M, N, K, stream()))
-        assert abs(out[0, 0].item() - float(Az[0, 0, 0].float()) * K / 16.0) < 1e-9
+        assert abs(out[0, 0].item() - float(Az.reshape(-1)[0].float()) * K / 16.0) < 1e-9
 
 
-
-
-@pytest.mark.parametrize("M,N,K", [(4131, 1536, 512), (1000, 512, 1024), (129, 192, 64), (66000, 512, 512)])
-def test_linear_split_f16_mfma_32x32x16_form(lib, monkeypatch, M, N, K):
-    """D3DP_X2_SHAPE=32: the same Linear on v_mfma_f32_32x32x16_f16 (another fragment layout, LDS swizzle, W-row
-    permutation and accumulator-to-row map; measured slower, profiles/r03_gemm_mfma_shape.md, kept as a cross-check).
-    Same fp32-class gate, and the packed / GELU / residual epilogues must agree with the default form to rounding of the
-    summation order."""
-    g = torch.Generator().manual_seed(M + 7 * N + K)
-    A = (torch.randn(M, K, generator=g) * 2).cuda()
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
-    bias = torch.randn(N, generator=g).cuda()
-    want = A.double() @ W.double().t() + bias.double()
-    f32_err = ((A @ W.t() + bias).double() - want).abs().mean().item()
-    A2 = torch.empty(2, M, K, dtype=torch.float16, device="cuda")
-    W2 = torch.empty(2, N, K, dtype=torch.float16, device="cuda")
-    w_scale = 2.0 ** (13 - int(np.floor(np.log2(W.abs().max().item()))))
-    _lib.check(lib.d3dp_op_split2(A.data_ptr(), A2.data_ptr(), M * K, 16.0, stream()))
-    _lib.check(lib.d3dp_op_split2(W.data_ptr(), W2.data_ptr(), N * K, w_scale, stream()))
-    res = {}
-    for shape in ("16", "32"):
-        monkeypatch.setenv("D3DP_X2_SHAPE", shape)
-        outs = []
-        for epi in (_lib.EPI_BIAS, _lib.EPI_GELU, _lib.EPI_RESID) + ((_lib.EPI_QKV_PACK,) if N % 192 == 0 else ()):
-            out = torch.ones(M, N, device="cuda")
-            _lib.check(lib.d3dp_op_linear_x2(epi, A2.data_ptr(), W2.data_ptr(), bias.data_ptr(), w_scale, out.data_ptr(),
-                                             M, N, K, stream()))
-            outs.append(out)
-        torch.cuda.synchronize()
-        res[shape] = outs
-    err = (res["32"][0].double() - want).abs().mean().item()
-    print(f"32x32x16 form M={M} N={N} K={K}: mean |err| {err:.3e} (torch fp32 matmul {f32_err:.3e})")
-    assert err <= 3.0 * f32_err
-    assert torch.allclose(res["32"][0], res["16"][0], atol=2e-5, rtol=2e-5)
-    assert torch.allclose(res["32"][2], res["16"][2], atol=2e-5, rtol=2e-5)           # x += ...
-    h16, h32 = (r[1].view(torch.float16)[:, :].reshape(-1)[:2 * M * N].view(2, M, N) for r in (res["16"], res["32"]))
-    assert torch.allclose((h32[0].double() + h32[1].double()) / 16, (h16[0].double() + h16[1].double()) / 16, atol=2e-5, rtol=2e-5)
-    if N % 192 == 0:
-        C = N // 3
-        assert torch.allclose(res["32"][3][:, :C], res["16"][3][:, :C], atol=2e-5, rtol=2e-5)
-        p16, p32 = (r[3][:, C:].contiguous().view(torch.float16).view(M, 4, C).double() for r in (res["16"], res["32"]))
-        for i in (0, 2):
-            assert torch.allclose((p32[:, i] + p32[:, i + 1]) / 16, (p16[:, i] + p16[:, i + 1]) / 16, atol=2e-5, rtol=2e-5)
 
 
 def test_linear_split_f16_rejects_k_not_multiple_of_64(lib):
@@ -370,6 +338,14 @@ def test_layernorm(lib, C_):
                                          stream()))
         got = out.float().cpu().double()
         assert torch.allclose(got, want, atol=3e-2 if bf else 2e-5, rtol=1e-2 if bf else 1e-5)
+    # out type 3: the split-fp16 operand of the EXACT Linears, h2i layout -- bit for bit the split of the fp32 result
+    out32 = torch.empty((T, C_), device="cuda")
+    _lib.check(lib.d3dp_op_layernorm(0, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), 1e-6, out32.data_ptr(), T, C_, stream()))
+    out2 = torch.full((2 * T * C_,), float("nan"), dtype=torch.float16, device="cuda")
+    _lib.check(lib.d3dp_op_layernorm(3, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), 1e-6, out2.data_ptr(), T, C_, stream()))
+    hi, lo = h2i_planes(out2, T, C_)
+    y = out32 * 16.0
+    assert torch.equal(hi, y.half()) and torch.equal(lo, (y - y.half().float()).half())
 
 
 # ------------------------------------------------------------------------------------------------ denoiser

@@ -57,8 +57,8 @@ def main():
             if a.check:
                 ref = A.double() @ W.double().t() + b.double()
                 if epi:
-                    got = out.view(torch.float16)[:2 * M * N].view(2, M, N)
-                    got = (got[0].double() + got[1].double()) / 16.0
+                    got = out.view(torch.float16)[:2 * M * N].view(M, N // 32, 2, 32)   # h2i layout: [hi 32 | lo 32] blocks
+                    got = (got[:, :, 0].double() + got[:, :, 1].double()).reshape(M, N) / 16.0
                     ref = torch.nn.functional.gelu(ref)
                 else:
                     got = out.view(M, N).double()
