@@ -32,7 +32,7 @@ if REPO not in sys.path:
 
 F_, J_, C_, DEPTH = 243, 17, 512, 8
 PEAK_MFMA_TFLOPS = 2500.0      # dense bf16 / fp16 MFMA, MI355X_MICROARCH.md (2.5 PFLOP/s)
-MFMA_STREAM_PFLOPS = 1.57   # measured ceiling of the EXACT Linear's MFMA stream alone (profiles/r02_gemm_probes.md)
+MFMA_STREAM_PFLOPS = 1.5    # measured rate of the EXACT Linear's MFMA stream alone: 1.57 (r02_gemm_probes.md), 1.45-1.60 (r03_gemm_mfma_shape.md)
 EXACT_PASSES = 3               # fp16-MFMA products per algorithmic multiply-add in exact mode (hi.hi, hi.lo, lo.hi)
 
 
@@ -99,7 +99,23 @@ def cpu_baseline(budget_s=24.0):
             "sample": f"oracle ddim_sample_flip F=243 B=1 H=1 K=1 (2 of the unit's 20 denoiser calls), median of "
                       f"{len(times)} runs at the best thread count = {t_k1:.3f} s; x10 DDIM steps to the K=10 unit",
             "host_cpus": ncpu, "thread_sweep_s": {str(k): round(v, 3) for k, v in sweep.items()},
-            "gflops": 2 * flops_per_denoiser_call() / t_k1 / 1e9}
+            "gflops": 2 * flops_per_denoiser_call() / t_k1 / 1e9,
+            "full_config_run": full_config_cpu_run()}
+
+
+def full_config_cpu_run():
+    """The UN-extrapolated CPU run of BASELINE configs[1] (B=4 H=5 K=5 F=243; tools/cpu_c2.py, committed under
+    profiles/): per FLOP it is 2.3x SLOWER than the B=1 H=1 sample above (the oracle, like the reference, materialises
+    the attention scores of the whole batch), i.e. the bounded sample OVERSTATES the CPU at a real batch size.  Its
+    hypothesis-clips/s are in K=5 units; `k10_units_per_s` rescales by FLOP to this benchmark's K=10 unit."""
+    path = os.path.join(REPO, "profiles", "r02_cpu_c2.json")
+    if not os.path.exists(path):
+        return None
+    j = json.load(open(path))
+    return {"source": "profiles/r02_cpu_c2.json (tools/cpu_c2.py, measured on a GPU box's host, not in this run)",
+            "workload": j["workload"], "threads": j["threads"], "seconds": j["seconds"], "gflops": j["gflops"],
+            "hypothesis_clips_per_s_K5_units": j["hypothesis_clips_per_s"],
+            "k10_units_per_s": j["hypothesis_clips_per_s"] / 2.0}
 
 
 def quick_parity():
@@ -136,7 +152,13 @@ def quick_parity():
     return out
 
 
-def timed_steps(model, x2d, x2f, steps, warmup, gen, gather):
+def device_sync(dev):
+    import torch
+    if dev == "cuda":
+        torch.cuda.synchronize()
+
+
+def timed_steps(model, x2d, x2f, steps, warmup, gen, gather, dev="cuda"):
     import torch
     import torch.distributed as dist
     from d3dp_amd.dist import all_gather_hypotheses
@@ -149,22 +171,41 @@ def timed_steps(model, x2d, x2f, steps, warmup, gen, gather):
         one()
     if gather:
         dist.barrier()
-    torch.cuda.synchronize()
+    device_sync(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
         out = one()
-    torch.cuda.synchronize()
+    device_sync(dev)
     if gather:
         dist.barrier()
     dt = time.perf_counter() - t0
     if gather:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt, out
 
 
-def shard_check(rank, world, numerics):
+class DryRunSampler:
+    """NOT the product path: a CPU stand-in with the sampler's call signature and independence structure (hypothesis h
+    depends only on x2d and noise[:, h]; tests/test_dist_cpu.py uses the same form), used ONLY by `--dist-dry-run N` to
+    drive this file's multi-rank control flow -- self-launch under torch.distributed.run, WORLD_SIZE check, shard_check,
+    timed loop with the all-gather inside, MAX-reduce of the time, the `multi_gpu` block -- over gloo on a box without
+    GPUs.  Its numbers say nothing about the library."""
+
+    def __init__(self, H, K, frames):
+        self.H, self.K, self.frames = H, K, frames
+
+    def __call__(self, x2d, _x3d, input_2d_flip=None, generator=None, noise=None):
+        import torch
+        B = x2d.shape[0]
+        if noise is None:
+            noise = [torch.randn(B, self.H, self.frames, J_, 3, generator=generator) for _ in range(self.K)]
+        m = (x2d.mean(dim=-1, keepdim=True) - input_2d_flip.mean(dim=-1, keepdim=True))[:, None]
+        return torch.stack([torch.tanh(n * 0.3 + m * (k + 1)) for k, n in enumerate(noise)], dim=1)
+
+
+def shard_check(rank, world, numerics, dev="cuda", make=None):
     """N ranks, each sampling its slice of GLOBAL noise draws (dist.shard_noise), must reproduce the 1-rank run with
     H_total = N * H_local hypotheses bit for bit (small problem: F=27, B=2, H_local=2, K=2; rank 0 runs the 1-rank form)."""
     import torch
@@ -172,13 +213,16 @@ def shard_check(rank, world, numerics):
     from d3dp_amd.weights import flip_2d, synthetic_inputs_2d, synthetic_noise
     Fr, B, Hl, K = 27, 2, 2, 2
     x2d_np = synthetic_inputs_2d(77, B, Fr)
-    x2d, x2f = torch.from_numpy(x2d_np).cuda(), torch.from_numpy(flip_2d(x2d_np)).cuda()
+    make = make or (lambda H_, K_, fr: build_model(H_, K_, numerics, 0, frames=fr))
+    x2d, x2f = torch.from_numpy(x2d_np).to(dev), torch.from_numpy(flip_2d(x2d_np)).to(dev)
     noise = [torch.from_numpy(synthetic_noise(90 + k, (B, world * Hl, Fr, J_, 3))) for k in range(K)]
-    local = build_model(Hl, K, numerics, 0, frames=Fr)(x2d, None, input_2d_flip=x2f, noise=shard_noise(noise, rank, world))
+    if dev != "cuda":
+        noise = [n.to(dev) for n in noise]
+    local = make(Hl, K, Fr)(x2d, None, input_2d_flip=x2f, noise=shard_noise(noise, rank, world))
     got = all_gather_hypotheses(local)
     ok = True
     if rank == 0:
-        want = build_model(world * Hl, K, numerics, 0, frames=Fr)(x2d, None, input_2d_flip=x2f, noise=noise)
+        want = make(world * Hl, K, Fr)(x2d, None, input_2d_flip=x2f, noise=noise)
         ok = bool(torch.equal(got, want))
     return ok
 
@@ -190,19 +234,22 @@ def roofline_from_profile(prof, numerics, B, H, K):
     n, ms = prof[dom]
     fl = gemm_flops[dom] * T_all * 2 * DEPTH              # 16 blocks
     ach = fl / (ms * 1e-3) / 1e12
+    passes = EXACT_PASSES if numerics == "exact" else 1
+    note = "peak = dense fp16 / bf16 MFMA peak of MI355X_MICROARCH.md (2.5 PFLOP/s); achieved = ALGORITHMIC FLOP / HIP-event time"
     if numerics == "exact":
-        peak = PEAK_MFMA_TFLOPS / EXACT_PASSES
-        note = (f"peak = {PEAK_MFMA_TFLOPS:.0f} TFLOP/s dense fp16 MFMA / {EXACT_PASSES} MFMA passes per algorithmic product "
-                f"(split-fp16 operands); matrix-pipe work = {EXACT_PASSES} x achieved.  Under this instruction stream the "
-                f"chip clocks at 1.7-1.9 GHz, not 2.4: the kernel's bare MFMA stream (no loads, LDS reads, stores or "
-                f"barriers) measured {MFMA_STREAM_PFLOPS} PFLOP/s of matrix work (profiles/r02_gemm_probes.md)")
-    else:
-        peak, note = PEAK_MFMA_TFLOPS, "dense bf16 MFMA peak"
-    r = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+        note += (f"; every algorithmic product costs {EXACT_PASSES} fp16-MFMA products (split-fp16 operands: hi.hi + hi.lo + "
+                 f"lo.hi), so the matrix pipes do {EXACT_PASSES} x achieved = `matrix_pipe_work_tflops` -- reported beside "
+                 f"`frac`, never instead of it.  Under this instruction stream the chip clocks at 1.7-1.9 GHz, not 2.4; the "
+                 f"kernel's bare MFMA stream (no loads, LDS reads, stores or barriers) runs at {MFMA_STREAM_PFLOPS} PFLOP/s "
+                 f"of matrix work (profiles/r02_gemm_probes.md, profiles/r03_gemm_mfma_shape.md)")
+    r = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+         "frac": ach / PEAK_MFMA_TFLOPS, "frac_algorithmic_of_dense_peak": ach / PEAK_MFMA_TFLOPS,
+         "mfma_passes_per_product": passes, "matrix_pipe_work_tflops": ach * passes,
+         "matrix_pipe_work_frac_of_dense_peak": ach * passes / PEAK_MFMA_TFLOPS,
          "traffic": None, "launches": n, "avg_launch_ms": ms / max(n, 1), "algorithmic_gflop_per_launch": fl / max(n, 1) / 1e9,
-         "peak_note": note, "frac_of_raw_mfma_peak": ach * (EXACT_PASSES if numerics == "exact" else 1) / PEAK_MFMA_TFLOPS}
+         "peak_note": note}
     if numerics == "exact":
-        r["frac_of_measured_mfma_stream"] = ach * EXACT_PASSES / (MFMA_STREAM_PFLOPS * 1e3)
+        r["matrix_pipe_work_frac_of_measured_mfma_stream"] = ach * EXACT_PASSES / (MFMA_STREAM_PFLOPS * 1e3)
     return r
 
 
@@ -219,14 +266,20 @@ def attach_traffic(roof, numerics, chunk_seqs):
     """HBM bytes per launch of the dominant kernel come from SEPARATE rocprofv3 --pmc passes (FETCH_SIZE doubled per
     MI355X_MICROARCH.md, WRITE_SIZE) stored under profiles/ next to the hash of the library they were measured on: the
     number is printed only when this run uses that very build."""
-    tpath = os.path.join(REPO, "profiles", "r02_gemm_traffic.json")
-    if not os.path.exists(tpath):
+    sha, tj, seen = lib_sha256(), None, []
+    for name in ("r03_gemm_traffic.json", "r02_gemm_traffic.json"):        # newest first; keyed by the library's hash
+        tpath = os.path.join(REPO, "profiles", name)
+        if os.path.exists(tpath):
+            cand = json.load(open(tpath)).get(numerics, {}).get(roof["kernel"])
+            if cand:
+                seen.append(name)
+                if cand.get("lib_sha256") == sha:
+                    tj = cand
+                    break
+    if chunk_seqs not in (0, 15) or not seen:
         return
-    tj = json.load(open(tpath)).get(numerics, {}).get(roof["kernel"])
-    if not tj or chunk_seqs not in (0, 15):
-        return
-    if tj.get("lib_sha256") != lib_sha256():
-        roof["traffic_note"] = "profiles/r02_gemm_traffic.json was measured on a different build of libd3dp_hip.so: not reported"
+    if tj is None:
+        roof["traffic_note"] = f"profiles/{seen[0]} was measured on a different build of libd3dp_hip.so: not reported"
         return
     roof["traffic"] = tj["hbm_bytes_per_launch"]
     roof["traffic_note"] = (f"HBM bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) at a mean of {tj.get('mean_rows_per_launch', 0):.0f} "
@@ -271,31 +324,45 @@ def main():
     ap.add_argument("--no-other-leg", action="store_true", help="skip timing the other numerics mode")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--dist-dry-run", type=int, default=0, metavar="N",
+                    help="no GPU needed: drive the N-rank control flow of this file (self-launch, WORLD_SIZE check, shard "
+                         "check, timed loop with the all-gather, MAX-reduce, multi_gpu block) over gloo with a CPU "
+                         "stand-in for the sampler; the JSON line is marked dry_run and measures nothing")
     a = ap.parse_args()
+    dry = a.dist_dry_run > 0
+    if dry:
+        a.gpus = a.dist_dry_run
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(a.gpus)
 
     import torch
     from d3dp_amd.dist import init_from_env, rank_generator
     from d3dp_amd.weights import flip_2d, synthetic_inputs_2d
-    rank, world, local = init_from_env()
-    if world != a.gpus:
-        raise SystemExit(f"bench.py: --gpus {a.gpus} but the job has WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
+    if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:      # before any rendezvous: a mismatched job must not hang
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the job has WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
+    rank, world, local = init_from_env("gloo" if dry else None)
+    dev = "cpu" if dry else "cuda"
+    if not dry:
+        torch.cuda.set_device(local)
     B, H, K = a.batch, a.hyps, a.ksteps
+    frames = F_
+    if dry:
+        B, H, K, frames = min(B, 2), min(H, 2), min(K, 2), 27
+        a.no_profile = True
+    make = (lambda H_, K_, fr: DryRunSampler(H_, K_, fr)) if dry else None
 
-    x2d_np = synthetic_inputs_2d(1234, B, F_)
-    x2d = torch.from_numpy(x2d_np).cuda()
-    x2f = torch.from_numpy(flip_2d(x2d_np)).cuda()
-    gen = rank_generator(1, rank, "cuda")
-    sharding_ok = shard_check(rank, world, a.numerics) if world > 1 else None
-    model = build_model(H, K, a.numerics, a.chunk_seqs)
-    dt, out = timed_steps(model, x2d, x2f, a.steps, a.warmup, gen, gather=world > 1)
-    assert out.shape == (B, K, H * world, F_, J_, 3) and bool(torch.isfinite(out).all())
+    x2d_np = synthetic_inputs_2d(1234, B, frames)
+    x2d = torch.from_numpy(x2d_np).to(dev)
+    x2f = torch.from_numpy(flip_2d(x2d_np)).to(dev)
+    gen = rank_generator(1, rank, dev)
+    sharding_ok = shard_check(rank, world, a.numerics, dev, make) if world > 1 else None
+    model = DryRunSampler(H, K, frames) if dry else build_model(H, K, a.numerics, a.chunk_seqs)
+    dt, out = timed_steps(model, x2d, x2f, a.steps, a.warmup, gen, gather=world > 1, dev=dev)
+    assert out.shape == (B, K, H * world, frames, J_, 3) and bool(torch.isfinite(out).all())
     units = B * H * world * a.steps
     value = units / dt
     flop_per_unit = 2 * K * flops_per_denoiser_call()
-    peak = PEAK_MFMA_TFLOPS / (EXACT_PASSES if a.numerics == "exact" else 1)
+    peak = PEAK_MFMA_TFLOPS
     dtypes = {"exact": "f16x2-split operands on fp16 MFMA, f32 accumulate (fp32-class: meets 1e-3 mm)",
               "fast": "bf16 operands, f32 accumulate (does NOT meet 1e-3 mm)"}
 
@@ -318,15 +385,15 @@ def main():
         import torch.distributed as dist
         from d3dp_amd.dist import all_gather_hypotheses
         local_preds = out[:, :, rank * H:(rank + 1) * H].contiguous()
-        torch.cuda.synchronize(); dist.barrier()
+        device_sync(dev); dist.barrier()
         t0 = time.perf_counter()
         for _ in range(5):
             all_gather_hypotheses(local_preds)
-        torch.cuda.synchronize()
+        device_sync(dev)
         ag_ms = (time.perf_counter() - t0) / 5 * 1e3
-        flag = torch.tensor([1 if sharding_ok else 0], device="cuda")
+        flag = torch.tensor([1 if sharding_ok else 0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        res["multi_gpu"] = {"backend": "nccl (RCCL)", "world_size": dist.get_world_size(),
+        res["multi_gpu"] = {"backend": "gloo (dry run)" if dry else "nccl (RCCL)", "world_size": dist.get_world_size(),
                             "all_gather_bytes_per_rank": local_preds.numel() * 4, "all_gather_ms": ag_ms,
                             "all_gather_gbps_per_rank_out": local_preds.numel() * 4 * (world - 1) / (ag_ms * 1e-3) / 1e9,
                             "sharded_equals_single_rank": bool(flag.item()),
@@ -342,7 +409,12 @@ def main():
         res["kernel_time_share"] = {k: round(ms / total, 4) for k, (_, ms) in prof.items() if ms > 0}
         res["kernel_ms_per_step"] = {k: round(ms, 3) for k, (_, ms) in prof.items() if ms > 0}
 
-    if rank == 0 and world == 1:
+    if dry:
+        res.update({"dry_run": True, "value": None, "ms_per_step": None, "data": "none (dry run)",
+                    "dtype": "none: CPU stand-in sampler over gloo, control flow only",
+                    "config": {"workload": f"DRY RUN of the {world}-rank control flow (B={B} H={H}/rank K={K} F={frames}); "
+                                           f"measures nothing", "parallelism": f"hshard{world}"}})
+    if rank == 0 and world == 1 and not dry:
         if not a.no_other_leg:
             other = "fast" if a.numerics == "exact" else "exact"
             del model

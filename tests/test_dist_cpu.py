@@ -76,3 +76,30 @@ def test_all_gather_layout_world2_gloo():
 def test_all_gather_is_identity_without_process_group():
     x = torch.randn(1, 2, 3, 4, 17, 3)
     assert all_gather_hypotheses(x) is x
+
+
+def test_bench_dist_dry_run_8_ranks():
+    """`python bench.py --dist-dry-run 8`: the N-rank control flow of bench.py (self-launch under torch.distributed.run,
+    WORLD_SIZE check, shard check, timed loop with the all-gather inside, MAX-reduce of the time, multi_gpu block) at the
+    world size of BASELINE configs[3], over gloo with a CPU stand-in for the sampler.  What stays untested without an
+    8-GPU node is the RCCL transport itself."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--dist-dry-run", "8", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["dry_run"] is True and d["n_gpus"] == 8 and d["value"] is None
+    mg = d["multi_gpu"]
+    assert mg["world_size"] == 8 and mg["sharded_equals_single_rank"] is True and mg["all_gather_bytes_per_rank"] > 0
+    assert d["config"]["parallelism"] == "hshard8"
+    # a job whose world size disagrees with --gpus must refuse to run
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r2 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--dist-dry-run", "4"], capture_output=True,
+                        text=True, timeout=120, env=env2, cwd=repo)
+    assert r2.returncode != 0 and "WORLD_SIZE=2" in (r2.stderr + r2.stdout)
