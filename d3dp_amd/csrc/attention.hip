@@ -645,7 +645,10 @@ __device__ __forceinline__ void store_o_x2(const f32x4 (&o)[4], float inv, void*
 // ordering is carried by explicit counted waits and barriers instead.
 __device__ __forceinline__ void lds_dma16(const char* g, const char* lds) {
   const unsigned la = (unsigned)(__UINTPTR_TYPE__)LPTR(lds);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory");   // (m0 is reserved: the compiler re-loads it before each of its own uses)
+  // m0 is declared clobbered (the compiler answers with "clobber list contains reserved registers" and
+  // re-materialises m0 before each of its own uses, of which these kernels have none): no instruction is added to the
+  // hand-counted pipeline
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory", "m0");
 }
 
 // 16-byte global load the compiler does not track (it would wait for it with counts that ignore the LDS-DMA operations

@@ -93,6 +93,8 @@ struct d3dp_ctx {
   d3dp_cfg cfg{};
   int device = 0;
   bool weights_set = false;
+  float range_bound = 0.f;       // d3dp_exact_range_bound (EXACT split-fp16 only)
+  unsigned* d_flag = nullptr;    // device word: bit 0 = a d3dp_denoise output held inf / nan (d3dp_status)
   char* arena = nullptr;
   size_t arena_bytes = 0;
   const float *spos = nullptr, *tpos = nullptr, *ew = nullptr, *eb = nullptr, *freq = nullptr, *t1w = nullptr,
@@ -264,6 +266,10 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   const char* nf = getenv("D3DP_NO_FOLD");               // (A/B switch while the folded epilogue is being evaluated)
   c->fold = !(nf && nf[0] == '1');
   HIP_TRY(hipGetDevice(&c->device));
+  if (hipMalloc((void**)&c->d_flag, sizeof(unsigned)) != hipSuccess || hipMemset(c->d_flag, 0, sizeof(unsigned)) != hipSuccess) {
+    delete c;
+    return fail(D3DP_EHIP, "d3dp_create: cannot allocate the status word");
+  }
   *out = c;
   return D3DP_OK;
 }
@@ -272,6 +278,7 @@ int d3dp_destroy(d3dp_ctx* c) {
   if (!c) return D3DP_OK;
   for (auto& e : c->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->arena) (void)hipFree(c->arena);
+  if (c->d_flag) (void)hipFree(c->d_flag);
   delete c;
   return D3DP_OK;
 }
@@ -356,8 +363,26 @@ int d3dp_set_weights(d3dp_ctx* c, const d3dp_weights* w, void* stream) {
     else if (it.mat && c->x2()) d3dp_launch_split2((const float*)it.src, c->arena + it.off, it.n, 1.0f / unscale[i], st);
     else HIP_TRY(hipMemcpyAsync(c->arena + it.off, it.src, it.n * 4, hipMemcpyDeviceToDevice, st));
   }
+  // provable range of every split-fp16 operand, from the weights alone (header: d3dp_exact_range_bound)
+  c->range_bound = 0.f;
+  unsigned* dbound = nullptr;
+  if (c->x2()) {
+    HIP_TRY(hipMalloc((void**)&dbound, sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(dbound, 0, sizeof(unsigned), st));
+    const float sq = sqrtf((float)(C - 1));
+    for (int kind = 0; kind < 2; ++kind)
+      for (int d = 0; d < g.depth; ++d) {
+        const d3dp_block_weights& b = (kind == 0 ? w->ste : w->tte)[d];
+        d3dp_launch_rowbound(b.qkv_w, b.norm1_w, b.norm1_b, b.qkv_b, 3 * (int)C, (int)C, sq, dbound, st);
+        d3dp_launch_rowbound(b.fc1_w, b.norm2_w, b.norm2_b, b.fc1_b, (int)Hd, (int)C, sq, dbound, st);
+      }
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(st));
+  if (dbound) {
+    HIP_TRY(hipMemcpy(&c->range_bound, dbound, sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(dbound));
+  }
   auto F32 = [&](size_t i) { return (const float*)(c->arena + items[i].off); };
   auto ANY = [&](size_t i) { return (const void*)(c->arena + items[i].off); };
   c->spos = F32(i_spos); c->tpos = F32(i_tpos); c->ew = F32(i_ew); c->eb = F32(i_eb); c->freq = F32(i_fr);
@@ -470,7 +495,25 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
                                   out + (size_t)seq0 * FJ * 3, Tc, C, st));
     }
   }
+  d3dp_launch_nonfinite_flag(out, (size_t)BH * FJ * 3, c->d_flag, st);    // 15.9 MB at B = 32, H = 20: microseconds
   HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
+int d3dp_exact_range_bound(const d3dp_ctx* c, float* bound) {
+  if (!c || !bound) return fail(D3DP_EINVAL, "d3dp_exact_range_bound: null argument");
+  if (!c->weights_set) return fail(D3DP_ESTATE, "d3dp_exact_range_bound: weights not set");
+  *bound = c->range_bound;
+  return D3DP_OK;
+}
+
+int d3dp_status(d3dp_ctx* c, int32_t* nonfinite) {
+  if (!c || !nonfinite) return fail(D3DP_EINVAL, "d3dp_status: null argument");
+  unsigned v = 0;
+  HIP_TRY(hipDeviceSynchronize());                     // every d3dp_denoise issued so far has written its verdict
+  HIP_TRY(hipMemcpy(&v, c->d_flag, sizeof v, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(c->d_flag, 0, sizeof v));
+  *nonfinite = (int32_t)(v & 1u);
   return D3DP_OK;
 }
 

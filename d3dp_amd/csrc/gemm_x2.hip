@@ -480,6 +480,33 @@ __global__ void absmax_kernel(const float* __restrict__ s, size_t n, unsigned* _
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
+// Worst-case magnitude of a Linear fed by a LayerNorm, from the weights alone (d3dp_exact_range_bound, d3dp_hip.h):
+// one wave per output row n: sum_k |W[n,k]| (s |gw[k]| + |gb[k]|) + |bias[n]|; block 0 also folds in the LayerNorm output
+// bound itself.  Non-negative floats order like their bit patterns: atomicMax on the bits.
+__global__ void rowbound_kernel(const float* __restrict__ W, const float* __restrict__ gw, const float* __restrict__ gb,
+                                const float* __restrict__ bias, int N, int K, float s, unsigned* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  float m = 0.f;
+  if (n < N) {
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc += fabsf(W[(size_t)n * K + k]) * (s * fabsf(gw[k]) + fabsf(gb[k]));
+    m = wave_sum(acc) + fabsf(bias[n]);
+  }
+  if (blockIdx.x == 0)
+    for (int k = threadIdx.x; k < K; k += blockDim.x) m = fmaxf(m, s * fabsf(gw[k]) + fabsf(gb[k]));
+  m = wave_max(m);
+  if (lane == 0 && m > 0.f) atomicMax(out, __float_as_uint(m < INFINITY ? m : INFINITY));
+}
+
+__global__ void nonfinite_flag_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ flag) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (; i < n; i += stride) bad |= !(fabsf(x[i]) <= 3.0e38f);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
 }  // namespace
 
 // out = epi((A W^T) unscale + bias) with A2/W2 split-fp16 operands in the h2i layout; EPI_BIAS: fp32 `outf`; EPI_GELU: `out2` in the h2i layout [M][N] (the fc2 operand);
@@ -534,4 +561,14 @@ void d3dp_launch_split2(const float* src, void* dst, size_t n, float scale, hipS
 void d3dp_launch_absmax(const float* src, size_t n, unsigned* out, hipStream_t st) {
   const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
   hipLaunchKernelGGL(absmax_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, n, out);
+}
+
+void d3dp_launch_rowbound(const float* W, const float* gw, const float* gb, const float* bias, int N, int K, float s,
+                          unsigned* out, hipStream_t st) {
+  hipLaunchKernelGGL(rowbound_kernel, dim3((N + 3) / 4), dim3(256), 0, st, W, gw, gb, bias, N, K, s, out);
+}
+
+void d3dp_launch_nonfinite_flag(const float* x, size_t n, unsigned* flag, hipStream_t st) {
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, x, n, flag);
 }

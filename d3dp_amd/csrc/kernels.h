@@ -16,6 +16,11 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
                              void* out2, int M, int N, int K, hipStream_t st);
 void d3dp_launch_split2(const float* src, void* dst, size_t n, float scale, hipStream_t st);
 void d3dp_launch_absmax(const float* src, size_t n, unsigned* out, hipStream_t st);
+// out[0] = max(out[0], max_n sum_k |W[n,k]| (s |gw[k]| + |gb[k]|) + |bias[n]|, max_k s |gw[k]| + |gb[k]|) as float bits
+void d3dp_launch_rowbound(const float* W, const float* gw, const float* gb, const float* bias, int N, int K, float s,
+                          unsigned* out, hipStream_t st);
+// flag[0] |= 1 if any of x[0..n) is inf / nan
+void d3dp_launch_nonfinite_flag(const float* x, size_t n, unsigned* flag, hipStream_t st);
 int d3dp_launch_linear_f32_splitk(const float* A, const float* W, float* out, int M, int N, int K, hipStream_t st);
 int d3dp_launch_linear_f32(int epi, const float* A, const float* W, const float* bias, float* out, int M, int N,
                            int K, hipStream_t st);

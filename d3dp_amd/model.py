@@ -60,11 +60,20 @@ class _TrainStep(torch.autograd.Function):
         ctx.save_for_backward(x_2d, x_3d, t)
         out = net._train_forward(x_2d, x_3d, t, masks)
         ctx.gen = net._train_gen
+        # the library reads the parameters' OWN storage (borrowed weights): remember what the forward saw
+        ctx.versions = tuple((p.data_ptr(), p._version) for p in params)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         x_2d, x_3d, t = ctx.saved_tensors
+        now = tuple((p.data_ptr(), p._version) for p in ctx.net.parameters())
+        if now != ctx.versions:
+            # PyTorch raises in the same situation ("one of the variables needed for gradient computation has been
+            # modified by an inplace operation"): differentiating with weights the forward never saw is silently wrong
+            raise RuntimeError("d3dp_amd: a parameter was modified (optimizer.step(), in-place op or re-allocation) between "
+                               "this forward and its backward(); the training kernels read the parameters in place, so the "
+                               "gradient would be taken at the NEW weights.  Call backward() before the optimizer step.")
         if ctx.gen != ctx.net._train_gen:
             ctx.net._train_forward(x_2d, x_3d, t, ctx.masks)
         grads = ctx.net._train_backward(x_2d, x_3d, t, ctx.masks, grad_out.contiguous())
@@ -178,7 +187,38 @@ class MixSTE2(nn.Module):
         if sig != self._weights_sig:
             self._push_weights(device, borrowed)
             self._weights_sig = sig
+            self._warn_if_range_unproven()
         return self._ctx
+
+    # -- EXACT mode's operand range (include/d3dp_hip.h: d3dp_exact_range_bound / d3dp_status) ------------------
+    SPLIT_RANGE = 4094.0
+
+    def exact_range_bound(self) -> float:
+        """Upper bound, provable from the current weights alone, of the magnitude any split-fp16 operand of EXACT mode
+        can take for ANY input; below ``SPLIT_RANGE`` the mode cannot overflow.  0.0 in the other modes."""
+        assert self._ctx is not None, "run one forward (or call _context(device)) first"
+        b = C.c_float()
+        _lib.check(_lib.load().d3dp_exact_range_bound(self._ctx, C.byref(b)), "d3dp_exact_range_bound")
+        return float(b.value)
+
+    def nonfinite_seen(self) -> bool:
+        """True if any denoiser call since the last query produced inf / nan (synchronises the device; resets)."""
+        assert self._ctx is not None, "run one forward first"
+        v = C.c_int32()
+        _lib.check(_lib.load().d3dp_status(self._ctx, C.byref(v)), "d3dp_status")
+        return bool(v.value)
+
+    def _warn_if_range_unproven(self):
+        if self._mode != _lib.MODE_EXACT:
+            return
+        b = self.exact_range_bound()
+        if not b < self.SPLIT_RANGE:
+            import warnings
+            warnings.warn(f"d3dp_amd: with these weights EXACT mode's split-fp16 operands are bounded only by {b:.4g} "
+                          f"(>= {self.SPLIT_RANGE:g}): an activation beyond that range turns the output into NaN where "
+                          f"the fp32 reference stays finite.  Check model.pose_estimator.nonfinite_seen() after sampling "
+                          f"(or set D3DP_CHECK_FINITE=1), or run with D3DP_EXACT_IMPL=bf16x3, which has no range limit.",
+                          RuntimeWarning, stacklevel=3)
 
     def refresh_weights(self) -> None:
         """Re-pack the library's weight copies on the next call.  Needed only after parameter writes that bypass
@@ -385,11 +425,7 @@ class D3DP(nn.Module):
         assert self.sampling_timesteps <= timesteps
         self.is_ddim_sampling = self.sampling_timesteps < timesteps
         self.ddim_sampling_eta = 1.
-        self.objective = 'pred_x0'
-        self.self_condition = False
         self.scale = args.scale
-        self.box_renewal = True
-        self.use_ensemble = True
 
         # the 12 fp64 buffers of the reference state_dict (diffusionpose.py:92-117)
         self.register_buffer('betas', betas)
@@ -568,9 +604,14 @@ class D3DP(nn.Module):
     def forward(self, input_2d, input_3d, input_2d_flip=None, **kw):
         """reference diffusionpose.py:269-287."""
         if not self.is_train:
-            if self.flip:
-                return self.ddim_sample_flip(input_2d, input_3d, input_2d_flip=input_2d_flip, **kw)
-            return self.ddim_sample(input_2d, input_3d, **kw)
+            out = (self.ddim_sample_flip(input_2d, input_3d, input_2d_flip=input_2d_flip, **kw) if self.flip
+                   else self.ddim_sample(input_2d, input_3d, **kw))
+            if os.environ.get("D3DP_CHECK_FINITE") == "1" and self.pose_estimator.nonfinite_seen():   # (synchronises)
+                raise _lib.D3DPHipError(
+                    "non-finite denoiser output: an activation left EXACT mode's split-fp16 range (provable bound for these "
+                    f"weights: {self.pose_estimator.exact_range_bound():.4g}, limit {MixSTE2.SPLIT_RANGE:g}) or the input "
+                    "held inf / nan; D3DP_EXACT_IMPL=bf16x3 has no range limit")
+            return out
         droppath = kw.pop("droppath", None)
         x_poses, _, t = self.prepare_targets(input_3d, **kw)
         return self.pose_estimator(input_2d, x_poses.float(), t.squeeze(-1), droppath=droppath)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D3DP_ABI_VERSION 1
+#define D3DP_ABI_VERSION 2
 
 enum {
   D3DP_OK = 0,
@@ -113,6 +113,20 @@ int d3dp_set_weights(d3dp_ctx* ctx, const d3dp_weights* w, void* stream);
 /* D3DP_MODE_TRAIN only: use the caller's fp32 device buffers in place (no packed copy, no launch, no synchronisation), so
  * an optimizer step needs no re-push.  The buffers must stay allocated while the context uses them. */
 int d3dp_set_weights_borrowed(d3dp_ctx* ctx, const d3dp_weights* w);
+
+/* EXACT mode's split-fp16 operands (x 16 = hi + lo, two fp16) hold |x| < D3DP_SPLIT_RANGE; beyond it the hi part is inf
+ * and the Linear returns NaN where the fp32 reference stays finite.  Two guards:
+ *  - d3dp_exact_range_bound: computed by d3dp_set_weights from the WEIGHTS ALONE, an upper bound of the magnitude any
+ *    split operand can take for ANY input -- LayerNorm outputs are at most sqrt(C-1) |gamma| + |beta| per channel, a Linear
+ *    row of them at most sum_k |w_k| (sqrt(C-1) |gamma_k| + |beta_k|) + |b| (q, k, v and the fc1 pre-activation; |GELU(x)|
+ *    <= |x|), an attention output is a convex combination of v.  bound < D3DP_SPLIT_RANGE proves the mode safe for every
+ *    input; otherwise safety is data dependent (bound = 0 in the other modes, which have no such limit);
+ *  - d3dp_status: d3dp_denoise ends with a scan of its output; *nonfinite = 1 if any call since the last d3dp_status
+ *    produced inf / nan (synchronises the device; resets the flag).  A non-finite result with bound >= D3DP_SPLIT_RANGE
+ *    means an activation left the range: use D3DP_EXACT_IMPL=bf16x3 (no range limit, twice the MFMA work). */
+#define D3DP_SPLIT_RANGE 4094.0f
+int d3dp_exact_range_bound(const d3dp_ctx* ctx, float* bound);
+int d3dp_status(d3dp_ctx* ctx, int32_t* nonfinite);
 
 /* Scratch needed by d3dp_denoise for a (B, H) call. */
 int d3dp_workspace_bytes(const d3dp_ctx* ctx, int32_t B, int32_t H, size_t* bytes);

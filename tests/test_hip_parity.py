@@ -669,6 +669,79 @@ def test_deferred_backward_recomputes_its_own_forward(golden_dir):
         assert (x - y).double().norm().item() <= 1e-5 * x.double().norm().item() + 1e-12
 
 
+def test_backward_after_optimizer_step_raises(golden_dir):
+    """The training kernels read the parameters' own storage (borrowed weights): a backward() issued after the weights
+    changed would differentiate at the NEW weights.  PyTorch raises in the equivalent situation; so do we."""
+    g = load_g(golden_dir, "g6_train_step")
+    cs, dep, Fr = int(g["cs"]), int(g["dep"]), int(g["frames"])
+    args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
+    x2d, gt, t = (torch.from_numpy(g[k]).cuda() for k in ("x2d", "gt", "t"))
+    noise = torch.from_numpy(g["noise"]).cuda()
+    m = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=True)
+    m.load_state_dict(make_state_dict(int(g["seed"]), cs, dep, Fr), strict=False)
+    m = m.cuda().eval()
+    loss = torch.mean(torch.norm(m(x2d, gt, t=t[:, None], noise=noise) - gt, dim=-1))
+    with torch.no_grad():
+        next(m.pose_estimator.parameters()).add_(1e-3)             # what optimizer.step() does
+    with pytest.raises(RuntimeError, match="modified"):
+        loss.backward()
+
+
+def test_exact_mode_range_guard(monkeypatch):
+    """EXACT mode's split-fp16 operands hold |x| < 4094.  (1) With ordinary weights the
+    library PROVES from the weights alone that no operand can leave the range (d3dp_exact_range_bound).  (2) With one
+    fc1 weight matrix scaled by 50 the proof fails and loading warns.  (3) Scaled by 5000 an activation really leaves the
+    range: the output is non-finite, d3dp_status reports it, D3DP_CHECK_FINITE=1 turns it into an exception -- and the
+    six-pass split-bf16 implementation (no range limit) still matches the fp32 oracle on the same weights."""
+    Fr, B, H, K, cs, dep = 9, 2, 2, 1, 512, 2
+    x2d = synthetic_inputs_2d(5, B, Fr)
+    x2f = flip_2d(x2d)
+    noises = [torch.from_numpy(synthetic_noise(70, (B, H, Fr, 17, 3)))]
+
+    def run(factor, check=False):
+        sd = make_state_dict(7, cs, dep, Fr)
+        key = [k for k in sd if k.endswith("STEblocks.1.mlp.fc1.weight")][0]
+        sd[key] = sd[key] * factor
+        args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
+        m = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=False, num_proposals=H, sampling_timesteps=K,
+                 numerics="exact")
+        m.load_state_dict(sd, strict=False)
+        m = m.cuda().eval()
+        if check:
+            monkeypatch.setenv("D3DP_CHECK_FINITE", "1")
+        out = m(torch.from_numpy(x2d).cuda(), None, input_2d_flip=torch.from_numpy(x2f).cuda(), noise=noises)
+        monkeypatch.delenv("D3DP_CHECK_FINITE", raising=False)
+        return m, out, sd
+
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                             # (1): no warning at all
+        m, out, _ = run(1.0)
+    b = m.pose_estimator.exact_range_bound()
+    print(f"provable operand bound with seed-generated weights: {b:.1f} (limit {m.pose_estimator.SPLIT_RANGE})")
+    assert 1.0 < b < m.pose_estimator.SPLIT_RANGE and torch.isfinite(out).all() and not m.pose_estimator.nonfinite_seen()
+    with pytest.warns(RuntimeWarning, match="split-fp16"):         # (2)
+        m, out, _ = run(50.0)
+    assert m.pose_estimator.exact_range_bound() >= m.pose_estimator.SPLIT_RANGE
+    assert torch.isfinite(out).all() and not m.pose_estimator.nonfinite_seen()   # unproven is not the same as overflowing
+    with pytest.warns(RuntimeWarning):                             # (3)
+        m, out, sd = run(5000.0)
+    assert not torch.isfinite(out).all() and m.pose_estimator.nonfinite_seen()
+    assert not m.pose_estimator.nonfinite_seen()                   # the query resets the flag
+    with pytest.warns(RuntimeWarning), pytest.raises(_lib.D3DPHipError, match="split-fp16 range"):
+        run(5000.0, check=True)
+    monkeypatch.setenv("D3DP_EXACT_IMPL", "bf16x3")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                             # no range limit, no warning
+        m, out, _ = run(5000.0)
+    monkeypatch.delenv("D3DP_EXACT_IMPL")
+    want = orc.ddim_sample_flip(orc.strip_prefix(sd), orc.cosine_schedule(1000), torch.from_numpy(x2d), torch.from_numpy(x2f),
+                                H, K, dep, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, noises)
+    e = orc.mpjpe_mm(out.cpu(), want)
+    print(f"fc1 x 5000, split-bf16 implementation vs the fp32 oracle: {e:.3e} mm")
+    assert torch.isfinite(out).all() and e < 1.0                   # (activations of 1e4: fp32 itself is noisy here)
+
+
 def test_ddim_sample_no_flip_runs():
     m = make_model(27, 512, 2, 2, 2, "exact", 21)
     m.flip = False
