@@ -128,7 +128,41 @@ struct d3dp_ctx {
   size_t y_size() const { return fast() ? 2 : 4; }
   // (clip, hypothesis) sequences per internal pass: 15 (61,965 tokens) measured best for FAST (working set near the
   // 256 MiB memory-side cache); EXACT is compute-bound in its Linears and gains 1.5 % from 30 (fewer, fuller tile rounds)
-  int chunk() const { return cfg.chunk_seqs > 0 ? cfg.chunk_seqs : (exact() ? 30 : 15); }
+  int chunk() const { return cfg.chunk_seqs != 0 ? std::abs(cfg.chunk_seqs) : (exact() ? 31 : 15); }   // (< 0: uniform passes, for A/B)
+  // EXACT split-fp16 Linears are persistent kernels over 256 x 128 tiles on n_cu workgroups: a pass over n sequences costs
+  // sum over the four Linears of ceil(row_tiles(n) * column_tiles / n_cu) tile rounds x k-depth, and a partly filled last
+  // round costs a full one (uniform chunks of 30 lose 4.4 % of the Linear time to it).  plan() splits `total` sequences
+  // into passes of at most chunk() that minimise that sum (dynamic programme; any split gives bit-identical results).
+  int n_cu = 0;
+  std::vector<int> plan_cache;
+  int plan_total = -1;
+  const std::vector<int>& plan(int total) {
+    if (total == plan_total) return plan_cache;
+    const int cap = std::min(chunk(), total), FJ = cfg.frames * cfg.joints;
+    plan_cache.clear();
+    plan_total = total;
+    if (!x2() || cfg.chunk_seqs < 0 || n_cu <= 0) {    // uniform passes (FAST, cross-check implementations)
+      for (int s0 = 0; s0 < total; s0 += cap) plan_cache.push_back(std::min(cap, total - s0));
+      return plan_cache;
+    }
+    const long tn[4] = {(3 * cfg.channels + 127) / 128, (cfg.channels + 127) / 128, (cfg.hidden + 127) / 128,
+                        (cfg.channels + 127) / 128};
+    const long kd[4] = {cfg.channels, cfg.channels, cfg.channels, cfg.hidden};
+    std::vector<double> cost(cap + 1, 0.0);
+    for (int n = 1; n <= cap; ++n) {
+      const long R = ((long)n * FJ + 255) / 256;
+      for (int k = 0; k < 4; ++k) cost[n] += (double)((R * tn[k] + n_cu - 1) / n_cu) * (double)kd[k];
+      cost[n] += 1e-3 * (double)kd[0];                   // (a pass has a fixed cost too: 7 launches per block)
+    }
+    std::vector<double> best(total + 1, 1e300);
+    std::vector<int> pick(total + 1, 0);
+    best[0] = 0.0;
+    for (int b = 1; b <= total; ++b)
+      for (int n = 1; n <= std::min(cap, b); ++n)
+        if (best[b - n] + cost[n] < best[b]) { best[b] = best[b - n] + cost[n]; pick[b] = n; }
+    for (int b = total; b > 0; b -= pick[b]) plan_cache.push_back(pick[b]);
+    return plan_cache;
+  }
 
   int flush_events() {
     for (size_t i = 0; i < used; ++i) {
@@ -266,6 +300,11 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   const char* nf = getenv("D3DP_NO_FOLD");               // (A/B switch while the folded epilogue is being evaluated)
   c->fold = !(nf && nf[0] == '1');
   HIP_TRY(hipGetDevice(&c->device));
+  {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    c->n_cu = prop.multiProcessorCount;
+  }
   if (hipMalloc((void**)&c->d_flag, sizeof(unsigned)) != hipSuccess || hipMemset(c->d_flag, 0, sizeof(unsigned)) != hipSuccess) {
     delete c;
     return fail(D3DP_EHIP, "d3dp_create: cannot allocate the status word");
@@ -464,8 +503,8 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
     Scope s(c, P_TIME, st);
     LAUNCH_TRY(d3dp_launch_time_mlp(t, c->freq, c->t1w, c->t1b, c->t3w, c->t3b, temb, B, C, st));
   }
-  for (int seq0 = 0; seq0 < BH; seq0 += chunk) {
-    const int n = std::min(chunk, BH - seq0);
+  int seq0 = 0;
+  for (const int n : c->plan(BH)) {
     const int Tc = n * FJ;
     {
       Scope s(c, P_EMBED, st);
@@ -494,6 +533,7 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
       LAUNCH_TRY(d3dp_launch_head(c->fast() ? 1 : 0, x, fold ? nullptr : y1, fold ? nullptr : y, c->tnw, c->tnb, g.eps_block, c->hnw, c->hnb, g.eps_head, c->hw, c->hb,
                                   out + (size_t)seq0 * FJ * 3, Tc, C, st));
     }
+    seq0 += n;
   }
   d3dp_launch_nonfinite_flag(out, (size_t)BH * FJ * 3, c->d_flag, st);    // 15.9 MB at B = 32, H = 20: microseconds
   HIP_TRY(hipGetLastError());

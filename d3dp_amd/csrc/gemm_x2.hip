@@ -71,15 +71,6 @@
 #ifndef D3DP_X2_LAG
 #define D3DP_X2_LAG 1
 #endif
-// EPI_RESID (proj, fc2): the epilogue reads the tile of the residual stream it adds to -- sixteen loads per lane whose
-// HBM latency is exposed once per tile (nothing else to do: the accumulators fill the registers).  With D3DP_X2_PFR the
-// compute waves touch the tile's 1024 lines (2 per lane) with a 4-byte LDS-DMA into a junk area six to eight k-steps
-// before the epilogue, so the epilogue's loads are L2 hits.  (Touching the A / W slabs the same way made the kernel 8-14 %
-// slower -- it is bound by the line-request rate of the vector memory path, profiles/r03_gemm_l2_prefetch.md; these are
-// 2 requests per lane and tile.)
-#ifndef D3DP_X2_PFR
-#define D3DP_X2_PFR 0
-#endif
 // cache-policy bits of the loaders' LDS-DMA (aux: 1 = sc0, 2 = nt, 16 = sc1), for A/B builds
 #ifndef D3DP_X2_AAUX
 #define D3DP_X2_AAUX 0
@@ -104,8 +95,7 @@ constexpr int XW_BYTES = XBN * 128;                  // 16 KiB
 constexpr int XSTAGE = XA_BYTES + XW_BYTES;          // 48 KiB
 constexpr int XNSTAGE = 3;
 constexpr int XBIAS_MAX = 2048;                      // floats of bias kept in LDS
-constexpr int XJUNK = XNSTAGE * XSTAGE + XBIAS_MAX * 4;  // 256 bytes nobody reads: destination of the prefetch touches
-constexpr int XLDS = XJUNK + 256;                        // 152.25 KiB
+constexpr int XLDS = XNSTAGE * XSTAGE + XBIAS_MAX * 4;   // 152 KiB
 constexpr int XNCW = 8;                              // compute waves (4 x 2); waves 8..11 are loaders
 
 // LDS image of a slab: 128-byte rows = 8 slots of 16 B (q = 4 plane + k-group of 8 columns); slot q of row r lives at
@@ -116,15 +106,6 @@ __device__ __forceinline__ int swz128(int row, int q) { return q ^ ((row >> 1) &
 
 // W row carried by LDS row q of a 64-column strip: MFMA tile ni = q>>4, operand row i = q&15 -> output column 4 i + ni
 __device__ __forceinline__ int colperm(int q) { return (q & 15) * 4 + (q >> 4); }
-
-// One 4-byte LDS-DMA per lane from base + voff into the junk area at LDS byte address `junk` (wave-uniform): brings the
-// lane's 128-byte line into the L2.  No register destination, nothing waits for it.  M0 is saved and restored inside the
-// statement (the compiler does not model it).
-__device__ __forceinline__ void touch_line(const void* base, unsigned voff, unsigned junk) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(base), "s"(junk) : "memory");
-}
 
 // Two fp16 planes of a 4-column group per lane -> ONE 16-byte store per lane: lanes 2j / 2j+1 hold neighbouring column
 // groups of the same row; the even lane collects both hi halves (8 columns of the hi plane), the odd lane both lo halves.
@@ -232,16 +213,6 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#if D3DP_X2_PFR
-    unsigned pfr = 0, pfr1 = 0;                        // byte offsets of this lane's two lines of the residual tile
-    const unsigned junk = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>(smem + XJUNK));
-    if constexpr (EPI == EPI_RESID) {                  // 256 rows x 512 bytes = 1024 lines: lines L512 and L512 + 512
-      const int t0 = L + ti * G, m0 = (t0 / tiles_n) * XBM, n0 = (t0 % tiles_n) * XBN, L512 = wave * 64 + lane;
-      const int pc = min(n0 + (L512 & 3) * 32, N - 4);
-      pfr = (unsigned)(min(m0 + (L512 >> 2), M - 1) * N + pc) * 4u;
-      pfr1 = (unsigned)(min(m0 + 128 + (L512 >> 2), M - 1) * N + pc) * 4u;
-    }
-#endif
 #if D3DP_X2_LAG
     // The last two products of row block 3 (al.wh, ah.wh: 8 MFMAs) are issued AFTER the next k-step's barrier, behind
     // that step's first fragment reads: they cover the LDS latency that otherwise idles the matrix pipe after every
@@ -301,12 +272,6 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
 #pragma unroll 1
     for (int ks = 0; ks < NK; ks += 2) {               // NK is even (K % 64 == 0, checked by the launcher)
       kstep(wfa, taa, wfb, tab);
-#if D3DP_X2_PFR
-      if constexpr (EPI == EPI_RESID) {
-        if (ks == NK - 8) touch_line(outf, pfr, junk);
-        if (ks == NK - 6) touch_line(outf, pfr1, junk);
-      }
-#endif
       kstep(wfb, tab, wfa, taa);
     }
 #pragma unroll
@@ -452,9 +417,6 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
       }
     }
   }
-#if D3DP_X2_PFR
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no touch may still be writing LDS when the workgroup's LDS is released
-#endif
 }
 
 // src[i] * scale -> h2i layout (common.h): blocks of 32 elements, dst[64 b .. 64 b + 31] = hi, dst[64 b + 32 .. 64 b + 63] = lo

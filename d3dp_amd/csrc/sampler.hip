@@ -8,7 +8,9 @@
 
 namespace {
 
-__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+// torch.clamp semantics (diffusionpose.py:148,164): NaN stays NaN -- fminf / fmaxf alone would turn it into a bound and
+// hide a broken denoiser output behind a plausible pose
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return x != x ? x : fminf(fmaxf(x, lo), hi); }
 
 // xt2[0:B]  = clamp(img, +-1.1 s) / s
 // xt2[B:2B] = the same with x negated and left/right joints swapped (perm[j] = source joint of j)

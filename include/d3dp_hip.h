@@ -62,7 +62,9 @@ typedef struct d3dp_cfg {
   float eps_block;       /* 1e-6: LayerNorm eps of blocks and Spatial/Temporal_norm (mixste.py:163) */
   float eps_head;        /* 1e-5: nn.LayerNorm default in head (mixste.py:208)                     */
   int32_t mode;          /* D3DP_MODE_*                              */
-  int32_t chunk_seqs;    /* (clip,hypothesis) sequences processed per internal pass; 0 = library default (30 EXACT, 15 FAST).
+  int32_t chunk_seqs;    /* most (clip,hypothesis) sequences per internal pass; 0 = library default (31 EXACT, 15 FAST).  EXACT
+                          * mode sizes its passes (<= this) so that the persistent Linear kernels' last tile rounds are full
+                          * (capi.hip plan()); results do not depend on the split, bit for bit.
                           * EXACT mode addresses a pass's Linear outputs with 32-bit byte offsets: chunk_seqs * F * J * 3 *
                           * channels * 4 must stay below 2^32 (169 sequences at F=243, J=17, C=512), else d3dp_denoise fails. */
 } d3dp_cfg;

@@ -726,7 +726,7 @@ def test_exact_mode_range_guard(monkeypatch):
     assert torch.isfinite(out).all() and not m.pose_estimator.nonfinite_seen()   # unproven is not the same as overflowing
     with pytest.warns(RuntimeWarning):                             # (3)
         m, out, sd = run(5000.0)
-    assert not torch.isfinite(out).all() and m.pose_estimator.nonfinite_seen()
+    assert m.pose_estimator.nonfinite_seen() and not torch.isfinite(out).all()   # NaN survives the sampler's clamps (torch.clamp semantics)
     assert not m.pose_estimator.nonfinite_seen()                   # the query resets the flag
     with pytest.warns(RuntimeWarning), pytest.raises(_lib.D3DPHipError, match="split-fp16 range"):
         run(5000.0, check=True)
