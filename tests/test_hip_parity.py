@@ -568,6 +568,41 @@ def test_c3_full_size_slices_vs_oracle():
         assert max(per_step) <= EXACT_TOL_MM
 
 
+def test_c3_full_size_all_slices_vs_reference_fixture(golden_dir):
+    """BASELINE configs[2] -- the benchmarked workload, F=243 H=20 K=10 B=16 -- against the REFERENCE run at full size,
+    ALL 3200 (clip, step, hypothesis) slices (the test above compares 2 of 320 trajectories).  Fixture g14
+    (tools/make_goldens.py: the reference, clip by clip, ~2.5 h of host CPU) keeps per slice the fp64 sum, sum of squares
+    and four Gaussian random projections w_p . x of the 12,393 output coordinates.  For an error vector e of a slice,
+    E[(w_p . e)^2] = |e|^2, so the projections measure RMS error, and by Jensen's inequality
+        MPJPE = mean_j |e_j|  <=  sqrt(mean_j |e_j|^2) = sqrt(3) * rms_coordinate(e),
+    i.e. sqrt(3) * rms is an UPPER bound of the slice's MPJPE.  Gates: the bound pooled over the 320 slices of every DDIM
+    step (1280 projections each: a tight estimate) <= 1e-3 mm; every single slice's own 4-projection estimate <= 4e-3 mm
+    (chi-square with 4 degrees of freedom: a slice at the pooled level exceeds 2.2x it with probability 1e-4)."""
+    g = load_g(golden_dir, "g14_sampler_c3")
+    cs, dep, Fr, B, H, K = (int(g[k]) for k in ("cs", "dep", "frames", "B", "H", "K"))
+    assert (Fr, B, H, K) == (243, 16, 20, 10)
+    x2d = synthetic_inputs_2d(int(g["x2d_seed"]), B, Fr)
+    noises = [torch.from_numpy(synthetic_noise(int(g["noise_seed"]) + k, (B, H, Fr, 17, 3))) for k in range(K)]
+    m = make_model(Fr, cs, dep, H, K, "exact", int(g["seed"]))
+    out = m(torch.from_numpy(x2d).cuda(), None, input_2d_flip=torch.from_numpy(flip_2d(x2d)).cuda(), noise=noises)
+    assert out.shape == (B, K, H, Fr, 17, 3) and torch.isfinite(out).all()
+    n = Fr * 17 * 3
+    o = out.double().reshape(B, K, H, n)                                      # on the GPU: 40 M doubles
+    w = torch.from_numpy(np.random.Generator(np.random.PCG64(int(g["proj_seed"]))).standard_normal(size=(4, n))).cuda()
+    d_proj = (o @ w.t()).cpu() - torch.from_numpy(g["proj"])                  # (B, K, H, 4) = w_p . e
+    d_sum = (o.sum(-1).cpu() - torch.from_numpy(g["sum"])).abs().max().item() / n
+    d_sq = ((o * o).sum(-1).cpu() - torch.from_numpy(g["sumsq"])).abs().max().item() / n
+    rms_slice = (d_proj ** 2).mean(-1).div(n).sqrt()                          # per-slice RMS coordinate error (m), 4 samples
+    rms_step = (d_proj ** 2).mean(dim=(0, 2, 3)).div(n).sqrt()                # pooled per DDIM step, 1280 samples
+    bound_step_mm = (3 ** 0.5) * rms_step * 1e3
+    worst_slice_mm = (3 ** 0.5) * rms_slice.max().item() * 1e3
+    print(f"[c3 all slices] MPJPE upper bound per step (mm): {['%.2e' % v for v in bound_step_mm.tolist()]}; worst single "
+          f"slice estimate {worst_slice_mm:.2e} mm; checksum deviations per coordinate (m): sum {d_sum:.2e} squares {d_sq:.2e}")
+    assert bound_step_mm.max().item() <= EXACT_TOL_MM
+    assert worst_slice_mm <= 4 * EXACT_TOL_MM
+    assert d_sum < 2e-7 and d_sq < 2e-7
+
+
 @pytest.mark.parametrize("numerics", ["exact", "fast"])
 def test_sampler_scale_and_live_oracle(numerics):
     """scale != 1 exercises the clamp/scale arithmetic; oracle computed live on the host CPU."""

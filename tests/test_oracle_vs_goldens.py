@@ -130,3 +130,27 @@ def test_g13_c2_full_size_slice(golden_dir):
     err = orc.mpjpe_mm(out[0, :, 0][:, kept], torch.from_numpy(g["out_kept"][b, :, h]))
     print(f"oracle slice (clip {b}, hypothesis {h}) vs reference full-size run: {err:.3e} mm")
     assert err <= 1e-3
+
+
+def test_g14_c3_full_size_slice(golden_dir):
+    """BASELINE configs[2] at full size (the benchmarked workload; reference run clip by clip, fixture g14): the oracle on
+    ONE (clip, hypothesis) trajectory, K=10 steps, against that slice's random-projection checksums.  sqrt(3) x the RMS
+    coordinate error estimated from the four projections bounds the slice's MPJPE from above (Jensen); pooled over the ten
+    steps (40 projections) it must sit at the reference's own batch-shape noise floor (4e-4 mm, test above)."""
+    g = np.load(os.path.join(golden_dir, "g14_sampler_c3.npz"))
+    cs, dep, Fr, B, H, K = (int(g[k]) for k in ("cs", "dep", "frames", "B", "H", "K"))
+    b, h = 9, 13
+    x2d = synthetic_inputs_2d(int(g["x2d_seed"]), B, Fr)
+    noises = [torch.from_numpy(synthetic_noise(int(g["noise_seed"]) + k, (B, H, Fr, 17, 3)))[b:b + 1, h:h + 1] for k in range(K)]
+    p = orc.strip_prefix(make_state_dict(int(g["seed"]), cs, dep, Fr))
+    out = orc.ddim_sample_flip(p, orc.cosine_schedule(1000), torch.from_numpy(x2d[b:b + 1]), torch.from_numpy(flip_2d(x2d[b:b + 1])),
+                               1, K, dep, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, noises)
+    n = Fr * 17 * 3
+    o = out[0, :, 0].double().reshape(K, n)
+    w = torch.from_numpy(np.random.Generator(np.random.PCG64(int(g["proj_seed"]))).standard_normal(size=(4, n)))
+    d = o @ w.t() - torch.from_numpy(g["proj"][b, :, h])
+    bound_mm = (3 ** 0.5) * float((d ** 2).mean().div(n).sqrt()) * 1e3
+    dsum = float((o.sum(-1) - torch.from_numpy(g["sum"][b, :, h])).abs().max()) / n
+    print(f"oracle trajectory (clip {b}, hypothesis {h}) vs the reference's full-size run: MPJPE <= {bound_mm:.3e} mm, "
+          f"mean signed deviation {dsum:.2e} m")
+    assert bound_mm <= 1e-3 and dsum < 2e-7
