@@ -1,0 +1,25 @@
+#!/bin/bash
+# final measurements of the round-3 build: tests, smoke, bench line, rocprofv3 kernel stats, in-pipeline PMC of the qkv GEMMs
+mkdir -p gpurun_out/final
+R=$PWD
+[ -n "$SKIP_TESTS" ] || python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -16 > gpurun_out/final/tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final/smoke.log 2>&1
+python bench.py --steps ${STEPS:-5} --warmup ${WARMUP:-2} > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/final/stats -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-parity > $R/gpurun_out/final/bench_prof.json 2> /dev/null
+for mode in exact fast; do
+  rx="f16x2_kernelILi0ELi1E"; [ $mode = fast ] && rx="Li8ELi4ELi1E"
+  B="$R/bench.py --steps 1 --warmup 0 --batch 4 --no-other-leg --no-cpu-baseline --no-parity --no-profile --numerics $mode"
+  for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    tag=$(echo $c | cut -d' ' -f1)
+    rocprofv3 --pmc $c --kernel-include-regex $rx --output-format csv -d $R/gpurun_out/final/pmc_${mode}_$tag -- python $B > /dev/null 2>&1
+  done
+done
+cd $R
+db=$(find gpurun_out/final/stats -name "*.db" | head -1); [ -n "$db" ] && python tools/rocprof_summary.py $db gpurun_out/final/kernel_stats.md > /dev/null
+for d in gpurun_out/final/pmc_*/; do f=$(find $d -name "*counter_collection.csv" | head -1); echo "== $d"; [ -n "$f" ] && python tools/pmc_summary.py $f gemm | grep -v "^$"; done > gpurun_out/final/pmc.log 2>&1
+sha256sum d3dp_amd/lib/libd3dp_hip.so > gpurun_out/final/lib.sha256
+find gpurun_out/final -name "*.csv" -size +10M -delete; rm -rf gpurun_out/final/stats
+tail -6 gpurun_out/final/tests.log; tail -2 gpurun_out/final/smoke.log; head -c 600 gpurun_out/final/bench.json; echo; cat gpurun_out/final/pmc.log | grep -E "==|FETCH|WRITE|MFMA|GRBM"
+# whole-step counters, both modes (FETCH_SIZE / WRITE_SIZE / matrix-pipe busy, one pass each)
+[ -n "$SKIP_STEP_PMC" ] || bash tools/r2_pmc_step.sh > gpurun_out/final/step_pmc.log 2>&1
