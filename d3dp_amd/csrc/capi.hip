@@ -71,6 +71,7 @@ struct BlockDev {
   const float *n1w, *n1b, *n2w, *n2b, *qkv_b, *proj_b, *fc1_b, *fc2_b;
   const void *qkv_w, *proj_w, *fc1_w, *fc2_w;   // bf16 (FAST); EXACT: 2 fp16 planes (default), 3 bf16 planes or fp32
   float qkv_u = 1.f, proj_u = 1.f, fc1_u = 1.f, fc2_u = 1.f;   // EXACT f16x2: 2^-s of the per-matrix pre-scale 2^s
+  const float* fc1_c12 = nullptr;   // fold_ln: [c2 | c1] of norm2 folded into fc1 (fc1_w then holds W diag(gamma)); see run_block
 };
 
 __global__ void to_bf16_kernel(const float* __restrict__ s, bf16* __restrict__ d, size_t n) {
@@ -94,6 +95,7 @@ struct d3dp_ctx {
   int device = 0;
   bool weights_set = false;
   float range_bound = 0.f;       // d3dp_exact_range_bound (EXACT split-fp16 only)
+  size_t ln_slice_floats = 0;    // fold_ln: floats of the slice-statistics part of the LN scratch (set per d3dp_denoise call)
   unsigned* d_flag = nullptr;    // device word: bit 0 = a d3dp_denoise output held inf / nan (d3dp_status)
   char* arena = nullptr;
   size_t arena_bytes = 0;
@@ -121,6 +123,14 @@ struct d3dp_ctx {
   // proj / fc2 add into the residual stream in their epilogue (x += ...), so the row kernels read x alone
   bool fold_resid() const { return x2() && fold; }
   bool fold = true;
+  // norm2 (mixste.py:115) has no kernel of its own: proj's epilogue leaves x + proj(...) a second time as fc1's split-fp16
+  // operand, UN-normalised, with (mean, M2) of each 64-column slice of each row; fc1 runs on W diag(gamma) and applies
+  // rstd (. - mean c1) + c2 in its epilogue (gemm_x2.hip EPI_RESID_LN / EPI_GELU_LN).  OFF by default (D3DP_FOLD_LN=1 turns it
+  // on): measured on configs[2], same box, interleaved -- 50.06 / 49.86 hypothesis-clips/s folded against 49.83 / 49.70 with the
+  // row kernel: the 284 ms/step of the LayerNorm kernel come back as +160 ms in proj (its tile epilogue now also splits, stores
+  // the operand and reduces the statistics with the matrix pipes idle) and +90 ms in fc1 (profiles/r03_fold_ln_ab.md).
+  bool fold_ln() const { return fold_resid() && fold_ln_on && 2 * cfg.hidden <= 2048; }
+  bool fold_ln_on = false;
   bool x3() const { return exact() && exact_impl == 1; }
   int act() const { return fast() ? 1 : (x3() ? 2 : (x2() ? 3 : 0)); }   // code understood by the row-wise launchers
   size_t act_size() const { return fast() ? 2 : (x3() ? 6 : 4); }    // bytes per element of a Linear-input activation
@@ -205,13 +215,13 @@ struct Scope {
 
 // out = epi(A W^T + bias).  out_f32: fp32 output even in FAST mode (the Linear outputs that feed a residual add).
 int linear(d3dp_ctx* c, int cls, int epi, int out_f32, const void* A, const void* W, float wu, const float* bias, void* out,
-           int M, int N, int K, hipStream_t st) {
+           int M, int N, int K, hipStream_t st, void* out2 = nullptr, float* aux = nullptr) {
   Scope s(c, cls, st);
   if (c->fast()) return d3dp_launch_linear_bf16_stream(epi, out_f32, A, W, bias, out, M, N, K, st);
   if (c->x2()) {
     // the qkv Linear writes the packed rows of the split-fp16 attention kernels (K and V already as fp16 planes)
     if (cls == P_QKV && c->x2_attn()) epi = EPI_QKV_PACK;
-    return d3dp_launch_linear_f16x2(epi, A, W, bias, wu * kActUnscale, (float*)out, out, M, N, K, st);
+    return d3dp_launch_linear_f16x2(epi, A, W, bias, wu * kActUnscale, (float*)out, out2 ? out2 : out, aux, c->d_flag, M, N, K, st);
   }
   if (c->x3()) return d3dp_launch_linear_bf16x3(epi, A, W, bias, (float*)out, out, M, N, K, st);
   return d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, st);
@@ -249,19 +259,31 @@ int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, hipSt
 // (activation type: bf16 in FAST mode -- one more bf16 rounding on the branch output, none on the fp32 residual
 // stream itself) and the next row-wise kernel (LN2 here; the norm pair / head in the caller) performs x += y while it has the row in
 // registers anyway.  On return y1 / y hold the proj / fc2 outputs that the CALLER's next kernel must add to x.
-int run_block(d3dp_ctx* c, const BlockDev& w, int axis, float* x, void* y1, void* y, void* bufA, void* bufB, int n_bh,
-              hipStream_t st) {
+int run_block(d3dp_ctx* c, const BlockDev& w, int axis, float* x, void* y1, void* y, void* bufA, void* bufB, float* lnst,
+              int n_bh, hipStream_t st) {
   const d3dp_cfg& g = c->cfg;
   const int Tc = n_bh * g.frames * g.joints, C = g.channels;
   LAUNCH_TRY(linear(c, P_QKV, EPI_BIAS, 0, bufA, w.qkv_w, w.qkv_u, w.qkv_b, bufB, Tc, 3 * C, C, st));
   LAUNCH_TRY(attention(c, axis, bufB, bufA, n_bh, st));
   const bool fold = c->fold_resid();   // EXACT split-fp16 Linears: x += proj / fc2 inside their epilogues
+  if (c->fold_ln()) {
+    // norm2 folded into proj's epilogue (statistics, un-normalised operand -> y1) and fc1's (normalisation): no row kernel
+    float* slices = lnst;                                                   // [Tc][C / 64][2]
+    float* rowstat = lnst + (size_t)c->ln_slice_floats;                     // [Tc + 256][2]
+    LAUNCH_TRY(linear(c, P_PROJ, EPI_RESID_LN, 0, bufA, w.proj_w, w.proj_u, w.proj_b, x, Tc, C, C, st, y1, slices));
+    {
+      Scope s(c, P_LN, st);
+      d3dp_launch_ln_combine(slices, rowstat, Tc, C, g.eps_block, st);
+    }
+    LAUNCH_TRY(linear(c, P_FC1, EPI_GELU_LN, 0, y1, w.fc1_w, w.fc1_u, w.fc1_c12, bufB, Tc, g.hidden, C, st, bufB, rowstat));
+  } else {
   LAUNCH_TRY(linear(c, P_PROJ, fold ? EPI_RESID : EPI_BIAS, 0, bufA, w.proj_w, w.proj_u, w.proj_b, fold ? (void*)x : y1, Tc, C, C, st));
   {
     Scope s(c, P_LN, st);      // xn = LN2(x + y1); x itself stays untouched (the caller's norm pair adds y1 and y)
     LAUNCH_TRY(d3dp_launch_ln(c->act(), x, fold ? nullptr : y1, 0, w.n2w, w.n2b, g.eps_block, bufA, Tc, C, st));
   }
   LAUNCH_TRY(linear(c, P_FC1, EPI_GELU, 0, bufA, w.fc1_w, w.fc1_u, w.fc1_b, bufB, Tc, g.hidden, C, st));
+  }
   LAUNCH_TRY(linear(c, P_FC2, fold ? EPI_RESID : EPI_BIAS, 0, bufB, w.fc2_w, w.fc2_u, w.fc2_b, fold ? (void*)x : y, Tc, C, g.hidden, st));
   return 0;
 }
@@ -297,8 +319,10 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->cfg = g;
   const char* xf = getenv("D3DP_EXACT_IMPL");
   c->exact_impl = (xf && !strcmp(xf, "bf16x3")) ? 1 : (xf && !strcmp(xf, "f32")) ? 2 : 0;
-  const char* nf = getenv("D3DP_NO_FOLD");               // (A/B switch while the folded epilogue is being evaluated)
+  const char* nf = getenv("D3DP_NO_FOLD");               // cross-check: residual adds (and norm2) in the row kernels
   c->fold = !(nf && nf[0] == '1');
+  const char* nl = getenv("D3DP_FOLD_LN");               // norm2 folded into proj / fc1 instead of its own row kernel
+  c->fold_ln_on = nl && nl[0] == '1';
   HIP_TRY(hipGetDevice(&c->device));
   {
     hipDeviceProp_t prop;
@@ -346,17 +370,31 @@ int d3dp_set_weights(d3dp_ctx* c, const d3dp_weights* w, void* stream) {
   const size_t i_tnw = add(w->temporal_norm_w, C, false), i_tnb = add(w->temporal_norm_b, C, false);
   const size_t i_hnw = add(w->head_norm_w, C, false), i_hnb = add(w->head_norm_b, C, false);
   const size_t i_hw = add(w->head_w, 3 * C, false), i_hb = add(w->head_b, 3, false);
-  struct BI { size_t v[12]; };
+  struct BI { size_t v[13]; };
   std::vector<BI> bis;
+  // fold_ln: fc1 runs on W diag(gamma2) with [c2 | c1] in place of its bias (computed into temporaries that live until the
+  // synchronisation below)
+  std::vector<float*> temps;
+  struct TempFree { std::vector<float*>& t; ~TempFree() { for (float* p : t) (void)hipFree(p); } } temp_free{temps};
   for (int kind = 0; kind < 2; ++kind)
     for (int d = 0; d < g.depth; ++d) {
       const d3dp_block_weights& b = (kind == 0 ? w->ste : w->tte)[d];
+      if (!b.norm1_w || !b.norm1_b || !b.qkv_w || !b.qkv_b || !b.proj_w || !b.proj_b || !b.norm2_w || !b.norm2_b || !b.fc1_w ||
+          !b.fc1_b || !b.fc2_w || !b.fc2_b) return fail(D3DP_EINVAL, "d3dp_set_weights: a weight pointer is null");
       BI bi;
       bi.v[0] = add(b.norm1_w, C, false); bi.v[1] = add(b.norm1_b, C, false);
       bi.v[2] = add(b.qkv_w, 3 * C * C, true); bi.v[3] = add(b.qkv_b, 3 * C, false);
       bi.v[4] = add(b.proj_w, C * C, true); bi.v[5] = add(b.proj_b, C, false);
       bi.v[6] = add(b.norm2_w, C, false); bi.v[7] = add(b.norm2_b, C, false);
-      bi.v[8] = add(b.fc1_w, Hd * C, true); bi.v[9] = add(b.fc1_b, Hd, false);
+      if (c->fold_ln()) {
+        float *wp = nullptr, *c12 = nullptr;
+        HIP_TRY(hipMalloc((void**)&wp, Hd * C * 4)); temps.push_back(wp);
+        HIP_TRY(hipMalloc((void**)&c12, 2 * Hd * 4)); temps.push_back(c12);
+        d3dp_launch_fold_ln(b.fc1_w, b.norm2_w, b.norm2_b, b.fc1_b, wp, c12, (int)Hd, (int)C, st);
+        bi.v[8] = add(wp, Hd * C, true); bi.v[9] = add(b.fc1_b, Hd, false); bi.v[12] = add(c12, 2 * Hd, false);
+      } else {
+        bi.v[8] = add(b.fc1_w, Hd * C, true); bi.v[9] = add(b.fc1_b, Hd, false); bi.v[12] = bi.v[9];
+      }
       bi.v[10] = add(b.fc2_w, C * Hd, true); bi.v[11] = add(b.fc2_b, C, false);
       bis.push_back(bi);
     }
@@ -402,25 +440,39 @@ int d3dp_set_weights(d3dp_ctx* c, const d3dp_weights* w, void* stream) {
     else if (it.mat && c->x2()) d3dp_launch_split2((const float*)it.src, c->arena + it.off, it.n, 1.0f / unscale[i], st);
     else HIP_TRY(hipMemcpyAsync(c->arena + it.off, it.src, it.n * 4, hipMemcpyDeviceToDevice, st));
   }
-  // provable range of every split-fp16 operand, from the weights alone (header: d3dp_exact_range_bound)
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  // provable range of the split-fp16 operands, from the weights alone (header: d3dp_exact_range_bound): computed on the
+  // host in fp64 -- once per weight load, 139 MB over PCIe
   c->range_bound = 0.f;
-  unsigned* dbound = nullptr;
   if (c->x2()) {
-    HIP_TRY(hipMalloc((void**)&dbound, sizeof(unsigned)));
-    HIP_TRY(hipMemsetAsync(dbound, 0, sizeof(unsigned), st));
-    const float sq = sqrtf((float)(C - 1));
+    std::vector<float> hw, hg, hb, hbias;
+    auto pull = [&](std::vector<float>& h, const float* d, size_t n) {
+      h.resize(n);
+      return hipMemcpy(h.data(), d, n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    };
+    const double sq = std::sqrt((double)(C - 1));
+    double worst = 0.0;
+    // max_n  sum_k |W[n,k]| (sq |gamma_k| + |beta_k|) + |bias_n|,  and the LayerNorm output bound max_k (sq |gamma_k| + |beta_k|)
+    auto rowbound = [&](const float* W, const float* gam, const float* bet, const float* bias, size_t N, size_t K) -> bool {
+      if (!pull(hw, W, N * K) || !pull(hg, gam, K) || !pull(hb, bet, K) || !pull(hbias, bias, N)) return false;
+      std::vector<double> in(K);
+      for (size_t k = 0; k < K; ++k) { in[k] = sq * std::fabs((double)hg[k]) + std::fabs((double)hb[k]); worst = std::max(worst, in[k]); }
+      for (size_t n = 0; n < N; ++n) {
+        double a = std::fabs((double)hbias[n]);
+        for (size_t k = 0; k < K; ++k) a += std::fabs((double)hw[n * K + k]) * in[k];
+        worst = std::max(worst, a);
+      }
+      return true;
+    };
     for (int kind = 0; kind < 2; ++kind)
       for (int d = 0; d < g.depth; ++d) {
         const d3dp_block_weights& b = (kind == 0 ? w->ste : w->tte)[d];
-        d3dp_launch_rowbound(b.qkv_w, b.norm1_w, b.norm1_b, b.qkv_b, 3 * (int)C, (int)C, sq, dbound, st);
-        d3dp_launch_rowbound(b.fc1_w, b.norm2_w, b.norm2_b, b.fc1_b, (int)Hd, (int)C, sq, dbound, st);
+        if (!rowbound(b.qkv_w, b.norm1_w, b.norm1_b, b.qkv_b, 3 * C, C) ||      // q, k, v (and the attention output <= max |v|)
+            !rowbound(b.fc1_w, b.norm2_w, b.norm2_b, b.fc1_b, Hd, C))           // the fc1 pre-activation (|GELU(x)| <= |x|)
+          return fail(D3DP_EHIP, "d3dp_set_weights: copying the weights to the host for the range bound failed");
       }
-  }
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(st));
-  if (dbound) {
-    HIP_TRY(hipMemcpy(&c->range_bound, dbound, sizeof(float), hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(dbound));
+    c->range_bound = (float)std::min(worst, 3.0e38);
   }
   auto F32 = [&](size_t i) { return (const float*)(c->arena + items[i].off); };
   auto ANY = [&](size_t i) { return (const void*)(c->arena + items[i].off); };
@@ -433,7 +485,7 @@ int d3dp_set_weights(d3dp_ctx* c, const d3dp_weights* w, void* stream) {
     const BI& bi = bis[k];
     BlockDev b{F32(bi.v[0]), F32(bi.v[1]), F32(bi.v[6]), F32(bi.v[7]), F32(bi.v[3]), F32(bi.v[5]), F32(bi.v[9]),
                F32(bi.v[11]), ANY(bi.v[2]), ANY(bi.v[4]), ANY(bi.v[8]), ANY(bi.v[10]),
-               unscale[bi.v[2]], unscale[bi.v[4]], unscale[bi.v[8]], unscale[bi.v[10]]};
+               unscale[bi.v[2]], unscale[bi.v[4]], unscale[bi.v[8]], unscale[bi.v[10]], F32(bi.v[12])};
     (k < (size_t)g.depth ? c->ste : c->tte).push_back(b);
   }
   c->weights_set = true;
@@ -474,7 +526,8 @@ int d3dp_workspace_bytes(const d3dp_ctx* c, int32_t B, int32_t H, size_t* bytes)
   const size_t Tc = n * g.frames * g.joints, C = g.channels;
   const size_t wide = (size_t)std::max(3 * g.channels, g.hidden);
   *bytes = align_up((size_t)B * C * 4) + align_up(Tc * C * 4) + 2 * align_up(Tc * C * c->y_size()) +
-           align_up(Tc * C * c->act_size()) + align_up(Tc * wide * c->wide_size());
+           align_up(Tc * C * c->act_size()) + align_up(Tc * wide * c->wide_size()) +
+           (c->fold_ln() ? align_up(Tc * ((C + 63) / 64) * 8) + align_up((Tc + 256) * 8) : 0);
   return D3DP_OK;
 }
 
@@ -497,7 +550,9 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
   void* y1 = p;            p += align_up(Tmax * C * c->y_size());
   void* y = p;             p += align_up(Tmax * C * c->y_size());
   void* bufA = p;          p += align_up(Tmax * C * c->act_size());
-  void* bufB = p;
+  void* bufB = p;          p += align_up(Tmax * (size_t)std::max(3 * g.channels, g.hidden) * c->wide_size());
+  float* lnst = (float*)p;                               // fold_ln: slice statistics, then (mean, rstd) per row
+  c->ln_slice_floats = align_up(Tmax * ((C + 63) / 64) * 8) / 4;
 
   {
     Scope s(c, P_TIME, st);
@@ -513,14 +568,14 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
     }
     const bool fold = c->fold_resid();
     for (int d = 0; d < g.depth; ++d) {
-      int r = run_block(c, c->ste[d], 0, x, y1, y, bufA, bufB, n, st);
+      int r = run_block(c, c->ste[d], 0, x, y1, y, bufA, bufB, lnst, n, st);
       if (r) return r;
       {
         Scope s(c, P_LN2, st);   // x += fc2 out; Spatial_norm (+ Temporal_pos after block 0); TTE block d's norm1
         LAUNCH_TRY(d3dp_launch_ln2(c->act(), x, fold ? nullptr : y1, fold ? nullptr : y, c->snw, c->snb, d == 0 ? c->tpos : nullptr, c->tte[d].n1w,
                                    c->tte[d].n1b, g.eps_block, bufA, Tc, C, F, J, st));
       }
-      r = run_block(c, c->tte[d], 1, x, y1, y, bufA, bufB, n, st);
+      r = run_block(c, c->tte[d], 1, x, y1, y, bufA, bufB, lnst, n, st);
       if (r) return r;
       if (d + 1 < g.depth) {
         Scope s(c, P_LN2, st);   // x += fc2 out; Temporal_norm; STE block d+1's norm1
@@ -553,7 +608,7 @@ int d3dp_status(d3dp_ctx* c, int32_t* nonfinite) {
   HIP_TRY(hipDeviceSynchronize());                     // every d3dp_denoise issued so far has written its verdict
   HIP_TRY(hipMemcpy(&v, c->d_flag, sizeof v, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(c->d_flag, 0, sizeof v));
-  *nonfinite = (int32_t)(v & 1u);
+  *nonfinite = (int32_t)(v != 0u);                     // bit 0: inf / nan in an output; bit 1: an operand left the split range
   return D3DP_OK;
 }
 
@@ -649,7 +704,8 @@ int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream) {
 int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* bias, float w_scale, void* out, int32_t M,
                       int32_t N, int32_t K, void* stream) {
   if (!A2 || !W2 || !bias || !out || !(w_scale > 0.f)) return fail(D3DP_EINVAL, "d3dp_op_linear_x2: bad argument");
-  LAUNCH_TRY(d3dp_launch_linear_f16x2(epi, A2, W2, bias, kActUnscale / w_scale, (float*)out, out, M, N, K, (hipStream_t)stream));
+  if (epi == EPI_RESID_LN || epi == EPI_GELU_LN) return fail(D3DP_EINVAL, "d3dp_op_linear_x2: epilogues 5 / 6 are internal to d3dp_denoise");
+  LAUNCH_TRY(d3dp_launch_linear_f16x2(epi, A2, W2, bias, kActUnscale / w_scale, (float*)out, out, nullptr, nullptr, M, N, K, (hipStream_t)stream));
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
 }

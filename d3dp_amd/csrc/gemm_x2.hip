@@ -36,6 +36,10 @@
 //   EPI_GELU     -> GELU (rational erf, common.h) re-split into two fp16 planes (the fc2 operand)
 //   EPI_QKV_PACK -> q fp32, k and v as fp16 planes: the packed rows the split-fp16 attention kernels read (attention.hip)
 //   EPI_RESID    -> x += A W^T + b in place on the fp32 residual stream (proj, fc2: mixste.py:113-115)
+//   EPI_RESID_LN -> the same, and the sum leaves a second time as the NEXT Linear's split-fp16 operand (un-normalised) together
+//                   with (mean, M2) of each 64-column slice of each row: the statistics of the LayerNorm that follows
+//   EPI_GELU_LN  -> EPI_GELU of a Linear with that LayerNorm folded in: LN(x) W^T + b = rstd (x W'^T - mean c1) + c2 with
+//                   W' = W diag(gamma), c1 = W' 1, c2 = W beta + b -- norm2 + fc1 (mixste.py:115) without a row kernel in between
 // Plane outputs leave as ONE 16-byte store per lane too (neighbouring lanes swap halves, store_planes_paired).
 // Timing probes of this kernel (loads / stores / MFMAs / barriers compiled out one at a time) and what they say about
 // the clock the chip sustains under this instruction mix: profiles/r02_gemm_probes.md.
@@ -95,7 +99,8 @@ constexpr int XW_BYTES = XBN * 128;                  // 16 KiB
 constexpr int XSTAGE = XA_BYTES + XW_BYTES;          // 48 KiB
 constexpr int XNSTAGE = 3;
 constexpr int XBIAS_MAX = 2048;                      // floats of bias kept in LDS
-constexpr int XLDS = XNSTAGE * XSTAGE + XBIAS_MAX * 4;   // 152 KiB
+constexpr int XROWSTAT = XNSTAGE * XSTAGE + XBIAS_MAX * 4;   // EPI_GELU_LN: 2 x [256 rows][mean, rstd] (tile t in buffer t & 1)
+constexpr int XLDS = XROWSTAT + 2 * XBM * 8;             // 156 KiB
 constexpr int XNCW = 8;                              // compute waves (4 x 2); waves 8..11 are loaders
 
 // LDS image of a slab: 128-byte rows = 8 slots of 16 B (q = 4 plane + k-group of 8 columns); slot q of row r lives at
@@ -127,8 +132,9 @@ __device__ __forceinline__ void store_planes_paired(char* dst, f16x4 ph, f16x4 p
 template <int EPI, int TAG>
 __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__ A2, const f16* __restrict__ W2,
                                                          const float* __restrict__ bias, float unscale,
-                                                         float* __restrict__ outf, f16* __restrict__ out2, int M, int N,
-                                                         int K, int tiles_n, int total_tiles) {
+                                                         float* __restrict__ outf, f16* __restrict__ out2,
+                                                         float* __restrict__ aux, unsigned* __restrict__ flag, int M,
+                                                         int N, int K, int tiles_n, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sbias = reinterpret_cast<float*>(smem + XNSTAGE * XSTAGE);
   const int G = gridDim.x;
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  for (int i = tid; i < N; i += (XNCW + 4) * 64) sbias[i] = bias[i];
+  for (int i = tid; i < (EPI == EPI_GELU_LN ? 2 * N : N); i += (XNCW + 4) * 64) sbias[i] = bias[i];   // (GELU_LN: c2 | c1)
   __syncthreads();
 
   if (wave >= XNCW) {
@@ -166,6 +172,17 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
           const int row = (lw * 4 + i) * 8 + lr;                        // LDS row of the W slab
           const int wrow = (row & 64) + colperm(row & 63);              // output column it carries
           pw[i] = W2 + (size_t)min(n0 + wrow, N - 1) * (2 * K) + swz128(row, lq) * 8;
+        }
+      }
+      if constexpr (EPI == EPI_GELU_LN) {
+        // the tile's 256 (mean, rstd) pairs: 2 KiB = two pieces, by loader wave 0, the OLDEST operations of this k-step
+        // (every counted wait below then covers them); buffer ti & 1 -- the epilogue of tile ti - 1 may still be reading
+        if (ks == 0 && lw == 0) {
+          const int t = L + ti * G;
+          const float* rs = aux + (size_t)(t / tiles_n) * XBM * 2 + lane * 4;     // (aux has 256 rows of slack: no clamp)
+          char* dst = smem + XROWSTAT + (ti & 1) * (XBM * 8);
+          __builtin_amdgcn_global_load_lds(GPTR(rs), LPTR(dst), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(GPTR(rs + 256), LPTR(dst + 1024), 16, 0, 0);
         }
       }
       char* base = smem + slot * XSTAGE;
@@ -332,11 +349,12 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
       unsigned off, pitch;
       bool planes;                                     // split the values and store fp16 planes (else fp32)
       char* base = reinterpret_cast<char*>(outf);
-      if constexpr (EPI == EPI_GELU) {                 // h2i rows (the fc2 operand): 4 N bytes per row; the pair's 8 columns
-        base = reinterpret_cast<char*>(out2);          // start at nb & ~7: even lane -> their hi slot, odd lane -> the lo slot
+      const int c0 = nb & ~7;                          // h2i rows: 4 N bytes per row; the lane pair's 8 columns start at c0:
+      const unsigned offp = (unsigned)pm0 * (N * 4) + (c0 >> 5) * 128 + (c0 & 31) * 2 + (odd ? 64 : 0);   // even lane -> hi slot, odd -> lo
+      if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_LN) {   // the fc2 operand
+        base = reinterpret_cast<char*>(out2);
         pitch = N * 4; planes = true;
-        const int c0 = nb & ~7;
-        off = (c0 >> 5) * 128 + (c0 & 31) * 2 + (odd ? 64 : 0);
+        off = offp - (unsigned)pm0 * pitch;
       } else if constexpr (TAG == 1) {
         // packed qkv row (12 C bytes, C = N / 3): q fp32 | k hi | k lo | v hi | v lo (fp16 planes x 16) -- the
         // K / V operand images of the split-fp16 attention kernels, which copy them into LDS without touching them
@@ -349,8 +367,21 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
       }
       off += (unsigned)pm0 * pitch;
       const int rows = M - pm0;                        // row k = mi*16 + r of this lane exists iff k < rows
+      [[maybe_unused]] float4 c1z = {};
+      [[maybe_unused]] const float* srow = nullptr;
+      if constexpr (EPI == EPI_GELU_LN) {
+        c1z = *reinterpret_cast<const float4*>(sbias + N + nb);
+        srow = reinterpret_cast<const float*>(smem + XROWSTAT + (ti & 1) * (XBM * 8)) + (wr * 64 + 4 * fg) * 2;
+      }
       auto value = [&](int mi, int r, int e) {
-        return fmaf(acc[mi][e][r], unscale, e == 0 ? bz.x : e == 1 ? bz.y : e == 2 ? bz.z : bz.w);
+        const float bze = e == 0 ? bz.x : e == 1 ? bz.y : e == 2 ? bz.z : bz.w;
+        if constexpr (EPI == EPI_GELU_LN) {            // rstd (x W'^T - mean c1) + c2
+          const float2 st = *reinterpret_cast<const float2*>(srow + (mi * 16 + r) * 2);
+          const float c1e = e == 0 ? c1z.x : e == 1 ? c1z.y : e == 2 ? c1z.z : c1z.w;
+          return fmaf(st.y, fmaf(acc[mi][e][r], unscale, -(st.x * c1e)), bze);
+        } else {
+          return fmaf(acc[mi][e][r], unscale, bze);
+        }
       };
       auto store_rows = [&](auto planes_c, auto checked_c) {
 #pragma unroll
@@ -363,7 +394,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
             if constexpr (decltype(planes_c)::value) {
               f16x4 ph, pl;
               float v[4] = {value(mi, r, 0), value(mi, r, 1), value(mi, r, 2), value(mi, r, 3)};
-              if constexpr (EPI == EPI_GELU) {
+              if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_LN) {
 #if D3DP_X2_PKGELU
                 const f32x2 g0 = gelu_erf_rational2((f32x2){v[0], v[1]}), g1 = gelu_erf_rational2((f32x2){v[2], v[3]});
                 v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
@@ -379,7 +410,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
                 ph[e] = h; pl[e] = l;
               }
               store_planes_paired(dst, ph, pl, odd, live);
-            } else if constexpr (EPI != EPI_RESID) {
+            } else if constexpr (EPI != EPI_RESID && EPI != EPI_RESID_LN) {
               if (live) OUT_STORE(reinterpret_cast<f32x4*>(dst), ((f32x4){value(mi, r, 0), value(mi, r, 1), value(mi, r, 2), value(mi, r, 3)}));
             }
           }
@@ -406,14 +437,66 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
               if (live) *reinterpret_cast<f32x4*>(base + (off + (unsigned)k * pitch)) = v;   // (re-read by the next row kernel: no nt hint)
             }
         }
+        if constexpr (EPI == EPI_RESID_LN && !decltype(planes_c)::value) {
+          // x += A W^T + b in place, in two halves of eight rows per lane (the sums stay in registers for what follows, and
+          // sixteen reads + sixteen sums + the accumulators would not fit the 168 registers of a 12-wave workgroup); each
+          // sum leaves a second time as the next Linear's operand (un-normalised, x 16, h2i), and the 16 lanes of a row
+          // group, which hold a row's 64 values, reduce (mean, M2) of this wave's slice of every row: two passes in registers,
+          // butterfly over the DPP row (xor 1, xor 2, half mirror, mirror: every lane ends with the sum)
+          auto rowsum16 = [](float x) {
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false));
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, false));
+            return x;
+          };
+          const int S = (N + 63) >> 6, slice = nb >> 6;
+          float* sdst = aux + ((size_t)pm0 * S + slice) * 2;
+          bool over = false;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            f32x4 res[2][4];
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int k = (half * 2 + m2) * 16 + r;
+                const bool live = !decltype(checked_c)::value || k < rows;
+                res[m2][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (live) res[m2][r] = *reinterpret_cast<const f32x4*>(base + (off + (unsigned)k * pitch));
+              }
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int mi = half * 2 + m2, k = mi * 16 + r;
+                const bool live = !decltype(checked_c)::value || k < rows;
+                const f32x4 v = {res[m2][r][0] + value(mi, r, 0), res[m2][r][1] + value(mi, r, 1),
+                                 res[m2][r][2] + value(mi, r, 2), res[m2][r][3] + value(mi, r, 3)};
+                if (live) *reinterpret_cast<f32x4*>(base + (off + (unsigned)k * pitch)) = v;
+                f16x4 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { f16 h, l; split2h(v[e], h, l); ph[e] = h; pl[e] = l; }
+                store_planes_paired(reinterpret_cast<char*>(out2) + (offp + (unsigned)k * (N * 4)), ph, pl, odd, live);
+                // exact range check of the un-normalised operand (its magnitude has no useful bound from the weights alone)
+                over |= !(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) < 65504.0f * kActUnscale);
+                const float mean = rowsum16((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
+                const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                const float q2 = rowsum16(fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3));
+                if (live && fi == 0) *reinterpret_cast<float2*>(sdst + (size_t)k * S * 2) = make_float2(mean, q2);
+              }
+          }
+          if (__builtin_expect(__any(over), 0) && lane == 0) atomicOr(flag, 2u);   // d3dp_status: operand left the split range
+        }
       };
       using T_ = std::true_type; using F_ = std::false_type;
+      constexpr bool kPlanesOnly = EPI == EPI_GELU || EPI == EPI_GELU_LN;
       if (rows >= 64) {                                // (all but the last row of tiles)
-        if (planes) { if constexpr (EPI == EPI_GELU || TAG == 1) store_rows(T_{}, F_{}); }
-        else { if constexpr (EPI != EPI_GELU) store_rows(F_{}, F_{}); }
+        if (planes) { if constexpr (kPlanesOnly || TAG == 1) store_rows(T_{}, F_{}); }
+        else { if constexpr (!kPlanesOnly) store_rows(F_{}, F_{}); }
       } else {
-        if (planes) { if constexpr (EPI == EPI_GELU || TAG == 1) store_rows(T_{}, T_{}); }
-        else { if constexpr (EPI != EPI_GELU) store_rows(F_{}, T_{}); }
+        if (planes) { if constexpr (kPlanesOnly || TAG == 1) store_rows(T_{}, T_{}); }
+        else { if constexpr (!kPlanesOnly) store_rows(F_{}, T_{}); }
       }
     }
   }
@@ -442,23 +525,38 @@ __global__ void absmax_kernel(const float* __restrict__ s, size_t n, unsigned* _
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
-// Worst-case magnitude of a Linear fed by a LayerNorm, from the weights alone (d3dp_exact_range_bound, d3dp_hip.h):
-// one wave per output row n: sum_k |W[n,k]| (s |gw[k]| + |gb[k]|) + |bias[n]|; block 0 also folds in the LayerNorm output
-// bound itself.  Non-negative floats order like their bit patterns: atomicMax on the bits.
-__global__ void rowbound_kernel(const float* __restrict__ W, const float* __restrict__ gw, const float* __restrict__ gb,
-                                const float* __restrict__ bias, int N, int K, float s, unsigned* __restrict__ out) {
+// rowstat[m] = (mean, 1 / sqrt(var + eps)) of row m from its S slices of 64 (mean_i, M2_i): mean = avg of means,
+// M2 = sum M2_i + 64 sum (mean_i - mean)^2 (the exact pairwise update for equal counts), var = M2 / (64 S)
+__global__ void ln_combine_kernel(const float* __restrict__ sl, float* __restrict__ rowstat, int M, int S, float eps) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float2* p = reinterpret_cast<const float2*>(sl) + (size_t)m * S;
+  float mean = 0.f;
+  for (int i = 0; i < S; ++i) mean += p[i].x;
+  mean *= 1.0f / (float)S;
+  float m2 = 0.f;
+  for (int i = 0; i < S; ++i) { const float d = p[i].x - mean; m2 += fmaf(64.0f * d, d, p[i].y); }
+  const float rstd = 1.0f / sqrtf(m2 * (1.0f / (64.0f * (float)S)) + eps);
+  reinterpret_cast<float2*>(rowstat)[m] = make_float2(mean, rstd);
+}
+
+// one wave per output row n: Wp[n][k] = W[n][k] gamma[k]; c12[n] = sum_k W[n][k] beta[k] + bias[n]; c12[N + n] = sum_k Wp[n][k]
+// (sums in fp64: they stand in for fp32 dot products of the reference, and are computed once per weight load)
+__global__ void fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ bias, float* __restrict__ Wp, float* __restrict__ c12, int N, int K) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  float m = 0.f;
-  if (n < N) {
-    float acc = 0.f;
-    for (int k = lane; k < K; k += 64) acc += fabsf(W[(size_t)n * K + k]) * (s * fabsf(gw[k]) + fabsf(gb[k]));
-    m = wave_sum(acc) + fabsf(bias[n]);
+  if (n >= N) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = lane; k < K; k += 64) {
+    const float w = W[(size_t)n * K + k], wp = w * gamma[k];
+    Wp[(size_t)n * K + k] = wp;
+    s1 += (double)wp;
+    s2 += (double)w * (double)beta[k];
   }
-  if (blockIdx.x == 0)
-    for (int k = threadIdx.x; k < K; k += blockDim.x) m = fmaxf(m, s * fabsf(gw[k]) + fabsf(gb[k]));
-  m = wave_max(m);
-  if (lane == 0 && m > 0.f) atomicMax(out, __float_as_uint(m < INFINITY ? m : INFINITY));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+  if (lane == 0) { c12[n] = (float)(s2 + (double)bias[n]); c12[N + n] = (float)s1; }
 }
 
 __global__ void nonfinite_flag_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ flag) {
@@ -478,16 +576,23 @@ __global__ void nonfinite_flag_kernel(const float* __restrict__ x, size_t n, uns
 // K must be a multiple of 64: the k-loop is unrolled by two k-steps of 32 (the lagged products alternate between two
 // register sets), and the loader / compute waves count barriers per k-step.
 int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const float* bias, float unscale, float* outf,
-                             void* out2, int M, int N, int K, hipStream_t st) {
+                             void* out2, float* aux, unsigned* flag, int M, int N, int K, hipStream_t st) {
   if (K % (2 * XBK) != 0 || N % 4 != 0 || N > XBIAS_MAX || M <= 0) return -1;
   if ((size_t)M * N * 4 >= ((size_t)1 << 32)) return -1;   // 32-bit byte offsets in the epilogue
-  if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_QKV_PACK && epi != EPI_RESID) return -1;
+  if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_QKV_PACK && epi != EPI_RESID && epi != EPI_RESID_LN &&
+      epi != EPI_GELU_LN) return -1;
+  if ((epi == EPI_RESID_LN || epi == EPI_GELU_LN) && (!aux || !out2)) return -1;
+  if (epi == EPI_RESID_LN && !flag) return -1;
+  if (epi == EPI_RESID_LN && N % 64 != 0) return -1;    // whole 64-column slices: every compute wave's columns exist
+  if (epi == EPI_GELU_LN && 2 * N > XBIAS_MAX) return -1;   // c2 | c1 in the bias area
   if (epi == EPI_QKV_PACK && (N % 3 != 0 || (N / 3) % 64 != 0)) return -1;
-  if (epi == EPI_GELU && N % 8 != 0) return -1;        // plane stores are paired across two 4-column groups
+  if ((epi == EPI_GELU || epi == EPI_GELU_LN || epi == EPI_RESID_LN) && N % 8 != 0) return -1;   // plane stores are paired across two 4-column groups
   const int tm = (M + XBM - 1) / XBM, tn = (N + XBN - 1) / XBN;
-  using KernT = void (*)(const f16*, const f16*, const float*, float, float*, f16*, int, int, int, int, int);
-  static const KernT kerns[4] = {gemm_f16x2_kernel<EPI_BIAS, 0>, gemm_f16x2_kernel<EPI_BIAS, 1>,
-                                 gemm_f16x2_kernel<EPI_GELU, 0>, gemm_f16x2_kernel<EPI_RESID, 0>};
+  using KernT = void (*)(const f16*, const f16*, const float*, float, float*, f16*, float*, unsigned*, int, int, int, int, int);
+  constexpr int NKERN = 6;
+  static const KernT kerns[NKERN] = {gemm_f16x2_kernel<EPI_BIAS, 0>, gemm_f16x2_kernel<EPI_BIAS, 1>,
+                                     gemm_f16x2_kernel<EPI_GELU, 0>, gemm_f16x2_kernel<EPI_RESID, 0>,
+                                     gemm_f16x2_kernel<EPI_RESID_LN, 0>, gemm_f16x2_kernel<EPI_GELU_LN, 0>};
   // per DEVICE: the 152 KiB dynamic-LDS opt-in of every instantiation and the CU count (one process may drive several
   // devices: nn.DataParallel callers)
   constexpr int kMaxDev = 64;
@@ -499,7 +604,7 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
   {
     std::lock_guard<std::mutex> lock(mu);
     if (n_cu[dev] == 0) {
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < NKERN; ++k)
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[k]), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 XLDS) != hipSuccess) return -3;
       hipDeviceProp_t prop;
@@ -509,9 +614,10 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
     cus = n_cu[dev];
   }
   const int total = tm * tn, grid = total < cus ? total : cus;
-  const KernT kern = kerns[epi == EPI_GELU ? 2 : epi == EPI_RESID ? 3 : epi == EPI_QKV_PACK ? 1 : 0];
+  const KernT kern = kerns[epi == EPI_GELU ? 2 : epi == EPI_RESID ? 3 : epi == EPI_QKV_PACK ? 1 : epi == EPI_RESID_LN ? 4
+                           : epi == EPI_GELU_LN ? 5 : 0];
   hipLaunchKernelGGL(kern, dim3(grid), dim3((XNCW + 4) * 64), XLDS, st, (const f16*)A2, (const f16*)W2, bias, unscale, outf,
-                     (f16*)out2, M, N, K, tn, total);
+                     (f16*)out2, aux, flag, M, N, K, tn, total);
   return 0;
 }
 
@@ -525,12 +631,16 @@ void d3dp_launch_absmax(const float* src, size_t n, unsigned* out, hipStream_t s
   hipLaunchKernelGGL(absmax_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, n, out);
 }
 
-void d3dp_launch_rowbound(const float* W, const float* gw, const float* gb, const float* bias, int N, int K, float s,
-                          unsigned* out, hipStream_t st) {
-  hipLaunchKernelGGL(rowbound_kernel, dim3((N + 3) / 4), dim3(256), 0, st, W, gw, gb, bias, N, K, s, out);
-}
-
 void d3dp_launch_nonfinite_flag(const float* x, size_t n, unsigned* flag, hipStream_t st) {
   const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
   hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, x, n, flag);
+}
+
+void d3dp_launch_ln_combine(const float* slices, float* rowstat, int M, int C, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(ln_combine_kernel, dim3((M + 255) / 256), dim3(256), 0, st, slices, rowstat, M, (C + 63) / 64, eps);
+}
+
+void d3dp_launch_fold_ln(const float* W, const float* gamma, const float* beta, const float* bias, float* Wp, float* c12,
+                         int N, int K, hipStream_t st) {
+  hipLaunchKernelGGL(fold_ln_kernel, dim3((N + 3) / 4), dim3(256), 0, st, W, gamma, beta, bias, Wp, c12, N, K);
 }

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_ATOMIC = 3, EPI_QKV_PACK = 4 };
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_ATOMIC = 3, EPI_QKV_PACK = 4, EPI_RESID_LN = 5, EPI_GELU_LN = 6 };
 
 // ---- gemm.hip ----------------------------------------------------------------------------------
 int d3dp_launch_linear_bf16_stream(int epi, int out_f32, const void* A, const void* W, const float* bias, void* out,
@@ -12,13 +12,20 @@ int d3dp_launch_linear_bf16x3(int epi, const void* A3, const void* W3, const flo
                               int N, int K, hipStream_t st);
 void d3dp_launch_split3(const float* src, void* dst, size_t n, hipStream_t st);
 // ---- gemm_x2.hip (EXACT mode: split-fp16 operands, three fp16-MFMA passes) ------------------------
+// EPI_RESID_LN: outf += ... as EPI_RESID, plus out2 = the SUM's split-fp16 operand (h2i, un-normalised) and aux =
+//   [M][ceil(N/64)][2] (mean, M2) of every 64-column slice of every row (the next LayerNorm's statistics, in pieces);
+// EPI_GELU_LN: a LayerNorm FOLDED into the Linear: A2 = un-normalised rows, W2 = W . diag(gamma), bias = [c2 | c1] (2 N floats:
+//   c2 = W beta + b, c1 = row sums of W diag(gamma)), aux = [M + 256][2] (mean, rstd) per row:
+//   out2 = split(GELU(rstd (A W'^T - mean c1) + c2)).
 int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const float* bias, float w_unscale, float* outf,
-                             void* out2, int M, int N, int K, hipStream_t st);
+                             void* out2, float* aux, unsigned* flag, int M, int N, int K, hipStream_t st);
+// rowstat[M][2] = (mean, 1 / sqrt(var + eps)) from the slice statistics EPI_RESID_LN wrote (S = ceil(C / 64) slices of 64)
+void d3dp_launch_ln_combine(const float* slices, float* rowstat, int M, int C, float eps, hipStream_t st);
+// Wp[n][k] = W[n][k] gamma[k];  c12[0..N) = sum_k W[n][k] beta[k] + bias[n],  c12[N..2N) = sum_k Wp[n][k]
+void d3dp_launch_fold_ln(const float* W, const float* gamma, const float* beta, const float* bias, float* Wp, float* c12,
+                         int N, int K, hipStream_t st);
 void d3dp_launch_split2(const float* src, void* dst, size_t n, float scale, hipStream_t st);
 void d3dp_launch_absmax(const float* src, size_t n, unsigned* out, hipStream_t st);
-// out[0] = max(out[0], max_n sum_k |W[n,k]| (s |gw[k]| + |gb[k]|) + |bias[n]|, max_k s |gw[k]| + |gb[k]|) as float bits
-void d3dp_launch_rowbound(const float* W, const float* gw, const float* gb, const float* bias, int N, int K, float s,
-                          unsigned* out, hipStream_t st);
 // flag[0] |= 1 if any of x[0..n) is inf / nan
 void d3dp_launch_nonfinite_flag(const float* x, size_t n, unsigned* flag, hipStream_t st);
 int d3dp_launch_linear_f32_splitk(const float* A, const float* W, float* out, int M, int N, int K, hipStream_t st);

@@ -121,10 +121,12 @@ int d3dp_set_weights_borrowed(d3dp_ctx* ctx, const d3dp_weights* w);
  *  - d3dp_exact_range_bound: computed by d3dp_set_weights from the WEIGHTS ALONE, an upper bound of the magnitude any
  *    split operand can take for ANY input -- LayerNorm outputs are at most sqrt(C-1) |gamma| + |beta| per channel, a Linear
  *    row of them at most sum_k |w_k| (sqrt(C-1) |gamma_k| + |beta_k|) + |b| (q, k, v and the fc1 pre-activation; |GELU(x)|
- *    <= |x|), an attention output is a convex combination of v.  bound < D3DP_SPLIT_RANGE proves the mode safe for every
- *    input; otherwise safety is data dependent (bound = 0 in the other modes, which have no such limit);
- *  - d3dp_status: d3dp_denoise ends with a scan of its output; *nonfinite = 1 if any call since the last d3dp_status
- *    produced inf / nan (synchronises the device; resets the flag).  A non-finite result with bound >= D3DP_SPLIT_RANGE
+ *    <= |x|), an attention output is a convex combination of v.  bound < D3DP_SPLIT_RANGE proves these operands safe for
+ *    every input (bound = 0 in the other modes, which have no such limit).  ONE operand is outside the proof: with norm2
+ *    folded into fc1 (D3DP_FOLD_LN=1, off by default) the proj Linear hands fc1 the un-normalised residual stream, whose
+ *    worst case (chained over the block) says nothing useful; that epilogue checks every value it splits, exactly, at run time;
+ *  - d3dp_status: *nonfinite = 1 if, since the last d3dp_status, that check fired or a d3dp_denoise output held inf / nan
+ *    (d3dp_denoise ends with a scan of its output).  Synchronises the device; resets the flags.  A non-finite result with bound >= D3DP_SPLIT_RANGE
  *    means an activation left the range: use D3DP_EXACT_IMPL=bf16x3 (no range limit, twice the MFMA work). */
 #define D3DP_SPLIT_RANGE 4094.0f
 int d3dp_exact_range_bound(const d3dp_ctx* ctx, float* bound);
@@ -261,7 +263,8 @@ int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream);
  * (N % 8 for epi 1), N <= 2048, M * N * 4 < 2^32.  Every operand value must stay below 65504 / scale in magnitude
  * (activations: |x| < 4094): d3dp_op_split2 saturates the hi plane at the fp16 maximum instead of producing inf.
  * Test-only environment switches read by the library: D3DP_X2_SHAPE=32 (the 32x32x16 MFMA form of this kernel),
- * D3DP_EXACT_IMPL=bf16x3|f32 and D3DP_NO_FOLD=1 (cross-check implementations of EXACT mode, read in d3dp_create). */
+ * D3DP_EXACT_IMPL=bf16x3|f32 and D3DP_NO_FOLD=1 (cross-check implementations of EXACT mode), D3DP_FOLD_LN=1 (norm2 folded into
+ * the proj / fc1 Linears; measured no faster than the row kernel and left off) -- all read in d3dp_create. */
 int d3dp_op_split2(const float* src, void* dst, size_t n, float scale, void* stream);
 int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* bias, float w_scale, void* out, int32_t M,
                       int32_t N, int32_t K, void* stream);

@@ -678,6 +678,31 @@ def test_exact_residual_adds_inside_the_linears_change_no_bit(golden_dir, monkey
     assert orc.mpjpe_mm(folded.cpu(), torch.from_numpy(g["out_t499"])) <= EXACT_TOL_MM
 
 
+@pytest.mark.parametrize("frames", [27, 243])
+def test_exact_norm2_folded_into_the_linears(golden_dir, monkeypatch, frames):
+    """D3DP_FOLD_LN=1 (built, measured and left off: no faster, capi.hip fold_ln): norm2 (mixste.py:115) without
+    a kernel of its own -- proj's epilogue leaves x + proj(...) as fc1's UN-normalised split-fp16 operand with the row
+    statistics in 64-column pieces, and fc1 = LN folded into the Linear (W diag(gamma), rstd (. - mean c1) + c2 in the
+    epilogue).  Against the reference goldens at three timesteps, and against the default (norm2 as a row kernel): the two
+    forms differ by rounding only and neither is systematically closer to the reference."""
+    g = load_g(golden_dir, f"g3_denoiser_F{frames}")
+    x2d = torch.from_numpy(synthetic_inputs_2d(int(g["x2d_seed"]), 1, frames)).cuda()
+    x3d = torch.from_numpy(synthetic_noise(int(g["x3d_seed"]), (1, 1, frames, 17, 3))).cuda()
+    outs = {}
+    for tag in ("kernel", "folded"):
+        if tag == "folded":
+            monkeypatch.setenv("D3DP_FOLD_LN", "1")
+        m = make_model(frames, 512, 8, 1, 1, "exact", int(g["seed"]))
+        outs[tag] = {tt: m.pose_estimator(x2d, x3d, torch.tensor([tt], device="cuda")).cpu() for tt in (999, 499, 99)}
+        assert not m.pose_estimator.nonfinite_seen()
+    for tt in (999, 499, 99):
+        ref = torch.from_numpy(g[f"out_t{tt}"])
+        ef, ek = orc.mpjpe_mm(outs["folded"][tt], ref), orc.mpjpe_mm(outs["kernel"][tt], ref)
+        d = orc.mpjpe_mm(outs["folded"][tt], outs["kernel"][tt])
+        print(f"F={frames} t={tt}: folded norm2 vs reference {ef:.3e} mm, norm2 kernel vs reference {ek:.3e} mm, apart {d:.3e} mm")
+        assert ef <= EXACT_TOL_MM and ek <= EXACT_TOL_MM and d <= 0.5 * EXACT_TOL_MM
+
+
 def test_deferred_backward_recomputes_its_own_forward(golden_dir):
     """Two forwards before the first backward share one activation workspace: the first backward must differentiate
     through ITS forward (it re-runs it), as plain autograd does in the reference."""
@@ -746,8 +771,10 @@ def test_exact_mode_range_guard(monkeypatch):
         m = m.cuda().eval()
         if check:
             monkeypatch.setenv("D3DP_CHECK_FINITE", "1")
-        out = m(torch.from_numpy(x2d).cuda(), None, input_2d_flip=torch.from_numpy(x2f).cuda(), noise=noises)
-        monkeypatch.delenv("D3DP_CHECK_FINITE", raising=False)
+        try:
+            out = m(torch.from_numpy(x2d).cuda(), None, input_2d_flip=torch.from_numpy(x2f).cuda(), noise=noises)
+        finally:
+            monkeypatch.delenv("D3DP_CHECK_FINITE", raising=False)
         return m, out, sd
 
     import warnings
@@ -767,6 +794,20 @@ def test_exact_mode_range_guard(monkeypatch):
     assert not m.pose_estimator.nonfinite_seen()                   # the query resets the flag
     with pytest.warns(RuntimeWarning), pytest.raises(_lib.D3DPHipError, match="split-fp16 range"):
         run(5000.0, check=True)
+    # the un-normalised residual operand proj hands to fc1 is outside the static proof: checked exactly at run time
+    args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
+    sd2 = make_state_dict(7, cs, dep, Fr)
+    key = [k for k in sd2 if k.endswith("STEblocks.1.attn.proj.bias")][0]
+    sd2[key] = sd2[key] + 5000.0                                   # x + proj(...) beyond 4094: no weight bound sees a bias
+    monkeypatch.setenv("D3DP_FOLD_LN", "1")                        # (the form in which that sum is a split operand)
+    m2 = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=False, num_proposals=H, sampling_timesteps=K, numerics="exact")
+    m2.load_state_dict(sd2, strict=False)
+    m2 = m2.cuda().eval()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                             # the static bound is fine ...
+        m2(torch.from_numpy(x2d).cuda(), None, input_2d_flip=torch.from_numpy(x2f).cuda(), noise=noises)
+    assert m2.pose_estimator.exact_range_bound() < m2.pose_estimator.SPLIT_RANGE and m2.pose_estimator.nonfinite_seen()   # ... the run is not
+    monkeypatch.delenv("D3DP_FOLD_LN")
     monkeypatch.setenv("D3DP_EXACT_IMPL", "bf16x3")
     with warnings.catch_warnings():
         warnings.simplefilter("error")                             # no range limit, no warning
