@@ -261,8 +261,8 @@ int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream);
  * (out += A W^T + b: the residual-adding form of proj and fc2).
  * Constraints (D3DP_EINVAL otherwise): K % 64 == 0 (the k-loop runs two 32-deep k-steps per iteration), N % 4 == 0
  * (N % 8 for epi 1), N <= 2048, M * N * 4 < 2^32.  Every operand value must stay below 65504 / scale in magnitude
- * (activations: |x| < 4094): d3dp_op_split2 saturates the hi plane at the fp16 maximum instead of producing inf.
- * Test-only environment switches read by the library: D3DP_X2_SHAPE=32 (the 32x32x16 MFMA form of this kernel),
+ * (activations: |x| < 4094): beyond it the hi value is inf and the product NaN (d3dp_exact_range_bound / d3dp_status).
+ * Test-only environment switches read by the library:
  * D3DP_EXACT_IMPL=bf16x3|f32 and D3DP_NO_FOLD=1 (cross-check implementations of EXACT mode), D3DP_FOLD_LN=1 (norm2 folded into
  * the proj / fc1 Linears; measured no faster than the row kernel and left off) -- all read in d3dp_create. */
 int d3dp_op_split2(const float* src, void* dst, size_t n, float scale, void* stream);
