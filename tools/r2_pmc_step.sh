@@ -5,9 +5,9 @@ R=$PWD
 cd /tmp && export TMPDIR=/tmp
 for mode in ${MODES:-exact fast}; do
   B="$R/bench.py --steps 1 --warmup 0 --batch 4 --no-other-leg --no-cpu-baseline --no-parity --no-profile --numerics $mode"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_step/${mode}_f -- python $B > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_step/${mode}_w -- python $B > /dev/null 2>&1
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_step/${mode}_m -- python $B > /dev/null 2>&1
+  timeout 180 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_step/${mode}_f -- python $B > /dev/null 2>&1
+  timeout 180 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_step/${mode}_w -- python $B > /dev/null 2>&1
+  timeout 180 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_step/${mode}_m -- python $B > /dev/null 2>&1
 done
 cd $R
 for mode in ${MODES:-exact fast}; do
