@@ -121,9 +121,13 @@ def load() -> C.CDLL:
                            "or `make -C d3dp_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None)
+        if fn is None:
+            if os.environ.get("D3DP_LIB_ANY_ABI") == "1":
+                continue
+            raise D3DPHipError(f"{LIB_PATH} does not export {name}")
         fn.restype, fn.argtypes = res, args
-    if lib.d3dp_abi_version() != ABI_VERSION:
+    if lib.d3dp_abi_version() != ABI_VERSION and os.environ.get("D3DP_LIB_ANY_ABI") != "1":   # (=1: A/B probes of old builds)
         raise D3DPHipError(f"ABI mismatch: library {lib.d3dp_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
     return lib

@@ -3,6 +3,7 @@
 R=$PWD; O=$R/gpurun_out/r3pmc; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 60 rocprofv3 -L 2>/dev/null | grep -oE "\b(TA_[A-Z0-9_]+|TCP_[A-Z0-9_]+|TCC_[A-Z0-9_]+)\b" | sort -u > $O/counter_names.txt
+export D3DP_LIB_ANY_ABI=1
 for v in r2 h2i; do
   L=$R/d3dp_amd/lib/variants/libd3dp_$v.so; [ $v = h2i ] && L=$R/d3dp_amd/lib/libd3dp_hip.so
   B="python $R/tools/gemm_bench.py --x2 --shapes qkv --m 123930 --iters 6"
