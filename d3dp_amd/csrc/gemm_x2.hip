@@ -13,7 +13,7 @@
 //
 // Structure (the FAST kernel's, gemm.hip): persistent, 256x128 output tile per workgroup pass, BK = 32, 8 compute waves
 // (4 x 2, 64x64 each = 4x4 MFMA tiles: 48 MFMA + 16 ds_read_b128 per k-step) + 4 LOADER waves.  Workgroups (<= one per
-// CU) walk tiles L, L+G, ...; the A and W slabs (two planes each: 48 KiB per k-step) stream through a 3-stage LDS ring
+// CU) walk tiles L, L+G, ...; the A and W slabs (hi | lo of 32 columns per row: 48 KiB per k-step) stream through a 3-stage LDS ring
 // as one continuous sequence of k-steps across tile boundaries.  Only the loader waves issue global_load_lds
 // (1 KiB pieces of 8 rows x 128 B = 8 whole lines, 12 per wave and k-step; round 2 had two separate planes and pieces of
 // 16 rows x 64 B = 16 half lines: the kernel is bound by the line-request rate of the CU's vector memory path,
@@ -33,7 +33,7 @@
 // product, 16 columns per lane, each store instruction touching 64 different lines with 16 bytes: the tile-end store
 // tail cost 11-17 us per 256x128 tile against 18-22 us for its 16 k-steps, fitted over the four Linear shapes.)
 //   EPI_BIAS     -> fp32 out (feeds the residual-adding row kernels)
-//   EPI_GELU     -> GELU (rational erf, common.h) re-split into two fp16 planes (the fc2 operand)
+//   EPI_GELU     -> GELU (rational erf, common.h) re-split into the h2i rows of the fc2 operand
 //   EPI_QKV_PACK -> q fp32, k and v as fp16 planes: the packed rows the split-fp16 attention kernels read (attention.hip)
 //   EPI_RESID    -> x += A W^T + b in place on the fp32 residual stream (proj, fc2: mixste.py:113-115)
 //   EPI_RESID_LN -> the same, and the sum leaves a second time as the NEXT Linear's split-fp16 operand (un-normalised) together
@@ -42,7 +42,7 @@
 //                   W' = W diag(gamma), c1 = W' 1, c2 = W beta + b -- norm2 + fc1 (mixste.py:115) without a row kernel in between
 // Plane outputs leave as ONE 16-byte store per lane too (neighbouring lanes swap halves, store_planes_paired).
 // Timing probes of this kernel (loads / stores / MFMAs / barriers compiled out one at a time) and what they say about
-// the clock the chip sustains under this instruction mix: profiles/r02_gemm_probes.md.
+// the clock the chip sustains under this instruction mix: profiles/r02_gemm_probes.md, profiles/r03_gemm_probes.md.
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
