@@ -153,3 +153,61 @@ def test_kernels_with_untracked_loads_do_not_spill(tmp_path):
     sizes = re.findall(r"\.set (\S*attn_temporal_x2_kernel\S*)\.private_seg_size, (\d+)", text)
     assert len(sizes) >= 8, sizes
     assert all(int(v) == 0 for _, v in sizes), [s for s in sizes if int(s[1])]
+    # the asm returns its destination registers before the data lands, so NOTHING -- no compiler copy, VALU
+    # operation or reuse -- may touch them between the load and the counted s_waitcnt that covers it.  Scan the ISA of every
+    # instantiation: from each untracked load forward to the first wait on vmcnt, following the problem loop's back edge.
+    n_loads = sum(_scan_untracked_loads(body, name) for name, body in _kernel_bodies(text, "attn_temporal_x2_kernel"))
+    assert n_loads >= 8 * 4, n_loads
+
+
+def _kernel_bodies(text, needle):
+    """(symbol, instruction lines) of every kernel whose mangled name contains `needle`."""
+    for m in re.finditer(r"^(_Z\S*%s\S*):\s*(?:;.*)?$" % needle, text, flags=re.M):
+        end = text.index("s_endpgm", m.end())
+        yield m.group(1), text[m.end():end].splitlines()
+
+
+def _vregs(line):
+    code = line.split(";")[0]
+    regs = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", code):
+        regs.update(range(int(a), int(b) + 1))
+    regs.update(int(a) for a in re.findall(r"\bv(\d+)\b", code))
+    return regs
+
+
+def _scan_untracked_loads(lines, name):
+    labels = {m.group(1): i for i, l in enumerate(lines) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
+    in_asm, count = False, 0
+    for i, l in enumerate(lines):
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
+        m = re.match(r"\s+global_load_dwordx4 v\[(\d+):(\d+)\], v\[\d+:\d+\], off\s*$", l.split(";")[0]) if in_asm else None
+        if not m:
+            continue
+        count += 1
+        dst = set(range(int(m.group(1)), int(m.group(2)) + 1))
+
+        def first_touch(start, stop):
+            """index of the first vmcnt wait in [start, stop), asserting nothing touches dst before it; None if no wait"""
+            for j in range(start, stop):
+                code = lines[j].split(";")[0].strip()
+                if not code or code.endswith(":") or code.startswith("."):
+                    continue
+                if code.startswith("s_waitcnt") and "vmcnt" in code:
+                    return j
+                assert not (_vregs(lines[j]) & dst), f"{name}: `{code}` touches v{sorted(dst)} of an untracked load before its wait"
+            return None
+
+        # the wait may sit behind the problem loop's back edge: scan to the first backward branch whose target precedes the
+        # load, then from that target (the loop header) up to the load
+        br = re.compile(r"\s+s_c?branch\S*\s+(\.LBB\d+_\d+)")
+        back = next((j for j in range(i + 1, len(lines))
+                     if (b := br.match(lines[j])) and labels.get(b.group(1), 1 << 30) <= i), None)
+        if first_touch(i + 1, back if back is not None else len(lines)) is None:
+            assert back is not None, f"{name}: no vmcnt wait after the untracked load at line {i}"
+            assert first_touch(labels[br.match(lines[back]).group(1)], i) is not None, \
+                f"{name}: no vmcnt wait covers the untracked load at line {i}"
+    return count
