@@ -142,6 +142,37 @@ def test_bench_reports_counter_traffic_only_for_the_build_it_was_measured_on(mon
     assert roof["traffic"] is None and "different build" in roof["traffic_note"]
 
 
+def test_bench_roofline_is_algorithmic_flop_over_the_guides_dense_peak():
+    """`roofline.frac` = ALGORITHMIC FLOP / time / the guide's dense fp16 peak (2.5 PFLOP/s); the three
+    MFMA products per algorithmic product of exact mode are reported beside it as matrix-pipe work, never as `frac`.  And
+    the newest traffic file whose library hash matches wins; the CPU baseline carries the un-extrapolated configs[1] run."""
+    import json
+    import bench
+    B, H, K = 16, 20, 10
+    prof = {"gemm_qkv": (3360, 1610.618), "gemm_proj": (3360, 663.7), "gemm_fc1": (3360, 1290.1), "gemm_fc2": (3360, 1123.6)}
+    r = bench.roofline_from_profile(prof, "exact", B, H, K)
+    flops = 2 * 3 * 512 * 512 * (2 * B * H * 243 * 17 * K) * 16
+    assert r["kernel"] == "gemm_qkv" and r["peak"] == 2500.0 and r["bound"] == "mfma"
+    assert abs(r["achieved"] - flops / 1.610618 / 1e12) < 1e-6 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / 2500.0) < 1e-12 and r["frac"] == r["frac_algorithmic_of_dense_peak"] < 0.2
+    assert r["mfma_passes_per_product"] == 3 and abs(r["matrix_pipe_work_tflops"] - 3 * r["achieved"]) < 1e-9
+    rf = bench.roofline_from_profile(prof, "fast", B, H, K)
+    assert rf["mfma_passes_per_product"] == 1 and rf["matrix_pipe_work_tflops"] == rf["achieved"]
+    full = bench.full_config_cpu_run()
+    assert full and 300 < full["gflops"] < 400 and abs(full["k10_units_per_s"] * 2 - full["hypothesis_clips_per_s_K5_units"]) < 1e-12
+    prof_dir = os.path.join(os.path.dirname(bench.__file__), "profiles")
+    t3 = json.load(open(os.path.join(prof_dir, "r03_gemm_traffic.json")))["exact"]["gemm_qkv"]
+    roof = {"kernel": "gemm_qkv", "traffic": None}
+    import pytest as _pt
+    mp = _pt.MonkeyPatch()
+    try:
+        mp.setattr(bench, "lib_sha256", lambda: t3["lib_sha256"])
+        bench.attach_traffic(roof, "exact", 0)
+    finally:
+        mp.undo()
+    assert roof["traffic"] == t3["hbm_bytes_per_launch"] and 1.3 < roof["traffic"] / t3["algorithmic_bytes_per_launch"] < 1.7
+
+
 def test_rational_erf_of_the_exact_fc1_epilogue_is_fp32_class():
     """common.h gelu_erf_rational (one rational x P(x^2)/Q(x^2) instead of libm's erff), restated in numpy with the same
     coefficients and fma order: against fp64 its GELU is as accurate as torch's own fp32 GELU on N(0,1) inputs."""
