@@ -209,3 +209,36 @@ def test_rational_erf_of_the_exact_fc1_epilogue_is_fp32_class():
     assert err.mean() < 1.5 * terr.mean() and err.max() < 1.5e-6, (err.mean(), terr.mean(), err.max())
     big = np.array([-30.0, -6.0, -4.0, 4.0, 6.0, 30.0], dtype=np.float32)      # beyond the clamp: erf = -1 / +1
     assert np.allclose(gelu(big), [0, 0, -1.3e-4, 4.0, 6.0, 30.0], atol=2e-4)
+
+
+def test_h2i_lds_image_of_the_exact_linear_is_conflict_free_and_complete():
+    """The LDS image of the EXACT Linear's operand slabs (gemm_x2.hip): rows of 128 bytes = 8 slots of 16 B (q = 4 plane +
+    k-group), slot q of row r at physical slot q ^ ((r >> 1) & 7).  (1) Every LDS-DMA piece (64 lanes x 16 B, lane ->
+    row lane >> 3, physical slot lane & 7) covers each (row, logical slot) of its 8 rows exactly once, from ONE 128-byte line
+    per row.  (2) A fragment read (lane: row fi = lane & 15, k-group fg = lane >> 4, one plane) is bank-conflict-free: the four
+    16-lane groups ds_read_b128 is serviced in (MI355X_MICROARCH.md, LDS table) each hit 16 different 16-byte slots of the
+    256-byte bank row.  (On the GPU: SQ_LDS_BANK_CONFLICT = 0, profiles/r03_gemm_pmc.md.)"""
+    swz = lambda row, q: q ^ ((row >> 1) & 7)
+    for piece in range(32):
+        seen = set()
+        for lane in range(64):
+            row, phys = piece * 8 + (lane >> 3), lane & 7
+            q = swz(row, phys)                               # the logical slot this lane fetches (involution)
+            assert swz(row, q) == phys and 0 <= q < 8
+            seen.add((row, q))
+        assert len(seen) == 64
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    for base_row in (0, 16, 64, 192):                        # row blocks of a wave advance in multiples of 16
+        for plane in (0, 1):
+            for g in groups:
+                slots = set()
+                for lane in g:
+                    row, q = base_row + (lane & 15), plane * 4 + (lane >> 4)
+                    addr = row * 128 + swz(row, q) * 16
+                    slots.add((addr // 16) % 16)
+                assert len(slots) == 16, (base_row, plane, g)
+    # the lo plane's slot is the hi plane's ^ 4 = byte offset ^ 64, as the kernel computes it
+    for row in range(32):
+        for kg in range(4):
+            assert (swz(row, kg) * 16) ^ 64 == swz(row, 4 + kg) * 16
