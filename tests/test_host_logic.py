@@ -242,3 +242,20 @@ def test_h2i_lds_image_of_the_exact_linear_is_conflict_free_and_complete():
     for row in range(32):
         for kg in range(4):
             assert (swz(row, kg) * 16) ^ 64 == swz(row, 4 + kg) * 16
+
+
+def test_h2i_layout_and_w_row_permutation_are_bijections():
+    """h2i (common.h): column c of a K-column row -> hi at ((c >> 5) << 6) | (c & 31), lo 32 further: a bijection onto the 2 K
+    fp16 of the row, 128-byte blocks = [hi of 32 columns | lo of the same].  W-row permutation of the Linear (gemm_x2.hip
+    colperm): LDS row q of a 64-column strip carries output column (q & 15) * 4 + (q >> 4), so the four MFMA tiles of a lane
+    (same operand row i, tile ni = 0..3) are four CONSECUTIVE columns -> one 16-byte store per row."""
+    for K in (64, 512, 1024):
+        offs = [((c >> 5) << 6) | (c & 31) for c in range(K)]
+        both = offs + [o + 32 for o in offs]
+        assert sorted(both) == list(range(2 * K))
+        for c in range(K):                                   # one k-step (32 columns), both values: one 128-byte block
+            assert offs[c] * 2 // 128 == c // 32 == (offs[c] + 32) * 2 // 128
+    colperm = lambda q: (q & 15) * 4 + (q >> 4)
+    assert sorted(colperm(q) for q in range(64)) == list(range(64))
+    for i in range(16):
+        assert [colperm(ni * 16 + i) for ni in range(4)] == [4 * i, 4 * i + 1, 4 * i + 2, 4 * i + 3]
