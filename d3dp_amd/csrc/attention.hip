@@ -18,6 +18,10 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef D3DP_ATTN_PAIR
+#define D3DP_ATTN_PAIR 1     // temporal split-fp16 kernel: both query tiles of a wave share one pass over the K image
+#endif
+
 namespace {
 
 __device__ __forceinline__ int seq_base(const SeqMap& m, int s) {
@@ -502,14 +506,61 @@ __device__ __forceinline__ void pv_chunk_x2_seq(const FragBases& fb, int plane, 
   }
 }
 
+// Softmax of one 16-query tile's score row s (S^T fragments: lane holds keys 16 t + 4 fg + r of query lane & 15) and
+// the split of the probabilities into fp16 pairs (x 1024); `denom` = 1024 x the softmax denominator of query (lane & 15).
+template <int NKT, bool MASK_ANY_TILE>
+__device__ __forceinline__ void softmax_split_x2(f32x4 (&s)[NKT], int n, int lane, f16x8 (&ph)[NKT / 2], f16x8 (&pl)[NKT / 2],
+                                                 float& denom) {
+  const int fg = lane >> 4;
+  const float cexp = 0.125f * 1.44269504088896340736f / (kActScale * kActScale);   // hd^-0.5 log2(e) / (16 * 16)
+  // keys >= n are masked.  The usual case (n in the last key tile: MASK_ANY_TILE = false, chosen by the launcher) touches
+  // that tile only; the per-element selects of the general form were a third of this kernel's VALU instructions, and
+  // their 64 loop-invariant lane masks cost registers.
+  if constexpr (!MASK_ANY_TILE) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * (NKT - 1) + 4 * fg + r >= n) s[NKT - 1][r] = -INFINITY;
+  } else {
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * t + 4 * fg + r >= n) s[t][r] = -INFINITY;
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  // p * 1024 = exp2(s cexp - mx cexp + 10): one fma and the bare v_exp_f32 per element (arguments <= 10; a probability
+  // below 2^-126 becomes 0 instead of a denormal); the denominator is accumulated at the same scale.
+  const float nb = fmaf(-mx, cexp, 10.0f);
+  float sum4[2] = {0.f, 0.f};                          // two independent chains
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float y = __builtin_amdgcn_exp2f(fmaf(s[t][r], cexp, nb));
+      sum4[r & 1] += y;
+      const f16 h = (f16)y;
+      ph[t >> 1][(t & 1) * 4 + r] = h;
+      pl[t >> 1][(t & 1) * 4 + r] = (f16)fmaf(y, 1.0f, -(float)h);
+    }
+  }
+  float sum = sum4[0] + sum4[1];
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  denom = sum;                                         // = 1024 x the softmax denominator
+}
+
 // Scores and softmax of one 16-query tile against NKT 16-key tiles resident in LDS.  fb: fragment bases into the K hi
 // image (the lo image is `plane` bytes further).  qh/ql: the tile's query fragments (d 0..31, 32..63), values x 16.
 // Returns the probabilities as split-fp16 B operands (x 1024) and 1024 x the softmax denominator of query (lane & 15).
 template <int NKT, bool MASK_ANY_TILE>
 __device__ __forceinline__ void attn_scores_x2(const FragBases& fb, int plane, const f16x8 (&qh)[2], const f16x8 (&ql)[2],
                                                int n, int lane, f16x8 (&ph)[NKT / 2], f16x8 (&pl)[NKT / 2], float& denom) {
-  const int fg = lane >> 4;
-  const float cexp = 0.125f * 1.44269504088896340736f / (kActScale * kActScale);   // hd^-0.5 log2(e) / (16 * 16)
   // S^T, two key tiles at a time with their MFMAs interleaved (two independent accumulator chains) and the fragments
   // of the next pair already on their way from LDS (see pv_chunks_x2)
   f32x4 s[NKT];
@@ -558,46 +609,49 @@ __device__ __forceinline__ void attn_scores_x2(const FragBases& fb, int plane, c
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  // keys >= n are masked.  The usual case (n in the last key tile: MASK_ANY_TILE = false, chosen by the launcher) touches
-  // that tile only; the per-element selects of the general form were a third of this kernel's VALU instructions, and
-  // their 64 loop-invariant lane masks cost registers.
-  if constexpr (!MASK_ANY_TILE) {
+  softmax_split_x2<NKT, MASK_ANY_TILE>(s, n, lane, ph, pl, denom);
+}
+
+// The same for BOTH 16-query tiles of a wave at once (temporal kernel, two tiles per wave): every K fragment is read from
+// LDS once for the two tiles (half the fragment reads) and the MFMAs run as FOUR independent accumulator chains (two query
+// tiles x two key tiles), so two MFMAs on the same accumulator are four instructions apart instead of two -- half of this
+// kernel's wave cycles were issue stalls behind dependent MFMAs with the matrix pipes 29 % busy (profiles/r03_attn_pmc.md).
+template <int NKT, bool MASK_ANY_TILE>
+__device__ __forceinline__ void attn_scores_x2_pair(const FragBases& fb, int plane, const f16x8 (&qh)[2][2],
+                                                    const f16x8 (&ql)[2][2], int n, int lane, f16x8 (&ph)[2][NKT / 2],
+                                                    f16x8 (&pl)[2][NKT / 2], float (&denom)[2]) {
+  f32x4 s0[NKT], s1[NKT];
+  auto read_k = [&](int t, f16x8 (&k)[4]) {
+    k[0] = *reinterpret_cast<const f16x8*>(fb.k0 + plane + t * 2048);   // lo, d 0..31
+    k[1] = *reinterpret_cast<const f16x8*>(fb.k1 + plane + t * 2048);   // lo, d 32..63
+    k[2] = *reinterpret_cast<const f16x8*>(fb.k0 + t * 2048);           // hi
+    k[3] = *reinterpret_cast<const f16x8*>(fb.k1 + t * 2048);
+  };
+  // (no register prefetch of the next pair's fragments here, unlike attn_scores_x2: s0 + s1 already hold 128 registers, and
+  //  the four chains leave the scheduler room to start a pair's MFMAs as its first fragments land)
+  f16x8 kc[2][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (16 * (NKT - 1) + 4 * fg + r >= n) s[NKT - 1][r] = -INFINITY;
-  } else {
-#pragma unroll
-    for (int t = 0; t < NKT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (16 * t + 4 * fg + r >= n) s[t][r] = -INFINITY;
+  for (int t = 0; t < NKT; t += 2) {
+    read_k(t, kc[0]);
+    read_k(t + 1, kc[1]);
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, b0 = a0, a1 = a0, b1 = a0;
+    // K fragment index / query operand of the six product terms: Kl.Qh (d 0..31, 32..63), Kh.Ql, Kh.Qh
+#define X2_PAIR_TERM(KI, Q, D)                                                                  \
+    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][KI], Q[0][D], a0, 0, 0, 0);               \
+    b0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][KI], Q[0][D], b0, 0, 0, 0);               \
+    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][KI], Q[1][D], a1, 0, 0, 0);               \
+    b1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][KI], Q[1][D], b1, 0, 0, 0);
+    X2_PAIR_TERM(0, qh, 0)
+    X2_PAIR_TERM(1, qh, 1)
+    X2_PAIR_TERM(2, ql, 0)
+    X2_PAIR_TERM(3, ql, 1)
+    X2_PAIR_TERM(2, qh, 0)
+    X2_PAIR_TERM(3, qh, 1)
+#undef X2_PAIR_TERM
+    s0[t] = a0; s0[t + 1] = b0; s1[t] = a1; s1[t + 1] = b1;
   }
-  float mx = -INFINITY;
-#pragma unroll
-  for (int t = 0; t < NKT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  // p * 1024 = exp2(s cexp - mx cexp + 10): one fma and the bare v_exp_f32 per element (arguments <= 10; a probability
-  // below 2^-126 becomes 0 instead of a denormal); the denominator is accumulated at the same scale.
-  const float nb = fmaf(-mx, cexp, 10.0f);
-  float sum4[2] = {0.f, 0.f};                          // two independent chains
-#pragma unroll
-  for (int t = 0; t < NKT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float y = __builtin_amdgcn_exp2f(fmaf(s[t][r], cexp, nb));
-      sum4[r & 1] += y;
-      const f16 h = (f16)y;
-      ph[t >> 1][(t & 1) * 4 + r] = h;
-      pl[t >> 1][(t & 1) * 4 + r] = (f16)fmaf(y, 1.0f, -(float)h);
-    }
-  }
-  float sum = sum4[0] + sum4[1];
-  sum += __shfl_xor(sum, 16, 64);
-  sum += __shfl_xor(sum, 32, 64);
-  denom = sum;                                         // = 1024 x the softmax denominator
+  softmax_split_x2<NKT, MASK_ANY_TILE>(s0, n, lane, ph[0], pl[0], denom[0]);
+  softmax_split_x2<NKT, MASK_ANY_TILE>(s1, n, lane, ph[1], pl[1], denom[1]);
 }
 
 // this lane's query fragments (16 fp32 of row q: d = fg*8 .. +7 and 32 + fg*8 .. +7), split
@@ -754,6 +808,25 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
     float denom[TPW];
     // (fragment bases re-derived per phase from the opaque lane id: the four V bases are not live during the scores)
     const FragBases fbk = make_frag_bases(kimg, vimg, opaque(lane));
+    if constexpr (TPW == 2 && D3DP_ATTN_PAIR) {
+      {                                                // both query tiles of the wave in one pass over K (a wave whose second
+                                                       // tile does not exist computes it on whatever its registers hold and
+                                                       // never stores it: one code path, no second register allocation)
+        f16x8 qh[2][2], ql[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float4 qf[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            settle(qr[u][i]);                          // (after the counted wait above)
+            qf[i] = make_float4(qr[u][i][0], qr[u][i][1], qr[u][i][2], qr[u][i][3]);
+          }
+          split8(qf[0], qf[1], qh[u][0], ql[u][0]);
+          split8(qf[2], qf[3], qh[u][1], ql[u][1]);
+        }
+        attn_scores_x2_pair<NKT, MASK_ANY_TILE>(fbk, PLANE, qh, ql, n, lane, ph, pl, denom);
+      }
+    } else {
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
       denom[u] = 1.f;
@@ -769,6 +842,7 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
         split8(qf[2], qf[3], qh[1], ql[1]);
         attn_scores_x2<NKT, MASK_ANY_TILE>(fbk, PLANE, qh, ql, n, lane, ph[u], pl[u], denom[u]);
       }
+    }
     }
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                      // 2: V image complete; nobody reads the K image any more
