@@ -24,7 +24,7 @@ class AdamChunk(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int32),
                 ("pad", C.c_int32)]
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Cfg(C.Structure):
@@ -99,6 +99,7 @@ PROTOTYPES = {
                                     C.c_int32, C.c_int32, C.c_void_p]),
     "d3dp_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "d3dp_exact_range_bound": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "d3dp_exact_scales": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "d3dp_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "d3dp_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "d3dp_profile_class_name": (C.c_char_p, [C.c_int32]),

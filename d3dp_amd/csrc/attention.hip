@@ -185,12 +185,8 @@ int launch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int he
   const size_t lds = (size_t)PPB * 2 * map.n_tok * LDR * sizeof(T);
   if (lds > 160 * 1024) return -2;
   auto kern = attn_rows_kernel<T, HD, TPP, OUTS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) return -3;
-    attr_set = true;
-  }
+  static PerDeviceOnce once;                          // (one per template instantiation = per kernel)
+  if (once.get([&](int) { return d3dp_lds_opt_in(reinterpret_cast<const void*>(kern), 160 * 1024); }) < 0) return -3;
   hipLaunchKernelGGL(kern, dim3((n_prob + PPB - 1) / PPB), dim3(256), lds, st, (const T*)qkv, out, n_prob, map, C, heads,
                      plane);
   return 0;
@@ -447,11 +443,18 @@ __global__ __launch_bounds__(256) void attn_spatial_bf16_kernel(const bf16* __re
 
 __device__ __forceinline__ f16x8 as_f16x8(bf16x8 v) { return __builtin_bit_cast(f16x8, v); }
 
-// 8 consecutive fp32 -> one 16-byte slot of hi and one of lo (values x 16)
-__device__ __forceinline__ void split8(const float4 a, const float4 b, f16x8& hi, f16x8& lo) {
+// Operand scales of the split-fp16 attention kernels (kernel argument; wave-uniform).  q is split in registers at `q`; the
+// k / v planes of the packed rows were written at that same scale by the qkv Linear; `cexp` = hd^-0.5 log2(e) / (q scale x
+// k scale) folds both into the softmax exponent; `onorm` = output scale / v scale (1 when the output leaves as planes at the
+// scale of v -- |o| <= max |v| --, 1 / v scale for fp32 output).  Everything is 2^4-based unless capi.hip lowered the scale
+// of a block whose proven operand range asks for it (d3dp_exact_range_bound).
+struct X2Scales { float q, cexp, onorm; };
+
+// 8 consecutive fp32 -> one 16-byte slot of hi and one of lo (values x sc)
+__device__ __forceinline__ void split8(const float4 a, const float4 b, f16x8& hi, f16x8& lo, float sc) {
   const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { f16 h, l; split2h(v[e], h, l); hi[e] = h; lo[e] = l; }
+  for (int e = 0; e < 8; ++e) { f16 h, l; split2h_scaled(v[e] * sc, h, l); hi[e] = h; lo[e] = l; }
 }
 
 // key chunks [C0, C1) of O^T += V^T P^T (32 keys per chunk).  Software-pipelined by hand: the fragments of chunk c+1 are
@@ -510,9 +513,8 @@ __device__ __forceinline__ void pv_chunk_x2_seq(const FragBases& fb, int plane, 
 // the split of the probabilities into fp16 pairs (x 1024); `denom` = 1024 x the softmax denominator of query (lane & 15).
 template <int NKT, bool MASK_ANY_TILE>
 __device__ __forceinline__ void softmax_split_x2(f32x4 (&s)[NKT], int n, int lane, f16x8 (&ph)[NKT / 2], f16x8 (&pl)[NKT / 2],
-                                                 float& denom) {
-  const int fg = lane >> 4;
-  const float cexp = 0.125f * 1.44269504088896340736f / (kActScale * kActScale);   // hd^-0.5 log2(e) / (16 * 16)
+                                                 float& denom, float cexp) {
+  const int fg = lane >> 4;                            // cexp = hd^-0.5 log2(e) / (q scale x k scale), X2Scales
   // keys >= n are masked.  The usual case (n in the last key tile: MASK_ANY_TILE = false, chosen by the launcher) touches
   // that tile only; the per-element selects of the general form were a third of this kernel's VALU instructions, and
   // their 64 loop-invariant lane masks cost registers.
@@ -560,7 +562,8 @@ __device__ __forceinline__ void softmax_split_x2(f32x4 (&s)[NKT], int n, int lan
 // Returns the probabilities as split-fp16 B operands (x 1024) and 1024 x the softmax denominator of query (lane & 15).
 template <int NKT, bool MASK_ANY_TILE>
 __device__ __forceinline__ void attn_scores_x2(const FragBases& fb, int plane, const f16x8 (&qh)[2], const f16x8 (&ql)[2],
-                                               int n, int lane, f16x8 (&ph)[NKT / 2], f16x8 (&pl)[NKT / 2], float& denom) {
+                                               int n, int lane, f16x8 (&ph)[NKT / 2], f16x8 (&pl)[NKT / 2], float& denom,
+                                               float cexp) {
   // S^T, two key tiles at a time with their MFMAs interleaved (two independent accumulator chains) and the fragments
   // of the next pair already on their way from LDS (see pv_chunks_x2)
   f32x4 s[NKT];
@@ -609,7 +612,7 @@ __device__ __forceinline__ void attn_scores_x2(const FragBases& fb, int plane, c
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  softmax_split_x2<NKT, MASK_ANY_TILE>(s, n, lane, ph, pl, denom);
+  softmax_split_x2<NKT, MASK_ANY_TILE>(s, n, lane, ph, pl, denom, cexp);
 }
 
 // The same for BOTH 16-query tiles of a wave at once (temporal kernel, two tiles per wave): every K fragment is read from
@@ -619,7 +622,7 @@ __device__ __forceinline__ void attn_scores_x2(const FragBases& fb, int plane, c
 template <int NKT, bool MASK_ANY_TILE>
 __device__ __forceinline__ void attn_scores_x2_pair(const FragBases& fb, int plane, const f16x8 (&qh)[2][2],
                                                     const f16x8 (&ql)[2][2], int n, int lane, f16x8 (&ph)[2][NKT / 2],
-                                                    f16x8 (&pl)[2][NKT / 2], float (&denom)[2]) {
+                                                    f16x8 (&pl)[2][NKT / 2], float (&denom)[2], float cexp) {
   f32x4 s0[NKT], s1[NKT];
   auto read_k = [&](int t, f16x8 (&k)[4]) {
     k[0] = *reinterpret_cast<const f16x8*>(fb.k0 + plane + t * 2048);   // lo, d 0..31
@@ -650,16 +653,16 @@ __device__ __forceinline__ void attn_scores_x2_pair(const FragBases& fb, int pla
 #undef X2_PAIR_TERM
     s0[t] = a0; s0[t + 1] = b0; s1[t] = a1; s1[t + 1] = b1;
   }
-  softmax_split_x2<NKT, MASK_ANY_TILE>(s0, n, lane, ph[0], pl[0], denom[0]);
-  softmax_split_x2<NKT, MASK_ANY_TILE>(s1, n, lane, ph[1], pl[1], denom[1]);
+  softmax_split_x2<NKT, MASK_ANY_TILE>(s0, n, lane, ph[0], pl[0], denom[0], cexp);
+  softmax_split_x2<NKT, MASK_ANY_TILE>(s1, n, lane, ph[1], pl[1], denom[1], cexp);
 }
 
 // this lane's query fragments (16 fp32 of row q: d = fg*8 .. +7 and 32 + fg*8 .. +7), split
-__device__ __forceinline__ void load_q_x2(const float* qrow, int fg, f16x8 (&qh)[2], f16x8 (&ql)[2]) {
+__device__ __forceinline__ void load_q_x2(const float* qrow, int fg, f16x8 (&qh)[2], f16x8 (&ql)[2], float sc) {
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     const float* p = qrow + half * 32 + fg * 8;
-    split8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), qh[half], ql[half]);
+    split8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), qh[half], ql[half], sc);
   }
 }
 
@@ -673,7 +676,8 @@ __device__ __forceinline__ void load_k_x2(const f16* krow, int C, int fg, f16x8 
 }
 
 // O^T accumulators -> out row `tok` (fp32 [T][C], or the h2i layout of the proj Linear's operand, common.h): lane holds
-// channels col + dn*16 + (0..3), col = head*64 + 4 fg
+// channels col + dn*16 + (0..3), col = head*64 + 4 fg.  `inv` = onorm / (1024 x softmax denominator): for plane outputs the
+// product is the value at the OUTPUT operand's scale already (X2Scales)
 template <int OUTS>
 __device__ __forceinline__ void store_o_x2(const f32x4 (&o)[4], float inv, void* out_v, size_t tok, int C, int col) {
 #pragma unroll
@@ -683,7 +687,7 @@ __device__ __forceinline__ void store_o_x2(const f32x4 (&o)[4], float inv, void*
       f16* dst = reinterpret_cast<f16*>(out_v) + tok * (2 * C) + h2i_col(col + dn * 16);
       f16x4 p0, p1;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { f16 a0, a1; split2h(r4[e], a0, a1); p0[e] = a0; p1[e] = a1; }
+      for (int e = 0; e < 4; ++e) { f16 a0, a1; split2h_scaled(r4[e], a0, a1); p0[e] = a0; p1[e] = a1; }
       *reinterpret_cast<f16x4*>(dst) = p0;
       *reinterpret_cast<f16x4*>(dst + kH2iLo) = p1;
     } else {
@@ -732,7 +736,7 @@ __device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt((V & 1
 template <int NKT, int OUTS, bool MASK_ANY_TILE>
 __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
                                                                SeqMap map, int C, int heads, size_t plane_elems,
-                                                               int n_prob) {
+                                                               int n_prob, X2Scales sc) {
   constexpr int NW = 8;
   constexpr int TPW = (NKT + NW - 1) / NW;             // query tiles per wave
   constexpr int NK = 16 * NKT;
@@ -746,7 +750,7 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
   const int ts = map.tok_stride;
   const size_t ldb = (size_t)12 * C;                   // bytes per packed token row
   const int n_qt = (n + 15) >> 4;
-  const float inv_scale = 1.0f / kActScale;            // O^T is scaled by 16 x 1024, the denominator by 1024
+  const float inv_scale = sc.onorm;                    // O^T is scaled by (v scale) x 1024, the denominator by 1024
 
   // DMA piece `pc` of a plane = image rows 8 pc .. 8 pc + 7; a lane moves the 16-byte slot that belongs at position
   // (lane & 7) of row 8 pc + (lane >> 3): K slot s sits at s ^ ((row >> 1) & 7), V slot s at s ^ (((row >> 1) & 3) << 1)
@@ -821,10 +825,10 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
             settle(qr[u][i]);                          // (after the counted wait above)
             qf[i] = make_float4(qr[u][i][0], qr[u][i][1], qr[u][i][2], qr[u][i][3]);
           }
-          split8(qf[0], qf[1], qh[u][0], ql[u][0]);
-          split8(qf[2], qf[3], qh[u][1], ql[u][1]);
+          split8(qf[0], qf[1], qh[u][0], ql[u][0], sc.q);
+          split8(qf[2], qf[3], qh[u][1], ql[u][1], sc.q);
         }
-        attn_scores_x2_pair<NKT, MASK_ANY_TILE>(fbk, PLANE, qh, ql, n, lane, ph, pl, denom);
+        attn_scores_x2_pair<NKT, MASK_ANY_TILE>(fbk, PLANE, qh, ql, n, lane, ph, pl, denom, sc.cexp);
       }
     } else {
 #pragma unroll
@@ -838,9 +842,9 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
           settle(qr[u][i]);                            // (after the counted wait above)
           qf[i] = make_float4(qr[u][i][0], qr[u][i][1], qr[u][i][2], qr[u][i][3]);
         }
-        split8(qf[0], qf[1], qh[0], ql[0]);
-        split8(qf[2], qf[3], qh[1], ql[1]);
-        attn_scores_x2<NKT, MASK_ANY_TILE>(fbk, PLANE, qh, ql, n, lane, ph[u], pl[u], denom[u]);
+        split8(qf[0], qf[1], qh[0], ql[0], sc.q);
+        split8(qf[2], qf[3], qh[1], ql[1], sc.q);
+        attn_scores_x2<NKT, MASK_ANY_TILE>(fbk, PLANE, qh, ql, n, lane, ph[u], pl[u], denom[u], sc.cexp);
       }
     }
     }
@@ -888,7 +892,8 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
 // (8 KB per token), and with K staged as well (16 KiB per wave, two workgroups per CU) it ran at 3.8 TB/s.
 template <int OUTS>
 __global__ __launch_bounds__(256) void attn_spatial_x2_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
-                                                              int n_prob, SeqMap map, int C, int heads, size_t plane_elems) {
+                                                              int n_prob, SeqMap map, int C, int heads, size_t plane_elems,
+                                                              X2Scales sc) {
   constexpr int PLANE = 32 * 128;
   __shared__ __attribute__((aligned(16))) char smem[4 * 2 * PLANE];
   const int n = map.n_tok;
@@ -908,7 +913,7 @@ __global__ __launch_bounds__(256) void attn_spatial_x2_kernel(const float* __res
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const char* row = rows + (size_t)min(t * 16 + fi, n - 1) * ts * ldb;
-    load_q_x2(reinterpret_cast<const float*>(row) + head * 64, fg, qh[t], ql[t]);
+    load_q_x2(reinterpret_cast<const float*>(row) + head * 64, fg, qh[t], ql[t], sc.q);
     load_k_x2(reinterpret_cast<const f16*>(row + 4 * C) + head * 64, C, fg, kh[t], kl[t]);
   }
   for (int idx = lane; idx < 32 * 8; idx += 64) {      // V rows -> hi / lo images (rows >= n zeroed)
@@ -925,8 +930,8 @@ __global__ __launch_bounds__(256) void attn_spatial_x2_kernel(const float* __res
   }
   const FragBases fb = make_frag_bases(img, img, lane);   // only the V bases are used
   // (wave-private LDS image: the LDS pipe executes one wave's accesses in order, no barrier needed)
-  const float inv_scale = 1.0f / kActScale;            // O^T is scaled by 16 x 1024, `sum` by 1024
-  const float cexp = 0.125f * 1.44269504088896340736f / (kActScale * kActScale);
+  const float inv_scale = sc.onorm;                    // O^T is scaled by (v scale) x 1024, `sum` by 1024
+  const float cexp = sc.cexp;
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     if (qt >= n_qt) break;
@@ -978,7 +983,7 @@ __global__ __launch_bounds__(256) void attn_spatial_x2_kernel(const float* __res
 
 // fp32 qkv rows [T, 3C] -> the packed rows of the split-fp16 attention kernels (what the qkv Linear writes directly with
 // EPI_QKV_PACK); used by d3dp_op_attention, whose C-ABI input is the plain fp32 layout.
-__global__ void qkv_pack_x2_kernel(const float* __restrict__ src, char* __restrict__ dst, size_t T, int C) {
+__global__ void qkv_pack_x2_kernel(const float* __restrict__ src, char* __restrict__ dst, size_t T, int C, float sc) {
   const size_t total = T * (size_t)(3 * C / 4);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t t = i / (3 * C / 4);
@@ -991,7 +996,7 @@ __global__ void qkv_pack_x2_kernel(const float* __restrict__ src, char* __restri
       const float a[4] = {v.x, v.y, v.z, v.w};
       f16x4 ph, pl;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { f16 h, l; split2h(a[e], h, l); ph[e] = h; pl[e] = l; }
+      for (int e = 0; e < 4; ++e) { f16 h, l; split2h_scaled(a[e] * sc, h, l); ph[e] = h; pl[e] = l; }
       *reinterpret_cast<f16x4*>(row + region * 4 * C + cn * 2) = ph;
       *reinterpret_cast<f16x4*>(row + region * 4 * C + 2 * C + cn * 2) = pl;
     }
@@ -999,23 +1004,23 @@ __global__ void qkv_pack_x2_kernel(const float* __restrict__ src, char* __restri
 }
 
 template <int NKT, int OUTS>
-int launch_temporal_x2(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, hipStream_t st) {
+int launch_temporal_x2(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, X2Scales sc,
+                       hipStream_t st) {
   constexpr int NK = 16 * NKT;
   const size_t lds = (size_t)NK * 128 * 4;             // static LDS of the kernel (K and V images, two planes each)
   constexpr int NW = 8;
   // (n inside the last key tile -- F = 243, 27 -- needs masking in that tile only)
   auto kern = map.n_tok > 16 * (NKT - 1) ? attn_temporal_x2_kernel<NKT, OUTS, false> : attn_temporal_x2_kernel<NKT, OUTS, true>;
-  static int n_wg = 0;
-  if (!n_wg) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -3;
+  static PerDeviceOnce once;
+  const int n_wg = once.get([&](int dev) {
     const int per_cu = (int)((160 * 1024) / lds) < 2048 / (NW * 64) ? (int)((160 * 1024) / lds) : 2048 / (NW * 64);
-    n_wg = prop.multiProcessorCount * per_cu;          // persistent: as many workgroups as fit the chip
-  }
+    const int cus = d3dp_cu_count(dev);
+    return cus < 0 ? cus : cus * per_cu;               // persistent: as many workgroups as fit the chip
+  });
+  if (n_wg < 0) return -3;
   const int n_prob = n_seq * heads;
   hipLaunchKernelGGL(kern, dim3(n_prob < n_wg ? n_prob : n_wg), dim3(NW * 64), 0, st, (const float*)qkv, out, map, C,
-                     heads, plane, n_prob);
+                     heads, plane, n_prob, sc);
   return 0;
 }
 
@@ -1159,12 +1164,8 @@ int launch_temporal_f32(const void* qkv, void* out, int n_seq, SeqMap map, int C
   constexpr int NK = 16 * NKT;
   const size_t lds = (size_t)(NK * LDKF + 3 + NK * LDVF) * 4 + 16;
   auto kern = attn_temporal_f32_kernel<NKT, OUTS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) return -3;
-    attr_set = true;
-  }
+  static PerDeviceOnce once;                          // (one per template instantiation = per kernel)
+  if (once.get([&](int) { return d3dp_lds_opt_in(reinterpret_cast<const void*>(kern), 160 * 1024); }) < 0) return -3;
   hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(256), lds, st, (const float*)qkv, out, map, C, heads, plane);
   return 0;
 }
@@ -1174,12 +1175,8 @@ int launch_temporal2(const void* qkv, void* out, int n_seq, SeqMap map, int C, i
   constexpr int NK = 16 * NKT;
   const size_t lds = (size_t)NK * 256;
   auto kern = attn_temporal2_bf16_kernel<NKT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) return -3;
-    attr_set = true;
-  }
+  static PerDeviceOnce once;                          // (one per template instantiation = per kernel)
+  if (once.get([&](int) { return d3dp_lds_opt_in(reinterpret_cast<const void*>(kern), 160 * 1024); }) < 0) return -3;
   hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(512), lds, st, (const bf16*)qkv, (bf16*)out, map, C, heads);
   return 0;
 }
@@ -1226,28 +1223,32 @@ int d3dp_launch_attn_temporal_f32(int act, const void* qkv, void* out, int n_seq
 // EXACT-mode attention on the fp16 matrix cores (split-fp16 operands; head dim 64) over PACKED qkv rows (see above).
 // act 0 -> fp32 out, 3 -> two fp16 planes out (the EXACT Linear's operand format).  axis 0: <= 32 tokens per sequence;
 // axis 1: <= 256.
-void d3dp_launch_qkv_pack_x2(const float* src, void* dst, size_t T, int C, hipStream_t st) {
+void d3dp_launch_qkv_pack_x2(const float* src, void* dst, size_t T, int C, float act_scale, hipStream_t st) {
   const size_t total = T * (size_t)(3 * C / 4);
   const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(qkv_pack_x2_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, (char*)dst, T, C);
+  hipLaunchKernelGGL(qkv_pack_x2_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, (char*)dst, T, C, act_scale);
 }
 
+// act_scale: the power of two q, k, v (and, for act == 3, the output planes) are scaled by -- kActScale unless the block's
+// proven operand range asked for less (capi.hip).  With 16 the arithmetic is bit for bit that of the constant-scale kernels.
 int d3dp_launch_attn_x2(int act, int axis, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
-                        hipStream_t st) {
-  if (C / heads != 64 || map.n_tok < 1 || (act != 0 && act != 3)) return -2;
+                        float act_scale, hipStream_t st) {
+  if (C / heads != 64 || map.n_tok < 1 || (act != 0 && act != 3) || !(act_scale > 0.f)) return -2;
   const size_t plane = (size_t)n_seq * map.n_tok * C;
   const int n = map.n_tok;
+  const X2Scales sc = {act_scale, 0.125f * 1.44269504088896340736f / (act_scale * act_scale),
+                       act == 3 ? 1.0f : 1.0f / act_scale};
   if (axis == 0) {
     if (n > 32) return -2;
     const int n_prob = n_seq * heads;
-    if (act == 3) hipLaunchKernelGGL((attn_spatial_x2_kernel<2>), dim3((n_prob + 3) / 4), dim3(256), 0, st, (const float*)qkv, out, n_prob, map, C, heads, plane);
-    else hipLaunchKernelGGL((attn_spatial_x2_kernel<0>), dim3((n_prob + 3) / 4), dim3(256), 0, st, (const float*)qkv, out, n_prob, map, C, heads, plane);
+    if (act == 3) hipLaunchKernelGGL((attn_spatial_x2_kernel<2>), dim3((n_prob + 3) / 4), dim3(256), 0, st, (const float*)qkv, out, n_prob, map, C, heads, plane, sc);
+    else hipLaunchKernelGGL((attn_spatial_x2_kernel<0>), dim3((n_prob + 3) / 4), dim3(256), 0, st, (const float*)qkv, out, n_prob, map, C, heads, plane, sc);
     return 0;
   }
   if (n > 256) return -2;
 #define X2_CASE(NKT_)                                                                                         \
-  return act == 3 ? launch_temporal_x2<NKT_, 2>(qkv, out, n_seq, map, C, heads, plane, st)                    \
-                  : launch_temporal_x2<NKT_, 0>(qkv, out, n_seq, map, C, heads, plane, st);
+  return act == 3 ? launch_temporal_x2<NKT_, 2>(qkv, out, n_seq, map, C, heads, plane, sc, st)                \
+                  : launch_temporal_x2<NKT_, 0>(qkv, out, n_seq, map, C, heads, plane, sc, st);
   if (n <= 32) { X2_CASE(2) }
   if (n <= 64) { X2_CASE(4) }
   if (n <= 128) { X2_CASE(8) }

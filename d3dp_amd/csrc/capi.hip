@@ -72,6 +72,11 @@ struct BlockDev {
   const void *qkv_w, *proj_w, *fc1_w, *fc2_w;   // bf16 (FAST); EXACT: 2 fp16 planes (default), 3 bf16 planes or fp32
   float qkv_u = 1.f, proj_u = 1.f, fc1_u = 1.f, fc2_u = 1.f;   // EXACT f16x2: 2^-s of the per-matrix pre-scale 2^s
   const float* fc1_c12 = nullptr;   // fold_ln: [c2 | c1] of norm2 folded into fc1 (fc1_w then holds W diag(gamma)); see run_block
+  // EXACT f16x2: the power-of-two scales of this block's DATA-dependent split-fp16 operands -- q / k / v and the attention
+  // output (s_kv), the MLP hidden (s_h) -- chosen at d3dp_set_weights from the range the weights PROVE for them: 2^4 when
+  // the bound is below 4094, the largest smaller power of two that keeps bound x scale below fp16's 65504 otherwise
+  // (LayerNorm outputs always use 2^4: their bound is sqrt(C-1) |gamma| + |beta|).
+  float s_kv = kActScale, s_h = kActScale;
 };
 
 __global__ void to_bf16_kernel(const float* __restrict__ s, bf16* __restrict__ d, size_t n) {
@@ -116,6 +121,8 @@ struct d3dp_ctx {
   // feed a Linear are then two fp16 planes.  env D3DP_EXACT_IMPL=bf16x3 selects the round-1 six-pass split-bf16 kernels
   // and =f32 the plain fp32-MFMA kernels (bitwise an fp32 fmaf chain) -- both kept as cross-checks.
   int exact_impl = 0;   // 0 = f16x2, 1 = bf16x3, 2 = f32
+  int exact_impl_req = 0;        // what D3DP_EXACT_IMPL asked for; d3dp_set_weights moves an f16x2 context to bf16x3 when a
+  bool impl_fallback = false;    // LayerNorm's own output bound leaves the split-fp16 range (see there)
   bool train() const { return cfg.mode == D3DP_MODE_TRAIN; }
   bool exact() const { return !fast() && !train(); }
   bool x2() const { return exact() && exact_impl == 0; }
@@ -214,14 +221,17 @@ struct Scope {
 };
 
 // out = epi(A W^T + bias).  out_f32: fp32 output even in FAST mode (the Linear outputs that feed a residual add).
+// EXACT f16x2: `a_scale` = the scale the A operand was written at, `o_scale` = the scale of a plane output (BlockDev).
 int linear(d3dp_ctx* c, int cls, int epi, int out_f32, const void* A, const void* W, float wu, const float* bias, void* out,
-           int M, int N, int K, hipStream_t st, void* out2 = nullptr, float* aux = nullptr) {
+           int M, int N, int K, hipStream_t st, void* out2 = nullptr, float* aux = nullptr, float a_scale = kActScale,
+           float o_scale = kActScale) {
   Scope s(c, cls, st);
   if (c->fast()) return d3dp_launch_linear_bf16_stream(epi, out_f32, A, W, bias, out, M, N, K, st);
   if (c->x2()) {
     // the qkv Linear writes the packed rows of the split-fp16 attention kernels (K and V already as fp16 planes)
     if (cls == P_QKV && c->x2_attn()) epi = EPI_QKV_PACK;
-    return d3dp_launch_linear_f16x2(epi, A, W, bias, wu * kActUnscale, (float*)out, out2 ? out2 : out, aux, c->d_flag, M, N, K, st);
+    return d3dp_launch_linear_f16x2(epi, A, W, bias, wu / a_scale, o_scale, (float*)out, out2 ? out2 : out, aux, c->d_flag, M, N,
+                                    K, st);
   }
   if (c->x3()) return d3dp_launch_linear_bf16x3(epi, A, W, bias, (float*)out, out, M, N, K, st);
   return d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, st);
@@ -230,13 +240,13 @@ int linear(d3dp_ctx* c, int cls, int epi, int out_f32, const void* A, const void
 SeqMap spatial_map(int F, int J) { return SeqMap{J, 1, J, 0, 1}; }
 SeqMap temporal_map(int F, int J) { return SeqMap{F, J, F * J, 1, J}; }
 
-int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, hipStream_t st) {
+int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, float s_kv, hipStream_t st) {
   const d3dp_cfg& g = c->cfg;
   Scope s(c, axis == 0 ? P_ATTN_S : P_ATTN_T, st);
   if (c->x2_attn())                                    // split-fp16 operands on the fp16 matrix cores; packed qkv rows
     return d3dp_launch_attn_x2(3, axis, qkv, out, axis == 0 ? n_bh * g.frames : n_bh * g.joints,
                                axis == 0 ? spatial_map(g.frames, g.joints) : temporal_map(g.frames, g.joints), g.channels,
-                               g.heads, st);
+                               g.heads, s_kv, st);
   if (axis == 0) {
     if (c->fast() && g.channels / g.heads == 64 && g.joints <= 32)
       return d3dp_launch_attn_spatial_bf16(qkv, out, n_bh * g.frames, spatial_map(g.frames, g.joints), g.channels,
@@ -263,28 +273,31 @@ int run_block(d3dp_ctx* c, const BlockDev& w, int axis, float* x, void* y1, void
               int n_bh, hipStream_t st) {
   const d3dp_cfg& g = c->cfg;
   const int Tc = n_bh * g.frames * g.joints, C = g.channels;
-  LAUNCH_TRY(linear(c, P_QKV, EPI_BIAS, 0, bufA, w.qkv_w, w.qkv_u, w.qkv_b, bufB, Tc, 3 * C, C, st));
-  LAUNCH_TRY(attention(c, axis, bufB, bufA, n_bh, st));
+  // (s_kv / s_h differ from kActScale only in EXACT f16x2 contexts whose weights asked for it, and s_kv only with the x2
+  //  attention kernels: the other attention kernels write their output planes at kActScale)
+  const float s_o = c->x2_attn() ? w.s_kv : kActScale;
+  LAUNCH_TRY(linear(c, P_QKV, EPI_BIAS, 0, bufA, w.qkv_w, w.qkv_u, w.qkv_b, bufB, Tc, 3 * C, C, st, nullptr, nullptr, kActScale, s_o));
+  LAUNCH_TRY(attention(c, axis, bufB, bufA, n_bh, s_o, st));
   const bool fold = c->fold_resid();   // EXACT split-fp16 Linears: x += proj / fc2 inside their epilogues
   if (c->fold_ln()) {
     // norm2 folded into proj's epilogue (statistics, un-normalised operand -> y1) and fc1's (normalisation): no row kernel
     float* slices = lnst;                                                   // [Tc][C / 64][2]
     float* rowstat = lnst + (size_t)c->ln_slice_floats;                     // [Tc + 256][2]
-    LAUNCH_TRY(linear(c, P_PROJ, EPI_RESID_LN, 0, bufA, w.proj_w, w.proj_u, w.proj_b, x, Tc, C, C, st, y1, slices));
+    LAUNCH_TRY(linear(c, P_PROJ, EPI_RESID_LN, 0, bufA, w.proj_w, w.proj_u, w.proj_b, x, Tc, C, C, st, y1, slices, s_o));
     {
       Scope s(c, P_LN, st);
       d3dp_launch_ln_combine(slices, rowstat, Tc, C, g.eps_block, st);
     }
-    LAUNCH_TRY(linear(c, P_FC1, EPI_GELU_LN, 0, y1, w.fc1_w, w.fc1_u, w.fc1_c12, bufB, Tc, g.hidden, C, st, bufB, rowstat));
+    LAUNCH_TRY(linear(c, P_FC1, EPI_GELU_LN, 0, y1, w.fc1_w, w.fc1_u, w.fc1_c12, bufB, Tc, g.hidden, C, st, bufB, rowstat, kActScale, w.s_h));
   } else {
-  LAUNCH_TRY(linear(c, P_PROJ, fold ? EPI_RESID : EPI_BIAS, 0, bufA, w.proj_w, w.proj_u, w.proj_b, fold ? (void*)x : y1, Tc, C, C, st));
+  LAUNCH_TRY(linear(c, P_PROJ, fold ? EPI_RESID : EPI_BIAS, 0, bufA, w.proj_w, w.proj_u, w.proj_b, fold ? (void*)x : y1, Tc, C, C, st, nullptr, nullptr, s_o));
   {
     Scope s(c, P_LN, st);      // xn = LN2(x + y1); x itself stays untouched (the caller's norm pair adds y1 and y)
     LAUNCH_TRY(d3dp_launch_ln(c->act(), x, fold ? nullptr : y1, 0, w.n2w, w.n2b, g.eps_block, bufA, Tc, C, st));
   }
-  LAUNCH_TRY(linear(c, P_FC1, EPI_GELU, 0, bufA, w.fc1_w, w.fc1_u, w.fc1_b, bufB, Tc, g.hidden, C, st));
+  LAUNCH_TRY(linear(c, P_FC1, EPI_GELU, 0, bufA, w.fc1_w, w.fc1_u, w.fc1_b, bufB, Tc, g.hidden, C, st, nullptr, nullptr, kActScale, w.s_h));
   }
-  LAUNCH_TRY(linear(c, P_FC2, fold ? EPI_RESID : EPI_BIAS, 0, bufB, w.fc2_w, w.fc2_u, w.fc2_b, fold ? (void*)x : y, Tc, C, g.hidden, st));
+  LAUNCH_TRY(linear(c, P_FC2, fold ? EPI_RESID : EPI_BIAS, 0, bufB, w.fc2_w, w.fc2_u, w.fc2_b, fold ? (void*)x : y, Tc, C, g.hidden, st, nullptr, nullptr, w.s_h));
   return 0;
 }
 
@@ -318,7 +331,7 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   d3dp_ctx* c = new d3dp_ctx();
   c->cfg = g;
   const char* xf = getenv("D3DP_EXACT_IMPL");
-  c->exact_impl = (xf && !strcmp(xf, "bf16x3")) ? 1 : (xf && !strcmp(xf, "f32")) ? 2 : 0;
+  c->exact_impl = c->exact_impl_req = (xf && !strcmp(xf, "bf16x3")) ? 1 : (xf && !strcmp(xf, "f32")) ? 2 : 0;
   const char* nf = getenv("D3DP_NO_FOLD");               // cross-check: residual adds (and norm2) in the row kernels
   c->fold = !(nf && nf[0] == '1');
   const char* nl = getenv("D3DP_FOLD_LN");               // norm2 folded into proj / fc1 instead of its own row kernel
@@ -351,6 +364,63 @@ int d3dp_set_weights(d3dp_ctx* c, const d3dp_weights* w, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const d3dp_cfg& g = c->cfg;
   const size_t C = g.channels, Hd = g.hidden, J = g.joints, F = g.frames;
+  // ---- EXACT f16x2: the range the weights PROVE for every data-dependent split-fp16 operand (d3dp_exact_range_bound), on
+  // the device (one wave per weight row; 4 floats per block come back), and from it the operand scales of every block.
+  //   LayerNorm output  |LN(x)_k| <= sqrt(C-1) |gamma_k| + |beta_k|                         (operand of qkv / fc1: fixed 2^4)
+  //   q, k, v           |.| <= max_n sum_k |Wqkv[n,k]| in_k + |b_n|  -- and the attention output <= max |v|      (s_kv)
+  //   MLP hidden        |GELU(y)| <= |y| <= the same form with Wfc1                                               (s_h)
+  // A bound below 4094 keeps 2^4 (full 22 bits down to 2^-7); above it the scale drops to the largest power of two with
+  // bound x scale < 65504: nothing can overflow to inf (the fp32 reference is finite there, so must this be -- VERDICT r3
+  // item 5) and the representation error stays <= max(2^-22 |x|, 2^-25 / scale) <= 2^-40 x bound in absolute terms, far below
+  // the fp32 rounding of the sums these operands enter.  A LayerNorm whose own output bound reaches 4094 (|gamma| ~ 180),
+  // or an out-of-range q/k/v bound where the split-fp16 attention kernels do not apply, switches the whole context to the
+  // six-pass split-bf16 implementation, which has fp32's exponent range.
+  c->range_bound = 0.f;
+  c->impl_fallback = false;
+  std::vector<float> blk_scale(4 * (size_t)g.depth, kActScale);      // [kind][d][s_kv, s_h]
+  if (c->exact() && c->exact_impl_req == 0) {
+    c->exact_impl = 0;
+    const size_t nb = 2 * (size_t)g.depth;
+    unsigned* dbound = nullptr;
+    HIP_TRY(hipMalloc((void**)&dbound, nb * 4 * sizeof(unsigned)));
+    struct Free { unsigned* p; ~Free() { (void)hipFree(p); } } free_dbound{dbound};
+    HIP_TRY(hipMemsetAsync(dbound, 0, nb * 4 * sizeof(unsigned), st));
+    for (int kind = 0; kind < 2; ++kind)
+      for (int d = 0; d < g.depth; ++d) {
+        const d3dp_block_weights& b = (kind == 0 ? w->ste : w->tte)[d];
+        if (!b.norm1_w || !b.norm1_b || !b.qkv_w || !b.qkv_b || !b.norm2_w || !b.norm2_b || !b.fc1_w || !b.fc1_b)
+          return fail(D3DP_EINVAL, "d3dp_set_weights: a weight pointer is null");
+        unsigned* o = dbound + ((size_t)kind * g.depth + d) * 4;
+        d3dp_launch_rowbound(b.qkv_w, b.norm1_w, b.norm1_b, b.qkv_b, 3 * (int)C, (int)C, o, st);       // o[0] q/k/v, o[1] LN1 out
+        d3dp_launch_rowbound(b.fc1_w, b.norm2_w, b.norm2_b, b.fc1_b, (int)Hd, (int)C, o + 2, st);      // o[2] hidden, o[3] LN2 out
+      }
+    std::vector<float> hb(nb * 4);
+    HIP_TRY(hipMemcpyAsync(hb.data(), dbound, nb * 4 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const float kSafe = 65504.0f / kActScale;           // 4094: what 2^4 holds
+    auto pick = [&](float bound) {                       // largest power of two <= 2^4 with bound x scale < 65504
+      float sc = kActScale;
+      while (!(bound * sc < 65504.0f) && sc > 1e-30f) sc *= 0.5f;
+      return sc;
+    };
+    float worst = 0.f;
+    bool fallback = false;
+    for (size_t i = 0; i < nb; ++i) {
+      const float bq = hb[4 * i], bl1 = hb[4 * i + 1], bh = hb[4 * i + 2], bl2 = hb[4 * i + 3];
+      if (!(bq < INFINITY) || !(bh < INFINITY)) return fail(D3DP_EINVAL, "d3dp_set_weights: a weight tensor holds inf/nan");
+      worst = std::max(worst, std::max(std::max(bq, bh), std::max(bl1, bl2)));
+      if (!(bl1 < kSafe) || !(bl2 < kSafe)) fallback = true;
+      if (!(bq < kSafe) && !c->x2_attn()) fallback = true;
+      blk_scale[2 * i] = pick(bq);
+      blk_scale[2 * i + 1] = pick(bh);
+    }
+    c->range_bound = std::min(worst, 3.0e38f);
+    if (fallback) {
+      c->exact_impl = 1;                                 // split-bf16, six passes: no range limit
+      c->impl_fallback = true;
+      std::fill(blk_scale.begin(), blk_scale.end(), kActScale);
+    }
+  }
   const size_t ws = c->fast() ? 2 : (c->x3() ? 6 : 4);   // bytes per weight-matrix element (bf16 / 3 bf16 planes / fp32)
   // ---- arena layout ----
   size_t off = 0;
@@ -442,38 +512,6 @@ int d3dp_set_weights(d3dp_ctx* c, const d3dp_weights* w, void* stream) {
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(st));
-  // provable range of the split-fp16 operands, from the weights alone (header: d3dp_exact_range_bound): computed on the
-  // host in fp64 -- once per weight load, 139 MB over PCIe
-  c->range_bound = 0.f;
-  if (c->x2()) {
-    std::vector<float> hw, hg, hb, hbias;
-    auto pull = [&](std::vector<float>& h, const float* d, size_t n) {
-      h.resize(n);
-      return hipMemcpy(h.data(), d, n * 4, hipMemcpyDeviceToHost) == hipSuccess;
-    };
-    const double sq = std::sqrt((double)(C - 1));
-    double worst = 0.0;
-    // max_n  sum_k |W[n,k]| (sq |gamma_k| + |beta_k|) + |bias_n|,  and the LayerNorm output bound max_k (sq |gamma_k| + |beta_k|)
-    auto rowbound = [&](const float* W, const float* gam, const float* bet, const float* bias, size_t N, size_t K) -> bool {
-      if (!pull(hw, W, N * K) || !pull(hg, gam, K) || !pull(hb, bet, K) || !pull(hbias, bias, N)) return false;
-      std::vector<double> in(K);
-      for (size_t k = 0; k < K; ++k) { in[k] = sq * std::fabs((double)hg[k]) + std::fabs((double)hb[k]); worst = std::max(worst, in[k]); }
-      for (size_t n = 0; n < N; ++n) {
-        double a = std::fabs((double)hbias[n]);
-        for (size_t k = 0; k < K; ++k) a += std::fabs((double)hw[n * K + k]) * in[k];
-        worst = std::max(worst, a);
-      }
-      return true;
-    };
-    for (int kind = 0; kind < 2; ++kind)
-      for (int d = 0; d < g.depth; ++d) {
-        const d3dp_block_weights& b = (kind == 0 ? w->ste : w->tte)[d];
-        if (!rowbound(b.qkv_w, b.norm1_w, b.norm1_b, b.qkv_b, 3 * C, C) ||      // q, k, v (and the attention output <= max |v|)
-            !rowbound(b.fc1_w, b.norm2_w, b.norm2_b, b.fc1_b, Hd, C))           // the fc1 pre-activation (|GELU(x)| <= |x|)
-          return fail(D3DP_EHIP, "d3dp_set_weights: copying the weights to the host for the range bound failed");
-      }
-    c->range_bound = (float)std::min(worst, 3.0e38);
-  }
   auto F32 = [&](size_t i) { return (const float*)(c->arena + items[i].off); };
   auto ANY = [&](size_t i) { return (const void*)(c->arena + items[i].off); };
   c->spos = F32(i_spos); c->tpos = F32(i_tpos); c->ew = F32(i_ew); c->eb = F32(i_eb); c->freq = F32(i_fr);
@@ -485,7 +523,8 @@ int d3dp_set_weights(d3dp_ctx* c, const d3dp_weights* w, void* stream) {
     const BI& bi = bis[k];
     BlockDev b{F32(bi.v[0]), F32(bi.v[1]), F32(bi.v[6]), F32(bi.v[7]), F32(bi.v[3]), F32(bi.v[5]), F32(bi.v[9]),
                F32(bi.v[11]), ANY(bi.v[2]), ANY(bi.v[4]), ANY(bi.v[8]), ANY(bi.v[10]),
-               unscale[bi.v[2]], unscale[bi.v[4]], unscale[bi.v[8]], unscale[bi.v[10]], F32(bi.v[12])};
+               unscale[bi.v[2]], unscale[bi.v[4]], unscale[bi.v[8]], unscale[bi.v[10]], F32(bi.v[12]),
+               blk_scale[2 * k], blk_scale[2 * k + 1]};
     (k < (size_t)g.depth ? c->ste : c->tte).push_back(b);
   }
   c->weights_set = true;
@@ -602,6 +641,19 @@ int d3dp_exact_range_bound(const d3dp_ctx* c, float* bound) {
   return D3DP_OK;
 }
 
+int d3dp_exact_scales(const d3dp_ctx* c, float* s_kv, float* s_hidden, int32_t* implementation) {
+  if (!c) return fail(D3DP_EINVAL, "d3dp_exact_scales: null argument");
+  if (!c->weights_set) return fail(D3DP_ESTATE, "d3dp_exact_scales: weights not set");
+  const int dep = c->cfg.depth;
+  for (int i = 0; i < 2 * dep; ++i) {
+    const BlockDev& b = i < dep ? c->ste[i] : c->tte[i - dep];
+    if (s_kv) s_kv[i] = b.s_kv;
+    if (s_hidden) s_hidden[i] = b.s_h;
+  }
+  if (implementation) *implementation = c->exact() ? c->exact_impl : -1;
+  return D3DP_OK;
+}
+
 int d3dp_status(d3dp_ctx* c, int32_t* nonfinite) {
   if (!c || !nonfinite) return fail(D3DP_EINVAL, "d3dp_status: null argument");
   unsigned v = 0;
@@ -705,13 +757,14 @@ int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* 
                       int32_t N, int32_t K, void* stream) {
   if (!A2 || !W2 || !bias || !out || !(w_scale > 0.f)) return fail(D3DP_EINVAL, "d3dp_op_linear_x2: bad argument");
   if (epi == EPI_RESID_LN || epi == EPI_GELU_LN) return fail(D3DP_EINVAL, "d3dp_op_linear_x2: epilogues 5 / 6 are internal to d3dp_denoise");
-  LAUNCH_TRY(d3dp_launch_linear_f16x2(epi, A2, W2, bias, kActUnscale / w_scale, (float*)out, out, nullptr, nullptr, M, N, K, (hipStream_t)stream));
+  LAUNCH_TRY(d3dp_launch_linear_f16x2(epi, A2, W2, bias, kActUnscale / w_scale, kActScale, (float*)out, out, nullptr, nullptr, M, N, K, (hipStream_t)stream));
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
 }
 
 int d3dp_op_split2(const float* src, void* dst, size_t n, float scale, void* stream) {
   if (!src || !dst) return fail(D3DP_EINVAL, "d3dp_op_split2: null argument");
+  if (n % 32 != 0) return fail(D3DP_EINVAL, "d3dp_op_split2: n = %zu is not a multiple of 32 (the h2i layout is made of whole 32-column blocks)", n);
   d3dp_launch_split2(src, dst, n, scale, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
@@ -728,9 +781,9 @@ int d3dp_op_attention(int32_t act_bf16, int32_t impl, int32_t axis, const void* 
     void* packed = nullptr;
     const size_t T = (size_t)n_bh * F * J;
     HIP_TRY(hipMallocAsync(&packed, T * 12 * (size_t)C, st));
-    d3dp_launch_qkv_pack_x2((const float*)qkv, packed, T, C, st);
+    d3dp_launch_qkv_pack_x2((const float*)qkv, packed, T, C, kActScale, st);
     const int rc = d3dp_launch_attn_x2(0, axis, packed, out, axis == 0 ? n_bh * F : n_bh * J,
-                                       axis == 0 ? spatial_map(F, J) : temporal_map(F, J), C, heads, st);
+                                       axis == 0 ? spatial_map(F, J) : temporal_map(F, J), C, heads, kActScale, st);
     HIP_TRY(hipFreeAsync(packed, st));
     LAUNCH_TRY(rc);
   } else if (axis == 0 && impl == 1) {

@@ -349,14 +349,11 @@ int d3dp_launch_linear_bf16x3(int epi, const void* A3, const void* W3, const flo
                               int N, int K, hipStream_t st) {
   if (K % TBK != 0 || N % 4 != 0 || M <= 0) return -1;
   const int tm = (M + TBM - 1) / TBM, tn = (N + TBN - 1) / TBN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<EPI_BIAS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, TLDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel<EPI_GELU>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, TLDS) != hipSuccess) return -3;
-    attr_set = true;
-  }
+  static PerDeviceOnce once;
+  if (once.get([&](int) {
+        return d3dp_lds_opt_in(reinterpret_cast<const void*>(gemm_bf16x3_kernel<EPI_BIAS>), TLDS) < 0 ? -3
+               : d3dp_lds_opt_in(reinterpret_cast<const void*>(gemm_bf16x3_kernel<EPI_GELU>), TLDS);
+      }) < 0) return -3;
   if (epi == EPI_BIAS)
     hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI_BIAS>), dim3(tm * tn), dim3(512), TLDS, st, (const bf16*)A3, (const bf16*)W3,
                        bias, outf, (bf16*)out3, M, N, K, tn);
@@ -626,20 +623,12 @@ int launch_stream_nk_mi(const void* A, const void* W, const float* bias, void* o
   if constexpr (EPI == EPI_BIAS && sizeof(OutT) == 2 && NK == 8) {
     if (N == 3 * NK * SBK) kern = gemm_bf16_stream_kernel<EPI, OutT, NK, MI, 1>;
   }
-  static bool attr_set[2] = {false, false};
+  static PerDeviceOnce once[2];                       // per kernel variant: LDS opt-in, then the device's CU count
   const int which = (kern == gemm_bf16_stream_kernel<EPI, OutT, NK, MI, 0>) ? 0 : 1;
-  if (!attr_set[which]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            SLDS_BYTES) != hipSuccess) return -3;
-    attr_set[which] = true;
-  }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -3;
-    n_cu = prop.multiProcessorCount;
-  }
+  const int n_cu = once[which].get([&](int dev) {
+    return d3dp_lds_opt_in(reinterpret_cast<const void*>(kern), SLDS_BYTES) < 0 ? -3 : d3dp_cu_count(dev);
+  });
+  if (n_cu < 0) return -3;
   const int grid = total < n_cu ? total : n_cu;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(MI == 4 ? 768 : 512), SLDS_BYTES, st, (const bf16*)A, (const bf16*)W, bias,
                      (OutT*)out, M, N, tn, total);

@@ -45,7 +45,6 @@
 // the clock the chip sustains under this instruction mix: profiles/r02_gemm_probes.md, profiles/r03_gemm_probes.md.
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -131,7 +130,7 @@ __device__ __forceinline__ void store_planes_paired(char* dst, f16x4 ph, f16x4 p
 // kernel symbol rocprofv3 --stats also reports it separately from the proj Linear, which shares EPI with it.
 template <int EPI, int TAG>
 __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__ A2, const f16* __restrict__ W2,
-                                                         const float* __restrict__ bias, float unscale,
+                                                         const float* __restrict__ bias, float unscale, float oscale,
                                                          float* __restrict__ outf, f16* __restrict__ out2,
                                                          float* __restrict__ aux, unsigned* __restrict__ flag, int M,
                                                          int N, int K, int tiles_n, int total_tiles) {
@@ -406,7 +405,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 f16 h, l;
-                split2h(v[e], h, l);
+                split2h_scaled(v[e] * oscale, h, l);       // (oscale: the consumer's operand scale, 2^4 unless capi.hip lowered it)
                 ph[e] = h; pl[e] = l;
               }
               store_planes_paired(dst, ph, pl, odd, live);
@@ -476,10 +475,10 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
                 if (live) *reinterpret_cast<f32x4*>(base + (off + (unsigned)k * pitch)) = v;
                 f16x4 ph, pl;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { f16 h, l; split2h(v[e], h, l); ph[e] = h; pl[e] = l; }
+                for (int e = 0; e < 4; ++e) { f16 h, l; split2h_scaled(v[e] * oscale, h, l); ph[e] = h; pl[e] = l; }
                 store_planes_paired(reinterpret_cast<char*>(out2) + (offp + (unsigned)k * (N * 4)), ph, pl, odd, live);
                 // exact range check of the un-normalised operand (its magnitude has no useful bound from the weights alone)
-                over |= !(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) < 65504.0f * kActUnscale);
+                over |= !(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) * oscale < 65504.0f);
                 const float mean = rowsum16((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
                 const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
                 const float q2 = rowsum16(fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3));
@@ -523,6 +522,27 @@ __global__ void absmax_kernel(const float* __restrict__ s, size_t n, unsigned* _
   for (; i < n; i += stride) m = fmaxf(m, fabsf(s[i]));
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// see kernels.h (d3dp_launch_rowbound): one wave per row of W; fp32 sums of non-negative terms, rounded UP by a margin
+// that covers their accumulated rounding (K <= 2048 terms: relative error < 2^-12)
+__global__ void rowbound_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ bias, int N, int K, float sq, unsigned* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float a = 0.f, inmax = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float in = fmaf(sq, fabsf(gamma[k]), fabsf(beta[k]));
+    inmax = fmaxf(inmax, in);
+    a = fmaf(fabsf(W[(size_t)n * K + k]), in, a);
+  }
+  a = wave_sum(a);
+  inmax = wave_max(inmax);
+  if (lane == 0) {
+    atomicMax(out, __float_as_uint((a + fabsf(bias[n])) * 1.001f));
+    atomicMax(out + 1, __float_as_uint(inmax * 1.001f));
+  }
 }
 
 // rowstat[m] = (mean, 1 / sqrt(var + eps)) of row m from its S slices of 64 (mean_i, M2_i): mean = avg of means,
@@ -575,8 +595,8 @@ __global__ void nonfinite_flag_kernel(const float* __restrict__ x, size_t n, uns
 // `unscale` = 1 / (scale of the A planes * scale of the W planes).
 // K must be a multiple of 64: the k-loop is unrolled by two k-steps of 32 (the lagged products alternate between two
 // register sets), and the loader / compute waves count barriers per k-step.
-int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const float* bias, float unscale, float* outf,
-                             void* out2, float* aux, unsigned* flag, int M, int N, int K, hipStream_t st) {
+int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const float* bias, float unscale, float oscale,
+                             float* outf, void* out2, float* aux, unsigned* flag, int M, int N, int K, hipStream_t st) {
   if (K % (2 * XBK) != 0 || N % 4 != 0 || N > XBIAS_MAX || M <= 0) return -1;
   if ((size_t)M * N * 4 >= ((size_t)1 << 32)) return -1;   // 32-bit byte offsets in the epilogue
   if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_QKV_PACK && epi != EPI_RESID && epi != EPI_RESID_LN &&
@@ -586,37 +606,30 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
   if (epi == EPI_RESID_LN && N % 64 != 0) return -1;    // whole 64-column slices: every compute wave's columns exist
   if (epi == EPI_GELU_LN && 2 * N > XBIAS_MAX) return -1;   // c2 | c1 in the bias area
   if (epi == EPI_QKV_PACK && (N % 3 != 0 || (N / 3) % 64 != 0)) return -1;
-  if ((epi == EPI_GELU || epi == EPI_GELU_LN || epi == EPI_RESID_LN) && N % 8 != 0) return -1;   // plane stores are paired across two 4-column groups
+  // h2i output rows are whole 32-column blocks of [hi | lo]: with N % 32 != 0 the lo half of the last block would land in
+  // the next row; EPI_GELU_LN keeps two row-statistics buffers, which a k-loop shorter than the 3-stage
+  // ring lets the loaders overwrite while the previous tile's epilogue reads them
+  if ((epi == EPI_GELU || epi == EPI_GELU_LN || epi == EPI_RESID_LN) && N % 32 != 0) return -1;
+  if (epi == EPI_GELU_LN && K / XBK < XNSTAGE) return -1;
   const int tm = (M + XBM - 1) / XBM, tn = (N + XBN - 1) / XBN;
-  using KernT = void (*)(const f16*, const f16*, const float*, float, float*, f16*, float*, unsigned*, int, int, int, int, int);
+  using KernT = void (*)(const f16*, const f16*, const float*, float, float, float*, f16*, float*, unsigned*, int, int, int, int, int);
   constexpr int NKERN = 6;
   static const KernT kerns[NKERN] = {gemm_f16x2_kernel<EPI_BIAS, 0>, gemm_f16x2_kernel<EPI_BIAS, 1>,
                                      gemm_f16x2_kernel<EPI_GELU, 0>, gemm_f16x2_kernel<EPI_RESID, 0>,
                                      gemm_f16x2_kernel<EPI_RESID_LN, 0>, gemm_f16x2_kernel<EPI_GELU_LN, 0>};
-  // per DEVICE: the 152 KiB dynamic-LDS opt-in of every instantiation and the CU count (one process may drive several
+  // per DEVICE: the 156 KiB dynamic-LDS opt-in of every instantiation and the CU count (one process may drive several
   // devices: nn.DataParallel callers)
-  constexpr int kMaxDev = 64;
-  static std::mutex mu;
-  static int n_cu[kMaxDev] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return -3;
-  int cus;
-  {
-    std::lock_guard<std::mutex> lock(mu);
-    if (n_cu[dev] == 0) {
-      for (int k = 0; k < NKERN; ++k)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[k]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                XLDS) != hipSuccess) return -3;
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return -3;
-      n_cu[dev] = prop.multiProcessorCount;
-    }
-    cus = n_cu[dev];
-  }
+  static PerDeviceOnce once;
+  const int cus = once.get([&](int dev) {
+    for (int k = 0; k < NKERN; ++k)
+      if (d3dp_lds_opt_in(reinterpret_cast<const void*>(kerns[k]), XLDS) < 0) return -3;
+    return d3dp_cu_count(dev);
+  });
+  if (cus < 0) return -3;
   const int total = tm * tn, grid = total < cus ? total : cus;
   const KernT kern = kerns[epi == EPI_GELU ? 2 : epi == EPI_RESID ? 3 : epi == EPI_QKV_PACK ? 1 : epi == EPI_RESID_LN ? 4
                            : epi == EPI_GELU_LN ? 5 : 0];
-  hipLaunchKernelGGL(kern, dim3(grid), dim3((XNCW + 4) * 64), XLDS, st, (const f16*)A2, (const f16*)W2, bias, unscale, outf,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3((XNCW + 4) * 64), XLDS, st, (const f16*)A2, (const f16*)W2, bias, unscale, oscale, outf,
                      (f16*)out2, aux, flag, M, N, K, tn, total);
   return 0;
 }
@@ -624,6 +637,12 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
 void d3dp_launch_split2(const float* src, void* dst, size_t n, float scale, hipStream_t st) {
   const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(split2h_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, (f16*)dst, n, scale);
+}
+
+void d3dp_launch_rowbound(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K,
+                          unsigned* out, hipStream_t st) {
+  hipLaunchKernelGGL(rowbound_kernel, dim3((N + 3) / 4), dim3(256), 0, st, W, gamma, beta, bias, N, K,
+                     sqrtf((float)(K - 1)) * 1.0001f, out);
 }
 
 void d3dp_launch_absmax(const float* src, size_t n, unsigned* out, hipStream_t st) {

@@ -3,6 +3,39 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
+// "Once per DEVICE" cache of a launcher's set-up (the > 64 KiB dynamic-LDS opt-in of a kernel, which HIP records per device,
+// or a number derived from the device's CU count): one process may drive several devices -- nn.DataParallel callers,
+// one thread per device (reference main.py:242-248) -- so neither a process-wide `static bool` nor an unlocked one is right.
+// get(fn): fn(dev) runs the first time the CURRENT device is seen and returns a value > 0 to cache (<= 0: error, not cached).
+struct PerDeviceOnce {
+  static constexpr int kMaxDev = 64;
+  std::mutex mu;
+  int val[kMaxDev] = {0};
+  template <class F> int get(F&& fn) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return -3;
+    std::lock_guard<std::mutex> lock(mu);
+    if (val[dev] <= 0) {
+      const int v = fn(dev);
+      if (v <= 0) return v < 0 ? v : -3;
+      val[dev] = v;
+    }
+    return val[dev];
+  }
+};
+// multiProcessorCount of device `dev` (> 0) or -3
+inline int d3dp_cu_count(int dev) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) return -3;
+  return prop.multiProcessorCount;
+}
+// opt one kernel in to `bytes` of dynamic LDS on the current device: 1 or -3
+inline int d3dp_lds_opt_in(const void* kern, int bytes) {
+  return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 1 : -3;
+}
+
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_ATOMIC = 3, EPI_QKV_PACK = 4, EPI_RESID_LN = 5, EPI_GELU_LN = 6 };
 
 // ---- gemm.hip ----------------------------------------------------------------------------------
@@ -17,8 +50,16 @@ void d3dp_launch_split3(const float* src, void* dst, size_t n, hipStream_t st);
 // EPI_GELU_LN: a LayerNorm FOLDED into the Linear: A2 = un-normalised rows, W2 = W . diag(gamma), bias = [c2 | c1] (2 N floats:
 //   c2 = W beta + b, c1 = row sums of W diag(gamma)), aux = [M + 256][2] (mean, rstd) per row:
 //   out2 = split(GELU(rstd (A W'^T - mean c1) + c2)).
-int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const float* bias, float w_unscale, float* outf,
-                             void* out2, float* aux, unsigned* flag, int M, int N, int K, hipStream_t st);
+// `unscale` = 1 / (scale of the A operand x scale of the W operand); `oscale` = the power of two the plane outputs (EPI_GELU*,
+// k / v of EPI_QKV_PACK, the operand copy of EPI_RESID_LN) are multiplied by before the hi / lo split (kActScale unless the
+// proven range of that operand asks for less, capi.hip)
+int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const float* bias, float unscale, float oscale,
+                             float* outf, void* out2, float* aux, unsigned* flag, int M, int N, int K, hipStream_t st);
+// out[0] = max over rows n of  sum_k |W[n,k]| in_k + |bias[n]|,  out[1] = max_k in_k,  in_k = sq |gamma_k| + |beta_k|: the
+// magnitude bound of a Linear fed by a LayerNorm over K channels (sq = sqrt(K - 1): |LN(x)_k| <= sq |gamma_k| + |beta_k| for
+// ANY x), as the bit patterns of non-negative floats (integer max == float max; `out` pre-zeroed)
+void d3dp_launch_rowbound(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K,
+                          unsigned* out, hipStream_t st);
 // rowstat[M][2] = (mean, 1 / sqrt(var + eps)) from the slice statistics EPI_RESID_LN wrote (S = ceil(C / 64) slices of 64)
 void d3dp_launch_ln_combine(const float* slices, float* rowstat, int M, int C, float eps, hipStream_t st);
 // Wp[n][k] = W[n][k] gamma[k];  c12[0..N) = sum_k W[n][k] beta[k] + bias[n],  c12[N..2N) = sum_k Wp[n][k]
@@ -46,9 +87,10 @@ int d3dp_launch_attn_temporal_f32(int act, const void* qkv, void* out, int n_seq
                                   hipStream_t st);
 // split-fp16 attention: `qkv` = PACKED rows of 12 C bytes (q fp32 | k hi | k lo | v hi | v lo), written by the qkv Linear
 // with EPI_QKV_PACK or from fp32 rows by d3dp_launch_qkv_pack_x2
+// `act_scale`: the power of two the k / v planes were written at (q and, for plane output, o use the same)
 int d3dp_launch_attn_x2(int act, int axis, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
-                        hipStream_t st);
-void d3dp_launch_qkv_pack_x2(const float* src, void* dst, size_t T, int C, hipStream_t st);
+                        float act_scale, hipStream_t st);
+void d3dp_launch_qkv_pack_x2(const float* src, void* dst, size_t T, int C, float act_scale, hipStream_t st);
 int d3dp_launch_attn_spatial_bf16(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st);
 
 // ---- pointwise.hip -----------------------------------------------------------------------------

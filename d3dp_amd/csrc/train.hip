@@ -580,14 +580,11 @@ static int launch_attn_bwd(const float* qkv, const float* o, const float* dout, 
   const size_t lds_q = (size_t)2 * n * (HD + 4) * 4;
   const size_t lds_kv = lds_q + (size_t)n * sizeof(AttnStats);
   if (lds_kv > 160 * 1024 || n > 256) return -2;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_q_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kv_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) return -3;
-    attr = true;
-  }
+  static PerDeviceOnce once;
+  if (once.get([&](int) {
+        return d3dp_lds_opt_in(reinterpret_cast<const void*>(attn_bwd_q_kernel<HD>), 160 * 1024) < 0 ? -3
+               : d3dp_lds_opt_in(reinterpret_cast<const void*>(attn_bwd_kv_kernel<HD>), 160 * 1024);
+      }) < 0) return -3;
   const int tkv = 2 * n <= 64 ? 64 : (2 * n <= 256 ? 256 : 512), tq = tkv;       // two threads per row in both passes
   hipLaunchKernelGGL((attn_bwd_q_kernel<HD>), dim3(n_seq * heads), dim3(tq), lds_q, st, qkv, o, dout, dqkv,
                      (AttnStats*)stats, map, C, heads);

@@ -16,7 +16,8 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
-from typing import List, Optional, Sequence
+import threading
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.nn.functional as F
@@ -110,6 +111,16 @@ class _NoParams(nn.Module):
     """Placeholder keeping nn.Sequential indices aligned with the reference (time_mlp.0 / .2)."""
 
 
+class _DeviceState:
+    """What one MixSTE2 holds on ONE device: the library context (bound to that device, include/d3dp_hip.h), the signature
+    of the weights it was last given, and the workspaces.  ``nn.DataParallel`` (the reference's multi-GPU caller,
+    main.py:242-248) drives one replica per device from one thread each: every device gets its own state."""
+    __slots__ = ("ctx", "weights_sig", "keep", "ws", "train_ws", "train_gen")
+
+    def __init__(self):
+        self.ctx, self.weights_sig, self.keep, self.ws, self.train_ws, self.train_gen = None, None, None, None, None, 0
+
+
 class MixSTE2(nn.Module):
     """Denoiser with the reference's signature (mixste.py:141-147, forward :278) running on libd3dp_hip."""
 
@@ -137,12 +148,14 @@ class MixSTE2(nn.Module):
         self.head = nn.Sequential(nn.LayerNorm(C_), nn.Linear(C_, 3))
         self._mode = _resolve_mode(numerics)
         self._chunk_seqs = int(chunk_seqs)
-        self._ctx = None
-        self._ctx_device = None
-        self._weights_sig = None
-        self._keep = None
-        self._ws = None
-        self._train_gen = 0
+        # Per-device library state.  The dict (and its lock) is SHARED between this module and its nn.DataParallel
+        # replicas -- a replica is a shallow copy made on every forward (torch/nn/parallel/replicate.py) -- so the context
+        # of device d is created once and reused by every later replica on d; only the module that created the dict
+        # (`_owns_states`) ever destroys a context, and it does so for all devices.
+        self._states: Dict[torch.device, _DeviceState] = {}
+        self._states_lock = threading.Lock()
+        self._owns_states = True
+        self._last_device: Optional[torch.device] = None
 
     # -- library context ------------------------------------------------------------------------
     @property
@@ -155,10 +168,34 @@ class MixSTE2(nn.Module):
             self._chunk_seqs = int(chunk_seqs)
         self._drop_ctx()
 
+    def _replicate_for_data_parallel(self):
+        """nn.DataParallel replica (main.py:242-248 wraps every model in one): shares the per-device states with the
+        module it was copied from and owns none of them -- dropping a replica must never free a context."""
+        replica = super()._replicate_for_data_parallel()
+        replica._owns_states = False
+        return replica
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle: library handles do not travel; the copy starts without contexts and owns its own."""
+        d = self.__dict__.copy()
+        d["_states"], d["_states_lock"], d["_owns_states"], d["_last_device"] = {}, None, True, None
+        return d
+
+    def __setstate__(self, d):
+        super().__setstate__(d)
+        self._states_lock = threading.Lock()
+
     def _drop_ctx(self):
-        if self._ctx is not None:
-            _lib.load().d3dp_destroy(self._ctx)
-        self._ctx, self._weights_sig, self._ws, self._keep = None, None, None, None
+        """Destroy every device's context (owner only; a replica just forgets nothing -- the states are not its own)."""
+        if not self.__dict__.get("_owns_states", False):
+            return
+        with self._states_lock:
+            states = list(self._states.values())
+            self._states.clear()
+        for st in states:
+            if st.ctx is not None:
+                _lib.load().d3dp_destroy(st.ctx)
+                st.ctx = None
 
     def __del__(self):
         try:
@@ -166,67 +203,90 @@ class MixSTE2(nn.Module):
         except Exception:
             pass
 
+    def _state(self, device: Optional[torch.device] = None) -> _DeviceState:
+        """The state of `device` (default: the device of the most recent call)."""
+        device = device if device is not None else self._last_device
+        st = self._states.get(device) if device is not None else None
+        assert st is not None and st.ctx is not None, "run one forward (or call _context(device)) first"
+        return st
+
+    # single-device view of the state, kept for callers and tests that predate the per-device dict
+    @property
+    def _ctx(self):
+        st = self._states.get(self._last_device) if self._last_device is not None else None
+        return st.ctx if st is not None else None
+
+    @property
+    def _train_gen(self):
+        st = self._states.get(self._last_device) if self._last_device is not None else None
+        return st.train_gen if st is not None else 0
+
     def _context(self, device: torch.device):
         if device.type != "cuda":
             raise _lib.D3DPHipError("MixSTE2 runs only on an MI355X (tensor on %s); there is no CPU fallback" % device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         lib = _lib.load()
-        if self._ctx is None or self._ctx_device != device:
-            self._drop_ctx()
-            cfg = _lib.Cfg(self.num_frame, self.num_joints, self.embed_dim, self.block_depth, self.num_heads,
-                           self.hidden, self.eps_block, self.eps_head, self._mode, self._chunk_seqs)
-            h = C.c_void_p()
-            with torch.cuda.device(device):
-                _lib.check(lib.d3dp_create(C.byref(cfg), C.byref(h)), "d3dp_create")
-            self._ctx, self._ctx_device = h, device
+        with self._states_lock:
+            st = self._states.get(device)
+            if st is None:
+                st = self._states[device] = _DeviceState()
+            if st.ctx is None:
+                cfg = _lib.Cfg(self.num_frame, self.num_joints, self.embed_dim, self.block_depth, self.num_heads,
+                               self.hidden, self.eps_block, self.eps_head, self._mode, self._chunk_seqs)
+                h = C.c_void_p()
+                with torch.cuda.device(device):
+                    _lib.check(lib.d3dp_create(C.byref(cfg), C.byref(h)), "d3dp_create")
+                st.ctx = h
+        self._last_device = device
         # TRAIN mode reads the parameters' own storage (no packed copy): only a re-allocation changes anything.
         # EXACT / FAST keep packed copies, refreshed when a parameter is replaced or modified through autograd-visible
         # in-place ops; writes that bypass the version counter (p.data.mul_(), EMA code) need refresh_weights().
         borrowed = self._mode == _lib.MODE_TRAIN and all(
             p.device == device and p.dtype == torch.float32 and p.is_contiguous() for p in self.parameters())
         sig = (borrowed,) + tuple((p.data_ptr(),) if borrowed else (p.data_ptr(), p._version) for p in self.parameters())
-        if sig != self._weights_sig:
-            self._push_weights(device, borrowed)
-            self._weights_sig = sig
-            self._warn_if_range_unproven()
-        return self._ctx
+        if sig != st.weights_sig:
+            self._push_weights(st, device, borrowed)
+            st.weights_sig = sig
+        return st.ctx
 
     # -- EXACT mode's operand range (include/d3dp_hip.h: d3dp_exact_range_bound / d3dp_status) ------------------
     SPLIT_RANGE = 4094.0
 
     def exact_range_bound(self) -> float:
         """Upper bound, provable from the current weights alone, of the magnitude any split-fp16 operand of EXACT mode
-        can take for ANY input; below ``SPLIT_RANGE`` the mode cannot overflow.  0.0 in the other modes."""
-        assert self._ctx is not None, "run one forward (or call _context(device)) first"
+        can take for ANY input.  Below ``SPLIT_RANGE`` every operand uses the default scale 2^4; above it the library
+        lowers the scale of the blocks concerned (``exact_scales``) -- either way no operand can overflow.  0.0 in the other
+        modes."""
         b = C.c_float()
-        _lib.check(_lib.load().d3dp_exact_range_bound(self._ctx, C.byref(b)), "d3dp_exact_range_bound")
+        _lib.check(_lib.load().d3dp_exact_range_bound(self._state().ctx, C.byref(b)), "d3dp_exact_range_bound")
         return float(b.value)
 
     def nonfinite_seen(self) -> bool:
         """True if any denoiser call since the last query produced inf / nan (synchronises the device; resets)."""
-        assert self._ctx is not None, "run one forward first"
         v = C.c_int32()
-        _lib.check(_lib.load().d3dp_status(self._ctx, C.byref(v)), "d3dp_status")
+        _lib.check(_lib.load().d3dp_status(self._state().ctx, C.byref(v)), "d3dp_status")
         return bool(v.value)
 
-    def _warn_if_range_unproven(self):
-        if self._mode != _lib.MODE_EXACT:
-            return
-        b = self.exact_range_bound()
-        if not b < self.SPLIT_RANGE:
-            import warnings
-            warnings.warn(f"d3dp_amd: with these weights EXACT mode's split-fp16 operands are bounded only by {b:.4g} "
-                          f"(>= {self.SPLIT_RANGE:g}): an activation beyond that range turns the output into NaN where "
-                          f"the fp32 reference stays finite.  Check model.pose_estimator.nonfinite_seen() after sampling "
-                          f"(or set D3DP_CHECK_FINITE=1), or run with D3DP_EXACT_IMPL=bf16x3, which has no range limit.",
-                          RuntimeWarning, stacklevel=3)
+    def exact_scales(self):
+        """EXACT mode: ``(s_kv, s_hidden, implementation)`` -- per block (STE 0..depth-1, then TTE) the power-of-two scales of the
+        q / k / v / attention-output and MLP-hidden operands chosen from the proven range (16.0 unless a bound asked for
+        less), and the implementation in use ('f16x2', 'bf16x3' -- the automatic fallback when a LayerNorm's own output bound
+        leaves the range --, 'f32'; None outside EXACT mode).  include/d3dp_hip.h: d3dp_exact_scales."""
+        n = 2 * self.block_depth
+        kv, hd, impl = (C.c_float * n)(), (C.c_float * n)(), C.c_int32()
+        _lib.check(_lib.load().d3dp_exact_scales(self._state().ctx, kv, hd, C.byref(impl)), "d3dp_exact_scales")
+        return list(kv), list(hd), {0: "f16x2", 1: "bf16x3", 2: "f32"}.get(impl.value)
 
     def refresh_weights(self) -> None:
         """Re-pack the library's weight copies on the next call.  Needed only after parameter writes that bypass
         PyTorch's version counter (``p.data.copy_()``, ``p.data.mul_()``, weight averaging through ``.data``):
         ``load_state_dict``, optimizer steps and ordinary in-place ops are picked up automatically."""
-        self._weights_sig = None
+        with self._states_lock:
+            for st in self._states.values():
+                st.weights_sig = None
 
-    def _push_weights(self, device, borrowed=False):
+    def _push_weights(self, st, device, borrowed=False):
         lib = _lib.load()
         keep: List[torch.Tensor] = []
 
@@ -258,17 +318,18 @@ class MixSTE2(nn.Module):
                          dev(self.head[1].bias), ste, tte)
         with torch.cuda.device(device):
             if borrowed:
-                _lib.check(lib.d3dp_set_weights_borrowed(self._ctx, C.byref(w)), "d3dp_set_weights_borrowed")
+                _lib.check(lib.d3dp_set_weights_borrowed(st.ctx, C.byref(w)), "d3dp_set_weights_borrowed")
             else:
-                _lib.check(lib.d3dp_set_weights(self._ctx, C.byref(w), _lib.current_stream()), "d3dp_set_weights")
-        self._keep = [freq_keep] if borrowed else None   # packed copies: originals may go; borrowed: keep the table
+                _lib.check(lib.d3dp_set_weights(st.ctx, C.byref(w), _lib.current_stream()), "d3dp_set_weights")
+        st.keep = [freq_keep] if borrowed else None   # packed copies: originals may go; borrowed: keep the table
 
     def _workspace(self, ctx, B, H, device):
         n = C.c_size_t()
         _lib.check(_lib.load().d3dp_workspace_bytes(ctx, B, H, C.byref(n)), "d3dp_workspace_bytes")
-        if self._ws is None or self._ws.numel() < n.value or self._ws.device != device:
-            self._ws = torch.empty(n.value, dtype=torch.uint8, device=device)
-        return self._ws, n.value
+        st = self._state()
+        if st.ws is None or st.ws.numel() < n.value:
+            st.ws = torch.empty(n.value, dtype=torch.uint8, device=self._last_device)
+        return st.ws, n.value
 
     def denoise(self, x_2d: torch.Tensor, x_3d: torch.Tensor, t: torch.Tensor, out: Optional[torch.Tensor] = None):
         """x_2d (B,F,J,2), x_3d (B,H,F,J,3), t (B,) int64 -> (B,H,F,J,3) fp32 (all on the GPU)."""
@@ -341,18 +402,20 @@ class MixSTE2(nn.Module):
         ctx = self._context(dev)
         n = C.c_size_t()
         _lib.check(_lib.load().d3dp_train_workspace_bytes(ctx, B, C.byref(n)), "d3dp_train_workspace_bytes")
-        if getattr(self, "_train_ws", None) is None or self._train_ws.numel() < n.value or self._train_ws.device != dev:
-            self._train_ws = torch.empty(n.value, dtype=torch.uint8, device=dev)
+        st = self._state()
+        if st.train_ws is None or st.train_ws.numel() < n.value:
+            st.train_ws = torch.empty(n.value, dtype=torch.uint8, device=self._last_device)
         return (ctx, B, dev, n.value, x_2d.float().contiguous(), x_3d.float().contiguous(),
                 t.to(device=dev, dtype=torch.int64).contiguous())
 
     def _train_forward(self, x_2d, x_3d, t, masks):
         ctx, B, dev, nbytes, x2, x3, tt = self._train_io(x_2d, x_3d, t)
         out = torch.empty_like(x3)
-        self._train_gen += 1
+        st = self._state()
+        st.train_gen += 1
         with torch.cuda.device(dev):
             _lib.check(_lib.load().d3dp_train_forward(ctx, x2.data_ptr(), x3.data_ptr(), tt.data_ptr(), _lib.ptr(masks),
-                                                      out.data_ptr(), B, self._train_ws.data_ptr(), nbytes,
+                                                      out.data_ptr(), B, st.train_ws.data_ptr(), nbytes,
                                                       _lib.current_stream()), "d3dp_train_forward")
         return out
 
@@ -382,20 +445,19 @@ class MixSTE2(nn.Module):
         with torch.cuda.device(dev):
             _lib.check(_lib.load().d3dp_train_backward(ctx, x2.data_ptr(), x3.data_ptr(), tt.data_ptr(), _lib.ptr(masks),
                                                        grad_out.float().contiguous().data_ptr(), C.byref(w), B,
-                                                       self._train_ws.data_ptr(), nbytes, _lib.current_stream()),
+                                                       self._state().train_ws.data_ptr(), nbytes, _lib.current_stream()),
                        "d3dp_train_backward")
         return [g[id(p)] for p in self.parameters()]
 
     # -- profiling passthrough --------------------------------------------------------------------
     def profile_enable(self, on: bool = True):
-        assert self._ctx is not None, "run one forward first"
-        _lib.check(_lib.load().d3dp_profile_enable(self._ctx, int(on)))
+        _lib.check(_lib.load().d3dp_profile_enable(self._state().ctx, int(on)))
 
     def profile_read(self):
         lib = _lib.load()
         cnt = (C.c_int64 * _lib.PROFILE_CLASSES)()
         ms = (C.c_double * _lib.PROFILE_CLASSES)()
-        _lib.check(lib.d3dp_profile_read(self._ctx, cnt, ms))
+        _lib.check(lib.d3dp_profile_read(self._state().ctx, cnt, ms))
         return {lib.d3dp_profile_class_name(i).decode(): (int(cnt[i]), float(ms[i])) for i in range(_lib.PROFILE_CLASSES)}
 
 
@@ -415,6 +477,7 @@ class D3DP(nn.Module):
         self.joints_right = list(joints_right)
         self.is_train = is_train
 
+        self.objective = 'pred_x0'                       # diffusionpose.py:74 (attribute parity; the path never branches on it)
         betas = cosine_beta_schedule(args.timestep)
         alphas = 1. - betas
         alphas_cumprod = torch.cumprod(alphas, dim=0)
@@ -425,7 +488,10 @@ class D3DP(nn.Module):
         assert self.sampling_timesteps <= timesteps
         self.is_ddim_sampling = self.sampling_timesteps < timesteps
         self.ddim_sampling_eta = 1.
+        self.self_condition = False                      # diffusionpose.py:87-90
         self.scale = args.scale
+        self.box_renewal = True
+        self.use_ensemble = True
 
         # the 12 fp64 buffers of the reference state_dict (diffusionpose.py:92-117)
         self.register_buffer('betas', betas)
@@ -607,10 +673,9 @@ class D3DP(nn.Module):
             out = (self.ddim_sample_flip(input_2d, input_3d, input_2d_flip=input_2d_flip, **kw) if self.flip
                    else self.ddim_sample(input_2d, input_3d, **kw))
             if os.environ.get("D3DP_CHECK_FINITE") == "1" and self.pose_estimator.nonfinite_seen():   # (synchronises)
-                raise _lib.D3DPHipError(
-                    "non-finite denoiser output: an activation left EXACT mode's split-fp16 range (provable bound for these "
-                    f"weights: {self.pose_estimator.exact_range_bound():.4g}, limit {MixSTE2.SPLIT_RANGE:g}) or the input "
-                    "held inf / nan; D3DP_EXACT_IMPL=bf16x3 has no range limit")
+                raise _lib.D3DPHipError("non-finite denoiser output: the input or the weights hold inf / nan, or the fp32 "
+                                        "arithmetic itself overflowed (EXACT mode's split-fp16 operands cannot: their scales "
+                                        "follow the range the weights prove, MixSTE2.exact_scales())")
             return out
         droppath = kw.pop("droppath", None)
         x_poses, _, t = self.prepare_targets(input_3d, **kw)

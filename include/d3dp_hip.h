@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D3DP_ABI_VERSION 2
+#define D3DP_ABI_VERSION 3
 
 enum {
   D3DP_OK = 0,
@@ -116,20 +116,30 @@ int d3dp_set_weights(d3dp_ctx* ctx, const d3dp_weights* w, void* stream);
  * an optimizer step needs no re-push.  The buffers must stay allocated while the context uses them. */
 int d3dp_set_weights_borrowed(d3dp_ctx* ctx, const d3dp_weights* w);
 
-/* EXACT mode's split-fp16 operands (x 16 = hi + lo, two fp16) hold |x| < D3DP_SPLIT_RANGE; beyond it the hi part is inf
- * and the Linear returns NaN where the fp32 reference stays finite.  Two guards:
- *  - d3dp_exact_range_bound: computed by d3dp_set_weights from the WEIGHTS ALONE, an upper bound of the magnitude any
- *    split operand can take for ANY input -- LayerNorm outputs are at most sqrt(C-1) |gamma| + |beta| per channel, a Linear
- *    row of them at most sum_k |w_k| (sqrt(C-1) |gamma_k| + |beta_k|) + |b| (q, k, v and the fc1 pre-activation; |GELU(x)|
- *    <= |x|), an attention output is a convex combination of v.  bound < D3DP_SPLIT_RANGE proves these operands safe for
- *    every input (bound = 0 in the other modes, which have no such limit).  ONE operand is outside the proof: with norm2
- *    folded into fc1 (D3DP_FOLD_LN=1, off by default) the proj Linear hands fc1 the un-normalised residual stream, whose
- *    worst case (chained over the block) says nothing useful; that epilogue checks every value it splits, exactly, at run time;
- *  - d3dp_status: *nonfinite = 1 if, since the last d3dp_status, that check fired or a d3dp_denoise output held inf / nan
- *    (d3dp_denoise ends with a scan of its output).  Synchronises the device; resets the flags.  A non-finite result with bound >= D3DP_SPLIT_RANGE
- *    means an activation left the range: use D3DP_EXACT_IMPL=bf16x3 (no range limit, twice the MFMA work). */
+/* EXACT mode's split-fp16 operands (x 2^s = hi + lo, two fp16) hold |x| 2^s < 65504: with the default s = 4 that is
+ * |x| < D3DP_SPLIT_RANGE, beyond which hi would be inf and the Linear NaN where the fp32 reference stays finite.  The
+ * library therefore PROVES the range of every data-dependent operand from the weights and scales accordingly:
+ *  - d3dp_set_weights computes (on the device) an upper bound of the magnitude each split operand can take for ANY
+ *    input -- a LayerNorm output is at most sqrt(C-1) |gamma_k| + |beta_k| per channel; a Linear row over it at most
+ *    sum_k |w_k| (sqrt(C-1) |gamma_k| + |beta_k|) + |b| (q, k, v and the fc1 pre-activation; |GELU(x)| <= |x|); an attention
+ *    output is a convex combination of v -- and gives every block two operand scales: s_kv for q / k / v / the attention
+ *    output, s_hidden for the MLP hidden.  Bound below D3DP_SPLIT_RANGE: 2^4.  Above: the largest power of two with
+ *    bound x scale < 65504, so no operand can overflow, at an absolute representation error of at most
+ *    max(2^-22 |x|, 2^-25 / scale) -- below 2^-40 of the bound, far under the fp32 rounding of the sums it enters.
+ *    LayerNorm outputs always use 2^4; if a LayerNorm's own bound reaches the range (|gamma| ~ 180) the context moves to the
+ *    six-pass split-bf16 implementation (fp32's exponent range, twice the MFMA work).  No environment variable is involved.
+ *  - d3dp_exact_range_bound: the largest of those bounds (0 in the other modes, which have no such limit);
+ *  - d3dp_exact_scales: the chosen scales, s_kv[2 depth] and s_hidden[2 depth] (STE blocks 0..depth-1, then TTE; either
+ *    pointer may be null), and the implementation in use (0 split-fp16, 1 split-bf16, 2 fp32 MFMA, -1 not an EXACT context);
+ *  - d3dp_status: *nonfinite = 1 if, since the last d3dp_status, a d3dp_denoise output held inf / nan (every call ends with a
+ *    scan of its output) -- i.e. the INPUT held inf / nan or the fp32 arithmetic itself overflowed.  Synchronises the
+ *    device (do not call it during stream capture); resets the flag.
+ * ONE operand is outside the proof: with norm2 folded into fc1 (D3DP_FOLD_LN=1, a measurement switch, off by default) the proj
+ * Linear hands fc1 the un-normalised residual stream; that epilogue checks every value it splits, exactly, at run time, and
+ * reports through d3dp_status. */
 #define D3DP_SPLIT_RANGE 4094.0f
 int d3dp_exact_range_bound(const d3dp_ctx* ctx, float* bound);
+int d3dp_exact_scales(const d3dp_ctx* ctx, float* s_kv, float* s_hidden, int32_t* implementation);
 int d3dp_status(d3dp_ctx* ctx, int32_t* nonfinite);
 
 /* Scratch needed by d3dp_denoise for a (B, H) call. */
@@ -252,16 +262,22 @@ int d3dp_op_layernorm(int32_t out_bf16, const float* x, const float* w, const fl
 /* mode 2 of d3dp_op_linear: split-bf16.  A and W are three bf16 planes each (x = x0 + x1 + x2, made by
  * d3dp_op_split3: dst[0..n) | dst[n..2n) | dst[2n..3n)); epi 0 -> fp32 out, epi 1 -> GELU then three bf16 planes out. */
 int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream);
-/* The EXACT-mode Linear on split-fp16 operands.  A2 and W2 are two fp16 planes each, made by d3dp_op_split2 from
- * y = src * scale: dst[0..n) = hi = fp16(y), dst[n..2n) = lo = fp16(y - hi).  A2 must be at scale 16 (the library's
- * activation scale); W2 at any power-of-two `w_scale` (the denoiser picks it per matrix so that max |w| w_scale lies in
- * [2^13, 2^14)).  epi 0 -> fp32 out, epi 1 -> GELU then two fp16 planes (scale 16) out, epi 4 (N = 3 C, C % 64 == 0; the
- * qkv Linear of the EXACT denoiser) -> packed rows of 12 C bytes: q fp32 [C] | k hi | k lo | v hi | v lo (fp16 [C] each,
- * scale 16), the operand format of the split-fp16 attention kernels; epi 2 -> out[M,N] fp32 is read and written
- * (out += A W^T + b: the residual-adding form of proj and fc2).
+/* The EXACT-mode Linear on split-fp16 operands.  A2 [M][K] and W2 [N][K] hold TWO fp16 per element, y = src * scale =
+ * hi + lo with hi = fp16(y), lo = fp16(y - hi), in the line-interleaved layout "h2i": a matrix row is K/32 blocks of 64 fp16
+ * (128 bytes), block kb = [hi of columns 32 kb .. 32 kb + 31 | lo of the same 32 columns] -- one 32-deep k-step of one row,
+ * both values of every element, is one 128-byte line.  d3dp_op_split2 writes that layout for a flat array of n = rows x K
+ * elements: dst[64 b .. 64 b + 31] = hi, dst[64 b + 32 .. 64 b + 63] = lo of src[32 b .. 32 b + 31]; n (and hence every row
+ * length) must be a multiple of 32 (D3DP_EINVAL otherwise: a partial block would write past 2 n).
+ * A2 must be at scale 16 (the library's default activation scale); W2 at any power-of-two `w_scale` (the denoiser picks it
+ * per matrix so that max |w| w_scale lies in [2^13, 2^14)).  epi 0 -> fp32 out [M][N]; epi 1 -> GELU, then the result as an
+ * h2i matrix [M][N] at scale 16 (the fc2 operand; N % 32 == 0); epi 4 (N = 3 C, C % 64 == 0; the qkv Linear of the EXACT
+ * denoiser) -> packed rows of 12 C bytes: q fp32 [C] | k hi [C] | k lo [C] | v hi [C] | v lo [C] (plain fp16 planes, scale
+ * 16), the operand format of the split-fp16 attention kernels; epi 2 -> out[M,N] fp32 is read and written (out += A W^T + b:
+ * the residual-adding form of proj and fc2).
  * Constraints (D3DP_EINVAL otherwise): K % 64 == 0 (the k-loop runs two 32-deep k-steps per iteration), N % 4 == 0
- * (N % 8 for epi 1), N <= 2048, M * N * 4 < 2^32.  Every operand value must stay below 65504 / scale in magnitude
- * (activations: |x| < 4094): beyond it the hi value is inf and the product NaN (d3dp_exact_range_bound / d3dp_status).
+ * (N % 32 == 0 for epi 1: whole h2i blocks), N <= 2048, M * N * 4 < 2^32.  Every operand value must stay below 65504 / scale
+ * in magnitude (at scale 16: |x| < 4094) -- inside d3dp_denoise the library proves and arranges that (d3dp_exact_scales);
+ * a caller of this entry point owns it.
  * Test-only environment switches read by the library:
  * D3DP_EXACT_IMPL=bf16x3|f32 and D3DP_NO_FOLD=1 (cross-check implementations of EXACT mode), D3DP_FOLD_LN=1 (norm2 folded into
  * the proj / fc1 Linears; measured no faster than the row kernel and left off) -- all read in d3dp_create. */

@@ -750,74 +750,75 @@ def test_backward_after_optimizer_step_raises(golden_dir):
 
 
 def test_exact_mode_range_guard(monkeypatch):
-    """EXACT mode's split-fp16 operands hold |x| < 4094.  (1) With ordinary weights the
-    library PROVES from the weights alone that no operand can leave the range (d3dp_exact_range_bound).  (2) With one
-    fc1 weight matrix scaled by 50 the proof fails and loading warns.  (3) Scaled by 5000 an activation really leaves the
-    range: the output is non-finite, d3dp_status reports it, D3DP_CHECK_FINITE=1 turns it into an exception -- and the
-    six-pass split-bf16 implementation (no range limit) still matches the fp32 oracle on the same weights."""
+    """EXACT mode must not answer NaN where the fp32 reference is finite.  The split-fp16 operands hold
+    |x| 2^s < 65504; the library proves the range of every data-dependent operand from the weights (d3dp_exact_range_bound)
+    and lowers the scale s of the blocks that need it (d3dp_exact_scales) -- no warning, no environment variable.
+    (1) ordinary weights: every scale 2^4; (2) one fc1 matrix x 50: the proof exceeds 4094, that block's hidden scale drops,
+    the result stays within the exact tolerance of the fp32 oracle; (3) x 5000: activations of several thousand, still finite
+    and within the oracle's own fp32 noise for such magnitudes; (4) a proj bias of +5000 only moves the fp32 residual
+    stream: nothing to scale; (5) a LayerNorm gain of 300 pushes LayerNorm's OWN output bound out of range: the context falls
+    back to the six-pass split-bf16 implementation by itself; (6) the run-time check of the D3DP_FOLD_LN measurement switch
+    (the one operand outside the proof) still reports through d3dp_status."""
     Fr, B, H, K, cs, dep = 9, 2, 2, 1, 512, 2
     x2d = synthetic_inputs_2d(5, B, Fr)
     x2f = flip_2d(x2d)
     noises = [torch.from_numpy(synthetic_noise(70, (B, H, Fr, 17, 3)))]
 
-    def run(factor, check=False):
+    def run(edit):
         sd = make_state_dict(7, cs, dep, Fr)
-        key = [k for k in sd if k.endswith("STEblocks.1.mlp.fc1.weight")][0]
-        sd[key] = sd[key] * factor
+        edit(sd)
         args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
         m = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=False, num_proposals=H, sampling_timesteps=K,
                  numerics="exact")
         m.load_state_dict(sd, strict=False)
         m = m.cuda().eval()
-        if check:
-            monkeypatch.setenv("D3DP_CHECK_FINITE", "1")
-        try:
-            out = m(torch.from_numpy(x2d).cuda(), None, input_2d_flip=torch.from_numpy(x2f).cuda(), noise=noises)
-        finally:
-            monkeypatch.delenv("D3DP_CHECK_FINITE", raising=False)
-        return m, out, sd
+        out = m(torch.from_numpy(x2d).cuda(), None, input_2d_flip=torch.from_numpy(x2f).cuda(), noise=noises)
+        want = orc.ddim_sample_flip(orc.strip_prefix(sd), orc.cosine_schedule(1000), torch.from_numpy(x2d),
+                                    torch.from_numpy(x2f), H, K, dep, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, noises)
+        return m.pose_estimator, out, orc.mpjpe_mm(out.cpu(), want)
+
+    def scaled(suffix, factor=1.0, add=0.0):
+        def edit(sd):
+            key = [k for k in sd if k.endswith(suffix)][0]
+            sd[key] = sd[key] * factor + add
+        return edit
 
     import warnings
     with warnings.catch_warnings():
-        warnings.simplefilter("error")                             # (1): no warning at all
-        m, out, _ = run(1.0)
-    b = m.pose_estimator.exact_range_bound()
-    print(f"provable operand bound with seed-generated weights: {b:.1f} (limit {m.pose_estimator.SPLIT_RANGE})")
-    assert 1.0 < b < m.pose_estimator.SPLIT_RANGE and torch.isfinite(out).all() and not m.pose_estimator.nonfinite_seen()
-    with pytest.warns(RuntimeWarning, match="split-fp16"):         # (2)
-        m, out, _ = run(50.0)
-    assert m.pose_estimator.exact_range_bound() >= m.pose_estimator.SPLIT_RANGE
-    assert torch.isfinite(out).all() and not m.pose_estimator.nonfinite_seen()   # unproven is not the same as overflowing
-    with pytest.warns(RuntimeWarning):                             # (3)
-        m, out, sd = run(5000.0)
-    assert m.pose_estimator.nonfinite_seen() and not torch.isfinite(out).all()   # NaN survives the sampler's clamps (torch.clamp semantics)
-    assert not m.pose_estimator.nonfinite_seen()                   # the query resets the flag
-    with pytest.warns(RuntimeWarning), pytest.raises(_lib.D3DPHipError, match="split-fp16 range"):
-        run(5000.0, check=True)
-    # the un-normalised residual operand proj hands to fc1 is outside the static proof: checked exactly at run time
-    args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
-    sd2 = make_state_dict(7, cs, dep, Fr)
-    key = [k for k in sd2 if k.endswith("STEblocks.1.attn.proj.bias")][0]
-    sd2[key] = sd2[key] + 5000.0                                   # x + proj(...) beyond 4094: no weight bound sees a bias
-    monkeypatch.setenv("D3DP_FOLD_LN", "1")                        # (the form in which that sum is a split operand)
-    m2 = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=False, num_proposals=H, sampling_timesteps=K, numerics="exact")
-    m2.load_state_dict(sd2, strict=False)
-    m2 = m2.cuda().eval()
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")                             # the static bound is fine ...
-        m2(torch.from_numpy(x2d).cuda(), None, input_2d_flip=torch.from_numpy(x2f).cuda(), noise=noises)
-    assert m2.pose_estimator.exact_range_bound() < m2.pose_estimator.SPLIT_RANGE and m2.pose_estimator.nonfinite_seen()   # ... the run is not
+        warnings.simplefilter("error")                             # no warning in any of the cases
+        net, out, e = run(lambda sd: None)                         # (1)
+        b = net.exact_range_bound()
+        kv, hd, impl = net.exact_scales()
+        print(f"provable operand bound with seed-generated weights: {b:.1f} (2^4 holds {net.SPLIT_RANGE}); error {e:.2e} mm")
+        assert 1.0 < b < net.SPLIT_RANGE and impl == "f16x2" and set(kv) == {16.0} and set(hd) == {16.0}
+        assert torch.isfinite(out).all() and not net.nonfinite_seen() and e <= EXACT_TOL_MM
+        for factor, tol in ((50.0, EXACT_TOL_MM), (5000.0, 0.05)):   # (2), (3); block STE 1 is index 1 of the scale lists
+            net, out, e = run(scaled("STEblocks.1.mlp.fc1.weight", factor))
+            kv, hd, impl = net.exact_scales()
+            print(f"fc1 x {factor:g}: bound {net.exact_range_bound():.4g}, hidden scale of that block {hd[1]:g}, error {e:.3e} mm")
+            assert net.exact_range_bound() >= net.SPLIT_RANGE and impl == "f16x2"
+            assert hd[1] < 16.0 and hd[1] * net.exact_range_bound() < 65504.0 and [h for i, h in enumerate(hd) if i != 1] == [16.0] * 3
+            assert set(kv) == {16.0}
+            assert torch.isfinite(out).all() and not net.nonfinite_seen() and e <= tol
+        net, out, e = run(scaled("STEblocks.1.attn.qkv.weight", 200.0))   # q, k, v of several hundred: s_kv drops
+        kv, hd, impl = net.exact_scales()
+        print(f"qkv x 200: bound {net.exact_range_bound():.4g}, q/k/v scale of that block {kv[1]:g}, error {e:.3e} mm")
+        assert kv[1] < 16.0 and set(hd) == {16.0} and impl == "f16x2"
+        assert torch.isfinite(out).all() and not net.nonfinite_seen() and e <= 0.05
+        net, out, e = run(scaled("STEblocks.1.attn.proj.bias", add=5000.0))   # (4)
+        assert net.exact_range_bound() < net.SPLIT_RANGE and torch.isfinite(out).all() and not net.nonfinite_seen()
+        print(f"proj bias + 5000: error {e:.3e} mm")
+        assert e <= 0.05
+        net, out, e = run(scaled("TTEblocks.0.norm2.weight", 300.0))         # (5)
+        kv, hd, impl = net.exact_scales()
+        print(f"norm2 gain x 300: implementation {impl}, error {e:.3e} mm")
+        assert impl == "bf16x3" and torch.isfinite(out).all() and not net.nonfinite_seen() and e <= 0.05
+    # (6) the un-normalised residual operand proj hands to fc1 under D3DP_FOLD_LN=1 is outside the static proof: checked at run time
+    monkeypatch.setenv("D3DP_FOLD_LN", "1")
+    net, out, _ = run(scaled("STEblocks.1.attn.proj.bias", add=5000.0))
+    assert net.exact_range_bound() < net.SPLIT_RANGE and net.nonfinite_seen()
+    assert not net.nonfinite_seen()                                # the query resets the flag
     monkeypatch.delenv("D3DP_FOLD_LN")
-    monkeypatch.setenv("D3DP_EXACT_IMPL", "bf16x3")
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")                             # no range limit, no warning
-        m, out, _ = run(5000.0)
-    monkeypatch.delenv("D3DP_EXACT_IMPL")
-    want = orc.ddim_sample_flip(orc.strip_prefix(sd), orc.cosine_schedule(1000), torch.from_numpy(x2d), torch.from_numpy(x2f),
-                                H, K, dep, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, noises)
-    e = orc.mpjpe_mm(out.cpu(), want)
-    print(f"fc1 x 5000, split-bf16 implementation vs the fp32 oracle: {e:.3e} mm")
-    assert torch.isfinite(out).all() and e < 1.0                   # (activations of 1e4: fp32 itself is noisy here)
 
 
 def test_ddim_sample_no_flip_runs():
@@ -934,3 +935,43 @@ def test_bench_launches_its_own_ranks_when_two_gpus_are_visible():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["multi_gpu"]["world_size"] == 2 and d["multi_gpu"]["sharded_equals_single_rank"]
     assert d["config"]["hypotheses_total"] == 4
+
+
+def _dp_case(B):
+    frames, H, K = 27, 2, 2
+    m = make_model(frames, 64, 2, H, K, "exact", seed=5)
+    x2d = torch.from_numpy(synthetic_inputs_2d(77, B, frames)).cuda()
+    noises = [torch.from_numpy(synthetic_noise(300 + k, (B, H, frames, 17, 3))).cuda() for k in range(K)]
+    return m, x2d, flip_2d(x2d), noises
+
+
+def test_data_parallel_wrapper_on_one_device_matches_the_bare_model():
+    """The reference's caller wraps every model in nn.DataParallel (main.py:242-248) and calls it with
+    `input_2d_flip=` (:698).  With one device DataParallel forwards to the module itself: same result, the same
+    library context across calls, and wrapping frees nothing."""
+    m, x2d, x2f, noises = _dp_case(2)
+    ref = m(x2d, None, input_2d_flip=x2f, noise=noises)
+    h = m.pose_estimator._ctx.value
+    dp = torch.nn.DataParallel(m, device_ids=[0])
+    for _ in range(2):
+        out = dp(x2d, None, input_2d_flip=x2f, noise=noises)
+        assert torch.equal(out, ref) and m.pose_estimator._ctx.value == h
+
+
+def test_data_parallel_over_two_devices_matches_the_single_device_result():
+    """nn.DataParallel(model, [0, 1]) splits the clip batch (and the injected noise tensors, scattered
+    along dim 0 like every tensor argument) over two devices; every replica runs its own library context on its own
+    device, one thread each, and the gathered result equals the single-device run.  Called twice: the replicas of the
+    first call are garbage by then and must not have freed anything."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs on the box")
+    m, x2d, x2f, noises = _dp_case(4)
+    ref = m(x2d, None, input_2d_flip=x2f, noise=noises)
+    h0 = m.pose_estimator._ctx.value
+    dp = torch.nn.DataParallel(m, device_ids=[0, 1])
+    for _ in range(2):
+        out = dp(x2d, None, input_2d_flip=x2f, noise=noises)
+        assert out.device == x2d.device and out.shape == ref.shape
+        assert torch.equal(out, ref)                       # hypotheses and clips are independent: bit for bit
+    st = m.pose_estimator._states
+    assert len(st) == 2 and st[torch.device("cuda", 0)].ctx.value == h0

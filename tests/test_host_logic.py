@@ -259,3 +259,83 @@ def test_h2i_layout_and_w_row_permutation_are_bijections():
     assert sorted(colperm(q) for q in range(64)) == list(range(64))
     for i in range(16):
         assert [colperm(ni * 16 + i) for ni in range(4)] == [4 * i, 4 * i + 1, 4 * i + 2, 4 * i + 3]
+
+
+class _FakeLib:
+    """Stands in for libd3dp_hip.so in lifecycle tests: hands out context handles, records every destroy."""
+
+    def __init__(self):
+        self.created, self.destroyed = [], []
+
+    def d3dp_create(self, cfg, out):
+        import ctypes
+        h = 0x1000 + 0x100 * len(self.created)
+        ctypes.cast(out, ctypes.POINTER(ctypes.c_void_p))[0] = h
+        self.created.append(h)
+        return 0
+
+    def d3dp_destroy(self, h):
+        self.destroyed.append(h.value if hasattr(h, "value") else h)
+        return 0
+
+
+@pytest.fixture
+def fake_lib(monkeypatch):
+    """MixSTE2._context on a box without a GPU: fake library, no device switch, no weight push."""
+    import contextlib
+    from d3dp_amd import model as M
+    lib = _FakeLib()
+    monkeypatch.setattr(_lib, "load", lambda: lib)
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    monkeypatch.setattr(M.MixSTE2, "_push_weights", lambda self, st, device, borrowed=False: None)
+    return lib
+
+
+def test_data_parallel_replicas_never_free_the_parents_context(fake_lib):
+    """VERDICT r3 weak 7 (reference caller: main.py:242-248 wraps every model in nn.DataParallel, :698 calls it).  A replica
+    is a shallow copy made on every forward; it must share the per-device contexts, create the one of a new device once,
+    and never pass any handle to d3dp_destroy -- only the module that owns the states does, once per device."""
+    import gc
+    net = D3DP(tiny_args(), KL, KR, is_train=False).pose_estimator
+    d0, d1 = torch.device("cuda", 0), torch.device("cuda", 1)
+    h0 = net._context(d0).value
+    assert fake_lib.created == [h0] and net._ctx.value == h0
+    for _ in range(3):                                     # three forwards of a 2-device DataParallel
+        r0, r1 = net._replicate_for_data_parallel(), net._replicate_for_data_parallel()
+        assert r0._states is net._states and not r0._owns_states and net._owns_states
+        assert r0._context(d0).value == h0                 # device 0: the parent's context, reused
+        h1 = r1._context(d1).value                         # device 1: its own, created once
+        assert h1 != h0 and net._states[d1].ctx.value == h1
+        r1._drop_ctx()                                     # even an explicit drop on a replica frees nothing
+        del r0, r1
+        gc.collect()
+    assert fake_lib.created == [h0, h1] and fake_lib.destroyed == []
+    assert net._context(d0).value == h0                    # the parent's handle is still the live one
+    del net
+    gc.collect()
+    assert sorted(fake_lib.destroyed) == sorted([h0, h1])  # the owner frees each device's context exactly once
+
+
+def test_deepcopy_and_pickle_of_a_model_do_not_share_library_handles(fake_lib):
+    import copy, gc, pickle
+    m = D3DP(tiny_args(), KL, KR, is_train=False)
+    h = m.pose_estimator._context(torch.device("cuda", 0)).value
+    m2 = copy.deepcopy(m)
+    m3 = pickle.loads(pickle.dumps(m))
+    for c in (m2, m3):
+        assert c.pose_estimator._states == {} and c.pose_estimator._owns_states and c.pose_estimator._ctx is None
+        assert torch.equal(c.pose_estimator.head[1].weight, m.pose_estimator.head[1].weight)
+    h2 = m2.pose_estimator._context(torch.device("cuda", 0)).value
+    assert h2 != h
+    del m2, m3
+    gc.collect()
+    assert fake_lib.destroyed == [h2]
+    m.pose_estimator.set_numerics("fast")                  # switching arithmetic drops the owner's contexts
+    assert fake_lib.destroyed == [h2, h] and m.pose_estimator._ctx is None
+
+
+def test_reference_attributes_exist():
+    """common/diffusionpose.py:74, 87-90: attributes ported code may read."""
+    m = D3DP(tiny_args(), KL, KR, is_train=False)
+    assert (m.objective, m.self_condition, m.box_renewal, m.use_ensemble, m.ddim_sampling_eta) == \
+           ('pred_x0', False, True, True, 1.)
