@@ -12,8 +12,11 @@ and reported beside it as `fast_mode`, never as `value`.
 
 `python bench.py --gpus N` launches its own N ranks (re-executes itself under torch.distributed.run) when it is not
 already inside a torchrun job; every rank samples its own H=20 hypotheses of the same clips (weak scaling, no
-data-path collective during sampling) and one RCCL all-gather assembles (B,K,N*20,F,17,3) on every rank inside the
-timed region.  Inputs are resident in HBM before the timed region starts.  Prints ONE JSON line on rank 0.
+data-path collective during sampling); inside the timed region one RCCL all-gather hands every rank all N*20 hypotheses
+and the fused JPMA kernel aggregates them where RCCL left them (north_star: "all-gather over xGMI before JPMA
+aggregation", reference main.py:700-718).  Inputs are resident in HBM before the timed region starts.  Prints ONE JSON
+line on rank 0; besides the headline it carries `configs` (BASELINE configs[1] and the configs[4] training step, timed in
+the same run) and, at N > 1, `multi_gpu` (all-gather -> JPMA and the 12x smaller winners exchange side by side).
 """
 from __future__ import annotations
 
@@ -55,7 +58,7 @@ def build_model(H, K, numerics, chunk_seqs, frames=F_):
     return m.cuda().eval()
 
 
-def cpu_baseline(budget_s=24.0):
+def cpu_baseline(budget_s=24.0, full=False):
     """The CPU oracle (a port of the reference path; the reference's own files cannot travel to the GPU box and
     hard-code CUDA) timed on this host's cores on a BOUNDED sample of the workload: F=243, B=1, H=1, K=1 (= 2 denoiser
     calls of the K=10 unit's 20).  The thread count is swept (oversubscribing a 128-thread host halves the rate) and the
@@ -100,7 +103,31 @@ def cpu_baseline(budget_s=24.0):
                       f"{len(times)} runs at the best thread count = {t_k1:.3f} s; x10 DDIM steps to the K=10 unit",
             "host_cpus": ncpu, "thread_sweep_s": {str(k): round(v, 3) for k, v in sweep.items()},
             "gflops": 2 * flops_per_denoiser_call() / t_k1 / 1e9,
-            "full_config_run": full_config_cpu_run()}
+            "full_config_run": full_config_cpu_run_live(best) if full else full_config_cpu_run()}
+
+
+def full_config_cpu_run_live(threads):
+    """`--cpu-full`: BASELINE configs[1] (B=4 H=5 K=5 F=243, 58.97 TFLOP) through the CPU oracle on this host, in full,
+    un-extrapolated (about three minutes on 16-32 threads)."""
+    import torch
+    from d3dp_amd.weights import H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, flip_2d, make_state_dict, synthetic_inputs_2d, synthetic_noise
+    from oracle import d3dp_oracle as orc
+    B, H, K = 4, 5, 5
+    p = orc.strip_prefix(make_state_dict(7, C_, DEPTH, F_))
+    x2d = synthetic_inputs_2d(1234, B, F_)
+    nz = [torch.from_numpy(synthetic_noise(1 + k, (B, H, F_, J_, 3))) for k in range(K)]
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        orc.ddim_sample_flip(p, orc.cosine_schedule(1000), torch.from_numpy(x2d), torch.from_numpy(flip_2d(x2d)), H, K, DEPTH,
+                             H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, nz)
+    dt = time.perf_counter() - t0
+    torch.set_num_threads(old)
+    fl = 2 * K * flops_per_denoiser_call() * B * H
+    return {"source": "measured in this run (--cpu-full)", "workload": f"BASELINE configs[1]: B={B} H={H} K={K} F=243",
+            "threads": threads, "seconds": dt, "gflops": fl / dt / 1e9, "hypothesis_clips_per_s_K5_units": B * H / dt,
+            "k10_units_per_s": B * H / dt / 2.0}
 
 
 def full_config_cpu_run():
@@ -158,14 +185,28 @@ def device_sync(dev):
         torch.cuda.synchronize()
 
 
+def jpma_inputs(x2d, frames, dev):
+    """Synthetic inputs of the consumer (main.py:706-718): root trajectories about 4 m in front of a Human3.6M camera
+    (intrinsics of d3dp_amd.cli's synthetic source) and the 2D keypoints the hypotheses are scored against."""
+    import torch
+    B = x2d.shape[0]
+    t = torch.linspace(0, 2.0, frames, device=dev)[None, :, None] + torch.arange(B, device=dev)[:, None, None] * 0.37
+    traj = torch.cat((0.3 * torch.sin(t), 0.1 * torch.cos(t), 4.0 + 0.2 * torch.sin(0.5 * t)), dim=-1)[:, :, None]   # (B,F,1,3)
+    cam = torch.tensor([2.29, 2.287, 0.0254, 0.0289, -0.2070, 0.2477, -0.0030, -0.0009, -0.0014], device=dev)
+    return traj.float().contiguous(), cam, x2d
+
+
 def timed_steps(model, x2d, x2f, steps, warmup, gen, gather, dev="cuda"):
+    """`gather` (N > 1): the step ends with the exchange and its consumer -- all-gather of every rank's hypotheses, JPMA on
+    the result (dist.jpma_allgather) -- and returns (local predictions, aggregated poses, selected hypothesis)."""
     import torch
     import torch.distributed as dist
-    from d3dp_amd.dist import all_gather_hypotheses
+    from d3dp_amd.dist import jpma_allgather
+    traj, cam, gt2 = jpma_inputs(x2d, x2d.shape[1], dev) if gather else (None, None, None)
 
     def one():
         preds = model(x2d, None, input_2d_flip=x2f, generator=gen)
-        return all_gather_hypotheses(preds) if gather else preds
+        return (preds,) + tuple(jpma_allgather(preds, traj, cam, gt2)) if gather else preds
 
     for _ in range(warmup):
         one()
@@ -184,6 +225,42 @@ def timed_steps(model, x2d, x2f, steps, warmup, gen, gather, dev="cuda"):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt, out
+
+
+def exchange_report(local_preds, x2d, world, dev, dry, reps=5):
+    """The two forms of the hypothesis exchange + JPMA, timed side by side on this rank's sampler output (median of
+    `reps`; barrier + device sync around each): (a) all-gather of the full stacks -> fused JPMA on the gathered layout,
+    (b) local winners -> all-gather of 5 floats per joint -> combine.  Both must select the same poses."""
+    import torch
+    import torch.distributed as dist
+    from d3dp_amd.dist import all_gather_raw, jpma_allgather, jpma_sharded
+    traj, cam, gt2 = jpma_inputs(x2d, x2d.shape[1], dev)
+
+    def clock(fn):
+        ts = []
+        for _ in range(reps):
+            device_sync(dev); dist.barrier()
+            t0 = time.perf_counter()
+            r = fn()
+            device_sync(dev)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return sorted(ts)[len(ts) // 2], r
+
+    ag_ms, _ = clock(lambda: all_gather_raw(local_preds))
+    full_ms, (agg_a, sel_a) = clock(lambda: jpma_allgather(local_preds, traj, cam, gt2))
+    red_ms, (agg_b, sel_b) = clock(lambda: jpma_sharded(local_preds, traj, cam, gt2))
+    same = bool(torch.equal(agg_a, agg_b)) and bool(torch.equal(sel_a.long(), sel_b.long()))
+    B, K, Hl, Fr, J = local_preds.shape[:5]
+    full_bytes, red_bytes = local_preds.numel() * 4, B * K * Fr * J * 5 * 4
+    return {"backend": "gloo (dry run)" if dry else "nccl (RCCL)", "world_size": world,
+            "timed_region": "sampling + all_gather + JPMA (dist.jpma_allgather) on every rank",
+            "all_gather_bytes_per_rank": full_bytes, "all_gather_ms": ag_ms,
+            "all_gather_gbps_per_rank_out": full_bytes * (world - 1) / (ag_ms * 1e-3) / 1e9,
+            "allgather_then_jpma": {"bytes_per_rank": full_bytes, "ms": full_ms,
+                                    "what": "ncclAllGather of (B,K,H_local,F,17,3), d3dp_jpma_gathered reads the result in place"},
+            "winners_exchange": {"bytes_per_rank": red_bytes, "ms": red_ms, "traffic_ratio": full_bytes / red_bytes,
+                                 "what": "d3dp_jpma_winners locally, ncclAllGather of (B,K,F,17,5), d3dp_jpma_combine"},
+            "both_select_the_same_poses": same}
 
 
 class DryRunSampler:
@@ -247,6 +324,7 @@ def roofline_from_profile(prof, numerics, B, H, K):
          "mfma_passes_per_product": passes, "matrix_pipe_work_tflops": ach * passes,
          "matrix_pipe_work_frac_of_dense_peak": ach * passes / PEAK_MFMA_TFLOPS,
          "traffic": None, "launches": n, "avg_launch_ms": ms / max(n, 1), "algorithmic_gflop_per_launch": fl / max(n, 1) / 1e9,
+         "mean_rows_per_launch": T_all * 2 * DEPTH / max(n, 1),
          "peak_note": note}
     if numerics == "exact":
         r["matrix_pipe_work_frac_of_measured_mfma_stream"] = ach * EXACT_PASSES / (MFMA_STREAM_PFLOPS * 1e3)
@@ -262,12 +340,14 @@ def lib_sha256():
     return h.hexdigest()
 
 
-def attach_traffic(roof, numerics, chunk_seqs):
-    """HBM bytes per launch of the dominant kernel come from SEPARATE rocprofv3 --pmc passes (FETCH_SIZE doubled per
-    MI355X_MICROARCH.md, WRITE_SIZE) stored under profiles/ next to the hash of the library they were measured on: the
-    number is printed only when this run uses that very build."""
+def attach_traffic(roof, numerics, chunk_seqs, batch=None):
+    """HBM bytes per launch of the dominant kernel, and the whole step's HBM traffic and matrix-pipe busy fraction, come from
+    SEPARATE rocprofv3 --pmc passes (FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES /
+    GRBM_GUI_ACTIVE; tools/gpu_round.sh) stored under profiles/ next to the hash of the library they were measured on.
+    They are printed only when this run uses that very build AND launches the kernel over the same number of rows (within
+    5 %): counters of another build or another pass size are not this run's traffic."""
     sha, tj, seen = lib_sha256(), None, []
-    for name in ("r03_gemm_traffic.json", "r02_gemm_traffic.json"):        # newest first; keyed by the library's hash
+    for name in ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json"):   # newest first; keyed by the library's hash
         tpath = os.path.join(REPO, "profiles", name)
         if os.path.exists(tpath):
             cand = json.load(open(tpath)).get(numerics, {}).get(roof["kernel"])
@@ -281,12 +361,26 @@ def attach_traffic(roof, numerics, chunk_seqs):
     if tj is None:
         roof["traffic_note"] = f"profiles/{seen[0]} was measured on a different build of libd3dp_hip.so: not reported"
         return
+    rows_file, rows_now = float(tj.get("mean_rows_per_launch", 0)), roof["mean_rows_per_launch"]
+    if not rows_file or abs(rows_file - rows_now) > 0.05 * rows_now:
+        roof["traffic_note"] = (f"profiles/{seen[-1]} holds counters at {rows_file:.0f} rows per launch; this run launches "
+                                f"{rows_now:.0f}: not reported")
+        return
     roof["traffic"] = tj["hbm_bytes_per_launch"]
-    roof["traffic_note"] = (f"HBM bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) at a mean of {tj.get('mean_rows_per_launch', 0):.0f} "
-                            f"rows per launch, separate rocprofv3 --pmc passes of this build inside the denoiser; algorithmic "
+    roof["traffic_note"] = (f"HBM bytes/launch (FETCH_SIZE x2 + WRITE_SIZE) at a mean of {rows_file:.0f} rows per launch (this "
+                            f"run: {rows_now:.0f}), separate rocprofv3 --pmc passes of this build inside the denoiser; algorithmic "
                             f"bytes/launch {tj['algorithmic_bytes_per_launch']} (read amplification "
                             f"{tj.get('read_amplification', float('nan')):.2f}x: the weight matrix is re-fetched by every XCD "
                             f"every tile round); hardware MFMA busy {tj.get('mfma_util_hw', float('nan')):.3f} of kernel cycles")
+    spath = os.path.join(REPO, "profiles", "r04_step_pmc.json")
+    if os.path.exists(spath):
+        st = json.load(open(spath)).get(numerics)
+        if st and st.get("lib_sha256") == sha and (batch is None or st.get("batch") == batch):
+            roof["hbm_tb_per_step"] = st["hbm_tb_per_step"]
+            roof["mfma_busy_hw"] = st["mfma_busy_hw"]
+            roof["step_counters_note"] = ("whole step, every kernel: HBM bytes (FETCH_SIZE x2 + WRITE_SIZE) and sum of "
+                                          "SQ_VALU_MFMA_BUSY_CYCLES / 1024 over sum of GRBM_GUI_ACTIVE / 8, one rocprofv3 --pmc "
+                                          f"pass per counter set of this build at --batch {st.get('batch')} (profiles/r04_step_pmc_{numerics}.md)")
 
 
 def profile_step(model, x2d, x2f, gen):
@@ -296,6 +390,78 @@ def profile_step(model, x2d, x2f, gen):
     prof = pe.profile_read()
     pe.profile_enable(False)
     return prof
+
+
+def other_configs(numerics, gen, with_cpu=True):
+    """The BASELINE configs the headline does not time, in the same run (VERDICT r3 missing 3):
+    configs[1] -- F=243 H=5 K=5 B=4 through the same sampler (5 steps after 1 warm-up), and
+    configs[4] -- one training step (q_sample + MixSTE2 forward / backward, MPJPE loss, DropPath on; F=243 H=1 B=4)."""
+    import torch
+    from d3dp_amd import D3DP
+    from d3dp_amd.weights import H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, flip_2d, make_state_dict, synthetic_inputs_2d, synthetic_noise
+    out = {}
+    B, H, K = 4, 5, 5
+    x2d_np = synthetic_inputs_2d(1234, B, F_)
+    x2d, x2f = torch.from_numpy(x2d_np).cuda(), torch.from_numpy(flip_2d(x2d_np)).cuda()
+    m = build_model(H, K, numerics, 0)
+    dt, _ = timed_steps(m, x2d, x2f, 5, 1, gen, gather=False)
+    fl = 2 * K * flops_per_denoiser_call() * B * H
+    out["c2_sampler"] = {"workload": f"BASELINE configs[1]: ddim_sample_flip F=243 B={B} H={H} K={K} flip-TTA, numerics={numerics}",
+                         "value": B * H * 5 / dt, "unit": "hypothesis-clips/s (K=5 units)", "ms_per_step": dt / 5 * 1e3, "steps": 5,
+                         "warmup": 1, "whole_path_tflops": fl * 5 / dt / 1e12,
+                         "whole_path_frac_of_mfma_peak": fl * 5 / dt / 1e12 / PEAK_MFMA_TFLOPS}
+    del m
+    torch.cuda.empty_cache()
+    # ---- configs[4]: the training step
+    args = SimpleNamespace(number_of_frames=F_, test_time_augmentation=True, timestep=1000, scale=1.0, cs=C_, dep=DEPTH)
+    sd = make_state_dict(7, C_, DEPTH, F_)
+    mt = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=True)
+    mt.load_state_dict(sd, strict=False)
+    mt = mt.cuda().train()
+    x2 = torch.from_numpy(synthetic_inputs_2d(901, B, F_)).cuda()
+    gt = torch.from_numpy(synthetic_noise(902, (B, F_, J_, 3))).cuda() * 0.3
+    gt[:, :, 0] = 0
+
+    def step():
+        mt.zero_grad(set_to_none=True)
+        pred = mt(x2, gt)                                  # prepare_targets (q_sample) + MixSTE2 train branch, DropPath on
+        loss = torch.mean(torch.norm(pred - gt, dim=-1))   # loss.py:6-13
+        loss.backward(loss.clone().detach())               # main.py:393
+        return loss
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dtt = (time.perf_counter() - t0) / n
+    tfl = 3 * B * flops_per_denoiser_call() / 1e12            # forward + 2x backward (SURVEY 8 D4)
+    tr = {"workload": "BASELINE configs[4]: q_sample + MixSTE2 fwd/bwd + MPJPE loss, F=243 H=1 B=4, DropPath on, every gradient",
+          "ms_per_step": dtt * 1e3, "steps": n, "warmup": 2, "algorithmic_tflop_per_step": tfl, "tflops": tfl / dtt,
+          "frac_of_mfma_peak": tfl / dtt / PEAK_MFMA_TFLOPS, "arithmetic": mt.pose_estimator.train_arithmetic()
+          if hasattr(mt.pose_estimator, "train_arithmetic") else "fp32 MFMA"}
+    del mt
+    torch.cuda.empty_cache()
+    if with_cpu:
+        from oracle import d3dp_oracle as orc
+        po = {k: v.clone().requires_grad_(True) for k, v in orc.strip_prefix(sd).items()}
+        tt = torch.tensor([3, 250, 640, 999])
+        xp = orc.prepare_targets(orc.cosine_schedule(1000), gt.cpu(), tt, torch.from_numpy(synthetic_noise(903, (B, F_, J_, 3))))
+        old = torch.get_num_threads()
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        t0 = time.perf_counter()
+        pr = orc.mixste_forward(po, x2.cpu(), xp, tt, DEPTH, droppath=None)
+        lo = torch.mean(torch.norm(pr - gt.cpu(), dim=-1))
+        lo.backward(lo.clone().detach())
+        tc = time.perf_counter() - t0
+        tr["cpu_oracle_autograd"] = {"seconds": tc, "threads": torch.get_num_threads(), "tflops": tfl / tc,
+                                     "what": "the same step through torch autograd over the CPU oracle (no DropPath), one run"}
+        torch.set_num_threads(old)
+    out["c5_train_step"] = tr
+    return out
 
 
 def relaunch_under_torchrun(n):
@@ -324,6 +490,8 @@ def main():
     ap.add_argument("--no-other-leg", action="store_true", help="skip timing the other numerics mode")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs[1] and the training step)")
+    ap.add_argument("--cpu-full", action="store_true", help="run the un-extrapolated BASELINE configs[1] CPU leg live (minutes)")
     ap.add_argument("--dist-dry-run", type=int, default=0, metavar="N",
                     help="no GPU needed: drive the N-rank control flow of this file (self-launch, WORLD_SIZE check, shard "
                          "check, timed loop with the all-gather, MAX-reduce, multi_gpu block) over gloo with a CPU "
@@ -358,7 +526,12 @@ def main():
     sharding_ok = shard_check(rank, world, a.numerics, dev, make) if world > 1 else None
     model = DryRunSampler(H, K, frames) if dry else build_model(H, K, a.numerics, a.chunk_seqs)
     dt, out = timed_steps(model, x2d, x2f, a.steps, a.warmup, gen, gather=world > 1, dev=dev)
-    assert out.shape == (B, K, H * world, frames, J_, 3) and bool(torch.isfinite(out).all())
+    if world > 1:
+        local_preds, agg, sel = out
+        assert agg.shape == (B, K, frames, J_, 3) and bool(torch.isfinite(agg).all()) and int(sel.max()) < H * world
+    else:
+        local_preds = out
+    assert local_preds.shape == (B, K, H, frames, J_, 3) and bool(torch.isfinite(local_preds).all())
     units = B * H * world * a.steps
     value = units / dt
     flop_per_unit = 2 * K * flops_per_denoiser_call()
@@ -383,29 +556,20 @@ def main():
     }
     if world > 1:
         import torch.distributed as dist
-        from d3dp_amd.dist import all_gather_hypotheses
-        local_preds = out[:, :, rank * H:(rank + 1) * H].contiguous()
-        device_sync(dev); dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            all_gather_hypotheses(local_preds)
-        device_sync(dev)
-        ag_ms = (time.perf_counter() - t0) / 5 * 1e3
         flag = torch.tensor([1 if sharding_ok else 0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        res["multi_gpu"] = {"backend": "gloo (dry run)" if dry else "nccl (RCCL)", "world_size": dist.get_world_size(),
-                            "all_gather_bytes_per_rank": local_preds.numel() * 4, "all_gather_ms": ag_ms,
-                            "all_gather_gbps_per_rank_out": local_preds.numel() * 4 * (world - 1) / (ag_ms * 1e-3) / 1e9,
-                            "sharded_equals_single_rank": bool(flag.item()),
-                            "shard_check": "F=27 B=2 H_local=2 K=2: N ranks on sliced global noise == 1 rank with H=2N, torch.equal"}
+        res["multi_gpu"] = exchange_report(local_preds, x2d, world, dev, dry)
+        res["multi_gpu"].update({"sharded_equals_single_rank": bool(flag.item()),
+                                 "shard_check": "F=27 B=2 H_local=2 K=2: N ranks on sliced global noise == 1 rank with H=2N, torch.equal"})
         assert bool(flag.item()), "N-rank sampling does not reproduce the 1-rank run"
+        assert res["multi_gpu"]["both_select_the_same_poses"], "the winners exchange and all-gather -> JPMA disagree"
 
     if rank == 0 and not a.no_profile:
         # per-kernel HIP-event timing (on the launch stream = torch's current stream) over ONE extra untimed step
         prof = profile_step(model, x2d, x2f, gen)
         total = sum(ms for _, ms in prof.values())
         res["roofline"] = roofline_from_profile(prof, a.numerics, B, H, K)
-        attach_traffic(res["roofline"], a.numerics, a.chunk_seqs)
+        attach_traffic(res["roofline"], a.numerics, a.chunk_seqs, B)
         res["kernel_time_share"] = {k: round(ms / total, 4) for k, (_, ms) in prof.items() if ms > 0}
         res["kernel_ms_per_step"] = {k: round(ms, 3) for k, (_, ms) in prof.items() if ms > 0}
 
@@ -417,7 +581,7 @@ def main():
     if rank == 0 and world == 1 and not dry:
         if not a.no_other_leg:
             other = "fast" if a.numerics == "exact" else "exact"
-            del model
+            model = None
             torch.cuda.empty_cache()
             mo = build_model(H, K, other, a.chunk_seqs)
             st, wu = max(1, min(a.steps, 5)), max(1, min(a.warmup, 2))
@@ -430,14 +594,16 @@ def main():
             if not a.no_profile:
                 po = profile_step(mo, x2d, x2f, gen)
                 leg["roofline"] = roofline_from_profile(po, other, B, H, K)
-                attach_traffic(leg["roofline"], other, a.chunk_seqs)
+                attach_traffic(leg["roofline"], other, a.chunk_seqs, B)
                 leg["kernel_ms_per_step"] = {k: round(ms, 3) for k, (_, ms) in po.items() if ms > 0}
             res[other + "_mode"] = leg
             del mo
         if not a.no_parity:
             res["parity"] = quick_parity()
+        if not a.no_configs:
+            res["configs"] = other_configs(a.numerics, gen, with_cpu=not a.no_cpu_baseline)
         if not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(full=a.cpu_full)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "d3dp_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.POINTER(Weights), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "d3dp_jpma": (C.c_int, [C.c_void_p] * 9 + [C.c_int32] * 6 + [C.c_void_p]),
+    "d3dp_jpma_gathered": (C.c_int, [C.c_void_p] * 9 + [C.c_int32] * 7 + [C.c_void_p]),
     "d3dp_clip_count": (C.c_int, [C.c_int32, C.c_int32]),
     "d3dp_clip_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_void_p]),

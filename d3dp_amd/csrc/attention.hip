@@ -701,6 +701,8 @@ __device__ __forceinline__ void store_o_x2(const f32x4 (&o)[4], float inv, void*
 // behind vmcnt(0) and (b) marks the instruction as a FLAT access of two address spaces, after which it stops counting
 // and turns EVERY vector-memory wait of the kernel into vmcnt(0) -- both would serialise the pipeline below, whose
 // ordering is carried by explicit counted waits and barriers instead.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"          // (the expected "clobber list contains reserved registers" note for m0)
 __device__ __forceinline__ void lds_dma16(const char* g, const char* lds) {
   const unsigned la = (unsigned)(__UINTPTR_TYPE__)LPTR(lds);
   // m0 is declared clobbered (the compiler answers with "clobber list contains reserved registers" and
@@ -708,6 +710,7 @@ __device__ __forceinline__ void lds_dma16(const char* g, const char* lds) {
   // hand-counted pipeline
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 // 16-byte global load the compiler does not track (it would wait for it with counts that ignore the LDS-DMA operations
 // queued behind it, i.e. far too early): the caller waits with wait_vmcnt and then passes the registers through settle().
@@ -777,7 +780,8 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
       lds_dma16(gj + 2 * C, img + PLANE + pc * 1024);
     }
   };
-  f32x4 qr[TPW][4];                                    // raw query fragments of the next problem
+  f32x4 qr[TPW][4] = {};                               // raw query fragments of the next problem (zero: a wave whose
+                                                       // second tile does not exist still runs the paired score path on it)
   auto load_q_raw = [&](const char* row0, int head) {
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {

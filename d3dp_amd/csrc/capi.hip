@@ -704,6 +704,19 @@ int d3dp_jpma(const float* pred, const float* traj, const float* cam, const floa
   return D3DP_OK;
 }
 
+int d3dp_jpma_gathered(const float* gathered, const float* traj, const float* cam, const float* gt2d, const float* gt3d,
+                       float* agg, int32_t* sel, float* err_sel, float* err_min, int32_t R, int32_t B, int32_t K,
+                       int32_t H_local, int32_t F, int32_t J, int32_t zero_root, void* stream) {
+  if (!gathered || !traj || !cam || !gt2d || !agg || R < 1 || B < 1 || K < 1 || H_local < 1)
+    return fail(D3DP_EINVAL, "d3dp_jpma_gathered: bad argument");
+  if ((err_sel || err_min) && !gt3d) return fail(D3DP_EINVAL, "d3dp_jpma_gathered: error outputs need gt3d");
+  LAUNCH_TRY(d3dp_launch_jpma(gathered, traj, cam, gt2d, gt3d, agg, sel, err_sel, err_min, nullptr, nullptr, nullptr, 0, B,
+                              K, R * H_local, F, J, zero_root ? 0 : -1, 0, (hipStream_t)stream, H_local,
+                              (size_t)B * K * H_local * F * J * 3));
+  HIP_TRY(hipGetLastError());
+  return D3DP_OK;
+}
+
 int d3dp_jpma_ex(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d, float* agg,
                  int32_t* sel, float* err_sel, float* err_min, float* jbest, float* mean, int32_t B, int32_t K, int32_t H,
                  int32_t F, int32_t J, int32_t root_joint, int32_t linear_projection, void* stream) {

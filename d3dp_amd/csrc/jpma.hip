@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void jpma_kernel(const float* __restrict__ pre
                                                    int* __restrict__ sel, float* __restrict__ err_sel,
                                                    float* __restrict__ err_min, float* __restrict__ win,
                                                    float* __restrict__ jbest, float* __restrict__ mean, int h_offset,
-                                                   int B, int K, int H, int F, int J, int root_joint, int linear) {
+                                                   int B, int K, int H, int F, int J, int root_joint, int linear,
+                                                   int h_inner, size_t outer_stride) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t FJ = (size_t)F * J, total = (size_t)B * K * FJ;
   if (i >= total) return;
@@ -57,11 +58,14 @@ __global__ __launch_bounds__(256) void jpma_kernel(const float* __restrict__ pre
   const float g2u = gt2d[(b * FJ + fj) * 2], g2v = gt2d[(b * FJ + fj) * 2 + 1];
   float g3[3] = {0.f, 0.f, 0.f};
   if (gt3d != nullptr) { g3[0] = gt3d[(b * FJ + fj) * 3]; g3[1] = gt3d[(b * FJ + fj) * 3 + 1]; g3[2] = gt3d[(b * FJ + fj) * 3 + 2]; }
-  const float* p = pred + (bk * H * FJ + fj) * 3;
+  // hypothesis h = r h_inner + hl lives at pred[r outer_stride + ((bk h_inner + hl) FJ + fj) 3]: h_inner = H (one contiguous
+  // (B,K,H,F,J,3) tensor) or the per-rank count of an all-gather result (R,B,K,H_local,F,J,3) consumed in place
+  const float* p = pred + (bk * h_inner * FJ + fj) * 3;
   float best2 = INFINITY, bx = 0.f, by = 0.f, bz = 0.f, best3 = 0.f, min3 = INFINITY;
   float mx = 0.f, my = 0.f, mz = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;      // pose of the smallest 3D error; running sum
   int bh = 0;
-  for (int h = 0; h < H; ++h, p += FJ * 3) {
+  for (int h = 0, hl = 0; h < H; ++h, ++hl, p += FJ * 3) {
+    if (hl == h_inner) { hl = 0; p += outer_stride - (size_t)h_inner * FJ * 3; }      // next rank's block
     float x[3] = {p[0], p[1], p[2]};
     if (j == root_joint) { x[0] = 0.f; x[1] = 0.f; x[2] = 0.f; }          // main.py:700 (joint 0), main_3dhp.py:777 (14)
     const float a[3] = {add(x[0], tr[0]), add(x[1], tr[1]), add(x[2], tr[2])};   // main.py:706-707
@@ -94,9 +98,12 @@ __global__ __launch_bounds__(256) void jpma_kernel(const float* __restrict__ pre
 
 int d3dp_launch_jpma(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d,
                      float* agg, int* sel, float* err_sel, float* err_min, float* win, float* jbest, float* mean,
-                     int h_offset, int B, int K, int H, int F, int J, int root_joint, int linear, hipStream_t st) {
+                     int h_offset, int B, int K, int H, int F, int J, int root_joint, int linear, hipStream_t st,
+                     int h_inner, size_t outer_stride) {
+  if (h_inner <= 0) h_inner = H;
+  if (H % h_inner != 0) return -1;
   const size_t total = (size_t)B * K * F * J;
   hipLaunchKernelGGL(jpma_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pred, traj, cam, gt2d, gt3d,
-                     agg, sel, err_sel, err_min, win, jbest, mean, h_offset, B, K, H, F, J, root_joint, linear);
+                     agg, sel, err_sel, err_min, win, jbest, mean, h_offset, B, K, H, F, J, root_joint, linear, h_inner, outer_stride);
   return 0;
 }

@@ -126,7 +126,8 @@ int d3dp_launch_q_sample(const float* x0, const float* noise, const double* a, c
 // ---- jpma.hip ----------------------------------------------------------------------------------
 int d3dp_launch_jpma(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d,
                      float* agg, int* sel, float* err_sel, float* err_min, float* win, float* jbest, float* mean,
-                     int h_offset, int B, int K, int H, int F, int J, int root_joint, int linear, hipStream_t st);
+                     int h_offset, int B, int K, int H, int F, int J, int root_joint, int linear, hipStream_t st,
+                     int h_inner = 0, size_t outer_stride = 0);   // (h_inner, outer_stride): see jpma_kernel; 0 = contiguous H
 
 // ---- capi.hip helpers shared with caller.hip ---------------------------------------------------------------------
 int d3dp_set_error(int code, const char* msg);        // records the message for d3dp_last_error(), returns code

@@ -17,9 +17,18 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> tuple:
+RCCL_ENV = ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_SOCKET_IFNAME", "NCCL_IB_DISABLE", "RCCL_MSCCL_ENABLE",
+            "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "MASTER_ADDR", "MASTER_PORT", "RANK", "LOCAL_RANK", "WORLD_SIZE")
+
+
+def init_from_env(backend: Optional[str] = None, timeout_s: float = 180.0) -> tuple:
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (set by torch.distributed.run).
-    Returns (rank, world_size, local_rank).  No-op for a single process."""
+    Returns (rank, world_size, local_rank).  No-op for a single process.
+
+    The rendezvous and the first collective are bounded by ``timeout_s`` and a failure names the environment RCCL reads:
+    on this ROCm stack cross-process device memory needs dmabuf IPC (``HSA_ENABLE_IPC_MODE_LEGACY=0``, exported here when
+    unset -- without it RCCL dies in hipIpcGetMemHandle), and a wrong MASTER_ADDR shows up as a silent hang otherwise."""
+    import datetime
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -28,11 +37,26 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+        try:
+            if backend == "nccl":
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                if torch.cuda.device_count() <= local:
+                    raise RuntimeError(f"LOCAL_RANK={local} but only {torch.cuda.device_count()} device(s) visible")
+                torch.cuda.set_device(local)
+                dist.init_process_group(backend, device_id=torch.device("cuda", local), **kw)
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)                         # the first collective builds the RCCL communicator
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
+            else:
+                dist.init_process_group(backend, **kw)
+        except Exception as e:
+            env = ", ".join(f"{k}={os.environ[k]}" for k in RCCL_ENV if k in os.environ)
+            raise RuntimeError(f"d3dp_amd.dist: rank {rank}/{world} could not join the {backend} process group within "
+                               f"{timeout_s:.0f} s: {type(e).__name__}: {e}\n  environment: {env}\n  (RCCL over xGMI needs one "
+                               f"visible GPU per rank and HSA_ENABLE_IPC_MODE_LEGACY=0; rendezvous on 127.0.0.1)") from e
     return rank, world, local
 
 
@@ -53,19 +77,63 @@ def shard_noise(noise: Optional[Sequence[torch.Tensor]], rank: int, world: int) 
     return [n[:, sl].contiguous() for n in noise]
 
 
+def all_gather_raw(preds_local: torch.Tensor, group=None) -> torch.Tensor:
+    """(B, K, H_local, F, J, 3) on every rank -> (R, B, K, H_local, F, J, 3) on every rank: exactly what ONE ncclAllGather
+    (RCCL) leaves, rank-major, not a byte moved afterwards.  Hypothesis h = r H_local + hl.  The consumers below read this
+    layout in place (d3dp_jpma_gathered); `gathered_view` presents it with the reference's axis order as a view."""
+    src = preds_local.contiguous()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return src[None]
+    world = dist.get_world_size(group)
+    gathered = torch.empty((world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(gathered.view(world * src.shape[0], *src.shape[1:]), src, group=group)
+    return gathered
+
+
+def gathered_view(gathered: torch.Tensor) -> torch.Tensor:
+    """(R, B, K, H_local, F, J, 3) -> (B, K, R, H_local, F, J, 3): a VIEW with the hypothesis axis split as (rank, local).
+    Reductions over hypotheses (min / mean over dims (2, 3)) need no copy; a flat H axis does (`all_gather_hypotheses`)."""
+    return gathered.permute(1, 2, 0, 3, 4, 5, 6)
+
+
 def all_gather_hypotheses(preds_local: torch.Tensor, group=None) -> torch.Tensor:
-    """(B, K, H_local, F, J, 3) on every rank -> (B, K, H_total, F, J, 3) on every rank, rank-major along H.
-    One ncclAllGather (RCCL) per batch; a no-op without an initialised process group."""
+    """(B, K, H_local, F, J, 3) on every rank -> (B, K, H_total, F, J, 3) on every rank, rank-major along H: the tensor the
+    reference's caller would hold (main.py:698).  One all-gather plus ONE COPY (a flat hypothesis axis cannot be a view of
+    the rank-major result): 158.6 MB per rank at configs[3] -- use `jpma_allgather`, which consumes the all-gather result
+    in place, when JPMA is what follows.  A no-op without an initialised process group."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return preds_local
-    world = dist.get_world_size(group)
-    B, K, Hl = preds_local.shape[:3]
-    src = preds_local.contiguous()
-    gathered = torch.empty((world * B,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
-    dist.all_gather_into_tensor(gathered, src, group=group)      # rank-major concatenation along dim 0
-    # (world, B, K, Hl, ...) -> (B, K, world*Hl, ...)
-    return gathered.view(world, B, K, Hl, *src.shape[3:]).permute(1, 2, 0, 3, 4, 5, 6).reshape(
-        B, K, world * Hl, *src.shape[3:])
+    g = all_gather_raw(preds_local, group)
+    R, B, K, Hl = g.shape[:4]
+    return gathered_view(g).reshape(B, K, R * Hl, *g.shape[4:])
+
+
+def jpma_allgather(preds_local: torch.Tensor, traj: torch.Tensor, cam: torch.Tensor, gt_2d: torch.Tensor,
+                   zero_root: bool = True, group=None):
+    """north_star's exchange: RCCL all-gather of every rank's hypotheses, then JPMA (reference main.py:700-718,
+    common/loss.py:54-76) -- with the fused HIP kernel reading the all-gather result where RCCL left it
+    (d3dp_jpma_gathered; no permute, no copy).  Returns (aggregated poses (B,K,F,J,3), global hypothesis index (B,K,F,J))
+    on every rank, equal bit for bit to `jpma_sharded` and to JPMA over the flat (B,K,H_total,F,J,3) tensor."""
+    g = all_gather_raw(preds_local, group)
+    R, B, K, Hl, Fr, J, _ = g.shape
+    if g.is_cuda:
+        from . import _lib
+        lib = _lib.load()
+        g = g.to(torch.float32)
+        traj = traj.to(torch.float32).reshape(B, Fr, 3).contiguous()
+        cam = cam.to(device=g.device, dtype=torch.float32).reshape(-1)[:9].contiguous()
+        gt_2d = gt_2d.to(torch.float32).contiguous()
+        agg = torch.empty((B, K, Fr, J, 3), dtype=torch.float32, device=g.device)
+        sel = torch.empty((B, K, Fr, J), dtype=torch.int32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(lib.d3dp_jpma_gathered(g.data_ptr(), traj.data_ptr(), cam.data_ptr(), gt_2d.data_ptr(), 0,
+                                              agg.data_ptr(), sel.data_ptr(), 0, 0, R, B, K, Hl, Fr, J, int(zero_root),
+                                              _lib.current_stream()), "d3dp_jpma_gathered")
+        return agg, sel
+    # host tensors (the gloo tests): the torch statement of the same selection on the flat layout
+    from .jpma import jpma_combine, jpma_winners
+    flat = gathered_view(g).reshape(B, K, R * Hl, Fr, J, 3)
+    return jpma_combine(jpma_winners(flat, traj, cam, gt_2d, h_offset=0, zero_root=zero_root)[None])
 
 
 def rank_generator(seed: int, rank: int, device) -> torch.Generator:

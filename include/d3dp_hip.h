@@ -183,6 +183,14 @@ int d3dp_q_sample(const float* x0, const float* noise, const double* sqrt_ac, co
 int d3dp_jpma(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d, float* agg,
               int32_t* sel, float* err_sel, float* err_min, int32_t B, int32_t K, int32_t H, int32_t F, int32_t J,
               int32_t zero_root, void* stream);
+/* d3dp_jpma straight on an all-gather result: `gathered` = (R, B, K, H_local, F, J, 3), rank-major, exactly what
+ * ncclAllGather leaves when every rank contributes its (B, K, H_local, F, J, 3) stack -- hypothesis h = r H_local + hl.
+ * Same outputs and the same selection, bit for bit, as d3dp_jpma on the (B, K, R H_local, F, J, 3) tensor that a
+ * permute + copy of `gathered` would produce (158.6 MB per rank and step at configs[3] that are never moved).
+ * Replaces: main.py:700-718 after the hypothesis exchange of SURVEY.md 8 E1. */
+int d3dp_jpma_gathered(const float* gathered, const float* traj, const float* cam, const float* gt2d, const float* gt3d,
+                       float* agg, int32_t* sel, float* err_sel, float* err_min, int32_t R, int32_t B, int32_t K,
+                       int32_t H_local, int32_t F, int32_t J, int32_t zero_root, void* stream);
 /* d3dp_jpma with the 3DHP evaluation's options and pose outputs (main_3dhp.py:777-835): root_joint = index of the joint
  * written as 0 before use (0 for Human3.6M, 14 for 3DHP, -1 none); linear_projection = camera.py:62-83
  * project_to_2d_linear (f * clamp(X/Z) + c) instead of the distortion model; jbest (B,K,F,J,3) = per joint the

@@ -11,7 +11,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from d3dp_amd import jpma
-from d3dp_amd.dist import all_gather_hypotheses, hypothesis_slice, jpma_sharded, shard_noise
+from d3dp_amd.dist import (all_gather_hypotheses, all_gather_raw, gathered_view, hypothesis_slice, jpma_allgather, jpma_sharded,
+                           shard_noise)
 
 
 def fake_sampler(x2d, noise):
@@ -51,6 +52,13 @@ def _worker(rank, world, port, out):
         sel_ref = torch.norm(rp_full - gt2[:, None, None], dim=-1).min(dim=2).indices
         ok = ok and torch.equal(agg_r, jpma.jpma_aggregate(z, rp_full, gt2)) and torch.equal(sel_r.long(), sel_ref)
         ok = ok and bool((sel_r[..., 0] == 0).all())          # zeroed root: all hypotheses tie -> global h = 0
+        # the all-gather result as RCCL leaves it, (R,B,K,H_local,...): the axis-ordered VIEW of it equals the flat tensor,
+        # and JPMA on it (north_star's "all-gather before JPMA", no permute copy) == the reduced exchange == the reference order
+        raw = all_gather_raw(local)
+        ok = ok and raw.shape == (world, B, K, H // world, Fr, 17, 3) and raw.is_contiguous()
+        ok = ok and torch.equal(gathered_view(raw).reshape(full.shape), full)
+        agg_g, sel_g = jpma_allgather(local, traj, cam, gt2)
+        ok = ok and torch.equal(agg_g, agg_r) and torch.equal(sel_g, sel_r)
         out[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
@@ -97,6 +105,11 @@ def test_bench_dist_dry_run_8_ranks():
     assert d["dry_run"] is True and d["n_gpus"] == 8 and d["value"] is None
     mg = d["multi_gpu"]
     assert mg["world_size"] == 8 and mg["sharded_equals_single_rank"] is True and mg["all_gather_bytes_per_rank"] > 0
+    # the consumer is inside the N-rank timed region, and both exchange forms are reported side by side
+    assert "JPMA" in mg["timed_region"] and mg["both_select_the_same_poses"] is True
+    full, red = mg["allgather_then_jpma"], mg["winners_exchange"]
+    assert full["ms"] > 0 and red["ms"] > 0 and full["bytes_per_rank"] == mg["all_gather_bytes_per_rank"]
+    assert abs(red["traffic_ratio"] - 2 * 3 / 5) < 1e-9          # H_local = 2 in the dry run: 2 poses of 3 floats vs 5 floats
     assert d["config"]["parallelism"] == "hshard8"
     # a job whose world size disagrees with --gpus must refuse to run
     env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")

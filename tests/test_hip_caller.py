@@ -106,6 +106,19 @@ def test_jpma_winners_combine_equals_full_jpma():
                                               h_offset=r * Hl) for r in range(R)])
     agg3, sel3 = jpma.jpma_combine(wins_cpu)
     assert torch.equal(sel3, sel.cpu()) and torch.equal(agg3, agg.cpu())
+    # JPMA straight on the all-gather layout (R, B, K, H_local, F, J, 3) -- what RCCL leaves, consumed in place by
+    # d3dp_jpma_gathered (dist.jpma_allgather): the same selection as on the flat tensor, bit for bit
+    from d3dp_amd import _lib
+    gathered = torch.stack([pred[:, :, r * Hl:(r + 1) * Hl] for r in range(R)]).contiguous()
+    agg4 = torch.empty_like(agg)
+    sel4 = torch.empty_like(sel)
+    _lib.check(_lib.load().d3dp_jpma_gathered(gathered.data_ptr(), traj.reshape(B, Fr, 3).contiguous().data_ptr(), cam.data_ptr(),
+                                              gt2.data_ptr(), 0, agg4.data_ptr(), sel4.data_ptr(), 0, 0, R, B, K, Hl, Fr, 17, 1,
+                                              _lib.current_stream()), "d3dp_jpma_gathered")
+    assert torch.equal(agg4, agg) and torch.equal(sel4, sel)
+    from d3dp_amd.dist import jpma_allgather                    # without a process group: R = 1, the same kernel
+    agg5, sel5 = jpma_allgather(pred, traj, cam, gt2)
+    assert torch.equal(agg5, agg) and torch.equal(sel5, sel)
 
 
 # ---- N4: Procrustes -----------------------------------------------------------------------------------------------------

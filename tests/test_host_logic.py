@@ -132,11 +132,16 @@ def test_bench_reports_counter_traffic_only_for_the_build_it_was_measured_on(mon
     import bench
     tj = json.load(open(os.path.join(os.path.dirname(bench.__file__), "profiles", "r02_gemm_traffic.json")))
     sha = tj["exact"]["gemm_qkv"]["lib_sha256"]
-    roof = {"kernel": "gemm_qkv", "traffic": None}
+    rows = tj["exact"]["gemm_qkv"]["mean_rows_per_launch"]
+    roof = {"kernel": "gemm_qkv", "traffic": None, "mean_rows_per_launch": rows * 1.03}
     monkeypatch.setattr(bench, "lib_sha256", lambda: sha)
     bench.attach_traffic(roof, "exact", 0)
     assert roof["traffic"] == tj["exact"]["gemm_qkv"]["hbm_bytes_per_launch"] > tj["exact"]["gemm_qkv"]["algorithmic_bytes_per_launch"]
-    roof = {"kernel": "gemm_qkv", "traffic": None}
+    # ... and only at the pass size the counters were taken at (the r03 numbers came from --batch 4)
+    roof = {"kernel": "gemm_qkv", "traffic": None, "mean_rows_per_launch": rows * 1.14}
+    bench.attach_traffic(roof, "exact", 0)
+    assert roof["traffic"] is None and "rows per launch" in roof["traffic_note"]
+    roof = {"kernel": "gemm_qkv", "traffic": None, "mean_rows_per_launch": rows}
     monkeypatch.setattr(bench, "lib_sha256", lambda: "0" * 64)
     bench.attach_traffic(roof, "exact", 0)
     assert roof["traffic"] is None and "different build" in roof["traffic_note"]
@@ -162,7 +167,8 @@ def test_bench_roofline_is_algorithmic_flop_over_the_guides_dense_peak():
     assert full and 300 < full["gflops"] < 400 and abs(full["k10_units_per_s"] * 2 - full["hypothesis_clips_per_s_K5_units"]) < 1e-12
     prof_dir = os.path.join(os.path.dirname(bench.__file__), "profiles")
     t3 = json.load(open(os.path.join(prof_dir, "r03_gemm_traffic.json")))["exact"]["gemm_qkv"]
-    roof = {"kernel": "gemm_qkv", "traffic": None}
+    roof = {"kernel": "gemm_qkv", "traffic": None, "mean_rows_per_launch": t3["mean_rows_per_launch"]}
+    assert abs(r["mean_rows_per_launch"] - 2 * B * H * 243 * 17 * K * 16 / 3360) < 1e-6
     import pytest as _pt
     mp = _pt.MonkeyPatch()
     try:

@@ -7,7 +7,7 @@ NAME=$1; FILE=$2; FLAGS=$3
 make -s >/dev/null
 mkdir -p ../lib/variants/obj
 O=../lib/variants/obj/${NAME}_${FILE%.hip}.o
-EXTRA=""; case $FILE in gemm*.hip) EXTRA=-fno-slp-vectorize;; attention.hip) EXTRA=-Wno-inline-asm;; jpma.hip) EXTRA=-ffp-contract=off;; esac
+EXTRA=""; case $FILE in gemm*.hip) EXTRA=-fno-slp-vectorize;; jpma.hip) EXTRA=-ffp-contract=off;; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $EXTRA $FLAGS -c $FILE -o $O
 OBJS=""; for f in gemm gemm_x2 attention pointwise sampler jpma caller train capi; do
   if [ "$f.hip" = "$FILE" ]; then OBJS="$OBJS $O"; else OBJS="$OBJS ../lib/obj/$f.o"; fi; done
