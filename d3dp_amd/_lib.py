@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("D3DP_LIB") or os.path.join(_HERE, "lib", "libd3dp_hip
 
 MODE_EXACT, MODE_FAST, MODE_TRAIN = 0, 1, 2
 MODE_SPLIT3 = 2   # d3dp_op_linear only: split-bf16 operands
-EPI_BIAS, EPI_GELU, EPI_RESID, EPI_QKV_PACK = 0, 1, 2, 4
+EPI_BIAS, EPI_GELU, EPI_RESID, EPI_QKV_PACK = 0, 1, 2, 4     # (| D << 8: the skewed schedule of epi 1 / 4, include/d3dp_hip.h)
 PROFILE_CLASSES = 12
 
 

@@ -138,6 +138,14 @@ struct d3dp_ctx {
   // the operand and reduces the statistics with the matrix pipes idle) and +90 ms in fc1 (profiles/r03_fold_ln_ab.md).
   bool fold_ln() const { return fold_resid() && fold_ln_on && 2 * cfg.hidden <= 2048; }
   bool fold_ln_on = false;
+  // The EXACT qkv / fc1 Linears run the SKEWED schedule of gemm_x2.hip (a tile's epilogue spread under the k-loop of the
+  // next): the order in which a token row sums its k-steps then depends on (row within its pass) / 16 mod 4.  Every sequence
+  // therefore starts at a multiple of 64 rows -- seq_pitch() rows per sequence, F J rounded up, the rest finite filler -- so
+  // that order is a function of the token's index within its sequence alone and results stay bit-identical whatever the batch
+  // composition, pass split or rank count (the H-sharding contract, tests/test_hip_parity.py::test_full_size_properties).
+  bool skew() const { return x2_attn() && skew_d > 0 && cfg.channels >= 128 * skew_d; }   // (K = C >= 4 D k-steps of 32)
+  int skew_d = 4;                // k-steps a parked row class takes to leave (1, 2, 4); D3DP_X2_SKEW=0: the plain schedule
+  int seq_pitch() const { const int fj = cfg.frames * cfg.joints; return skew() ? (fj + 63) / 64 * 64 : fj; }
   bool x3() const { return exact() && exact_impl == 1; }
   int act() const { return fast() ? 1 : (x3() ? 2 : (x2() ? 3 : 0)); }   // code understood by the row-wise launchers
   size_t act_size() const { return fast() ? 2 : (x3() ? 6 : 4); }    // bytes per element of a Linear-input activation
@@ -155,20 +163,28 @@ struct d3dp_ctx {
   int plan_total = -1;
   const std::vector<int>& plan(int total) {
     if (total == plan_total) return plan_cache;
-    const int cap = std::min(chunk(), total), FJ = cfg.frames * cfg.joints;
+    const int cap = std::min(chunk(), total), SP = seq_pitch();
     plan_cache.clear();
     plan_total = total;
     if (!x2() || cfg.chunk_seqs < 0 || n_cu <= 0) {    // uniform passes (FAST, cross-check implementations)
       for (int s0 = 0; s0 < total; s0 += cap) plan_cache.push_back(std::min(cap, total - s0));
       return plan_cache;
     }
+    // per Linear (qkv, proj, fc1, fc2): column strips, k-depth, and whether it runs the skewed schedule -- there a
+    // workgroup owns the row tiles of one row group inside one strip (ceil(R / Q) tiles, Q = n_cu / strips row groups)
+    // plus the flush of 3 D k-steps; in the plain schedule tiles are dealt round robin (ceil(R strips / n_cu) rounds)
     const long tn[4] = {(3 * cfg.channels + 127) / 128, (cfg.channels + 127) / 128, (cfg.hidden + 127) / 128,
                         (cfg.channels + 127) / 128};
     const long kd[4] = {cfg.channels, cfg.channels, cfg.channels, cfg.hidden};
+    const bool sk[4] = {skew(), false, skew(), false};
     std::vector<double> cost(cap + 1, 0.0);
     for (int n = 1; n <= cap; ++n) {
-      const long R = ((long)n * FJ + 255) / 256;
-      for (int k = 0; k < 4; ++k) cost[n] += (double)((R * tn[k] + n_cu - 1) / n_cu) * (double)kd[k];
+      const long R = ((long)n * SP + 255) / 256;
+      for (int k = 0; k < 4; ++k) {
+        const long Q = n_cu / tn[k];
+        if (sk[k] && Q >= 1) cost[n] += ((double)((R + std::min(Q, R) - 1) / std::min(Q, R)) + 3.0 * skew_d * 32.0 / (double)kd[k]) * (double)kd[k];
+        else cost[n] += (double)((R * tn[k] + n_cu - 1) / n_cu) * (double)kd[k];
+      }
       cost[n] += 1e-3 * (double)kd[0];                   // (a pass has a fixed cost too: 7 launches per block)
     }
     std::vector<double> best(total + 1, 1e300);
@@ -230,23 +246,27 @@ int linear(d3dp_ctx* c, int cls, int epi, int out_f32, const void* A, const void
   if (c->x2()) {
     // the qkv Linear writes the packed rows of the split-fp16 attention kernels (K and V already as fp16 planes)
     if (cls == P_QKV && c->x2_attn()) epi = EPI_QKV_PACK;
+    // qkv and fc1 (epilogues without loads) run the skewed schedule when the context has it on (seq_pitch() pads for it)
+    const int skew_d = c->skew() && (epi == EPI_QKV_PACK || epi == EPI_GELU) ? c->skew_d : 0;
     return d3dp_launch_linear_f16x2(epi, A, W, bias, wu / a_scale, o_scale, (float*)out, out2 ? out2 : out, aux, c->d_flag, M, N,
-                                    K, st);
+                                    K, st, skew_d);
   }
   if (c->x3()) return d3dp_launch_linear_bf16x3(epi, A, W, bias, (float*)out, out, M, N, K, st);
   return d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, st);
 }
 
-SeqMap spatial_map(int F, int J) { return SeqMap{J, 1, J, 0, 1}; }
-SeqMap temporal_map(int F, int J) { return SeqMap{F, J, F * J, 1, J}; }
+// (sp: rows per (clip, hypothesis) sequence in the token buffers, >= F J; d3dp_ctx::seq_pitch)
+SeqMap spatial_map(int F, int J, int sp = 0) { return sp > F * J ? SeqMap{J, F, sp, J, 1} : SeqMap{J, 1, J, 0, 1}; }
+SeqMap temporal_map(int F, int J, int sp = 0) { return SeqMap{F, J, sp > F * J ? sp : F * J, 1, J}; }
 
 int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, float s_kv, hipStream_t st) {
   const d3dp_cfg& g = c->cfg;
   Scope s(c, axis == 0 ? P_ATTN_S : P_ATTN_T, st);
   if (c->x2_attn())                                    // split-fp16 operands on the fp16 matrix cores; packed qkv rows
     return d3dp_launch_attn_x2(3, axis, qkv, out, axis == 0 ? n_bh * g.frames : n_bh * g.joints,
-                               axis == 0 ? spatial_map(g.frames, g.joints) : temporal_map(g.frames, g.joints), g.channels,
-                               g.heads, s_kv, st);
+                               axis == 0 ? spatial_map(g.frames, g.joints, c->seq_pitch())
+                                         : temporal_map(g.frames, g.joints, c->seq_pitch()),
+                               g.channels, g.heads, s_kv, st);
   if (axis == 0) {
     if (c->fast() && g.channels / g.heads == 64 && g.joints <= 32)
       return d3dp_launch_attn_spatial_bf16(qkv, out, n_bh * g.frames, spatial_map(g.frames, g.joints), g.channels,
@@ -272,7 +292,7 @@ int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, float
 int run_block(d3dp_ctx* c, const BlockDev& w, int axis, float* x, void* y1, void* y, void* bufA, void* bufB, float* lnst,
               int n_bh, hipStream_t st) {
   const d3dp_cfg& g = c->cfg;
-  const int Tc = n_bh * g.frames * g.joints, C = g.channels;
+  const int Tc = n_bh * c->seq_pitch(), C = g.channels;
   // (s_kv / s_h differ from kActScale only in EXACT f16x2 contexts whose weights asked for it, and s_kv only with the x2
   //  attention kernels: the other attention kernels write their output planes at kActScale)
   const float s_o = c->x2_attn() ? w.s_kv : kActScale;
@@ -334,6 +354,8 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->exact_impl = c->exact_impl_req = (xf && !strcmp(xf, "bf16x3")) ? 1 : (xf && !strcmp(xf, "f32")) ? 2 : 0;
   const char* nf = getenv("D3DP_NO_FOLD");               // cross-check: residual adds (and norm2) in the row kernels
   c->fold = !(nf && nf[0] == '1');
+  const char* sk = getenv("D3DP_X2_SKEW");               // 0: the plain (un-skewed) schedule of the EXACT qkv / fc1 Linears; 1, 2, 4: D
+  if (sk && (sk[0] == '0' || sk[0] == '1' || sk[0] == '2' || sk[0] == '4') && sk[1] == 0) c->skew_d = sk[0] - '0';
   const char* nl = getenv("D3DP_FOLD_LN");               // norm2 folded into proj / fc1 instead of its own row kernel
   c->fold_ln_on = nl && nl[0] == '1';
   HIP_TRY(hipGetDevice(&c->device));
@@ -562,7 +584,7 @@ int d3dp_workspace_bytes(const d3dp_ctx* c, int32_t B, int32_t H, size_t* bytes)
   if (!c || !bytes || B < 1 || H < 1) return fail(D3DP_EINVAL, "d3dp_workspace_bytes: bad argument");
   const d3dp_cfg& g = c->cfg;
   const size_t n = (size_t)std::min(c->chunk(), B * H);
-  const size_t Tc = n * g.frames * g.joints, C = g.channels;
+  const size_t Tc = n * c->seq_pitch(), C = g.channels;
   const size_t wide = (size_t)std::max(3 * g.channels, g.hidden);
   *bytes = align_up((size_t)B * C * 4) + align_up(Tc * C * 4) + 2 * align_up(Tc * C * c->y_size()) +
            align_up(Tc * C * c->act_size()) + align_up(Tc * wide * c->wide_size()) +
@@ -580,9 +602,9 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
   if (workspace_bytes < need) return fail(D3DP_ESTATE, "workspace %zu < required %zu bytes", workspace_bytes, need);
   hipStream_t st = (hipStream_t)stream;
   const d3dp_cfg& g = c->cfg;
-  const int C = g.channels, F = g.frames, J = g.joints, FJ = F * J;
+  const int C = g.channels, F = g.frames, J = g.joints, FJ = F * J, SP = c->seq_pitch();
   const int BH = B * H, chunk = std::min(c->chunk(), BH);
-  const size_t Tmax = (size_t)chunk * FJ;
+  const size_t Tmax = (size_t)chunk * SP;
   char* p = (char*)workspace;
   float* temb = (float*)p; p += align_up((size_t)B * C * 4);
   float* x = (float*)p;    p += align_up(Tmax * C * 4);
@@ -599,11 +621,11 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
   }
   int seq0 = 0;
   for (const int n : c->plan(BH)) {
-    const int Tc = n * FJ;
+    const int Tc = n * SP;
     {
       Scope s(c, P_EMBED, st);
       LAUNCH_TRY(d3dp_launch_embed_ln(c->act(), x2d, x_t, temb, c->ew, c->eb, c->spos, c->ste[0].n1w, c->ste[0].n1b,
-                                      g.eps_block, x, bufA, seq0, n, H, F, J, C, st));
+                                      g.eps_block, x, bufA, seq0, n, H, F, J, C, st, SP));
     }
     const bool fold = c->fold_resid();
     for (int d = 0; d < g.depth; ++d) {
@@ -612,20 +634,20 @@ int d3dp_denoise(d3dp_ctx* c, const float* x2d, const float* x_t, const int64_t*
       {
         Scope s(c, P_LN2, st);   // x += fc2 out; Spatial_norm (+ Temporal_pos after block 0); TTE block d's norm1
         LAUNCH_TRY(d3dp_launch_ln2(c->act(), x, fold ? nullptr : y1, fold ? nullptr : y, c->snw, c->snb, d == 0 ? c->tpos : nullptr, c->tte[d].n1w,
-                                   c->tte[d].n1b, g.eps_block, bufA, Tc, C, F, J, st));
+                                   c->tte[d].n1b, g.eps_block, bufA, Tc, C, F, J, st, SP));
       }
       r = run_block(c, c->tte[d], 1, x, y1, y, bufA, bufB, lnst, n, st);
       if (r) return r;
       if (d + 1 < g.depth) {
         Scope s(c, P_LN2, st);   // x += fc2 out; Temporal_norm; STE block d+1's norm1
         LAUNCH_TRY(d3dp_launch_ln2(c->act(), x, fold ? nullptr : y1, fold ? nullptr : y, c->tnw, c->tnb, nullptr, c->ste[d + 1].n1w, c->ste[d + 1].n1b,
-                                   g.eps_block, bufA, Tc, C, F, J, st));
+                                   g.eps_block, bufA, Tc, C, F, J, st, SP));
       }
     }
     {
       Scope s(c, P_HEAD, st);    // x += fc2 out; Temporal_norm; head LayerNorm; Linear(C,3)
       LAUNCH_TRY(d3dp_launch_head(c->fast() ? 1 : 0, x, fold ? nullptr : y1, fold ? nullptr : y, c->tnw, c->tnb, g.eps_block, c->hnw, c->hnb, g.eps_head, c->hw, c->hb,
-                                  out + (size_t)seq0 * FJ * 3, Tc, C, st));
+                                  out + (size_t)seq0 * FJ * 3, Tc, C, st, FJ, SP));
     }
     seq0 += n;
   }
@@ -769,8 +791,18 @@ int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream) {
 int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* bias, float w_scale, void* out, int32_t M,
                       int32_t N, int32_t K, void* stream) {
   if (!A2 || !W2 || !bias || !out || !(w_scale > 0.f)) return fail(D3DP_EINVAL, "d3dp_op_linear_x2: bad argument");
+  const int skew_d = (epi >> 8) & 7;                     // epi | (D << 8), D = 1, 2, 4: the skewed schedule (epi 1 and 4)
+  epi &= 255;
   if (epi == EPI_RESID_LN || epi == EPI_GELU_LN) return fail(D3DP_EINVAL, "d3dp_op_linear_x2: epilogues 5 / 6 are internal to d3dp_denoise");
-  LAUNCH_TRY(d3dp_launch_linear_f16x2(epi, A2, W2, bias, kActUnscale / w_scale, kActScale, (float*)out, out, nullptr, nullptr, M, N, K, (hipStream_t)stream));
+  if (skew_d) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (!d3dp_x2_skew_applies(epi, M, N, K, skew_d, prop.multiProcessorCount))
+      return fail(D3DP_EINVAL, "d3dp_op_linear_x2: the skewed schedule (D = %d) does not apply to epi %d, M = %d, N = %d, K = %d", skew_d, epi, M, N, K);
+  }
+  LAUNCH_TRY(d3dp_launch_linear_f16x2(epi, A2, W2, bias, kActUnscale / w_scale, kActScale, (float*)out, out, nullptr, nullptr, M, N, K, (hipStream_t)stream, skew_d));
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
 }

@@ -84,6 +84,11 @@
 #ifndef D3DP_NT_OUT
 #define D3DP_NT_OUT 1
 #endif
+// skewed kernel: VALU per MFMA requested from the scheduler (sched_group_barrier) inside a row block's region; 0 = leave
+// the order inside a region to the compiler
+#ifndef D3DP_X2_SKEW_SGB
+#define D3DP_X2_SKEW_SGB 0
+#endif
 #if D3DP_NT_OUT
 #define OUT_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #else
@@ -501,6 +506,286 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same Linear with a ROW-CLASS SKEWED schedule: a tile's epilogue runs UNDER the k-loop of the next tile.
+//
+// In the kernel above all eight compute waves reach a tile's epilogue together (one s_barrier per k-step keeps them in
+// lock-step), so its VALU work and stores -- 12 % of the qkv Linear, 27 % of fc1 with its GELU (profiles/r03_gemm_probes.md)
+// -- run with the matrix pipes idle; parking a finished 256 x 128 tile beside the next one's accumulators would take 64 more
+// registers than a 12-wave workgroup has.  Here the four 16-row blocks of a wave's 64 rows (row class c = 0..3) end their
+// tiles at DIFFERENT k-steps: class c switches to its next tile when ks == c D.  Sums over k commute, so class c simply
+// runs the k-steps of a tile in the rotated order c D, ..., NK - 1, 0, ..., c D - 1; all classes still consume the SAME W
+// slab in every k-step (consecutive tiles of a workgroup lie in one 128-column strip), and only the A rows of class c
+// belong to another tile for a while -- a matter of which rows the loader waves fetch.  At most ONE class is between tiles
+// at any time: its 16 finished values per lane are PARKED (16 registers) and leave over the next D k-steps, 4 / D output
+// rows per k-step, their VALU work and stores issued between that k-step's 48 MFMAs.
+//   registers  Which accumulator block parks must not be a run-time choice (selecting acc[c] dynamically costs the register
+//              allocator ~40 registers of copies, and unrolling a whole tile round spills as well): the block that parks is
+//              always accumulator block 0.  After it parks, the blocks shift down (acc[p] <- acc[p + 1], acc[3] <- 0: 40
+//              v_mov per D k-steps) and the LOADERS rotate the LDS image to match: with rot = number of parks so far, LDS
+//              row slot p of every 64-row group holds the rows of class (p + rot) & 3.  The compute code is static.
+//   schedule   workgroup L owns strip L % tiles_n and the row-tile range [lo, hi) of its row group L / tiles_n (Q = G /
+//              tiles_n row groups; G - Q tiles_n workgroups idle).  Round ti = NK k-steps; class c works on tile ti (ks >= c D)
+//              or ti - 1.  (hi - lo) full rounds and a flush of 3 D k-steps: in the first c D steps class c has no tile yet
+//              (its sums are discarded), in the flush the classes that are done multiply rows nobody stores -- 1.5 D k-steps
+//              of matrix work lost per launch and workgroup, against one exposed epilogue per tile.
+//   loaders    A piece i of loader wave lw lands in LDS rows lw 64 + 8 i .. + 7 (row slot i >> 1) as before; it FETCHES the
+//              rows of class ((i >> 1) + rot) & 3, from tile ti or ti - 1 as that class stands; pointers re-derived at the
+//              four park steps of a round.  W pieces: one strip for the whole launch.  Ring, barriers, vmcnt: unchanged.
+//   numerics   the rotation changes the ORDER of a row's fp32 partial sums with its row class: capi.hip pads every sequence
+//              to a multiple of 64 rows (d3dp_ctx::seq_pitch), which makes the class a function of the token's index in its
+//              sequence -- results stay bit-identical across batch compositions, pass splits and ranks.
+// Built for the two Linears whose epilogue is pure register work: EPI_BIAS / TAG 1 (qkv, packed rows) and EPI_GELU (fc1).
+// proj / fc2 (x += ..., their epilogue waits on loads of the residual rows) keep the kernel above.
+template <int EPI, int TAG, int D>
+__global__ __launch_bounds__(768) void gemm_f16x2_skew_kernel(const f16* __restrict__ A2, const f16* __restrict__ W2,
+                                                              const float* __restrict__ bias, float unscale, float oscale,
+                                                              float* __restrict__ outf, f16* __restrict__ out2, int M, int N,
+                                                              int K, int tiles_n, int tm, int Q) {
+  static_assert(D == 1 || D == 2 || D == 4, "a parked class leaves in D k-steps, 4 / D rows per k-step");
+  static_assert(EPI == EPI_GELU || (EPI == EPI_BIAS && TAG == 1), "epilogues without loads only");
+  constexpr int RPK = 4 / D;                           // output rows (of the parked class) per k-step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sbias = reinterpret_cast<float*>(smem + XNSTAGE * XSTAGE);
+  const int G = gridDim.x;
+  const int L = xcd_remap(blockIdx.x, G);
+  const int strip = L % tiles_n, rg = L / tiles_n;
+  const int lo = rg < Q ? (int)((long)rg * tm / Q) : 0, hi = rg < Q ? (int)((long)(rg + 1) * tm / Q) : 0;
+  const int n_tiles = hi - lo;
+  const int NK = K / XBK;                              // >= 4 D (launcher)
+  const int gtot = n_tiles > 0 ? n_tiles * NK + 3 * D : 0;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  for (int i = tid; i < N; i += (XNCW + 4) * 64) sbias[i] = bias[i];
+  __syncthreads();
+  if (gtot == 0) return;
+
+  if (wave >= XNCW) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = wave - XNCW;
+    const int lr = lane >> 3, lq = lane & 7;
+    const f16* pa[8];
+    const f16* pw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (lw * 4 + i) * 8 + lr;
+      const int wrow = (row & 64) + colperm(row & 63);
+      pw[i] = W2 + (size_t)min(strip * XBN + wrow, N - 1) * (2 * K) + swz128(row, lq) * 8;
+    }
+    int ti = 0, ks = 0, slot = 0;                      // (round, k-step, ring slot) of the next slab to issue
+    auto issue = [&]() {
+      if ((ks & (D - 1)) == 0 && ks < 4 * D) {         // a park step: the LDS image rotates and one class changes tile
+        const int rot = (ks / D + 1) & 3;              // parks so far, mod 4, once this step's park is done
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int cls = ((i >> 1) + rot) & 3;        // the class whose rows row slot i >> 1 holds from this k-step on
+          int j = ks >= cls * D ? ti : ti - 1;         // that class has switched to tile ti in this round, or has not yet
+          j = min(max(j, 0), n_tiles - 1);             // (before its first tile / after its last: any valid rows)
+          const int lds_row = (lw * 8 + i) * 8 + lr;   // where the piece lands (the swizzle goes by the LDS row)
+          const int row = lw * 64 + cls * 16 + (i & 1) * 8 + lr;
+          pa[i] = A2 + (size_t)min((lo + j) * XBM + row, M - 1) * (2 * K) + swz128(lds_row, lq) * 8;
+        }
+      }
+      char* base = smem + slot * XSTAGE;
+      const int ko = ks * (2 * XBK);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds(GPTR(pa[i] + ko), LPTR(base + (lw * 8 + i) * 1024), 16, 0, D3DP_X2_AAUX);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds(GPTR(pw[i] + ko), LPTR(base + XA_BYTES + (lw * 4 + i) * 1024), 16, 0, D3DP_X2_WAUX);
+      if (++ks == NK) { ks = 0; ++ti; }
+      slot = (slot == XNSTAGE - 1) ? 0 : slot + 1;
+    };
+    issue();
+    if (gtot > 1) issue();
+    for (int g = 0; g < gtot; ++g) {
+      if (g + 1 < gtot) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      X2_BARRIER();
+      if (g + 2 < gtot) issue();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute waves
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int offA = (wr * 64 + fi) * 128 + swz128(fi, fg) * 16, offAl = offA ^ 64;
+  const int offW = XA_BYTES + (wc * 64 + fi) * 128 + swz128(fi, fg) * 16, offWl = offW ^ 64;
+  __builtin_amdgcn_s_setprio(1);
+
+  // what does not change over the launch: this lane's four output columns nb .. nb + 3 of the workgroup's strip.  (A wave's
+  // 64 columns lie in one region of the packed qkv row: `planes` is wave-uniform.)
+  const int nbw = strip * XBN + wc * 64;               // wave-uniform
+  const int nb = nbw + 4 * fi;
+  const bool cols_live = nb < N;
+  const bool odd = fi & 1;
+  const unsigned pitch = (unsigned)N * 4;              // bytes per output row in every form (fp32 [N], h2i [2 N] fp16, packed 12 C)
+  bool planes;
+  unsigned coff;
+  char* base;
+  {
+    const int c0 = nb & ~7;
+    if constexpr (EPI == EPI_GELU) {                   // the fc2 operand, h2i: even lane -> hi slot of the pair's 8 columns, odd -> lo
+      base = reinterpret_cast<char*>(out2);
+      planes = true;
+      coff = (c0 >> 5) * 128 + (c0 & 31) * 2 + (odd ? 64 : 0);
+    } else {                                           // packed qkv row: q fp32 | k hi | k lo | v hi | v lo
+      base = reinterpret_cast<char*>(outf);
+      const int C = N / 3, region = nbw / C, cn = nb - region * C;
+      planes = region != 0;
+      coff = planes ? region * 4 * C + cn * 2 + (odd ? 2 * C - 8 : 0) : cn * 4;
+    }
+  }
+  const int row0 = wr * 64 + 4 * fg;                   // this lane's row (r = 0) of row class 0 inside a tile
+
+  f32x4 acc[4][4];                                     // acc[p]: the class whose rows LDS row slot p holds ((p + rot) & 3)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 park[4];                                       // the class between tiles: park[ni][r]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) park[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  unsigned joff = 0;                                   // byte offset of row r = 0 of the parked class (+ coff)
+  int jrows = 0;                                       // its rows r < jrows exist (<= 0: nothing to store)
+
+  // value e of output row r of the parked class, through the epilogue's arithmetic (the lane's four biases are re-read
+  // from LDS in every k-step that needs them -- one ds_read_b128 -- instead of living in registers across the k-loop)
+  const float* bias4 = sbias + min(nb, N - 4);
+  auto value = [&](int r, int e, const float4& bz) {
+    return fmaf(park[e][r], unscale, e == 0 ? bz.x : e == 1 ? bz.y : e == 2 ? bz.z : bz.w);
+  };
+  // one output row of the parked class: 4 values per lane -> one 16-byte store per lane
+  auto store_row = [&](int r, float (&v)[4]) {
+    const bool live = cols_live && r < jrows;
+    char* dst = base + (joff + (unsigned)r * pitch);
+    if (planes) {
+      f16x4 ph, pl;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f16 h, l;
+        split2h_scaled(v[e] * oscale, h, l);
+        ph[e] = h; pl[e] = l;
+      }
+      store_planes_paired(dst, ph, pl, odd, live);
+    } else {
+      if (live) OUT_STORE(reinterpret_cast<f32x4*>(dst), ((f32x4){v[0], v[1], v[2], v[3]}));
+    }
+  };
+  // the class in accumulator block 0 changes tile: park it, shift the blocks down, start its next tile from zero in block 3
+  // (the loaders rotate the LDS image by one row slot at the same k-step)
+  auto park_and_shift = [&](int cls, int tile) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      park[j] = acc[0][j];
+      acc[0][j] = acc[1][j]; acc[1][j] = acc[2][j]; acc[2][j] = acc[3][j];
+      acc[3][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int m_row = (lo + tile) * XBM + row0 + cls * 16;      // tile < 0 (no tile finished yet): nothing is stored
+    jrows = tile >= 0 ? M - m_row : 0;
+    joff = (unsigned)m_row * pitch + coff;
+  };
+
+  int slot = 0;
+  // one k-step; JOB: RPK rows of the parked class leave beside its MFMAs (a compile-time flag: a run-time branch inside the
+  // k-step would cut its MFMAs and the epilogue's VALU into separate scheduling regions); r0 = first of those rows
+  auto kstep = [&](auto job_c, int r0) {
+    constexpr bool JOB = decltype(job_c)::value;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    X2_BARRIER();
+    __builtin_amdgcn_sched_barrier(0);
+    const char* sb = smem + slot * XSTAGE;
+    slot = (slot == XNSTAGE - 1) ? 0 : slot + 1;
+    f16x8 wf[4][2], ah[2], al[2];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        wf[ni][pl] = *reinterpret_cast<const f16x8*>(sb + (pl ? offWl : offW) + ni * 2048);
+    ah[0] = *reinterpret_cast<const f16x8*>(sb + offA);
+    al[0] = *reinterpret_cast<const f16x8*>(sb + offAl);
+    [[maybe_unused]] float4 bz = {};
+    if constexpr (JOB) bz = *reinterpret_cast<const float4*>(bias4);
+    __builtin_amdgcn_sched_barrier(0);
+    // value e of a leaving row is computed beside accumulator block e's twelve MFMAs (GELU: ~20 VALU per value), the row
+    // is split and stored beside the last block's
+    [[maybe_unused]] float ev[RPK][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int b = mi & 1;
+      if (mi < 3) {                                    // next block's fragments while this one multiplies
+        ah[b ^ 1] = *reinterpret_cast<const f16x8*>(sb + offA + (mi + 1) * 2048);
+        al[b ^ 1] = *reinterpret_cast<const f16x8*>(sb + offAl + (mi + 1) * 2048);
+      }
+      if constexpr (JOB) {
+#pragma unroll
+        for (int rr = 0; rr < RPK; ++rr) {
+          float x = value(r0 + rr, mi, bz);
+          if constexpr (EPI == EPI_GELU) x = gelu_erf_rational(x);
+          ev[rr][mi] = x;
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], wf[ni][1], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[b], wf[ni][0], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], wf[ni][0], acc[mi][ni], 0, 0, 0);
+      if constexpr (JOB) {
+        if (mi == 3) {
+#pragma unroll
+          for (int rr = 0; rr < RPK; ++rr) store_row(r0 + rr, ev[rr]);
+        }
+      }
+#if D3DP_X2_SKEW_SGB
+      // ask the scheduler for an even mix: one MFMA, then up to D3DP_X2_SKEW_SGB VALU, twelve times over
+      if constexpr (JOB) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, D3DP_X2_SKEW_SGB, 0);
+        }
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  const int rest = NK - 4 * D;                         // k-steps of a round in which no class is between tiles
+#pragma unroll 1
+  for (int ti = 0; ti <= n_tiles; ++ti) {
+    const int ngrp = ti < n_tiles ? 4 : 3;             // (the flush: classes 0..2 leave in 3 D k-steps; class 3 after the loop)
+#pragma unroll 1
+    for (int grp = 0; grp < ngrp; ++grp) {
+      park_and_shift(grp, ti - 1);                     // class grp has just finished tile ti - 1
+#pragma unroll
+      for (int s = 0; s < D; ++s) kstep(std::true_type{}, s * RPK);   // (the row index must be a constant: park[e][r])
+    }
+    if (ti < n_tiles) {
+#pragma unroll 1
+      for (int s = 0; s < rest; ++s) kstep(std::false_type{}, 0);
+    }
+  }
+  // the last class (3) of the last tile sits in accumulator block 0 by now: nothing left to hide it under
+  {
+    park_and_shift(3, n_tiles - 1);
+    const float4 bz = *reinterpret_cast<const float4*>(bias4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = value(r, e, bz);
+        if constexpr (EPI == EPI_GELU) v[e] = gelu_erf_rational(v[e]);
+      }
+      store_row(r, v);
+    }
+  }
+}
+
 // src[i] * scale -> h2i layout (common.h): blocks of 32 elements, dst[64 b .. 64 b + 31] = hi, dst[64 b + 32 .. 64 b + 63] = lo
 // of elements 32 b .. 32 b + 31 (n % 32 == 0; any row length that is a multiple of 32)
 __global__ void split2h_kernel(const float* __restrict__ s, f16* __restrict__ d, size_t n, float scale) {
@@ -595,8 +880,22 @@ __global__ void nonfinite_flag_kernel(const float* __restrict__ x, size_t n, uns
 // `unscale` = 1 / (scale of the A planes * scale of the W planes).
 // K must be a multiple of 64: the k-loop is unrolled by two k-steps of 32 (the lagged products alternate between two
 // register sets), and the loader / compute waves count barriers per k-step.
+// skew_d: 0 = the plain schedule; 1, 2, 4 = the row-class skewed kernel with its parked class leaving in that many k-steps
+// (EPI_QKV_PACK and EPI_GELU only; falls back to the plain kernel where the schedule does not apply: see d3dp_x2_skew_applies)
+bool d3dp_x2_skew_applies(int epi, int M, int N, int K, int skew_d, int n_cu) {
+  if (skew_d != 1 && skew_d != 2 && skew_d != 4) return false;
+  if (epi != EPI_QKV_PACK && epi != EPI_GELU) return false;
+  const int tn = (N + XBN - 1) / XBN, tm = (M + XBM - 1) / XBM;
+  if (K % XBK != 0 || K / XBK < 4 * skew_d) return false;   // four classes, D k-steps apart, inside one tile round
+  if (N % XBN != 0) return false;                        // whole strips (the denoiser's 1536 and 1024)
+  (void)tm;
+  return n_cu / tn >= 1;                                 // (any M: with fewer row tiles than row groups, fewer groups work --
+                                                         //  the schedule, and with it the summation order, must not depend on M)
+}
+
 int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const float* bias, float unscale, float oscale,
-                             float* outf, void* out2, float* aux, unsigned* flag, int M, int N, int K, hipStream_t st) {
+                             float* outf, void* out2, float* aux, unsigned* flag, int M, int N, int K, hipStream_t st,
+                             int skew_d) {
   if (K % (2 * XBK) != 0 || N % 4 != 0 || N > XBIAS_MAX || M <= 0) return -1;
   if ((size_t)M * N * 4 >= ((size_t)1 << 32)) return -1;   // 32-bit byte offsets in the epilogue
   if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_QKV_PACK && epi != EPI_RESID && epi != EPI_RESID_LN &&
@@ -626,6 +925,23 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
     return d3dp_cu_count(dev);
   });
   if (cus < 0) return -3;
+  if (d3dp_x2_skew_applies(epi, M, N, K, skew_d, cus)) {
+    using SkewT = void (*)(const f16*, const f16*, const float*, float, float, float*, f16*, int, int, int, int, int, int);
+    static const SkewT skews[6] = {gemm_f16x2_skew_kernel<EPI_BIAS, 1, 1>, gemm_f16x2_skew_kernel<EPI_BIAS, 1, 2>,
+                                   gemm_f16x2_skew_kernel<EPI_BIAS, 1, 4>, gemm_f16x2_skew_kernel<EPI_GELU, 0, 1>,
+                                   gemm_f16x2_skew_kernel<EPI_GELU, 0, 2>, gemm_f16x2_skew_kernel<EPI_GELU, 0, 4>};
+    static PerDeviceOnce once_skew;
+    if (once_skew.get([&](int) {
+          for (int k = 0; k < 6; ++k)
+            if (d3dp_lds_opt_in(reinterpret_cast<const void*>(skews[k]), XLDS) < 0) return -3;
+          return 1;
+        }) < 0) return -3;
+    const int Q = cus / tn < tm ? cus / tn : tm;         // row groups: Q tn workgroups work, the others idle
+    const SkewT kern = skews[(epi == EPI_GELU ? 3 : 0) + (skew_d == 1 ? 0 : skew_d == 2 ? 1 : 2)];
+    hipLaunchKernelGGL(kern, dim3(cus), dim3((XNCW + 4) * 64), XLDS, st, (const f16*)A2, (const f16*)W2, bias, unscale, oscale,
+                       outf, (f16*)out2, M, N, K, tn, tm, Q);
+    return 0;
+  }
   const int total = tm * tn, grid = total < cus ? total : cus;
   const KernT kern = kerns[epi == EPI_GELU ? 2 : epi == EPI_RESID ? 3 : epi == EPI_QKV_PACK ? 1 : epi == EPI_RESID_LN ? 4
                            : epi == EPI_GELU_LN ? 5 : 0];

@@ -54,7 +54,11 @@ void d3dp_launch_split3(const float* src, void* dst, size_t n, hipStream_t st);
 // k / v of EPI_QKV_PACK, the operand copy of EPI_RESID_LN) are multiplied by before the hi / lo split (kActScale unless the
 // proven range of that operand asks for less, capi.hip)
 int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const float* bias, float unscale, float oscale,
-                             float* outf, void* out2, float* aux, unsigned* flag, int M, int N, int K, hipStream_t st);
+                             float* outf, void* out2, float* aux, unsigned* flag, int M, int N, int K, hipStream_t st,
+                             int skew_d = 0);
+// skew_d (1, 2, 4): the row-class skewed schedule of gemm_x2.hip for EPI_QKV_PACK / EPI_GELU -- a tile's epilogue leaves under the
+// next tile's k-loop, D k-steps per 16-row class; d3dp_x2_skew_applies says whether the launcher will use it for a shape
+bool d3dp_x2_skew_applies(int epi, int M, int N, int K, int skew_d, int n_cu);
 // out[0] = max over rows n of  sum_k |W[n,k]| in_k + |bias[n]|,  out[1] = max_k in_k,  in_k = sq |gamma_k| + |beta_k|: the
 // magnitude bound of a Linear fed by a LayerNorm over K channels (sq = sqrt(K - 1): |LN(x)_k| <= sq |gamma_k| + |beta_k| for
 // ANY x), as the bit patterns of non-negative floats (integer max == float max; `out` pre-zeroed)
@@ -99,7 +103,8 @@ int d3dp_launch_time_mlp(const int64_t* t, const float* freq, const float* w1, c
 // x[T,C] = embed(x2d, x3d) + spos + temb ;  xn = LN1(x)
 int d3dp_launch_embed_ln(int act_bf16, const float* x2d, const float* x3d, const float* temb, const float* ew,
                          const float* eb, const float* spos, const float* lnw, const float* lnb, float eps, float* x,
-                         void* xn, int seq0, int n_seq, int H, int F, int J, int C, hipStream_t st);
+                         void* xn, int seq0, int n_seq, int H, int F, int J, int C, hipStream_t st, int SP = 0);
+// (SP: rows per sequence in x / xn, >= F J; 0 = F J.  Rows F J .. SP - 1 of every sequence are finite filler.)
 // xn = LN(x)
 // (residual adds: ln normalises x + yadd (writing the sum back only if write_x); ln2 / head form (x + yadd0) + yadd;
 //  yadd has the activation type: bf16 in FAST mode, fp32 in EXACT mode)
@@ -107,11 +112,12 @@ int d3dp_launch_ln(int act_bf16, float* x, const void* yadd, int write_x, const 
                    void* xn, int T, int C, hipStream_t st);
 // x = LN_a(x) (+ pos[f]) in place ; xn = LN_b(x)   (shared Spatial/Temporal norm fused with the next block's norm1)
 int d3dp_launch_ln2(int act_bf16, float* x, const void* yadd0, const void* yadd, const float* wa, const float* ba, const float* pos,
-                    const float* wb, const float* bb, float eps, void* xn, int T, int C, int F, int J, hipStream_t st);
+                    const float* wb, const float* bb, float eps, void* xn, int T, int C, int F, int J, hipStream_t st,
+                    int SP = 0);
 // out[T,3] = Linear(LN_head(LN_a(x)))
 int d3dp_launch_head(int act_bf16, const float* x, const void* yadd0, const void* yadd, const float* wa, const float* ba, float eps_a, const float* wh,
                      const float* bh, float eps_h, const float* w, const float* b, float* out, int T, int C,
-                     hipStream_t st);
+                     hipStream_t st, int FJ = 0, int SP = 0);   // (rows at pitch SP per sequence -> compact out rows; 0 = compact in)
 
 // ---- sampler.hip -------------------------------------------------------------------------------
 int d3dp_launch_ddim_pre(const float* img, float* xt2, const int* perm, float scale, int B, int per_b, int J,

@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const Y
                                                   const YT* __restrict__ yadd, const float* __restrict__ wa,
                                                   const float* __restrict__ ba, const float* __restrict__ pos,
                                                   const float* __restrict__ wb, const float* __restrict__ bb, float eps,
-                                                  typename ActOut<C, XN>::ptr xn, size_t plane, int T, int F, int J) {
+                                                  typename ActOut<C, XN>::ptr xn, size_t plane, int T, int F, int J,
+                                                  int SP) {
   using R = Row<C>;
   const int lane = threadIdx.x & 63;
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -244,8 +245,8 @@ __global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const Y
   }
   R::norm(v, wa, ba, eps, lane, y);
   if (pos != nullptr) {
-    const int f = (tok / J) % F;
-    float pv[R::NV];
+    const int f = min((tok % SP) / J, F - 1);          // (SP: rows per sequence, >= F J; the pad rows behind a sequence
+    float pv[R::NV];                                   //  carry finite filler that nothing reads: any frame will do)
     R::load(pos + (size_t)f * C, lane, pv);
 #pragma unroll
     for (int i = 0; i < R::NV; ++i) y[i] += pv[i];
@@ -262,17 +263,22 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
                                                        const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                        float eps, float* __restrict__ x,
                                                        typename ActOut<C, XN>::ptr xn, size_t plane, int seq0,
-                                                       int n_seq, int H, int F, int J) {
+                                                       int n_seq, int H, int F, int J, int SP) {
   using R = Row<C>;
   const int lane = threadIdx.x & 63;
-  const int tl = blockIdx.x * 4 + (threadIdx.x >> 6);          // chunk-local token
+  const int tl = blockIdx.x * 4 + (threadIdx.x >> 6);          // chunk-local row: sequence tl / SP, token tl % SP
   const int FJ = F * J;
-  if (tl >= n_seq * FJ) return;
-  const int seq = seq0 + tl / FJ, fj = tl % FJ, nj = fj % J;
+  if (tl >= n_seq * SP) return;
+  // SP >= F J rows per sequence (capi.hip: a multiple of 64 when the skewed Linear schedule is in use): the pad rows get
+  // the embedding of an all-zero input at joint 0 -- finite filler that flows through the row-wise kernels and the Linears
+  // and is never read by an attention kernel nor written to the output
+  const bool pad = (tl % SP) >= FJ;
+  const int seq = seq0 + tl / SP, fj = pad ? 0 : tl % SP, nj = fj % J;
   const int b = seq / H;
   const float* p2 = x2d + ((size_t)b * FJ + fj) * 2;
   const float* p3 = x3d + ((size_t)seq * FJ + fj) * 3;
-  const float in5[5] = {p2[0], p2[1], p3[0], p3[1], p3[2]};    // channel order [u, v, x, y, z], mixste.py:228
+  float in5[5] = {p2[0], p2[1], p3[0], p3[1], p3[2]};          // channel order [u, v, x, y, z], mixste.py:228
+  if (pad) { in5[0] = in5[1] = in5[2] = in5[3] = in5[4] = 0.f; }
   float v[R::NV], y[R::NV];
 #pragma unroll
   for (int i = 0; i < R::NV; ++i) {
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
                                                    const float* __restrict__ ba, float eps_a,
                                                    const float* __restrict__ wh, const float* __restrict__ bh,
                                                    float eps_h, const float* __restrict__ w, const float* __restrict__ b,
-                                                   float* __restrict__ out, int T) {
+                                                   float* __restrict__ out, int T, int FJ, int SP) {
   using R = Row<C>;
   const int lane = threadIdx.x & 63;
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -326,7 +332,9 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
     for (int i = 0; i < R::NV; ++i) a = fmaf(z[i], wv[i], a);
     acc[o] = wave_sum(a) + b[o];
   }
-  if (lane < 3) out[(size_t)tok * 3 + lane] = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : acc[2]);
+  // rows are (sequence, token) at pitch SP >= FJ; the output is compact
+  const int fj = tok % SP;
+  if (lane < 3 && fj < FJ) out[((size_t)(tok / SP) * FJ + fj) * 3 + lane] = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : acc[2]);
 }
 
 // one workgroup per batch element; sin/cos table `freq` is supplied by the host (computed with the
@@ -383,15 +391,17 @@ int d3dp_launch_time_mlp(const int64_t* t, const float* freq, const float* w1, c
 //        3 = split-fp16 activation planes (y fp32)
 int d3dp_launch_embed_ln(int act_bf16, const float* x2d, const float* x3d, const float* temb, const float* ew,
                          const float* eb, const float* spos, const float* lnw, const float* lnb, float eps, float* x,
-                         void* xn, int seq0, int n_seq, int H, int F, int J, int C, hipStream_t st) {
-  const int T = n_seq * F * J;
+                         void* xn, int seq0, int n_seq, int H, int F, int J, int C, hipStream_t st, int SP) {
+  if (SP <= 0) SP = F * J;
+  if (SP < F * J) return -1;
+  const int T = n_seq * SP;
   dim3 g((T + 3) / 4), blk(256);
   const size_t plane = (size_t)T * C;
   DISPATCH_C(C,
-    if (act_bf16 == 1) hipLaunchKernelGGL((embed_ln_kernel<CC, bf16>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, plane, seq0, n_seq, H, F, J);
-    else if (act_bf16 == 2) hipLaunchKernelGGL((embed_ln_kernel<CC, b3>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, plane, seq0, n_seq, H, F, J);
-    else if (act_bf16 == 3) hipLaunchKernelGGL((embed_ln_kernel<CC, h2>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (f16*)xn, plane, seq0, n_seq, H, F, J);
-    else hipLaunchKernelGGL((embed_ln_kernel<CC, float>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (float*)xn, plane, seq0, n_seq, H, F, J))
+    if (act_bf16 == 1) hipLaunchKernelGGL((embed_ln_kernel<CC, bf16>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, plane, seq0, n_seq, H, F, J, SP);
+    else if (act_bf16 == 2) hipLaunchKernelGGL((embed_ln_kernel<CC, b3>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, plane, seq0, n_seq, H, F, J, SP);
+    else if (act_bf16 == 3) hipLaunchKernelGGL((embed_ln_kernel<CC, h2>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (f16*)xn, plane, seq0, n_seq, H, F, J, SP);
+    else hipLaunchKernelGGL((embed_ln_kernel<CC, float>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (float*)xn, plane, seq0, n_seq, H, F, J, SP))
   return 0;
 }
 
@@ -408,23 +418,25 @@ int d3dp_launch_ln(int act_bf16, float* x, const void* yadd, int write_x, const 
 }
 
 int d3dp_launch_ln2(int act_bf16, float* x, const void* yadd0, const void* yadd, const float* wa, const float* ba, const float* pos,
-                    const float* wb, const float* bb, float eps, void* xn, int T, int C, int F, int J, hipStream_t st) {
+                    const float* wb, const float* bb, float eps, void* xn, int T, int C, int F, int J, hipStream_t st, int SP) {
+  if (SP <= 0) SP = F * J;
   dim3 g((T + 3) / 4), blk(256);
   const size_t plane = (size_t)T * C;
   DISPATCH_C(C,
-    if (act_bf16 == 1) hipLaunchKernelGGL((ln2_kernel<CC, bf16, bf16>), g, blk, 0, st, x, (const bf16*)yadd0, (const bf16*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, plane, T, F, J);
-    else if (act_bf16 == 2) hipLaunchKernelGGL((ln2_kernel<CC, b3, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, plane, T, F, J);
-    else if (act_bf16 == 3) hipLaunchKernelGGL((ln2_kernel<CC, h2, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, pos, wb, bb, eps, (f16*)xn, plane, T, F, J);
-    else hipLaunchKernelGGL((ln2_kernel<CC, float, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, pos, wb, bb, eps, (float*)xn, plane, T, F, J))
+    if (act_bf16 == 1) hipLaunchKernelGGL((ln2_kernel<CC, bf16, bf16>), g, blk, 0, st, x, (const bf16*)yadd0, (const bf16*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, plane, T, F, J, SP);
+    else if (act_bf16 == 2) hipLaunchKernelGGL((ln2_kernel<CC, b3, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, plane, T, F, J, SP);
+    else if (act_bf16 == 3) hipLaunchKernelGGL((ln2_kernel<CC, h2, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, pos, wb, bb, eps, (f16*)xn, plane, T, F, J, SP);
+    else hipLaunchKernelGGL((ln2_kernel<CC, float, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, pos, wb, bb, eps, (float*)xn, plane, T, F, J, SP))
   return 0;
 }
 
 int d3dp_launch_head(int act_bf16, const float* x, const void* yadd0, const void* yadd, const float* wa, const float* ba, float eps_a, const float* wh,
                      const float* bh, float eps_h, const float* w, const float* b, float* out, int T, int C,
-                     hipStream_t st) {
+                     hipStream_t st, int FJ, int SP) {
+  if (FJ <= 0 || SP <= 0) { FJ = SP = 1 << 30; }       // compact rows: out row = input row
   dim3 g((T + 3) / 4), blk(256);
   DISPATCH_C(C,
-    if (act_bf16 == 1) hipLaunchKernelGGL((head_kernel<CC, bf16>), g, blk, 0, st, x, (const bf16*)yadd0, (const bf16*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T);
-    else hipLaunchKernelGGL((head_kernel<CC, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T))
+    if (act_bf16 == 1) hipLaunchKernelGGL((head_kernel<CC, bf16>), g, blk, 0, st, x, (const bf16*)yadd0, (const bf16*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T, FJ, SP);
+    else hipLaunchKernelGGL((head_kernel<CC, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T, FJ, SP))
   return 0;
 }

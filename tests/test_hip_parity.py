@@ -179,6 +179,68 @@ def test_linear_split_f16_is_fp32_class(lib, M, N, K):
 
 
 
+def unpack_qkv_rows(buf, M, C):
+    """Packed rows of the EXACT qkv Linear (epi 4): q fp32 [C] | k hi | k lo | v hi | v lo (fp16 [C] each, x 16) -> (M, 3C) fp64."""
+    raw = buf.view(torch.uint8).reshape(M, 12 * C)
+    q = raw[:, :4 * C].contiguous().view(torch.float32).double()
+    h = raw[:, 4 * C:].contiguous().view(torch.float16).reshape(M, 4, C).double()
+    return torch.cat((q, (h[:, 0] + h[:, 1]) / 16.0, (h[:, 2] + h[:, 3]) / 16.0), dim=1)
+
+
+@pytest.mark.parametrize("D", [4, 2, 1])
+@pytest.mark.parametrize("M", [70000, 4131 + 29, 300])
+def test_linear_split_f16_skewed_schedule(lib, M, D):
+    """The row-class skewed schedule of the EXACT qkv and fc1 Linears (gemm_x2.hip: a tile's epilogue leaves under the next
+    tile's k-loop).  Against fp64 like the plain kernel; and structurally: 16-row blocks of class 0 ((m / 16) % 4 == 0) sum
+    their k-steps in the natural order, so they are BIT-IDENTICAL to the plain kernel's, the other classes differ by summation
+    order only; and the result of a row depends on (m % 64) and its inputs alone -- the same rows 64 further down the
+    matrix come out bit-identical (the batch-invariance the padded sequence pitch builds on)."""
+    K, C = 512, 512
+    g = torch.Generator().manual_seed(M + D)
+    A = torch.randn(M, K, generator=g) * 2
+    bd = torch.randn(3 * C, generator=g).cuda()
+    Ad = A.cuda()
+    A2 = torch.empty(2, M, K, dtype=torch.float16, device="cuda")
+    _lib.check(lib.d3dp_op_split2(Ad.data_ptr(), A2.data_ptr(), M * K, 16.0, stream()))
+    cls = (torch.arange(M) // 16) % 4
+    for epi, N in ((_lib.EPI_QKV_PACK, 3 * C), (_lib.EPI_GELU, 2 * C)):
+        W = torch.randn(N, K, generator=g) / K ** 0.5
+        W2 = torch.empty(2, N, K, dtype=torch.float16, device="cuda")
+        w_scale = 2.0 ** (13 - int(np.floor(np.log2(W.abs().max().item()))))
+        _lib.check(lib.d3dp_op_split2(W.cuda().data_ptr(), W2.data_ptr(), N * K, w_scale, stream()))
+        want = A.double() @ W.double().t() + bd[:N].cpu().double()
+        if epi == _lib.EPI_GELU:
+            want = torch.nn.functional.gelu(want)
+
+        def run(e, a2, m):
+            nbytes = m * (12 * C if epi == _lib.EPI_QKV_PACK else 4 * N)
+            out = torch.full((nbytes,), 0xFF, dtype=torch.uint8, device="cuda")
+            _lib.check(lib.d3dp_op_linear_x2(e, a2.data_ptr(), W2.data_ptr(), bd.data_ptr(), w_scale, out.data_ptr(), m, N, K,
+                                             stream()), "d3dp_op_linear_x2")
+            torch.cuda.synchronize()
+            return out.cpu()
+
+        def value(raw, m):
+            if epi == _lib.EPI_QKV_PACK:
+                return unpack_qkv_rows(raw, m, C)
+            hi, lo = h2i_planes(raw.view(torch.float16), m, N)
+            return (hi.double() + lo.double()) / 16.0
+
+        plain, skew = run(epi, A2, M), run(epi | (D << 8), A2, M)
+        e_plain, e_skew = (value(plain, M) - want).abs().mean().item(), (value(skew, M) - want).abs().mean().item()
+        print(f"skewed schedule D={D} epi={epi} M={M}: mean |err| {e_skew:.3e} (plain schedule {e_plain:.3e})")
+        assert e_skew <= 1.5 * e_plain + 1e-9 and torch.isfinite(value(skew, M)).all()
+        rb = (12 * C) if epi == _lib.EPI_QKV_PACK else 4 * N
+        p2, s2 = plain.reshape(M, rb), skew.reshape(M, rb)
+        assert torch.equal(p2[cls == 0], s2[cls == 0])          # class 0: the natural k order
+        assert not torch.equal(p2[cls == 1], s2[cls == 1])      # the others: rotated (different roundings somewhere)
+        # shift the matrix down by 64 rows: every original row keeps its class and must keep its bits
+        A2s = torch.zeros(2 * (M + 64) * K, dtype=torch.float16, device="cuda")
+        A2s[2 * 64 * K:] = A2.reshape(-1)
+        shifted = run(epi | (D << 8), A2s, M + 64).reshape(M + 64, rb)
+        assert torch.equal(shifted[64:], s2)
+
+
 def test_linear_split_f16_rejects_k_not_multiple_of_64(lib):
     """The k-loop runs two k-steps of 32 per iteration: K = 96 must be refused, not mis-computed."""
     M, N, K = 300, 128, 96

@@ -345,3 +345,82 @@ def test_reference_attributes_exist():
     m = D3DP(tiny_args(), KL, KR, is_train=False)
     assert (m.objective, m.self_condition, m.box_renewal, m.use_ensemble, m.ddim_sampling_eta) == \
            ('pred_x0', False, True, True, 1.)
+
+
+def _simulate_skewed_linear(M, tm, tiles_n, G, NK, D):
+    """Index-level model of gemm_f16x2_skew_kernel (d3dp_amd/csrc/gemm_x2.hip), written from the kernel's formulas: per
+    workgroup the loader's row pointers (rotating LDS image), the compute waves' park / shift / store sequence.  Returns,
+    per (row tile, strip, row class), the list of k-steps that were accumulated into what got stored, and the store count."""
+    from collections import defaultdict
+    Q = G // tiles_n
+    stored = defaultdict(list)                     # (tile_row, strip, cls) -> [tuple of k-steps accumulated] per store
+    for L in range(G):
+        strip, rg = L % tiles_n, L // tiles_n
+        lo = rg * tm // Q if rg < Q else 0
+        hi = (rg + 1) * tm // Q if rg < Q else 0
+        n_tiles = hi - lo
+        if n_tiles <= 0:
+            continue
+        gtot = n_tiles * NK + 3 * D
+        # ---- loader: slab g holds, in LDS row slot p, rows of (class, tile j) at k-offset ks
+        slabs, pa, ti, ks = [], [None] * 4, 0, 0
+        for g in range(gtot):
+            if ks % D == 0 and ks < 4 * D:
+                rot = (ks // D + 1) & 3
+                for p in range(4):
+                    cls = (p + rot) & 3
+                    j = ti if ks >= cls * D else ti - 1
+                    pa[p] = (cls, min(max(j, 0), n_tiles - 1), j)      # (class, clamped tile, wanted tile)
+            slabs.append((list(pa), ks))
+            ks += 1
+            if ks == NK:
+                ks, ti = 0, ti + 1
+        # ---- compute: acc[p] = list of (class, tile, ks) contributions
+        acc = [[] for _ in range(4)]
+        g = 0
+
+        def park_and_shift(cls, tile):
+            parked = acc[0]
+            acc[0], acc[1], acc[2], acc[3] = acc[1], acc[2], acc[3], []
+            if tile >= 0:
+                stored[(lo + tile, strip, cls)].append(tuple(parked))
+
+        def kstep():
+            nonlocal g
+            rows, ksg = slabs[g]
+            for p in range(4):
+                acc[p].append((rows[p][0], rows[p][1], rows[p][2], ksg))
+            g += 1
+
+        for ti in range(n_tiles + 1):
+            for grp in range(4 if ti < n_tiles else 3):
+                park_and_shift(grp, ti - 1)
+                for _ in range(D):
+                    kstep()
+            if ti < n_tiles:
+                for _ in range(NK - 4 * D):
+                    kstep()
+        park_and_shift(3, n_tiles - 1)
+        assert g == gtot                                   # compute and loader waves count the same barriers
+    return stored
+
+
+@pytest.mark.parametrize("tm,tiles_n,G,NK,D", [(504, 12, 256, 16, 4), (504, 8, 256, 16, 2), (37, 12, 256, 16, 4),
+                                               (274, 4, 256, 16, 1), (100, 8, 64, 8, 2), (23, 12, 30, 4, 1)])
+def test_skewed_linear_schedule_covers_every_tile_exactly_once(tm, tiles_n, G, NK, D):
+    """The skewed schedule of the EXACT qkv / fc1 Linears: every (row tile, strip, 16-row class) is stored exactly once, and
+    what is stored has accumulated every k-step of ITS OWN tile and class exactly once, in the rotated order class D, ...,
+    NK - 1, 0, ..., class D - 1 -- nothing from a neighbouring tile, nothing from the ramp or the flush."""
+    stored = _simulate_skewed_linear(tm * 256, tm, tiles_n, G, NK, D)
+    assert len(stored) == tm * tiles_n * 4
+    for (tile, strip, cls), stores in stored.items():
+        assert len(stores) == 1, (tile, strip, cls)
+        contrib = stores[0]
+        assert len(contrib) == NK
+        want_order = [(cls * D + i) % NK for i in range(NK)]
+        assert [k for (_, _, _, k) in contrib] == want_order
+        # rows fetched: the class's own, from the tile it was on (clamped == wanted: no ramp / flush filler inside)
+        assert all(c == cls for (c, _, _, _) in contrib)
+        Q = G // tiles_n
+        rg = next(r for r in range(Q) if r * tm // Q <= tile < (r + 1) * tm // Q)
+        assert all(jc == jw == tile - rg * tm // Q for (_, jc, jw, _) in contrib)

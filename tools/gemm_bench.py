@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--shapes", default="qkv,proj,fc1,fc2")
     ap.add_argument("--x3", action="store_true", help="six-pass split-bf16 kernel (three planes per operand)")
     ap.add_argument("--x2", action="store_true", help="EXACT-mode split-fp16 kernel (two planes per operand, three passes)")
+    ap.add_argument("--real-epi", action="store_true", help="--x2: the epilogues the denoiser launches (qkv: packed rows, proj / fc2: x += ..., fc1: GELU planes)")
+    ap.add_argument("--skew", type=int, default=0, help="--x2 --real-epi: D of the skewed schedule for qkv and fc1 (0 = plain)")
     ap.add_argument("--check", action="store_true", help="compare each result with torch (fp32 matmul of the bf16 operands)")
     ap.add_argument("--cache", default="hot", choices=["hot", "cold", "produced"],
                     help="state of A before each timed launch: hot = same buffers back to back; cold = 1 GB written in "
@@ -35,6 +37,8 @@ def main():
     if a.x2:
         for name in a.shapes.split(","):
             N, K, epi = shapes[name]
+            if a.real_epi:
+                epi = {"qkv": 4 | (a.skew << 8), "proj": 2, "fc1": 1 | (a.skew << 8), "fc2": 2}.get(name, epi)
             A = torch.randn(M, K, device="cuda")
             W = torch.randn(N, K, device="cuda") / K ** 0.5
             A2 = torch.empty(2, M, K, dtype=torch.float16, device="cuda")
@@ -54,7 +58,7 @@ def main():
                     ts.append(e0.elapsed_time(e1))
             ts.sort()
             med = ts[len(ts) // 2]
-            if a.check:
+            if a.check and not a.real_epi:
                 ref = A.double() @ W.double().t() + b.double()
                 if epi:
                     got = out.view(torch.float16)[:2 * M * N].view(M, N // 32, 2, 32)   # h2i layout: [hi 32 | lo 32] blocks

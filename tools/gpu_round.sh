@@ -1,0 +1,75 @@
+#!/bin/bash
+# One parametrised driver for everything this repo runs on the GPU box (replaces the per-call scratch scripts of rounds 2-3):
+#   tools/gpu_round.sh STAGE [STAGE ...]      results under gpurun_out/$TAG/ (TAG defaults to "r04")
+# stages
+#   guard        the new kernels once, small, under a short timeout (a hang here must not take the rest of the call with it);
+#                on failure the remaining stages run with D3DP_X2_SKEW=0
+#   tests        pytest -m gpu (PYTEST_ARGS to narrow)
+#   smoke        __graft_entry__.smoke()
+#   ab           short bench runs, one per entry of AB (";"-separated "name:ENV=V ENV=V ..." entries; LIB=path selects a variant build)
+#   bench        the driver-style bench line (STEPS / WARMUP)
+#   stats        rocprofv3 --kernel-trace --stats of one bench step -> kernel_stats.md
+#   pmc_gemm     FETCH_SIZE / WRITE_SIZE / MFMA-busy of the qkv Linear inside the denoiser at the bench's own pass sizes
+#   pmc_step     the same counters over every kernel of one step
+#   gemm         tools/gemm_bench.py micro-benchmark of the four Linear shapes (GEMM_ARGS)
+#   train        tools/train_bench.py
+set -u
+TAG=${TAG:-r04}; R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O
+export TMPDIR=/tmp
+QUICK="--no-cpu-baseline --no-other-leg --no-parity --no-configs"
+json_line() { python -c "
+import sys, json
+l = [x for x in sys.stdin.read().splitlines() if x.startswith('{')]
+d = json.loads(l[-1]); k = d.get('kernel_ms_per_step', {})
+print('$1', round(d['value'], 2), round(d['ms_per_step'], 1), {n: round(v) for n, v in k.items() if v > 40})"; }
+for stage in "$@"; do
+  case $stage in
+    guard)
+      if ! timeout 240 python -m pytest tests/test_hip_parity.py -q -x -k "skewed_schedule and 300" > $O/guard.log 2>&1; then
+        echo "guard FAILED: skewed schedule off for the rest of this call" | tee -a $O/guard.log; export D3DP_X2_SKEW=0
+      fi; tail -5 $O/guard.log ;;
+    tests)
+      timeout 1500 python -m pytest tests -m gpu -q --durations=8 -rs ${PYTEST_ARGS:-} > $O/tests_full.log 2>&1; tail -30 $O/tests_full.log > $O/tests.log; tail -12 $O/tests.log ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -3 $O/smoke.log ;;
+    ab)
+      IFS=';' read -ra ENTRIES <<< "${AB:-base:}"
+      for e in "${ENTRIES[@]}"; do
+        name=${e%%:*}; envs=${e#*:}
+        ( for kv in $envs; do case $kv in LIB=*) export D3DP_LIB=$R/d3dp_amd/lib/variants/libd3dp_${kv#LIB=}.so;; *) export $kv;; esac; done
+          timeout 400 python bench.py --steps ${AB_STEPS:-2} --warmup 1 $QUICK ${AB_ARGS:-} 2>$O/ab_$name.err | json_line $name ) >> $O/ab.log
+      done; cat $O/ab.log ;;
+    bench)
+      timeout 900 python bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-5} ${BENCH_ARGS:-} > $O/bench.json 2> $O/bench.err; head -c 900 $O/bench.json; echo ;;
+    stats)
+      ( cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats -d $O/stats -- python $R/bench.py --steps 1 --warmup 1 $QUICK > $O/bench_prof.json 2>/dev/null )
+      db=$(find $O/stats -name "*.db" | head -1); [ -n "$db" ] && python tools/rocprof_summary.py $db $O/kernel_stats.md > /dev/null; rm -rf $O/stats; head -30 $O/kernel_stats.md ;;
+    pmc_gemm)
+      for mode in ${MODES:-exact}; do
+        rx="f16x2_(skew_)?kernelILi0ELi1E"; [ $mode = fast ] && rx="Li8ELi4ELi1E"
+        B="$R/bench.py --steps 1 --warmup 0 --no-profile --numerics $mode $QUICK"
+        for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+          t=$(echo $c | cut -d' ' -f1)
+          ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-include-regex "$rx" --output-format csv -d $O/pmc_${mode}_$t -- python $B > /dev/null 2>&1 )
+        done
+      done
+      for d in $O/pmc_*_*/; do f=$(find $d -name "*counter_collection.csv" | head -1); echo "== $d"; [ -n "$f" ] && python tools/pmc_summary.py $f gemm | grep -v "^$"; done > $O/pmc.log 2>&1
+      find $O -name "*.csv" -size +10M -delete; grep -E "==|FETCH|WRITE|MFMA|GRBM" $O/pmc.log ;;
+    pmc_step)
+      for mode in ${MODES:-exact}; do
+        B="$R/bench.py --steps 1 --warmup 0 --no-profile --numerics $mode $QUICK"
+        ( cd /tmp
+          timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/step_${mode}_f -- python $B > /dev/null 2>&1
+          timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/step_${mode}_w -- python $B > /dev/null 2>&1
+          timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/step_${mode}_m -- python $B > /dev/null 2>&1 )
+        python tools/pmc_step_summary.py $O/step_pmc_$mode.md $(find $O/step_${mode}_f $O/step_${mode}_w $O/step_${mode}_m -name "*counter_collection.csv") > /dev/null
+        head -14 $O/step_pmc_$mode.md
+      done; find $O -name "*.csv" -size +20M -delete ;;
+    gemm)
+      timeout 300 python tools/gemm_bench.py --x2 ${GEMM_ARGS:---m 128960 --iters 10} > $O/gemm_bench.log 2>&1; cat $O/gemm_bench.log ;;
+    train)
+      timeout 300 python tools/train_bench.py ${TRAIN_ARGS:-10} > $O/train_bench.log 2>&1; tail -3 $O/train_bench.log ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done
+sha256sum d3dp_amd/lib/libd3dp_hip.so > $O/lib.sha256
