@@ -780,8 +780,11 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
       lds_dma16(gj + 2 * C, img + PLANE + pc * 1024);
     }
   };
-  f32x4 qr[TPW][4] = {};                               // raw query fragments of the next problem (zero: a wave whose
-                                                       // second tile does not exist still runs the paired score path on it)
+  // raw query fragments of the next problem.  (Not zero-initialised on purpose: the compiler would place the zeroing of
+  // the lanes / tiles that load nothing right behind the untracked loads, inside their in-flight window, which the ISA scan
+  // of tests/test_abi.py forbids.  A wave whose second tile does not exist -- 129..240 frames -- runs the paired score path
+  // on whatever these registers hold and never stores the result.)
+  f32x4 qr[TPW][4];
   auto load_q_raw = [&](const char* row0, int head) {
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
