@@ -445,10 +445,16 @@ __device__ __forceinline__ f16x8 as_f16x8(bf16x8 v) { return __builtin_bit_cast(
 
 // Operand scales of the split-fp16 attention kernels (kernel argument; wave-uniform).  q is split in registers at `q`; the
 // k / v planes of the packed rows were written at that same scale by the qkv Linear; `cexp` = hd^-0.5 log2(e) / (q scale x
-// k scale) folds both into the softmax exponent; `onorm` = output scale / v scale (1 when the output leaves as planes at the
-// scale of v -- |o| <= max |v| --, 1 / v scale for fp32 output).  Everything is 2^4-based unless capi.hip lowered the scale
-// of a block whose proven operand range asks for it (d3dp_exact_range_bound).
-struct X2Scales { float q, cexp, onorm; };
+// k scale) folds both into the softmax exponent; `onorm` = 1 / v scale brings O^T back to its true scale; `oplane` = the scale
+// at which a plane output is split (that of v: |o| <= max |v|).  Everything is 2^4-based unless capi.hip lowered the scale of
+// a block whose proven operand range asks for it (d3dp_exact_range_bound).
+// The true-scale value is formed FIRST and the (power-of-two, hence exact) plane scale applied inside the split on purpose:
+// with  x = o * (1 / denom)  handed to the split directly, hipcc (ROCm 7.2) folds the fp16 conversion of the INEXACT product
+// into v_fma_mixlo_f16 for the lo half -- f16(o * inv) rounded once from the exact product -- while the stored hi half is
+// v_cvt_pk_f16_f32 of the fp32-rounded product: wherever the two roundings disagree (about 1 element in 2^13) hi + lo is off
+// by a whole fp16 ulp of hi, and the denoiser's error against the reference tripled (gpurun c5: 6.4e-4 -> 1.8e-3 mm).  The
+// exact scaling in between makes both halves round the same number.
+struct X2Scales { float q, cexp, onorm, oplane; };
 
 // 8 consecutive fp32 -> one 16-byte slot of hi and one of lo (values x sc)
 __device__ __forceinline__ void split8(const float4 a, const float4 b, f16x8& hi, f16x8& lo, float sc) {
@@ -676,10 +682,11 @@ __device__ __forceinline__ void load_k_x2(const f16* krow, int C, int fg, f16x8 
 }
 
 // O^T accumulators -> out row `tok` (fp32 [T][C], or the h2i layout of the proj Linear's operand, common.h): lane holds
-// channels col + dn*16 + (0..3), col = head*64 + 4 fg.  `inv` = onorm / (1024 x softmax denominator): for plane outputs the
-// product is the value at the OUTPUT operand's scale already (X2Scales)
+// channels col + dn*16 + (0..3), col = head*64 + 4 fg.  `inv` = onorm / (1024 x softmax denominator): o * inv is the TRUE-scale
+// value; plane outputs are split at `oplane` (see X2Scales for why in this order)
 template <int OUTS>
-__device__ __forceinline__ void store_o_x2(const f32x4 (&o)[4], float inv, void* out_v, size_t tok, int C, int col) {
+__device__ __forceinline__ void store_o_x2(const f32x4 (&o)[4], float inv, void* out_v, size_t tok, int C, int col,
+                                           float oplane) {
 #pragma unroll
   for (int dn = 0; dn < 4; ++dn) {
     const float r4[4] = {o[dn][0] * inv, o[dn][1] * inv, o[dn][2] * inv, o[dn][3] * inv};
@@ -687,7 +694,7 @@ __device__ __forceinline__ void store_o_x2(const f32x4 (&o)[4], float inv, void*
       f16* dst = reinterpret_cast<f16*>(out_v) + tok * (2 * C) + h2i_col(col + dn * 16);
       f16x4 p0, p1;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { f16 a0, a1; split2h_scaled(r4[e], a0, a1); p0[e] = a0; p1[e] = a1; }
+      for (int e = 0; e < 4; ++e) { f16 a0, a1; split2h_scaled(r4[e] * oplane, a0, a1); p0[e] = a0; p1[e] = a1; }
       *reinterpret_cast<f16x4*>(dst) = p0;
       *reinterpret_cast<f16x4*>(dst + kH2iLo) = p1;
     } else {
@@ -881,7 +888,7 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
         const int l = opaque(lane);
         const int q = qt * 16 + (l & 15);
         if (q < n)
-          store_o_x2<OUTS>(o, inv_scale / denom[u], out_v, (size_t)(tok0 + q * ts), C, head * 64 + (l >> 4) * 4);
+          store_o_x2<OUTS>(o, inv_scale / denom[u], out_v, (size_t)(tok0 + q * ts), C, head * 64 + (l >> 4) * 4, sc.oplane);
       }
     }
     if (!has_next) break;
@@ -984,7 +991,7 @@ __global__ __launch_bounds__(256) void attn_spatial_x2_kernel(const float* __res
 #pragma unroll
     for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
     pv_chunk_x2_seq<0>(fb, PLANE, ph[0], pl[0], o);
-    if (q < n) store_o_x2<OUTS>(o, inv_scale / sum, out_v, (size_t)(base + q * ts), C, head * 64 + fg * 4);
+    if (q < n) store_o_x2<OUTS>(o, inv_scale / sum, out_v, (size_t)(base + q * ts), C, head * 64 + fg * 4, sc.oplane);
   }
 }
 
@@ -1244,7 +1251,7 @@ int d3dp_launch_attn_x2(int act, int axis, const void* qkv, void* out, int n_seq
   const size_t plane = (size_t)n_seq * map.n_tok * C;
   const int n = map.n_tok;
   const X2Scales sc = {act_scale, 0.125f * 1.44269504088896340736f / (act_scale * act_scale),
-                       act == 3 ? 1.0f : 1.0f / act_scale};
+                       1.0f / act_scale, act_scale};
   if (axis == 0) {
     if (n > 32) return -2;
     const int n_prob = n_seq * heads;

@@ -144,8 +144,14 @@ struct d3dp_ctx {
   // that order is a function of the token's index within its sequence alone and results stay bit-identical whatever the batch
   // composition, pass split or rank count (the H-sharding contract, tests/test_hip_parity.py::test_full_size_properties).
   bool skew() const { return x2_attn() && skew_d > 0 && cfg.channels >= 128 * skew_d; }   // (K = C >= 4 D k-steps of 32)
-  int skew_d = 4;                // k-steps a parked row class takes to leave (1, 2, 4); D3DP_X2_SKEW=0: the plain schedule
-  int seq_pitch() const { const int fj = cfg.frames * cfg.joints; return skew() ? (fj + 63) / 64 * 64 : fj; }
+  int skew_d = 0;                // D3DP_X2_SKEW=1|2|4: k-steps a parked row class takes to leave.  OFF by default: measured
+                                 // 3 % slower on the whole step (gemm_x2.hip, DESIGN.md 7: the Linear is bound by its vector-memory
+                                 // instruction rate, and an epilogue's stores cost the same wherever they issue)
+  int seq_pitch() const {
+    const int fj = cfg.frames * cfg.joints;
+    return (pad_override < 0 ? skew() : (pad_override > 0 && x2_attn())) ? (fj + 63) / 64 * 64 : fj;
+  }
+  int pad_override = -1;         // D3DP_SEQ_PAD=0|1: measurement switch (pad without the skewed schedule, or the reverse)
   bool x3() const { return exact() && exact_impl == 1; }
   int act() const { return fast() ? 1 : (x3() ? 2 : (x2() ? 3 : 0)); }   // code understood by the row-wise launchers
   size_t act_size() const { return fast() ? 2 : (x3() ? 6 : 4); }    // bytes per element of a Linear-input activation
@@ -354,8 +360,10 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->exact_impl = c->exact_impl_req = (xf && !strcmp(xf, "bf16x3")) ? 1 : (xf && !strcmp(xf, "f32")) ? 2 : 0;
   const char* nf = getenv("D3DP_NO_FOLD");               // cross-check: residual adds (and norm2) in the row kernels
   c->fold = !(nf && nf[0] == '1');
-  const char* sk = getenv("D3DP_X2_SKEW");               // 0: the plain (un-skewed) schedule of the EXACT qkv / fc1 Linears; 1, 2, 4: D
+  const char* sk = getenv("D3DP_X2_SKEW");               // 1, 2, 4: the skewed schedule of the EXACT qkv / fc1 Linears (0 / unset: plain)
   if (sk && (sk[0] == '0' || sk[0] == '1' || sk[0] == '2' || sk[0] == '4') && sk[1] == 0) c->skew_d = sk[0] - '0';
+  const char* pd = getenv("D3DP_SEQ_PAD");
+  if (pd && (pd[0] == '0' || pd[0] == '1') && pd[1] == 0) c->pad_override = pd[0] - '0';
   const char* nl = getenv("D3DP_FOLD_LN");               // norm2 folded into proj / fc1 instead of its own row kernel
   c->fold_ln_on = nl && nl[0] == '1';
   HIP_TRY(hipGetDevice(&c->device));

@@ -89,6 +89,18 @@
 #ifndef D3DP_X2_SKEW_SGB
 #define D3DP_X2_SKEW_SGB 0
 #endif
+// where the leaving rows' VALU work and stores go inside a k-step: 1 = in ONE packet right behind the k-step's fragment
+// reads, in front of its first MFMA -- the window in which every wave of the workgroup waits for LDS after the barrier
+// anyway (measured: interleaved with the MFMAs the same work cost as much as an exposed epilogue, gpurun c2); 0 = beside
+// the MFMAs of the four row blocks
+#ifndef D3DP_X2_SKEW_TOP
+#define D3DP_X2_SKEW_TOP 1
+#endif
+// timing probes of the skewed kernel (results INVALID): 1 = the leaving rows' VALU work and stores sit behind a condition
+// that is false at run time (the schedule alone); 2 = no accumulator shift at a park
+#ifndef D3DP_X2_SKEW_PROBE
+#define D3DP_X2_SKEW_PROBE 0
+#endif
 #if D3DP_NT_OUT
 #define OUT_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #else
@@ -651,6 +663,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_skew_kernel(const f16* __restr
   for (int j = 0; j < 4; ++j) park[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   unsigned joff = 0;                                   // byte offset of row r = 0 of the parked class (+ coff)
   int jrows = 0;                                       // its rows r < jrows exist (<= 0: nothing to store)
+  [[maybe_unused]] float4 jbz = {};                    // (D3DP_X2_SKEW_TOP) the lane's four biases, re-read at every park
 
   // value e of output row r of the parked class, through the epilogue's arithmetic (the lane's four biases are re-read
   // from LDS in every k-step that needs them -- one ds_read_b128 -- instead of living in registers across the k-loop)
@@ -681,12 +694,17 @@ __global__ __launch_bounds__(768) void gemm_f16x2_skew_kernel(const f16* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       park[j] = acc[0][j];
+#if !(D3DP_X2_SKEW_PROBE & 2)
       acc[0][j] = acc[1][j]; acc[1][j] = acc[2][j]; acc[2][j] = acc[3][j];
       acc[3][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
     }
     const int m_row = (lo + tile) * XBM + row0 + cls * 16;      // tile < 0 (no tile finished yet): nothing is stored
     jrows = tile >= 0 ? M - m_row : 0;
     joff = (unsigned)m_row * pitch + coff;
+#if D3DP_X2_SKEW_TOP
+    jbz = *reinterpret_cast<const float4*>(bias4);
+#endif
   };
 
   int slot = 0;
@@ -708,10 +726,28 @@ __global__ __launch_bounds__(768) void gemm_f16x2_skew_kernel(const f16* __restr
     ah[0] = *reinterpret_cast<const f16x8*>(sb + offA);
     al[0] = *reinterpret_cast<const f16x8*>(sb + offAl);
     [[maybe_unused]] float4 bz = {};
+#if !D3DP_X2_SKEW_TOP
     if constexpr (JOB) bz = *reinterpret_cast<const float4*>(bias4);
+#endif
     __builtin_amdgcn_sched_barrier(0);
-    // value e of a leaving row is computed beside accumulator block e's twelve MFMAs (GELU: ~20 VALU per value), the row
-    // is split and stored beside the last block's
+#if D3DP_X2_SKEW_TOP
+    if constexpr (JOB && !(D3DP_X2_SKEW_PROBE & 1)) {
+      // the leaving rows of this k-step, whole, while the fragment reads above are in flight (nothing here depends on them)
+#pragma unroll
+      for (int rr = 0; rr < RPK; ++rr) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = value(r0 + rr, e, jbz);
+          if constexpr (EPI == EPI_GELU) v[e] = gelu_erf_rational(v[e]);
+        }
+        store_row(r0 + rr, v);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+    // (D3DP_X2_SKEW_TOP == 0) value e of a leaving row is computed beside accumulator block e's twelve MFMAs (GELU: ~20 VALU
+    // per value), the row is split and stored beside the last block's
     [[maybe_unused]] float ev[RPK][4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -720,7 +756,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_skew_kernel(const f16* __restr
         ah[b ^ 1] = *reinterpret_cast<const f16x8*>(sb + offA + (mi + 1) * 2048);
         al[b ^ 1] = *reinterpret_cast<const f16x8*>(sb + offAl + (mi + 1) * 2048);
       }
-      if constexpr (JOB) {
+      if constexpr (JOB && !(D3DP_X2_SKEW_PROBE & 1) && !D3DP_X2_SKEW_TOP) {
 #pragma unroll
         for (int rr = 0; rr < RPK; ++rr) {
           float x = value(r0 + rr, mi, bz);
@@ -734,10 +770,21 @@ __global__ __launch_bounds__(768) void gemm_f16x2_skew_kernel(const f16* __restr
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[b], wf[ni][0], acc[mi][ni], 0, 0, 0);
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], wf[ni][0], acc[mi][ni], 0, 0, 0);
-      if constexpr (JOB) {
+      if constexpr (JOB && !(D3DP_X2_SKEW_PROBE & 1) && !D3DP_X2_SKEW_TOP) {
         if (mi == 3) {
 #pragma unroll
           for (int rr = 0; rr < RPK; ++rr) store_row(r0 + rr, ev[rr]);
+        }
+      }
+      if constexpr (JOB && (D3DP_X2_SKEW_PROBE & 1)) {
+        if (mi == 3 && unscale == -12345.f) {          // (never true: keeps the parked values, and with them the MFMAs, live)
+#pragma unroll
+          for (int rr = 0; rr < RPK; ++rr) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = value(r0 + rr, e, bz);
+            store_row(r0 + rr, v);
+          }
         }
       }
 #if D3DP_X2_SKEW_SGB
