@@ -152,6 +152,9 @@ struct d3dp_ctx {
     return (pad_override < 0 ? skew() : (pad_override > 0 && x2_attn())) ? (fj + 63) / 64 * 64 : fj;
   }
   int pad_override = -1;         // D3DP_SEQ_PAD=0|1: measurement switch (pad without the skewed schedule, or the reverse)
+  int pingpong = 0;              // D3DP_X2_PP=1: the ping-pong form of the EXACT Linear (gemm_x2.hip; bit-identical results;
+                                 // measured 1.5-2 % SLOWER on the whole step, gpurun c8: the fragment reads, not their latency, are
+                                 // what the matrix pipe waits for -- 171 B/clk of LDS reads at full MFMA rate against 128 B/clk)
   bool x3() const { return exact() && exact_impl == 1; }
   int act() const { return fast() ? 1 : (x3() ? 2 : (x2() ? 3 : 0)); }   // code understood by the row-wise launchers
   size_t act_size() const { return fast() ? 2 : (x3() ? 6 : 4); }    // bytes per element of a Linear-input activation
@@ -255,7 +258,7 @@ int linear(d3dp_ctx* c, int cls, int epi, int out_f32, const void* A, const void
     // qkv and fc1 (epilogues without loads) run the skewed schedule when the context has it on (seq_pitch() pads for it)
     const int skew_d = c->skew() && (epi == EPI_QKV_PACK || epi == EPI_GELU) ? c->skew_d : 0;
     return d3dp_launch_linear_f16x2(epi, A, W, bias, wu / a_scale, o_scale, (float*)out, out2 ? out2 : out, aux, c->d_flag, M, N,
-                                    K, st, skew_d);
+                                    K, st, skew_d, c->pingpong);
   }
   if (c->x3()) return d3dp_launch_linear_bf16x3(epi, A, W, bias, (float*)out, out, M, N, K, st);
   return d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, st);
@@ -362,6 +365,8 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->fold = !(nf && nf[0] == '1');
   const char* sk = getenv("D3DP_X2_SKEW");               // 1, 2, 4: the skewed schedule of the EXACT qkv / fc1 Linears (0 / unset: plain)
   if (sk && (sk[0] == '0' || sk[0] == '1' || sk[0] == '2' || sk[0] == '4') && sk[1] == 0) c->skew_d = sk[0] - '0';
+  const char* pp = getenv("D3DP_X2_PP");
+  if (pp && (pp[0] == '0' || pp[0] == '1') && pp[1] == 0) c->pingpong = pp[0] - '0';
   const char* pd = getenv("D3DP_SEQ_PAD");
   if (pd && (pd[0] == '0' || pd[0] == '1') && pd[1] == 0) c->pad_override = pd[0] - '0';
   const char* nl = getenv("D3DP_FOLD_LN");               // norm2 folded into proj / fc1 instead of its own row kernel
@@ -800,6 +805,7 @@ int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* 
                       int32_t N, int32_t K, void* stream) {
   if (!A2 || !W2 || !bias || !out || !(w_scale > 0.f)) return fail(D3DP_EINVAL, "d3dp_op_linear_x2: bad argument");
   const int skew_d = (epi >> 8) & 7;                     // epi | (D << 8), D = 1, 2, 4: the skewed schedule (epi 1 and 4)
+  const int pingpong = (epi >> 11) & 1;                  // epi | 2048: the ping-pong form (bit-identical results)
   epi &= 255;
   if (epi == EPI_RESID_LN || epi == EPI_GELU_LN) return fail(D3DP_EINVAL, "d3dp_op_linear_x2: epilogues 5 / 6 are internal to d3dp_denoise");
   if (skew_d) {
@@ -810,7 +816,7 @@ int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* 
     if (!d3dp_x2_skew_applies(epi, M, N, K, skew_d, prop.multiProcessorCount))
       return fail(D3DP_EINVAL, "d3dp_op_linear_x2: the skewed schedule (D = %d) does not apply to epi %d, M = %d, N = %d, K = %d", skew_d, epi, M, N, K);
   }
-  LAUNCH_TRY(d3dp_launch_linear_f16x2(epi, A2, W2, bias, kActUnscale / w_scale, kActScale, (float*)out, out, nullptr, nullptr, M, N, K, (hipStream_t)stream, skew_d));
+  LAUNCH_TRY(d3dp_launch_linear_f16x2(epi, A2, W2, bias, kActUnscale / w_scale, kActScale, (float*)out, out, nullptr, nullptr, M, N, K, (hipStream_t)stream, skew_d, pingpong));
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
 }

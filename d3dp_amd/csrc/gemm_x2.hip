@@ -97,7 +97,8 @@
 #define D3DP_X2_SKEW_TOP 1
 #endif
 // timing probes of the skewed kernel (results INVALID): 1 = the leaving rows' VALU work and stores sit behind a condition
-// that is false at run time (the schedule alone); 2 = no accumulator shift at a park
+// that is false at run time (the schedule alone); 2 = no accumulator shift at a park; 4 = the VALU work runs, the stores do
+// not (kept live through an empty asm); 8 = the stores run on the raw parked values, no epilogue arithmetic
 #ifndef D3DP_X2_SKEW_PROBE
 #define D3DP_X2_SKEW_PROBE 0
 #endif
@@ -518,6 +519,346 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
   }
 }
 
+// The tile epilogue of gemm_f16x2_kernel as a function (the ping-pong kernel below calls it from two places; the kernel above
+// keeps its own inline copy so that building without the ping-pong path reproduces its code exactly).  `acc`: this wave's
+// 64 x 64 block of tile `t`; `ti`: the workgroup's running tile index (EPI_GELU_LN's row-statistics buffer parity).
+template <int EPI, int TAG>
+__device__ __forceinline__ void x2_tile_epilogue(f32x4 (&acc)[4][4], int t, int ti, int tiles_n, int M, int N, int wr, int wc,
+                                                 int fi, int fg, int lane, float unscale, float oscale, float* __restrict__ outf,
+                                                 f16* __restrict__ out2, float* __restrict__ aux, unsigned* __restrict__ flag,
+                                                 const float* sbias, char* smem) {
+  // ---- tile epilogue: lane holds out[m = pm0 + mi*16 + r][n = nb + ni], pm0 = tile row + wr*64 + 4 fg, nb = tile column
+  // + wc*64 + 4 fi.  Every store address is  uniform base + 32-bit lane offset  (the launcher refuses outputs of 4 GiB or
+  // more), advanced row by row: per-row 64-bit address arithmetic was most of the epilogue's VALU work, and it runs
+  // with the matrix pipes idle.
+  const int pm0 = (t / tiles_n) * XBM + wr * 64 + 4 * fg, nb = (t % tiles_n) * XBN + wc * 64 + 4 * fi;
+  if (nb < N && (!(D3DP_X2_PROBE & 4) || unscale == -12345.f)) {
+    const float4 bz = *reinterpret_cast<const float4*>(sbias + nb);
+    const bool odd = fi & 1;
+    unsigned off, pitch;
+    bool planes;                                     // split the values and store fp16 planes (else fp32)
+    char* base = reinterpret_cast<char*>(outf);
+    const int c0 = nb & ~7;                          // h2i rows: 4 N bytes per row; the lane pair's 8 columns start at c0:
+    const unsigned offp = (unsigned)pm0 * (N * 4) + (c0 >> 5) * 128 + (c0 & 31) * 2 + (odd ? 64 : 0);   // even lane -> hi slot, odd -> lo
+    if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_LN) {   // the fc2 operand
+      base = reinterpret_cast<char*>(out2);
+      pitch = N * 4; planes = true;
+      off = offp - (unsigned)pm0 * pitch;
+    } else if constexpr (TAG == 1) {
+      // packed qkv row (12 C bytes, C = N / 3): q fp32 | k hi | k lo | v hi | v lo (fp16 planes x 16) -- the
+      // K / V operand images of the split-fp16 attention kernels, which copy them into LDS without touching them
+      const int C = N / 3, region = nb / C, cn = nb - region * C;      // a wave's 64 columns lie in one region
+      pitch = N * 4; planes = region != 0;
+      off = planes ? region * 4 * C + cn * 2 + (odd ? 2 * C - 8 : 0) : cn * 4;
+    } else {
+      pitch = N * 4; planes = false;
+      off = nb * 4;
+    }
+    off += (unsigned)pm0 * pitch;
+    const int rows = M - pm0;                        // row k = mi*16 + r of this lane exists iff k < rows
+    [[maybe_unused]] float4 c1z = {};
+    [[maybe_unused]] const float* srow = nullptr;
+    if constexpr (EPI == EPI_GELU_LN) {
+      c1z = *reinterpret_cast<const float4*>(sbias + N + nb);
+      srow = reinterpret_cast<const float*>(smem + XROWSTAT + (ti & 1) * (XBM * 8)) + (wr * 64 + 4 * fg) * 2;
+    }
+    auto value = [&](int mi, int r, int e) {
+      const float bze = e == 0 ? bz.x : e == 1 ? bz.y : e == 2 ? bz.z : bz.w;
+      if constexpr (EPI == EPI_GELU_LN) {            // rstd (x W'^T - mean c1) + c2
+        const float2 st = *reinterpret_cast<const float2*>(srow + (mi * 16 + r) * 2);
+        const float c1e = e == 0 ? c1z.x : e == 1 ? c1z.y : e == 2 ? c1z.z : c1z.w;
+        return fmaf(st.y, fmaf(acc[mi][e][r], unscale, -(st.x * c1e)), bze);
+      } else {
+        return fmaf(acc[mi][e][r], unscale, bze);
+      }
+    };
+    auto store_rows = [&](auto planes_c, auto checked_c) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = mi * 16 + r;
+          const bool live = !decltype(checked_c)::value || k < rows;
+          char* dst = base + (off + (unsigned)k * pitch);
+          if constexpr (decltype(planes_c)::value) {
+            f16x4 ph, pl;
+            float v[4] = {value(mi, r, 0), value(mi, r, 1), value(mi, r, 2), value(mi, r, 3)};
+            if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_LN) {
+#if D3DP_X2_PKGELU
+              const f32x2 g0 = gelu_erf_rational2((f32x2){v[0], v[1]}), g1 = gelu_erf_rational2((f32x2){v[2], v[3]});
+              v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
+#else
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gelu_erf_rational(v[e]);
+#endif
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              f16 h, l;
+              split2h_scaled(v[e] * oscale, h, l);       // (oscale: the consumer's operand scale, 2^4 unless capi.hip lowered it)
+              ph[e] = h; pl[e] = l;
+            }
+            store_planes_paired(dst, ph, pl, odd, live);
+          } else if constexpr (EPI != EPI_RESID && EPI != EPI_RESID_LN) {
+            if (live) OUT_STORE(reinterpret_cast<f32x4*>(dst), ((f32x4){value(mi, r, 0), value(mi, r, 1), value(mi, r, 2), value(mi, r, 3)}));
+          }
+        }
+      if constexpr (EPI == EPI_RESID && !decltype(planes_c)::value) {
+        // x += A W^T + b in place (the residual stream): all sixteen reads of the tile in flight before the first add
+        f32x4 res[4][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int k = mi * 16 + r;
+            const bool live = !decltype(checked_c)::value || k < rows;
+            res[mi][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (live) res[mi][r] = *reinterpret_cast<const f32x4*>(base + (off + (unsigned)k * pitch));
+          }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int k = mi * 16 + r;
+            const bool live = !decltype(checked_c)::value || k < rows;
+            const f32x4 v = {res[mi][r][0] + value(mi, r, 0), res[mi][r][1] + value(mi, r, 1),
+                             res[mi][r][2] + value(mi, r, 2), res[mi][r][3] + value(mi, r, 3)};
+            if (live) *reinterpret_cast<f32x4*>(base + (off + (unsigned)k * pitch)) = v;   // (re-read by the next row kernel: no nt hint)
+          }
+      }
+      if constexpr (EPI == EPI_RESID_LN && !decltype(planes_c)::value) {
+        // x += A W^T + b in place, in two halves of eight rows per lane (the sums stay in registers for what follows, and
+        // sixteen reads + sixteen sums + the accumulators would not fit the 168 registers of a 12-wave workgroup); each
+        // sum leaves a second time as the next Linear's operand (un-normalised, x 16, h2i), and the 16 lanes of a row
+        // group, which hold a row's 64 values, reduce (mean, M2) of this wave's slice of every row: two passes in registers,
+        // butterfly over the DPP row (xor 1, xor 2, half mirror, mirror: every lane ends with the sum)
+        auto rowsum16 = [](float x) {
+          x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
+          x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));
+          x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false));
+          x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, false));
+          return x;
+        };
+        const int S = (N + 63) >> 6, slice = nb >> 6;
+        float* sdst = aux + ((size_t)pm0 * S + slice) * 2;
+        bool over = false;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          f32x4 res[2][4];
+#pragma unroll
+          for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int k = (half * 2 + m2) * 16 + r;
+              const bool live = !decltype(checked_c)::value || k < rows;
+              res[m2][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+              if (live) res[m2][r] = *reinterpret_cast<const f32x4*>(base + (off + (unsigned)k * pitch));
+            }
+#pragma unroll
+          for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int mi = half * 2 + m2, k = mi * 16 + r;
+              const bool live = !decltype(checked_c)::value || k < rows;
+              const f32x4 v = {res[m2][r][0] + value(mi, r, 0), res[m2][r][1] + value(mi, r, 1),
+                               res[m2][r][2] + value(mi, r, 2), res[m2][r][3] + value(mi, r, 3)};
+              if (live) *reinterpret_cast<f32x4*>(base + (off + (unsigned)k * pitch)) = v;
+              f16x4 ph, pl;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { f16 h, l; split2h_scaled(v[e] * oscale, h, l); ph[e] = h; pl[e] = l; }
+              store_planes_paired(reinterpret_cast<char*>(out2) + (offp + (unsigned)k * (N * 4)), ph, pl, odd, live);
+              // exact range check of the un-normalised operand (its magnitude has no useful bound from the weights alone)
+              over |= !(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) * oscale < 65504.0f);
+              const float mean = rowsum16((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
+              const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+              const float q2 = rowsum16(fmaf(d0, d0, d1 * d1) + fmaf(d2, d2, d3 * d3));
+              if (live && fi == 0) *reinterpret_cast<float2*>(sdst + (size_t)k * S * 2) = make_float2(mean, q2);
+            }
+        }
+        if (__builtin_expect(__any(over), 0) && lane == 0) atomicOr(flag, 2u);   // d3dp_status: operand left the split range
+      }
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    constexpr bool kPlanesOnly = EPI == EPI_GELU || EPI == EPI_GELU_LN;
+    if (rows >= 64) {                                // (all but the last row of tiles)
+      if (planes) { if constexpr (kPlanesOnly || TAG == 1) store_rows(T_{}, F_{}); }
+      else { if constexpr (!kPlanesOnly) store_rows(F_{}, F_{}); }
+    } else {
+      if (planes) { if constexpr (kPlanesOnly || TAG == 1) store_rows(T_{}, T_{}); }
+      else { if constexpr (!kPlanesOnly) store_rows(F_{}, T_{}); }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PING-PONG form of the same Linear: the two compute waves of a SIMD work half a k-step apart.
+//
+// Measured on the kernel above with its loads AND its epilogue compiled out (gpurun c7, profiles/r04_gemm_probes.md): 463 us for
+// the qkv shape at M = 128,960 = 1.22 us = 2500 cycles per k-step, of which the matrix pipe needs 96 MFMAs x 16 = 1536.  All
+// eight compute waves pass the k-step's barrier together, all read their fragments from LDS together (the pipe idles), then
+// both waves of every SIMD push their 48 MFMAs through the one pipe together: the pipe is never fed during the read phase.
+// Here the compute waves form two teams -- X = waves 0..3, Y = waves 4..7: one wave of each per SIMD (waves go to SIMDs round
+// robin) -- and a k-step has TWO barriers, A and B:
+//     phase a (after A_g):  X reads ALL its fragments of slab g           | Y multiplies slab g - 1 (48 MFMAs, the pipe to itself)
+//     phase b (after B_g):  X multiplies slab g                           | Y reads all its fragments of slab g
+// so while one team waits for LDS the other owns the matrix pipe.  A wave holds one k-step's fragments (16 x 16 bytes per lane)
+// instead of streaming the A fragments behind the MFMAs: nothing reads slab g after phase b(g), the ring and the loaders'
+// schedule (slab g + 2 issued behind A_g, landed by A_{g+2}) are those of the kernel above; the lagged MFMAs are gone (they
+// existed to cover the read phase).  A tile's epilogue falls into the team's read phase at the start of its next tile, beside
+// the other team's MFMAs (team Y: after the MFMAs of its last k-step, in phase a).
+template <int EPI, int TAG>
+__global__ __launch_bounds__(768) void gemm_f16x2_pp_kernel(const f16* __restrict__ A2, const f16* __restrict__ W2,
+                                                            const float* __restrict__ bias, float unscale, float oscale,
+                                                            float* __restrict__ outf, f16* __restrict__ out2,
+                                                            float* __restrict__ aux, unsigned* __restrict__ flag, int M,
+                                                            int N, int K, int tiles_n, int total_tiles) {
+  static_assert(EPI == EPI_BIAS || EPI == EPI_GELU || EPI == EPI_RESID, "the LayerNorm-folding epilogues keep the kernel above");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sbias = reinterpret_cast<float*>(smem + XNSTAGE * XSTAGE);
+  const int G = gridDim.x;
+  const int L = xcd_remap(blockIdx.x, G);
+  const int n_my = (total_tiles - L + G - 1) / G;      // tiles L, L+G, ...
+  const int NK = K / XBK;
+  const int gtot = n_my * NK;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  for (int i = tid; i < N; i += (XNCW + 4) * 64) sbias[i] = bias[i];
+  __syncthreads();
+  if (gtot == 0) return;
+
+  if (wave >= XNCW) {
+    // ------------------------------------------------------------------ loader waves (as above, two barriers per k-step)
+    const int lw = wave - XNCW;
+    const int lr = lane >> 3, lq = lane & 7;
+    int ti = 0, ks = 0, slot = 0;
+    const f16* pa[8];
+    const f16* pw[4];
+    auto issue = [&]() {
+      if (ks == 0) {
+        const int t = L + ti * G;
+        const int m0 = (t / tiles_n) * XBM, n0 = (t % tiles_n) * XBN;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = (lw * 8 + i) * 8 + lr;
+          pa[i] = A2 + (size_t)min(m0 + row, M - 1) * (2 * K) + swz128(row, lq) * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = (lw * 4 + i) * 8 + lr;
+          const int wrow = (row & 64) + colperm(row & 63);
+          pw[i] = W2 + (size_t)min(n0 + wrow, N - 1) * (2 * K) + swz128(row, lq) * 8;
+        }
+      }
+      char* base = smem + slot * XSTAGE;
+      const int ko = ks * (2 * XBK);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds(GPTR(pa[i] + ko), LPTR(base + (lw * 8 + i) * 1024), 16, 0, D3DP_X2_AAUX);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds(GPTR(pw[i] + ko), LPTR(base + XA_BYTES + (lw * 4 + i) * 1024), 16, 0, D3DP_X2_WAUX);
+      if (++ks == NK) { ks = 0; ++ti; }
+      slot = (slot == XNSTAGE - 1) ? 0 : slot + 1;
+    };
+    issue();
+    if (gtot > 1) issue();
+    for (int g = 0; g < gtot; ++g) {
+      if (g + 1 < gtot) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      X2_BARRIER();                                    // A_g: slab g has landed; nobody reads slab g - 1 any more
+      if (g + 2 < gtot) issue();                       // slab g + 2 into the slot of slab g - 1
+      X2_BARRIER();                                    // B_g
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute waves
+  const int team = wave >> 2;                          // 0 = X, 1 = Y
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int offA = (wr * 64 + fi) * 128 + swz128(fi, fg) * 16, offAl = offA ^ 64;
+  const int offW = XA_BYTES + (wc * 64 + fi) * 128 + swz128(fi, fg) * 16, offWl = offW ^ 64;
+  f32x4 acc[4][4];
+  f16x8 wf[4][2], ah[4], al[4];                        // one k-step's fragments
+  __builtin_amdgcn_s_setprio(1);
+  int slot = 0;
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto read_all = [&]() {
+    const char* sb = smem + slot * XSTAGE;
+    slot = (slot == XNSTAGE - 1) ? 0 : slot + 1;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        wf[ni][pl] = *reinterpret_cast<const f16x8*>(sb + (pl ? offWl : offW) + ni * 2048);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      ah[mi] = *reinterpret_cast<const f16x8*>(sb + offA + mi * 2048);
+      al[mi] = *reinterpret_cast<const f16x8*>(sb + offAl + mi * 2048);
+    }
+  };
+  auto mfma_all = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      // small terms first; the three products of one output tile are four MFMAs apart (no back-to-back dependency)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], wf[ni][1], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], wf[ni][0], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], wf[ni][0], acc[mi][ni], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto epilogue = [&](int ti) {
+    x2_tile_epilogue<EPI, TAG>(acc, L + ti * G, ti, tiles_n, M, N, wr, wc, fi, fg, lane, unscale, oscale, outf, out2, aux, flag,
+                               sbias, smem);
+  };
+
+  // (one pass more than there are k-steps: the last tile's epilogue runs where every other tile's does, so the epilogue is
+  //  instantiated once per team -- two more copies of it cost registers the kernel does not have)
+  if (team == 0) {
+    int ks = 0, ti = 0;
+#pragma unroll 1
+    for (int g = 0; g <= gtot; ++g) {
+      if (g < gtot) X2_BARRIER();                      // A_g
+      if (ks == 0) {
+        if (g > 0) epilogue(ti - 1);                   // the finished tile leaves beside team Y's MFMAs
+        zero_acc();
+      }
+      if (g == gtot) break;
+      read_all();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      X2_BARRIER();                                    // B_g
+      mfma_all();
+      if (++ks == NK) { ks = 0; ++ti; }
+    }
+  } else {
+    int ks = 0, ti = 0;
+#pragma unroll 1
+    for (int g = 0; g <= gtot; ++g) {
+      if (g < gtot) X2_BARRIER();                      // A_g
+      if (g > 0) mfma_all();                           // slab g - 1
+      if (ks == 0) {
+        if (g > 0) epilogue(ti - 1);
+        zero_acc();
+      }
+      if (g == gtot) break;
+      X2_BARRIER();                                    // B_g
+      read_all();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (++ks == NK) { ks = 0; ++ti; }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The same Linear with a ROW-CLASS SKEWED schedule: a tile's epilogue runs UNDER the k-loop of the next tile.
 //
@@ -675,6 +1016,10 @@ __global__ __launch_bounds__(768) void gemm_f16x2_skew_kernel(const f16* __restr
   auto store_row = [&](int r, float (&v)[4]) {
     const bool live = cols_live && r < jrows;
     char* dst = base + (joff + (unsigned)r * pitch);
+#if D3DP_X2_SKEW_PROBE & 8
+    if (live) OUT_STORE(reinterpret_cast<f32x4*>(dst), ((f32x4){park[0][r & 3], park[1][r & 3], park[2][r & 3], park[3][r & 3]}));
+    return;
+#endif
     if (planes) {
       f16x4 ph, pl;
 #pragma unroll
@@ -683,9 +1028,17 @@ __global__ __launch_bounds__(768) void gemm_f16x2_skew_kernel(const f16* __restr
         split2h_scaled(v[e] * oscale, h, l);
         ph[e] = h; pl[e] = l;
       }
+#if D3DP_X2_SKEW_PROBE & 4
+      asm volatile("" :: "v"(ph), "v"(pl));
+#else
       store_planes_paired(dst, ph, pl, odd, live);
+#endif
     } else {
+#if D3DP_X2_SKEW_PROBE & 4
+      asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+#else
       if (live) OUT_STORE(reinterpret_cast<f32x4*>(dst), ((f32x4){v[0], v[1], v[2], v[3]}));
+#endif
     }
   };
   // the class in accumulator block 0 changes tile: park it, shift the blocks down, start its next tile from zero in block 3
@@ -738,8 +1091,12 @@ __global__ __launch_bounds__(768) void gemm_f16x2_skew_kernel(const f16* __restr
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+#if D3DP_X2_SKEW_PROBE & 8
+          v[e] = 0.f;
+#else
           v[e] = value(r0 + rr, e, jbz);
           if constexpr (EPI == EPI_GELU) v[e] = gelu_erf_rational(v[e]);
+#endif
         }
         store_row(r0 + rr, v);
       }
@@ -942,7 +1299,7 @@ bool d3dp_x2_skew_applies(int epi, int M, int N, int K, int skew_d, int n_cu) {
 
 int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const float* bias, float unscale, float oscale,
                              float* outf, void* out2, float* aux, unsigned* flag, int M, int N, int K, hipStream_t st,
-                             int skew_d) {
+                             int skew_d, int pingpong) {
   if (K % (2 * XBK) != 0 || N % 4 != 0 || N > XBIAS_MAX || M <= 0) return -1;
   if ((size_t)M * N * 4 >= ((size_t)1 << 32)) return -1;   // 32-bit byte offsets in the epilogue
   if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_QKV_PACK && epi != EPI_RESID && epi != EPI_RESID_LN &&
@@ -990,6 +1347,20 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
     return 0;
   }
   const int total = tm * tn, grid = total < cus ? total : cus;
+  if (pingpong && (epi == EPI_BIAS || epi == EPI_QKV_PACK || epi == EPI_GELU || epi == EPI_RESID)) {
+    static const KernT pps[4] = {gemm_f16x2_pp_kernel<EPI_BIAS, 0>, gemm_f16x2_pp_kernel<EPI_BIAS, 1>,
+                                 gemm_f16x2_pp_kernel<EPI_GELU, 0>, gemm_f16x2_pp_kernel<EPI_RESID, 0>};
+    static PerDeviceOnce once_pp;
+    if (once_pp.get([&](int) {
+          for (int k = 0; k < 4; ++k)
+            if (d3dp_lds_opt_in(reinterpret_cast<const void*>(pps[k]), XLDS) < 0) return -3;
+          return 1;
+        }) < 0) return -3;
+    const KernT kern = pps[epi == EPI_GELU ? 2 : epi == EPI_RESID ? 3 : epi == EPI_QKV_PACK ? 1 : 0];
+    hipLaunchKernelGGL(kern, dim3(grid), dim3((XNCW + 4) * 64), XLDS, st, (const f16*)A2, (const f16*)W2, bias, unscale, oscale,
+                       outf, (f16*)out2, aux, flag, M, N, K, tn, total);
+    return 0;
+  }
   const KernT kern = kerns[epi == EPI_GELU ? 2 : epi == EPI_RESID ? 3 : epi == EPI_QKV_PACK ? 1 : epi == EPI_RESID_LN ? 4
                            : epi == EPI_GELU_LN ? 5 : 0];
   hipLaunchKernelGGL(kern, dim3(grid), dim3((XNCW + 4) * 64), XLDS, st, (const f16*)A2, (const f16*)W2, bias, unscale, oscale, outf,

@@ -290,8 +290,11 @@ int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream);
  * gemm_x2.hip: a tile's epilogue leaves under the k-loop of the workgroup's next tile, D k-steps per 16-row class; the
  * 16-row blocks (m / 16) % 4 = c of the output sum their k-steps in the order c D, ..., K/32 - 1, 0, ..., c D - 1) -- needs
  * N % 128 == 0 and K >= 128 D (D3DP_EINVAL otherwise).
+ * epi | 2048: the PING-PONG form of the kernel (two wave teams half a k-step apart: one reads its fragments from LDS while
+ * the other owns the matrix pipe); same arithmetic in the same order: bit-identical results.  An experiment kept behind
+ * D3DP_X2_PP=1: measured slightly slower.
  * Test-only environment switches read by the library:
- * D3DP_X2_SKEW=1|2|4 (the skewed schedule above for the denoiser's qkv / fc1 Linears; measured slower, off by default), D3DP_EXACT_IMPL=bf16x3|f32 and D3DP_NO_FOLD=1 (cross-check implementations of EXACT mode), D3DP_FOLD_LN=1 (norm2 folded into
+ * D3DP_X2_PP=1 (the ping-pong form of the EXACT Linear), D3DP_X2_SKEW=1|2|4 (the skewed schedule above for the denoiser's qkv / fc1 Linears; measured slower, off by default), D3DP_EXACT_IMPL=bf16x3|f32 and D3DP_NO_FOLD=1 (cross-check implementations of EXACT mode), D3DP_FOLD_LN=1 (norm2 folded into
  * the proj / fc1 Linears; measured no faster than the row kernel and left off) -- all read in d3dp_create. */
 int d3dp_op_split2(const float* src, void* dst, size_t n, float scale, void* stream);
 int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* bias, float w_scale, void* out, int32_t M,

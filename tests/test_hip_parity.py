@@ -241,6 +241,32 @@ def test_linear_split_f16_skewed_schedule(lib, M, D):
         assert torch.equal(shifted[64:], s2)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(70000, 1536, 512, 4), (4131, 1024, 512, 1), (66000, 512, 1024, 2), (129, 192, 64, 0),
+                                       (1000, 512, 512, 2), (300, 1536, 512, 4), (25000, 1024, 512, 1)])
+def test_linear_split_f16_pingpong_is_bit_identical(lib, M, N, K, epi):
+    """The ping-pong form of the EXACT Linear (gemm_x2.hip: the two compute waves of a SIMD half a k-step apart -- one reads
+    its fragments while the other multiplies) runs the same MFMAs in the same order on the same operands: every epilogue's
+    output equals the lock-step kernel's bit for bit."""
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    A = (torch.randn(M, K, generator=g) * 2).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    x0 = torch.randn(M, N, generator=g).cuda()
+    A2 = torch.empty(2, M, K, dtype=torch.float16, device="cuda")
+    W2 = torch.empty(2, N, K, dtype=torch.float16, device="cuda")
+    w_scale = 2.0 ** (13 - int(np.floor(np.log2(W.abs().max().item()))))
+    _lib.check(lib.d3dp_op_split2(A.data_ptr(), A2.data_ptr(), M * K, 16.0, stream()))
+    _lib.check(lib.d3dp_op_split2(W.data_ptr(), W2.data_ptr(), N * K, w_scale, stream()))
+    outs = []
+    for flag in (0, 2048):
+        out = x0.clone() if epi == 2 else torch.full((M, N), float("nan"), device="cuda")
+        _lib.check(lib.d3dp_op_linear_x2(epi | flag, A2.data_ptr(), W2.data_ptr(), bias.data_ptr(), w_scale, out.data_ptr(), M, N,
+                                         K, stream()), "d3dp_op_linear_x2")
+        torch.cuda.synchronize()
+        outs.append(out.view(torch.int32).cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_skewed_schedule_end_to_end_keeps_parity_and_batch_invariance(monkeypatch):
     """D3DP_X2_SKEW=4 (the experiment of gemm_x2.hip kept behind a switch: measured slower, off by default) through the whole
     denoiser: every sequence is padded to a multiple of 64 rows, so a token's summation order depends on its index in its

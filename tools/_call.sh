@@ -1,7 +1,9 @@
-O=gpurun_out/c5; mkdir -p $O
-T="python -m pytest tests/test_hip_parity.py -q -s -k g3_full_width_denoiser"
-for v in dbgA dbgB dbgC; do
-  echo "== $v" >> $O/num.log
-  ( export D3DP_LIB=$PWD/d3dp_amd/lib/variants/libd3dp_$v.so D3DP_X2_SKEW=0; timeout 200 $T 2>&1 | grep -E "^\[F=|^F\[F=|passed|failed|Error" | head -8 >> $O/num.log )
+O=gpurun_out/c8; mkdir -p $O
+timeout 300 python -m pytest tests/test_hip_parity.py -q -x -k "pingpong" 2>&1 | tail -4 | tee $O/pp_test.log
+G="python tools/gemm_bench.py --x2 --real-epi --m 128960 --iters 10"
+for spec in "plain" "pp" "plain" "pp"; do
+  echo "== $spec" >> $O/gemm.log
+  if [ $spec = pp ]; then timeout 120 $G --pp 2>&1 | grep "^x2" >> $O/gemm.log; else timeout 120 $G 2>&1 | grep "^x2" >> $O/gemm.log; fi
 done
-cat $O/num.log
+cat $O/gemm.log
+TAG=c8 AB='pp1:D3DP_X2_PP=1;pp0:D3DP_X2_PP=0;pp1b:D3DP_X2_PP=1;pp0b:D3DP_X2_PP=0' bash tools/gpu_round.sh ab
