@@ -154,7 +154,7 @@ struct d3dp_ctx {
   int pad_override = -1;         // D3DP_SEQ_PAD=0|1: measurement switch (pad without the skewed schedule, or the reverse)
   int pingpong = 0;              // D3DP_X2_PP=1: the ping-pong form of the EXACT Linear (gemm_x2.hip; bit-identical results;
                                  // measured 1.5-2 % SLOWER on the whole step, gpurun c8: the fragment reads, not their latency, are
-                                 // what the matrix pipe waits for -- 171 B/clk of LDS reads at full MFMA rate against 128 B/clk)
+                                 // what the matrix pipe waits for -- 117 B/clk of LDS traffic at the full MFMA rate against a peak of 128)
   bool x3() const { return exact() && exact_impl == 1; }
   int act() const { return fast() ? 1 : (x3() ? 2 : (x2() ? 3 : 0)); }   // code understood by the row-wise launchers
   size_t act_size() const { return fast() ? 2 : (x3() ? 6 : 4); }    // bytes per element of a Linear-input activation
