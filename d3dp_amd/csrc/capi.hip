@@ -152,6 +152,7 @@ struct d3dp_ctx {
     return (pad_override < 0 ? skew() : (pad_override > 0 && x2_attn())) ? (fj + 63) / 64 * 64 : fj;
   }
   int pad_override = -1;         // D3DP_SEQ_PAD=0|1: measurement switch (pad without the skewed schedule, or the reverse)
+  bool train_x2 = true;          // D3DP_TRAIN_IMPL=f32: the training Linears on the fp32 matrix cores (round-1 path, cross-check)
   int pingpong = 0;              // D3DP_X2_PP=1: the ping-pong form of the EXACT Linear (gemm_x2.hip; bit-identical results;
                                  // measured 1.5-2 % SLOWER on the whole step, gpurun c8: the fragment reads, not their latency, are
                                  // what the matrix pipe waits for -- 117 B/clk of LDS traffic at the full MFMA rate against a peak of 128)
@@ -365,6 +366,8 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->fold = !(nf && nf[0] == '1');
   const char* sk = getenv("D3DP_X2_SKEW");               // 1, 2, 4: the skewed schedule of the EXACT qkv / fc1 Linears (0 / unset: plain)
   if (sk && (sk[0] == '0' || sk[0] == '1' || sk[0] == '2' || sk[0] == '4') && sk[1] == 0) c->skew_d = sk[0] - '0';
+  const char* ti = getenv("D3DP_TRAIN_IMPL");
+  c->train_x2 = !(ti && !strcmp(ti, "f32"));
   const char* pp = getenv("D3DP_X2_PP");
   if (pp && (pp[0] == '0' || pp[0] == '1') && pp[1] == 0) c->pingpong = pp[0] - '0';
   const char* pd = getenv("D3DP_SEQ_PAD");
@@ -910,6 +913,9 @@ struct TrainLayout {
   size_t o_xin, o_qkv, o_att, o_xmid, o_hpre, o_xout;
   // temporaries
   size_t xn, y, hid, dA, dB, dC, dqkv, dh, z, At, Xt, Wt, dtemb, stats;
+  // split-fp16 operands of the training Linears (X2Train below): row form [rows][2 K] and transposed form [features][2 Tp]
+  size_t op_a, op_w, op_at, op_xt, part, slots;
+  size_t Tp_max;                    // columns (tokens, padded) of a transposed operand row
   size_t total_floats;
 };
 
@@ -934,6 +940,16 @@ TrainLayout train_layout(const d3dp_cfg& g, int B) {
   L.At = take(wide * L.Tpad); L.Xt = take(wide * L.Tpad); L.Wt = take(wide * wide);
   L.dtemb = take((size_t)B * L.C);
   L.stats = take(d3dp_train_attn_stats_bytes(B * std::max(g.frames, g.joints), std::max(g.frames, g.joints), g.heads) / 4 + 64);
+  {
+    const size_t fmax = std::max<size_t>(3 * L.C, L.Hd), kmax = std::max<size_t>(L.C, L.Hd);
+    L.Tp_max = ((L.T + 31) / 32 + 64) * 32;          // (room for rounding the k-steps up to a multiple of the split count)
+    L.op_a = take(L.T * fmax);                       // [T][2 fmax] fp16 = T fmax floats
+    L.op_w = take(fmax * kmax);                      // [N][2 K] or [K][2 N] fp16
+    L.op_at = take(fmax * L.Tp_max);                 // dY^T: [N][2 Tp] fp16
+    L.op_xt = take(kmax * L.Tp_max);                 // X^T:  [K][2 Tp] fp16
+    L.part = take((size_t)(1024 + 64) * 256 * 128);  // split-K partial products: at most ~ (CUs + tiles) output tiles
+    L.slots = take(2 * 8192);                        // absmax words | 1 / scale per operand
+  }
   L.total_floats = off;
   return L;
 }
@@ -947,6 +963,68 @@ const float* mask_ptr(const float* masks, const d3dp_cfg& g, int B, int blk, int
 int lin32(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, hipStream_t st) {
   return d3dp_launch_linear_f32(EPI_BIAS, A, W, bias, out, M, N, K, st);
 }
+
+// The training step's Linears on the split-fp16 scheme of EXACT inference (three fp16-MFMA passes, fp32-class; gemm_x2.hip
+// gemm_f16x2_dyn_kernel) instead of the fp32 matrix cores (1/16 of the fp16 rate).  Every operand -- activations, weights,
+// GRADIENTS -- is split at the power of two its own absmax asks for, computed and consumed on the device: no range is
+// assumed and nothing synchronises.  forward: out = A W^T + b;  dgrad: dX = dY W (W^T split as the "weight" operand);
+// wgrad: dW = dY^T X contracts over the batch's tokens into a handful of output tiles -> split-K over Z chunks of tokens,
+// partial products summed in a fixed order (deterministic; the fp32 path's split-K used atomics).
+struct X2Train {
+  hipStream_t st;
+  float* ws;
+  const TrainLayout& L;
+  int n_cu;
+  int next = 0;                                        // next absmax / unscale slot
+  unsigned* amax() const { return reinterpret_cast<unsigned*>(ws + L.slots); }
+  float* uns() const { return ws + L.slots + 8192; }
+  int begin() { next = 0; return hipMemsetAsync(ws + L.slots, 0, 8192 * 4, st) == hipSuccess ? 0 : -3; }
+  int slot_for(const float* src, size_t n) {           // absmax of a tensor into a fresh slot
+    if (next >= 8192) return -1;
+    d3dp_launch_absmax(src, n, amax() + next, st);
+    return next++;
+  }
+  void rows(const float* src, int R, int C, void* dst, int slot) {          // [R][C] -> [R][2 C]
+    d3dp_launch_split2_dyn(src, dst, R, C, C, amax() + slot, uns() + slot, st);
+  }
+  void cols(const float* src, int R, int C, int Rpad, void* dst, int slot) {   // [R][C] -> [C][2 Rpad]
+    d3dp_launch_split2_t_dyn(src, dst, R, C, Rpad, amax() + slot, uns() + slot, st);
+  }
+  // out[T, N] = A[T, K] W[N, K]^T + bias
+  int forward(const float* A, const float* W, const float* bias, float* out, int T, int N, int K) {
+    const int sa = slot_for(A, (size_t)T * K), sw = slot_for(W, (size_t)N * K);
+    if (sa < 0 || sw < 0) return -1;
+    rows(A, T, K, ws + L.op_a, sa);
+    rows(W, N, K, ws + L.op_w, sw);
+    return d3dp_launch_linear_f16x2_dyn(ws + L.op_a, ws + L.op_w, bias, uns() + sa, uns() + sw, out, T, N, K, 1, st);
+  }
+  // dX[T, K] = dY[T, N] W[N, K]   (sdy: the absmax slot of dY, shared with wgrad)
+  int dgrad(const float* dY, int sdy, const float* W, float* dX, int T, int N, int K) {
+    const int sw = slot_for(W, (size_t)N * K);
+    if (sw < 0) return -1;
+    rows(dY, T, N, ws + L.op_a, sdy);
+    cols(W, N, K, N, ws + L.op_w, sw);                 // W^T: [K][2 N]  (N % 32 == 0: the model's widths)
+    return d3dp_launch_linear_f16x2_dyn(ws + L.op_a, ws + L.op_w, nullptr, uns() + sdy, uns() + sw, dX, T, K, N, 1, st);
+  }
+  // dW[N, K] = dY[T, N]^T X[T, K]
+  int wgrad(const float* dY, int sdy, const float* X, float* dW, int T, int N, int K) {
+    const int sx = slot_for(X, (size_t)T * K);
+    if (sx < 0) return -1;
+    const int tiles = ((N + 255) / 256) * ((K + 127) / 128);
+    const int nk = (T + 31) / 32;
+    int Z = std::max(1, std::min(std::min(n_cu / tiles, 64), nk / 4));
+    const int nkz = (nk + Z - 1) / Z;
+    const int Tp = Z * nkz * 32;
+    if ((size_t)Tp > L.Tp_max || (size_t)Z * N * K > (size_t)(1024 + 64) * 256 * 128) return -1;
+    cols(dY, T, N, Tp, ws + L.op_at, sdy);             // dY^T: [N][2 Tp]
+    cols(X, T, K, Tp, ws + L.op_xt, sx);               // X^T:  [K][2 Tp]
+    const int r = d3dp_launch_linear_f16x2_dyn(ws + L.op_at, ws + L.op_xt, nullptr, uns() + sdy, uns() + sx, ws + L.part, N, K,
+                                               Tp, Z, st);
+    if (r) return r;
+    d3dp_launch_sum_partials(ws + L.part, dW, (size_t)N * K, Z, st);
+    return 0;
+  }
+};
 
 }  // namespace
 
@@ -970,6 +1048,12 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
   float* ws = (float*)workspace;
   const int T = (int)L.T, C = g.channels, F = g.frames, J = g.joints, Hd = g.hidden;
   float *xn = ws + L.xn, *y = ws + L.y, *hid = ws + L.hid;
+  X2Train x2{st, ws, L, c->n_cu};
+  const bool use_x2 = c->train_x2 && C % 32 == 0 && Hd % 32 == 0;
+  if (use_x2) LAUNCH_TRY(x2.begin());
+  auto lin = [&](const float* A, const float* W, const float* bias, float* out, int M, int N, int K) {
+    return use_x2 ? x2.forward(A, W, bias, out, M, N, K) : lin32(A, W, bias, out, M, N, K, st);
+  };
   LAUNCH_TRY(d3dp_launch_time_mlp(t, c->freq, c->t1w, c->t1b, c->t3w, c->t3b, ws + L.temb, B, C, st));
   float* slab0 = ws + L.saved0;
   LAUNCH_TRY(d3dp_launch_embed_ln(0, x2d, x3d, ws + L.temb, c->ew, c->eb, c->spos, c->ste[0].n1w, c->ste[0].n1b,
@@ -978,15 +1062,15 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     const int kind = blk & 1, d = blk >> 1;
     const BlockDev& w = kind ? c->tte[d] : c->ste[d];
     float* S = ws + L.saved0 + (size_t)blk * L.saved_stride;
-    LAUNCH_TRY(lin32(xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C, st));
+    LAUNCH_TRY(lin(xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C));
     if (kind == 0) LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * F, spatial_map(F, J), C, g.heads, st));
     else LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st));
-    LAUNCH_TRY(lin32(S + L.o_att, (const float*)w.proj_w, w.proj_b, y, T, C, C, st));
+    LAUNCH_TRY(lin(S + L.o_att, (const float*)w.proj_w, w.proj_b, y, T, C, C));
     LAUNCH_TRY(d3dp_train_add_mask_ln(S + L.o_xin, y, mask_ptr(masks, g, B, blk, 0), kind, F, J, w.n2w, w.n2b, g.eps_block,
                                       S + L.o_xmid, xn, T, C, st));
-    LAUNCH_TRY(lin32(xn, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, st));
+    LAUNCH_TRY(lin(xn, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C));
     LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, st));
-    LAUNCH_TRY(lin32(hid, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd, st));
+    LAUNCH_TRY(lin(hid, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd));
     LAUNCH_TRY(d3dp_train_add_mask_ln(S + L.o_xmid, y, mask_ptr(masks, g, B, blk, 1), kind, F, J, nullptr, nullptr,
                                       g.eps_block, S + L.o_xout, nullptr, T, C, st));
     // shared norm -> next block's input (or x_final)
@@ -1044,8 +1128,16 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
   float *xn = ws + L.xn, *hid = ws + L.hid, *dA = ws + L.dA, *dB = ws + L.dB, *dC = ws + L.dC, *dqkv = ws + L.dqkv,
         *dh = ws + L.dh, *At = ws + L.At, *Xt = ws + L.Xt, *Wt = ws + L.Wt;
 
-  // wgrad: dW[N, K] = dY[T, N]^T X[T, K]  (both operands transposed to [*, Tpad], zero padded)
+  X2Train x2{st, ws, L, c->n_cu};
+  const bool use_x2 = c->train_x2 && C % 32 == 0 && Hd % 32 == 0;
+  if (use_x2) LAUNCH_TRY(x2.begin());
+  int sdy = -1;                                          // absmax slot of the dY the next wgrad / dgrad pair shares
+  // wgrad: dW[N, K] = dY[T, N]^T X[T, K]  (fp32 path: both operands transposed to [*, Tpad], zero padded)
   auto wgrad = [&](const float* dY, int N, const float* X, int K, float* dW) -> int {
+    if (use_x2) {
+      sdy = x2.slot_for(dY, (size_t)T * N);
+      return sdy < 0 ? -1 : x2.wgrad(dY, sdy, X, dW, T, N, K);
+    }
     int r;
     if ((r = d3dp_train_transpose_pad(dY, At, T, N, Tp, st))) return r;
     if ((r = d3dp_train_transpose_pad(X, Xt, T, K, Tp, st))) return r;
@@ -1054,6 +1146,7 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
   };
   // dgrad: dX[T, K] = dY[T, N] W[N, K]   (W transposed to [K, N])
   auto dgrad = [&](const float* dY, int N, const float* W, int K, float* dX) -> int {
+    if (use_x2) return sdy < 0 ? -1 : x2.dgrad(dY, sdy, W, dX, T, N, K);     // (always right behind the wgrad of the same dY)
     int r;
     if ((r = d3dp_train_transpose_pad(W, Wt, N, K, N, st))) return r;
     return lin32(dY, Wt, zb, dX, T, K, N, st);

@@ -1190,6 +1190,200 @@ __global__ __launch_bounds__(768) void gemm_f16x2_skew_kernel(const f16* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The training step's Linear (forward, dgrad and the split-K wgrad of SURVEY.md row A13) on the same three-pass split-fp16
+// scheme: out_z[M, N] = (A2 . W2^T over the k-steps of chunk z) x dynA[0] x dynW[0] (+ bias), fp32 out.
+//   * operand scales are DEVICE values: gradients have no range known on the host, so every operand is split at the power
+//     of two its own absmax asks for (split2h_dyn_kernel / split2h_t_dyn_kernel below write 1 / scale next to the planes) and
+//     this kernel reads the two factors -- no host synchronisation anywhere in the step;
+//   * Z chunks of the contraction (k-steps z NKz .. (z + 1) NKz - 1 of rows of 2 Kfull fp16) go to Z x tiles work items:
+//     wgrad contracts over the 16,524 tokens of a batch into at most 24 output tiles, far too few for 256 CUs unsplit; the
+//     partial results are summed in a fixed order by sum_partials_kernel (deterministic, unlike the fp32-atomic split-K of
+//     the fp32-MFMA path this replaces).
+// Structure: the lock-step kernel above without the lagged MFMAs and with the plain fp32 epilogue (8 + 4 waves, 256 x 128 x 32
+// tiles, 3-stage LDS-DMA ring, one barrier per k-step).
+__global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restrict__ A2, const f16* __restrict__ W2,
+                                                             const float* __restrict__ bias, const float* __restrict__ dynA,
+                                                             const float* __restrict__ dynW, float* __restrict__ out, int M,
+                                                             int N, int Kfull, int NKz, int tiles_n, int tiles_per_z,
+                                                             int total_items) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int G = gridDim.x;
+  const int L = xcd_remap(blockIdx.x, G);
+  const int n_my = (total_items - L + G - 1) / G;      // work items L, L+G, ...: item = z tiles_per_z + tile
+  const int gtot = n_my * NKz;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (gtot <= 0) return;
+
+  if (wave >= XNCW) {
+    const int lw = wave - XNCW;
+    const int lr = lane >> 3, lq = lane & 7;
+    int ti = 0, ks = 0, slot = 0;
+    const f16* pa[8];
+    const f16* pw[4];
+    auto issue = [&]() {
+      if (ks == 0) {
+        const int item = L + ti * G;
+        const int z = item / tiles_per_z, t = item - z * tiles_per_z;
+        const int m0 = (t / tiles_n) * XBM, n0 = (t % tiles_n) * XBN;
+        const size_t k0 = (size_t)z * NKz * (2 * XBK);   // first k-step of the chunk, in fp16 elements of an h2i row
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = (lw * 8 + i) * 8 + lr;
+          pa[i] = A2 + (size_t)min(m0 + row, M - 1) * (2 * Kfull) + k0 + swz128(row, lq) * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = (lw * 4 + i) * 8 + lr;
+          const int wrow = (row & 64) + colperm(row & 63);
+          pw[i] = W2 + (size_t)min(n0 + wrow, N - 1) * (2 * Kfull) + k0 + swz128(row, lq) * 8;
+        }
+      }
+      char* base = smem + slot * XSTAGE;
+      const int ko = ks * (2 * XBK);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) __builtin_amdgcn_global_load_lds(GPTR(pa[i] + ko), LPTR(base + (lw * 8 + i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds(GPTR(pw[i] + ko), LPTR(base + XA_BYTES + (lw * 4 + i) * 1024), 16, 0, 0);
+      if (++ks == NKz) { ks = 0; ++ti; }
+      slot = (slot == XNSTAGE - 1) ? 0 : slot + 1;
+    };
+    issue();
+    if (gtot > 1) issue();
+    for (int g = 0; g < gtot; ++g) {
+      if (g + 1 < gtot) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      X2_BARRIER();
+      if (g + 2 < gtot) issue();
+    }
+    return;
+  }
+
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int offA = (wr * 64 + fi) * 128 + swz128(fi, fg) * 16, offAl = offA ^ 64;
+  const int offW = XA_BYTES + (wc * 64 + fi) * 128 + swz128(fi, fg) * 16, offWl = offW ^ 64;
+  const float unscale = dynA[0] * dynW[0];             // 1 / (scale of A x scale of W): powers of two, exact
+  __builtin_amdgcn_s_setprio(1);
+  int slot = 0;
+#pragma unroll 1
+  for (int ti = 0; ti < n_my; ++ti) {
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ks = 0; ks < NKz; ++ks) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      X2_BARRIER();
+      const char* sb = smem + slot * XSTAGE;
+      slot = (slot == XNSTAGE - 1) ? 0 : slot + 1;
+      f16x8 wf[4][2];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          wf[ni][pl] = *reinterpret_cast<const f16x8*>(sb + (pl ? offWl : offW) + ni * 2048);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(sb + offA + mi * 2048);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(sb + offAl + mi * 2048);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wf[ni][1], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wf[ni][0], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wf[ni][0], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    // epilogue: lane holds out[pm0 + mi*16 + r][nb + ni]; one 16-byte store per (mi, r)
+    const int item = L + ti * G;
+    const int z = item / tiles_per_z, t = item - z * tiles_per_z;
+    const int pm0 = (t / tiles_n) * XBM + wr * 64 + 4 * fg, nb = (t % tiles_n) * XBN + wc * 64 + 4 * fi;
+    if (nb < N) {                                      // (N % 4 == 0: a lane's four columns exist together)
+      float4 bz = {0.f, 0.f, 0.f, 0.f};
+      if (bias != nullptr) bz = *reinterpret_cast<const float4*>(bias + nb);
+      float* o = out + (size_t)z * M * N + nb;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = pm0 + mi * 16 + r;
+          if (m < M)
+            *reinterpret_cast<f32x4*>(o + (size_t)m * N) =
+                (f32x4){fmaf(acc[mi][0][r], unscale, bz.x), fmaf(acc[mi][1][r], unscale, bz.y),
+                        fmaf(acc[mi][2][r], unscale, bz.z), fmaf(acc[mi][3][r], unscale, bz.w)};
+        }
+    }
+  }
+}
+
+// scale of a split operand from its absmax (bit pattern of a non-negative float, absmax_kernel): the power of two that
+// puts the largest magnitude in [2^13, 2^14) (as capi.hip does for the inference weights); 1 for an all-zero tensor
+__device__ __forceinline__ float dyn_scale(unsigned amax_bits) {
+  const float m = __uint_as_float(amax_bits);
+  if (!(m > 0.f) || !(m < INFINITY)) return 1.0f;
+  int e;
+  frexpf(m, &e);                                       // m = f 2^e, f in [0.5, 1)
+  return ldexpf(1.0f, 14 - e);
+}
+
+// src [R][C] fp32 -> dst [R][2 Cpad] h2i (columns C .. Cpad - 1 zero), scale from the tensor's absmax; unscale[0] = 1 / scale
+__global__ void split2h_dyn_kernel(const float* __restrict__ s, f16* __restrict__ d, int R, int C, int Cpad,
+                                   const unsigned* __restrict__ amax, float* __restrict__ unscale) {
+  const float sc = dyn_scale(amax[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) unscale[0] = 1.0f / sc;
+  const size_t n = (size_t)R * Cpad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / Cpad;
+    const int c = (int)(i - r * Cpad);
+    f16 a = (f16)0.f, b = (f16)0.f;
+    if (c < C) split2h_scaled(s[r * C + c] * sc, a, b);
+    f16* row = d + r * 2 * (size_t)Cpad;
+    row[h2i_col(c)] = a;
+    row[h2i_col(c) + kH2iLo] = b;
+  }
+}
+
+// src [R][C] fp32 -> dst [C][2 Rpad] h2i: the TRANSPOSE as a split operand (rows R .. Rpad - 1 zero).  32 x 32 tiles through LDS;
+// one tile = one 128-byte h2i block (hi of 32 source rows | lo of the same) of 32 destination rows.
+__global__ __launch_bounds__(256) void split2h_t_dyn_kernel(const float* __restrict__ s, f16* __restrict__ d, int R, int C,
+                                                            int Rpad, const unsigned* __restrict__ amax,
+                                                            float* __restrict__ unscale) {
+  __shared__ float tile[32][33];
+  const float sc = dyn_scale(amax[0]);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) unscale[0] = 1.0f / sc;
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    tile[k][tx] = (r < R && c < C) ? s[(size_t)r * C + c] * sc : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k;                              // destination row; tx = source row within the block
+    if (c < C) {
+      f16 a, b;
+      split2h_scaled(tile[tx][k], a, b);
+      f16* blk = d + (size_t)c * 2 * Rpad + (size_t)blockIdx.x * 64;
+      blk[tx] = a;
+      blk[32 + tx] = b;
+    }
+  }
+}
+
+// out[i] = sum_z part[z n + i] in the order z = 0, 1, ... (the deterministic end of a split-K product)
+__global__ void sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int Z) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float a = part[i];
+    for (int z = 1; z < Z; ++z) a += part[(size_t)z * n + i];
+    out[i] = a;
+  }
+}
+
 // src[i] * scale -> h2i layout (common.h): blocks of 32 elements, dst[64 b .. 64 b + 31] = hi, dst[64 b + 32 .. 64 b + 63] = lo
 // of elements 32 b .. 32 b + 31 (n % 32 == 0; any row length that is a multiple of 32)
 __global__ void split2h_kernel(const float* __restrict__ s, f16* __restrict__ d, size_t n, float scale) {
@@ -1396,4 +1590,40 @@ void d3dp_launch_ln_combine(const float* slices, float* rowstat, int M, int C, f
 void d3dp_launch_fold_ln(const float* W, const float* gamma, const float* beta, const float* bias, float* Wp, float* c12,
                          int N, int K, hipStream_t st) {
   hipLaunchKernelGGL(fold_ln_kernel, dim3((N + 3) / 4), dim3(256), 0, st, W, gamma, beta, bias, Wp, c12, N, K);
+}
+
+// ---- training-step launchers (gemm_f16x2_dyn_kernel and its operand kernels) ---------------------------------------
+// out_z[M, N] = A2 (chunk z) . W2 (chunk z)^T x dynA x dynW (+ bias): Kfull = Z NKz 32 columns per operand row
+int d3dp_launch_linear_f16x2_dyn(const void* A2, const void* W2, const float* bias, const float* dynA, const float* dynW,
+                                 float* out, int M, int N, int Kfull, int Z, hipStream_t st) {
+  if (M <= 0 || N % 4 != 0 || Z < 1 || Kfull % (XBK * Z) != 0) return -1;
+  const int NKz = Kfull / XBK / Z;
+  const int tm = (M + XBM - 1) / XBM, tn = (N + XBN - 1) / XBN;
+  static PerDeviceOnce once;
+  const int cus = once.get([&](int dev) {
+    return d3dp_lds_opt_in(reinterpret_cast<const void*>(gemm_f16x2_dyn_kernel), XNSTAGE * XSTAGE) < 0 ? -3 : d3dp_cu_count(dev);
+  });
+  if (cus < 0) return -3;
+  const int items = tm * tn * Z, grid = items < cus ? items : cus;
+  hipLaunchKernelGGL(gemm_f16x2_dyn_kernel, dim3(grid), dim3((XNCW + 4) * 64), XNSTAGE * XSTAGE, st, (const f16*)A2,
+                     (const f16*)W2, bias, dynA, dynW, out, M, N, Kfull, NKz, tn, tm * tn, items);
+  return 0;
+}
+
+void d3dp_launch_split2_dyn(const float* src, void* dst, int R, int C, int Cpad, const unsigned* amax, float* unscale,
+                            hipStream_t st) {
+  const size_t n = (size_t)R * Cpad;
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(split2h_dyn_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, (f16*)dst, R, C, Cpad, amax, unscale);
+}
+
+void d3dp_launch_split2_t_dyn(const float* src, void* dst, int R, int C, int Rpad, const unsigned* amax, float* unscale,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(split2h_t_dyn_kernel, dim3(Rpad / 32, (C + 31) / 32), dim3(256), 0, st, src, (f16*)dst, R, C, Rpad, amax,
+                     unscale);
+}
+
+void d3dp_launch_sum_partials(const float* part, float* out, size_t n, int Z, hipStream_t st) {
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, part, out, n, Z);
 }

@@ -72,6 +72,20 @@ void d3dp_launch_ln_combine(const float* slices, float* rowstat, int M, int C, f
 void d3dp_launch_fold_ln(const float* W, const float* gamma, const float* beta, const float* bias, float* Wp, float* c12,
                          int N, int K, hipStream_t st);
 void d3dp_launch_split2(const float* src, void* dst, size_t n, float scale, hipStream_t st);
+// ---- the training step's split-fp16 Linear (gemm_x2.hip, gemm_f16x2_dyn_kernel): operand scales live on the device ----
+// out_z[M, N] (z = 0 .. Z-1, M N floats apart) = A2[M][2 Kfull] . W2[N][2 Kfull]^T over k-chunk z, x dynA[0] x dynW[0], + bias
+// (bias may be null).  Kfull % (32 Z) == 0, N % 4 == 0.
+int d3dp_launch_linear_f16x2_dyn(const void* A2, const void* W2, const float* bias, const float* dynA, const float* dynW,
+                                 float* out, int M, int N, int Kfull, int Z, hipStream_t st);
+// src [R][C] fp32 -> h2i [R][2 Cpad] (zero columns behind C) at the power of two the tensor's absmax (amax[0], bits of a
+// float >= 0, d3dp_launch_absmax) asks for; unscale[0] = 1 / that scale
+void d3dp_launch_split2_dyn(const float* src, void* dst, int R, int C, int Cpad, const unsigned* amax, float* unscale,
+                            hipStream_t st);
+// the TRANSPOSE as a split operand: src [R][C] -> h2i [C][2 Rpad] (zero behind R; Rpad % 32 == 0)
+void d3dp_launch_split2_t_dyn(const float* src, void* dst, int R, int C, int Rpad, const unsigned* amax, float* unscale,
+                              hipStream_t st);
+// out[i] = sum over z of part[z n + i], z ascending
+void d3dp_launch_sum_partials(const float* part, float* out, size_t n, int Z, hipStream_t st);
 void d3dp_launch_absmax(const float* src, size_t n, unsigned* out, hipStream_t st);
 // flag[0] |= 1 if any of x[0..n) is inf / nan
 void d3dp_launch_nonfinite_flag(const float* x, size_t n, unsigned* flag, hipStream_t st);
