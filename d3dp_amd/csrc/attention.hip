@@ -455,6 +455,9 @@ __device__ __forceinline__ f16x8 as_f16x8(bf16x8 v) { return __builtin_bit_cast(
 // by a whole fp16 ulp of hi, and the denoiser's error against the reference tripled (gpurun c5: 6.4e-4 -> 1.8e-3 mm).  The
 // exact scaling in between makes both halves round the same number.
 struct X2Scales { float q, cexp, onorm, oplane; };
+#ifndef D3DP_ATTN_STORE16
+#define D3DP_ATTN_STORE16 1
+#endif
 
 // 8 consecutive fp32 -> one 16-byte slot of hi and one of lo (values x sc)
 __device__ __forceinline__ void split8(const float4 a, const float4 b, f16x8& hi, f16x8& lo, float sc) {
@@ -691,12 +694,29 @@ __device__ __forceinline__ void store_o_x2(const f32x4 (&o)[4], float inv, void*
   for (int dn = 0; dn < 4; ++dn) {
     const float r4[4] = {o[dn][0] * inv, o[dn][1] * inv, o[dn][2] * inv, o[dn][3] * inv};
     if constexpr (OUTS == 2) {
-      f16* dst = reinterpret_cast<f16*>(out_v) + tok * (2 * C) + h2i_col(col + dn * 16);
       f16x4 p0, p1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { f16 a0, a1; split2h_scaled(r4[e] * oplane, a0, a1); p0[e] = a0; p1[e] = a1; }
+#if D3DP_ATTN_STORE16
+      // ONE 16-byte store per lane instead of two of 8 bytes (the store side of these latency-bound
+      // kernels).  Lanes l and l ^ 16 hold neighbouring 4-channel groups of the same row (fg even / odd): v_permlane16_swap
+      // exchanges the odd 16-lane rows of its first operand with the even rows of its second, so with (hi, lo) as operands the
+      // even-row lane ends up with both hi halves -- 8 consecutive channels of the hi slot -- and the odd-row lane with both
+      // lo halves.  (Both lanes share `lane & 15`, i.e. the caller's q < n predicate.)
+      const uint2 h = __builtin_bit_cast(uint2, p0), l = __builtin_bit_cast(uint2, p1);
+      const auto sx = __builtin_amdgcn_permlane16_swap(h.x, l.x, false, false);
+      const auto sy = __builtin_amdgcn_permlane16_swap(h.y, l.y, false, false);
+      using u32x4 = unsigned __attribute__((ext_vector_type(4)));
+      const u32x4 out16 = {sx[0], sy[0], sx[1], sy[1]};  // even row: hi own | hi partner; odd row: lo partner | lo own
+      const bool oddrow = (col >> 2) & 1;                // fg odd (col = head 64 + 4 fg)
+      const int c8 = (col & ~7) + dn * 16;               // first of the pair's 8 channels
+      f16* dst = reinterpret_cast<f16*>(out_v) + tok * (2 * C) + h2i_col(c8) + (oddrow ? kH2iLo : 0);
+      *reinterpret_cast<u32x4*>(dst) = out16;
+#else
+      f16* dst = reinterpret_cast<f16*>(out_v) + tok * (2 * C) + h2i_col(col + dn * 16);
       *reinterpret_cast<f16x4*>(dst) = p0;
       *reinterpret_cast<f16x4*>(dst + kH2iLo) = p1;
+#endif
     } else {
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(out_v) + tok * C + col + dn * 16) = make_float4(r4[0], r4[1], r4[2], r4[3]);
     }

@@ -1331,20 +1331,27 @@ __device__ __forceinline__ float dyn_scale(unsigned amax_bits) {
   return ldexpf(1.0f, 14 - e);
 }
 
-// src [R][C] fp32 -> dst [R][2 Cpad] h2i (columns C .. Cpad - 1 zero), scale from the tensor's absmax; unscale[0] = 1 / scale
+// src [R][C] fp32 -> dst [R][2 Cpad] h2i (columns C .. Cpad - 1 zero), scale from the tensor's absmax; unscale[0] = 1 / scale.
+// A thread owns 8 consecutive columns (C % 8 == 0, Cpad % 32 == 0): two 16-byte loads, one 16-byte store per plane.
 __global__ void split2h_dyn_kernel(const float* __restrict__ s, f16* __restrict__ d, int R, int C, int Cpad,
                                    const unsigned* __restrict__ amax, float* __restrict__ unscale) {
   const float sc = dyn_scale(amax[0]);
   if (blockIdx.x == 0 && threadIdx.x == 0) unscale[0] = 1.0f / sc;
-  const size_t n = (size_t)R * Cpad;
+  const int G8 = Cpad / 8;
+  const size_t n = (size_t)R * G8;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t r = i / Cpad;
-    const int c = (int)(i - r * Cpad);
-    f16 a = (f16)0.f, b = (f16)0.f;
-    if (c < C) split2h_scaled(s[r * C + c] * sc, a, b);
-    f16* row = d + r * 2 * (size_t)Cpad;
-    row[h2i_col(c)] = a;
-    row[h2i_col(c) + kH2iLo] = b;
+    const size_t r = i / G8;
+    const int c = (int)(i - r * G8) * 8;
+    f16x8 hi = {}, lo = {};
+    if (c < C) {
+      const float4 a = *reinterpret_cast<const float4*>(s + r * C + c), b = *reinterpret_cast<const float4*>(s + r * C + c + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { f16 h, l; split2h_scaled(v[e] * sc, h, l); hi[e] = h; lo[e] = l; }
+    }
+    f16* row = d + r * 2 * (size_t)Cpad + h2i_col(c);
+    *reinterpret_cast<f16x8*>(row) = hi;
+    *reinterpret_cast<f16x8*>(row + kH2iLo) = lo;
   }
 }
 
@@ -1397,14 +1404,24 @@ __global__ void split2h_kernel(const float* __restrict__ s, f16* __restrict__ d,
   }
 }
 
-// out[0] = max |src[i]| (as the bit pattern of a non-negative float: integer max == float max); out pre-zeroed
-__global__ void absmax_kernel(const float* __restrict__ s, size_t n, unsigned* __restrict__ out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// out[0] = max |src[i]| (as the bit pattern of a non-negative float: integer max == float max); out pre-zeroed.
+// One atomic per WORKGROUP (the training step calls this three hundred times per step: with one atomic per wave the 4,096
+// same-address atomics of a 34 MB tensor took 56 us, five times the read itself -- profiles/r04_train_step_kernel_stats.md)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ s, size_t n, unsigned* __restrict__ out) {
+  __shared__ float part[4];
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   float m = 0.f;
-  for (; i < n; i += stride) m = fmaxf(m, fabsf(s[i]));
+  const size_t n4 = n / 4;
+  const float4* s4 = reinterpret_cast<const float4*>(s);   // (operands are 16-byte aligned: whole tensors)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = s4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(s[i]));
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
 }
 
 // see kernels.h (d3dp_launch_rowbound): one wave per row of W; fp32 sums of non-negative terms, rounded UP by a margin
@@ -1574,7 +1591,7 @@ void d3dp_launch_rowbound(const float* W, const float* gamma, const float* beta,
 }
 
 void d3dp_launch_absmax(const float* src, size_t n, unsigned* out, hipStream_t st) {
-  const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  const unsigned blocks = (unsigned)((n / 4 + 255) / 256 < 512 ? (n / 4 + 255) / 256 : 512);
   hipLaunchKernelGGL(absmax_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, n, out);
 }
 
@@ -1612,7 +1629,7 @@ int d3dp_launch_linear_f16x2_dyn(const void* A2, const void* W2, const float* bi
 
 void d3dp_launch_split2_dyn(const float* src, void* dst, int R, int C, int Cpad, const unsigned* amax, float* unscale,
                             hipStream_t st) {
-  const size_t n = (size_t)R * Cpad;
+  const size_t n = (size_t)R * (Cpad / 8);
   const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(split2h_dyn_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, (f16*)dst, R, C, Cpad, amax, unscale);
 }

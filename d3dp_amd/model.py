@@ -449,6 +449,13 @@ class MixSTE2(nn.Module):
                        "d3dp_train_backward")
         return [g[id(p)] for p in self.parameters()]
 
+    def train_arithmetic(self) -> str:
+        """What the training step's Linears run on (bench.py reports it next to the step time)."""
+        if os.environ.get("D3DP_TRAIN_IMPL") == "f32":
+            return "fp32 MFMA Linears (D3DP_TRAIN_IMPL=f32), fp32 VALU attention"
+        return ("split-fp16 Linears (forward, dgrad, split-K wgrad: three fp16-MFMA passes, fp32 accumulate, device-side operand "
+                "scales), fp32 VALU attention")
+
     # -- profiling passthrough --------------------------------------------------------------------
     def profile_enable(self, on: bool = True):
         _lib.check(_lib.load().d3dp_profile_enable(self._state().ctx, int(on)))

@@ -23,7 +23,7 @@ from oracle import d3dp_oracle as orc
 
 pytestmark = pytest.mark.gpu
 EXACT_TOL_MM = 1e-3
-FAST_TOL_MM = 12.0          # vs the fp32 oracle: reported; ~2x the largest deviation measured (2.4 ... 6.5 mm)
+FAST_TOL_MM = 8.0           # vs the fp32 oracle: reported; above the largest deviation measured in four rounds (2.1 ... 6.5 mm)
 
 
 @pytest.fixture(scope="module")
@@ -1009,7 +1009,7 @@ def test_training_step_config5_vs_oracle_autograd():
     pred, loss = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"config-5 training step (fwd+bwd, fp32 MFMA): {dt * 1e3:.1f} ms = {3 * 4 * 294.86e9 / dt / 1e12:.1f} TFLOP/s")
+    print(f"config-5 training step (fwd+bwd, {m.pose_estimator.train_arithmetic()}): {dt * 1e3:.1f} ms = {3 * 4 * 294.86e9 / dt / 1e12:.1f} TFLOP/s")
     po = {k: v.clone().requires_grad_(True) for k, v in orc.strip_prefix(sd).items()}
     xp = orc.prepare_targets(orc.cosine_schedule(1000), gt, t[:, 0], noise)
     pred_o = orc.mixste_forward(po, x2d, xp, t[:, 0], dep, droppath=dpd)
