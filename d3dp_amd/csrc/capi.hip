@@ -1064,6 +1064,8 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     float* S = ws + L.saved0 + (size_t)blk * L.saved_stride;
     LAUNCH_TRY(lin(xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C));
     if (kind == 0) LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * F, spatial_map(F, J), C, g.heads, st));
+    else if (use_x2 && C / g.heads == 64)                // temporal axis on the fp32 matrix cores (bitwise an fp32 fmaf chain per
+      LAUNCH_TRY(d3dp_launch_attn_temporal_f32(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st));   // product)
     else LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st));
     LAUNCH_TRY(lin(S + L.o_att, (const float*)w.proj_w, w.proj_b, y, T, C, C));
     LAUNCH_TRY(d3dp_train_add_mask_ln(S + L.o_xin, y, mask_ptr(masks, g, B, blk, 0), kind, F, J, w.n2w, w.n2b, g.eps_block,

@@ -46,7 +46,7 @@ for stage in "$@"; do
       db=$(find $O/stats -name "*.db" | head -1); [ -n "$db" ] && python tools/rocprof_summary.py $db $O/kernel_stats.md > /dev/null; rm -rf $O/stats; head -30 $O/kernel_stats.md ;;
     pmc_gemm)
       for mode in ${MODES:-exact}; do
-        rx="f16x2_(skew_)?kernelILi0ELi1E"; [ $mode = fast ] && rx="Li8ELi4ELi1E"
+        rx="f16x2_kernelILi0ELi1E"; [ $mode = fast ] && rx="Li8ELi4ELi1E"
         B="$R/bench.py --steps 1 --warmup 0 --no-profile --numerics $mode $QUICK"
         for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
           t=$(echo $c | cut -d' ' -f1)

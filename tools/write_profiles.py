@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/<TAG>/ (written by tools/gpu_round.sh on the GPU box) into the committed artefacts under profiles/:
+  <RN>_bench_c3.json, <RN>_bench_c3_kernel_stats.md, <RN>_gemm_traffic.json (qkv Linear: HBM bytes per launch, keyed by the
+  library's sha256 and the rows per launch), <RN>_step_pmc_<mode>.md + <RN>_step_pmc.json (whole step: HBM bytes, matrix-pipe
+  busy fraction), <RN>_gpu_tests.log.      usage: write_profiles.py TAG [RN]"""
+import json
+import os
+import re
+import shutil
+import sys
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = sys.argv[1]
+RN = sys.argv[2] if len(sys.argv) > 2 else "r04"
+F = os.path.join(R, "gpurun_out", TAG)
+P = os.path.join(R, "profiles")
+F_, J_, C_ = 243, 17, 512
+
+
+def last_json(path):
+    return json.loads([l for l in open(path).read().splitlines() if l.startswith("{")][-1])
+
+
+sha = open(os.path.join(F, "lib.sha256")).read().split()[0]
+d = last_json(os.path.join(F, "bench.json"))
+json.dump(d, open(os.path.join(P, RN + "_bench_c3.json"), "w"), indent=1)
+B, Hh, K = d["config"]["global_batch"], d["config"]["hypotheses_total"], 10
+for name in ("tests.log", "smoke.log"):
+    if os.path.exists(os.path.join(F, name)):
+        with open(os.path.join(P, RN + "_gpu_tests.log"), "a" if name == "smoke.log" else "w") as o:
+            o.write(open(os.path.join(F, name)).read())
+
+# ---- qkv Linear counters: "== dir" lines followed by "| NAME | mean | dispatches |"
+ctr, cur = {}, None
+if os.path.exists(os.path.join(F, "pmc.log")):
+    for l in open(os.path.join(F, "pmc.log")):
+        m = re.match(r"== .*pmc_(exact|fast)_(\w+)/", l)
+        if m:
+            cur = m.group(1)
+            continue
+        m = re.match(r"\| (\w+) \| (\d+) \| (\d+) \|", l)
+        if m and cur:
+            ctr.setdefault(cur, {})[m.group(1)] = (float(m.group(2)), int(m.group(3)))
+
+
+def entry(mode, elem):
+    c = ctr[mode]
+    n = c["FETCH_SIZE"][1]                                  # qkv launches in one bench step
+    rows = 2 * B * Hh * F_ * J_ * K * 16 / n                # token rows per launch (2: flip TTA, 16 blocks)
+    fetch, write = c["FETCH_SIZE"][0] * 1024 * 2, c["WRITE_SIZE"][0] * 1024
+    alg_in = rows * C_ * elem + 3 * C_ * C_ * elem
+    alg_out = rows * 3 * C_ * elem
+    busy, cyc = c["SQ_VALU_MFMA_BUSY_CYCLES"][0] / 1024, c["GRBM_GUI_ACTIVE"][0] / 8
+    return {"lib_sha256": sha, "fetch_size_kib_raw": c["FETCH_SIZE"][0], "fetch_bytes_corrected_x2": fetch,
+            "write_bytes": write, "hbm_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": int(alg_in + alg_out),
+            "algorithmic_read_bytes": int(alg_in), "read_amplification": round(fetch / alg_in, 3),
+            "mfma_busy_cycles_per_simd": busy, "kernel_cycles": cyc, "mfma_util_hw": busy / cyc,
+            "launches_profiled": n, "mean_rows_per_launch": rows, "batch": B}
+
+
+if ctr:
+    t = {"source": "rocprofv3 --pmc <counter> --kernel-include-regex <qkv Linear symbol> -- python bench.py --steps 1 --warmup 0 "
+                   "--no-profile --numerics <mode> (the bench's own batch: 16 clips); tools/gpu_round.sh pmc_gemm, one pass per "
+                   "counter set; FETCH_SIZE doubled per MI355X_MICROARCH.md (calibrated in profiles/r02_gemm_pmc.md)"}
+    for mode, elem in (("exact", 4), ("fast", 2)):
+        if mode in ctr and "FETCH_SIZE" in ctr[mode]:
+            t[mode] = {"gemm_qkv": entry(mode, elem)}
+    json.dump(t, open(os.path.join(P, RN + "_gemm_traffic.json"), "w"), indent=1)
+    print(json.dumps(t.get("exact", {}), indent=1))
+
+# ---- whole-step counters
+steps = {}
+for mode in ("exact", "fast"):
+    src = os.path.join(F, f"step_pmc_{mode}.md")
+    if not os.path.exists(src):
+        continue
+    shutil.copy(src, os.path.join(P, f"{RN}_step_pmc_{mode}.md"))
+    rows = [l for l in open(src) if l.startswith("| `")]
+    head = [h.strip() for h in open(src).readline().strip().strip("|").split("|")]
+    tot = {h: 0.0 for h in head[2:]}
+    for l in rows:
+        cells = [x.strip() for x in l.strip().strip("|").split("|")]
+        for h, v in zip(head[2:], cells[2:]):
+            tot[h] += float(v)
+    hbm = tot.get("FETCH_SIZE", 0) * 1024 * 2 + tot.get("WRITE_SIZE", 0) * 1024
+    busy = (tot["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (tot["GRBM_GUI_ACTIVE"] / 8) if tot.get("GRBM_GUI_ACTIVE") else None
+    tokens_blocks = 2 * B * Hh * F_ * J_ * K * 16
+    steps[mode] = {"lib_sha256": sha, "batch": B, "hbm_tb_per_step": hbm / 1e12, "mfma_busy_hw": busy,
+                   "hbm_kb_per_token_block": hbm / tokens_blocks / 1e3,
+                   "source": f"profiles/{RN}_step_pmc_{mode}.md: sum over every kernel of one bench step (tools/gpu_round.sh pmc_step)"}
+if steps:
+    json.dump(steps, open(os.path.join(P, RN + "_step_pmc.json"), "w"), indent=1)
+    print(json.dumps(steps, indent=1))
+
+if os.path.exists(os.path.join(F, "kernel_stats.md")):
+    prof = last_json(os.path.join(F, "bench_prof.json")) if os.path.exists(os.path.join(F, "bench_prof.json")) else {}
+    hdr = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-leg --no-parity "
+           "--no-configs   (tools/gpu_round.sh stats)",
+           "# warm-up + timed step + the profiled step of BASELINE configs[2] in EXACT numerics (the headline).",
+           "# gemm_f16x2_kernel<0,1> = the EXACT qkv Linear (own symbol); <2,0> = proj and fc2 (x += ... in place), <1,0> = fc1 + GELU.",
+           f"# bench.py's roofline.avg_launch_ms (HIP events on the launch stream) in the un-profiled run of the same build: "
+           f"{d['roofline']['avg_launch_ms'] * 1e3:.1f} us"
+           + (f", in this profiled run: {prof['roofline']['avg_launch_ms'] * 1e3:.1f} us." if prof.get("roofline") else "."), ""]
+    open(os.path.join(P, RN + "_bench_c3_kernel_stats.md"), "w").write("\n".join(hdr) + open(os.path.join(F, "kernel_stats.md")).read())
+print("value", d["value"], "sha", sha[:12])
