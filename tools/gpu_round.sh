@@ -59,9 +59,11 @@ for stage in "$@"; do
       for mode in ${MODES:-exact}; do
         B="$R/bench.py --steps 1 --warmup 0 --no-profile --numerics $mode $QUICK"
         ( cd /tmp
-          timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/step_${mode}_f -- python $B > /dev/null 2>&1
-          timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/step_${mode}_w -- python $B > /dev/null 2>&1
-          timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/step_${mode}_m -- python $B > /dev/null 2>&1 )
+          # (the library's own kernels only: without a filter rocprofv3 7.2 segfaults on this run at --batch 16)
+          KR="gemm|attn_|ln_kernel|ln2_kernel|embed_ln|head_kernel|time_mlp|ddim_|nonfinite"
+          timeout 500 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KR" --output-format csv -d $O/step_${mode}_f -- python $B > $O/step_${mode}_f.log 2>&1
+          timeout 500 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KR" --output-format csv -d $O/step_${mode}_w -- python $B > $O/step_${mode}_w.log 2>&1
+          timeout 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-include-regex "$KR" --output-format csv -d $O/step_${mode}_m -- python $B > $O/step_${mode}_m.log 2>&1 )
         python tools/pmc_step_summary.py $O/step_pmc_$mode.md $(find $O/step_${mode}_f $O/step_${mode}_w $O/step_${mode}_m -name "*counter_collection.csv") > /dev/null
         head -14 $O/step_pmc_$mode.md
       done; find $O -name "*.csv" -size +20M -delete ;;
