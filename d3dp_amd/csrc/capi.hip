@@ -154,8 +154,8 @@ struct d3dp_ctx {
   int pad_override = -1;         // D3DP_SEQ_PAD=0|1: measurement switch (pad without the skewed schedule, or the reverse)
   bool train_x2 = true;          // D3DP_TRAIN_IMPL=f32: the training Linears on the fp32 matrix cores (round-1 path, cross-check)
   int pingpong = 0;              // D3DP_X2_PP=1: the ping-pong form of the EXACT Linear (gemm_x2.hip; bit-identical results;
-                                 // measured 1.5-2 % SLOWER on the whole step, gpurun c8: the fragment reads, not their latency, are
-                                 // what the matrix pipe waits for -- 117 B/clk of LDS traffic at the full MFMA rate against a peak of 128)
+                                 // measured 1.5-2 % SLOWER on the whole step, gpurun c8); 2 = D3DP_X2_WIDE=1: the 256 x 256
+                                 // tile form (bit-identical; ties with the default, profiles/r04_gemm_probes.md section 4)
   bool x3() const { return exact() && exact_impl == 1; }
   int act() const { return fast() ? 1 : (x3() ? 2 : (x2() ? 3 : 0)); }   // code understood by the row-wise launchers
   size_t act_size() const { return fast() ? 2 : (x3() ? 6 : 4); }    // bytes per element of a Linear-input activation
@@ -370,6 +370,8 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->train_x2 = !(ti && !strcmp(ti, "f32"));
   const char* pp = getenv("D3DP_X2_PP");
   if (pp && (pp[0] == '0' || pp[0] == '1') && pp[1] == 0) c->pingpong = pp[0] - '0';
+  const char* wide = getenv("D3DP_X2_WIDE");           // D3DP_X2_WIDE=1: the 256 x 256 tile form (bit-identical results)
+  if (wide && wide[0] == '1' && wide[1] == 0) c->pingpong = 2;
   const char* pd = getenv("D3DP_SEQ_PAD");
   if (pd && (pd[0] == '0' || pd[0] == '1') && pd[1] == 0) c->pad_override = pd[0] - '0';
   const char* nl = getenv("D3DP_FOLD_LN");               // norm2 folded into proj / fc1 instead of its own row kernel
@@ -808,7 +810,7 @@ int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* 
                       int32_t N, int32_t K, void* stream) {
   if (!A2 || !W2 || !bias || !out || !(w_scale > 0.f)) return fail(D3DP_EINVAL, "d3dp_op_linear_x2: bad argument");
   const int skew_d = (epi >> 8) & 7;                     // epi | (D << 8), D = 1, 2, 4: the skewed schedule (epi 1 and 4)
-  const int pingpong = (epi >> 11) & 1;                  // epi | 2048: the ping-pong form (bit-identical results)
+  const int pingpong = (epi >> 12) & 1 ? 2 : (epi >> 11) & 1;   // epi | 2048: the ping-pong form, | 4096: the wide form (bit-identical results)
   epi &= 255;
   if (epi == EPI_RESID_LN || epi == EPI_GELU_LN) return fail(D3DP_EINVAL, "d3dp_op_linear_x2: epilogues 5 / 6 are internal to d3dp_denoise");
   if (skew_d) {

@@ -522,18 +522,20 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
 // The tile epilogue of gemm_f16x2_kernel as a function (the ping-pong kernel below calls it from two places; the kernel above
 // keeps its own inline copy so that building without the ping-pong path reproduces its code exactly).  `acc`: this wave's
 // 64 x 64 block of tile `t`; `ti`: the workgroup's running tile index (EPI_GELU_LN's row-statistics buffer parity).
+// (x2_epilogue_at: the same for a 64 x 64 block at an explicit position -- lane rows pm0 + mi*16 + r, lane columns nb..nb+3;
+// `rs_row`: the block's first lane row inside the tile, EPI_GELU_LN's row statistics only.  `sbias` may be LDS or global.)
 template <int EPI, int TAG>
-__device__ __forceinline__ void x2_tile_epilogue(f32x4 (&acc)[4][4], int t, int ti, int tiles_n, int M, int N, int wr, int wc,
-                                                 int fi, int fg, int lane, float unscale, float oscale, float* __restrict__ outf,
-                                                 f16* __restrict__ out2, float* __restrict__ aux, unsigned* __restrict__ flag,
-                                                 const float* sbias, char* smem) {
+__device__ __forceinline__ void x2_epilogue_at(f32x4 (&acc)[4][4], const int pm0, const int nb, int ti, int M, int N, int rs_row,
+                                               int fi, int lane, float unscale, float oscale, float* __restrict__ outf,
+                                               f16* __restrict__ out2, float* __restrict__ aux, unsigned* __restrict__ flag,
+                                               const float* sbias, char* smem, const f32x4* bias_regs = nullptr) {
   // ---- tile epilogue: lane holds out[m = pm0 + mi*16 + r][n = nb + ni], pm0 = tile row + wr*64 + 4 fg, nb = tile column
   // + wc*64 + 4 fi.  Every store address is  uniform base + 32-bit lane offset  (the launcher refuses outputs of 4 GiB or
   // more), advanced row by row: per-row 64-bit address arithmetic was most of the epilogue's VALU work, and it runs
   // with the matrix pipes idle.
-  const int pm0 = (t / tiles_n) * XBM + wr * 64 + 4 * fg, nb = (t % tiles_n) * XBN + wc * 64 + 4 * fi;
   if (nb < N && (!(D3DP_X2_PROBE & 4) || unscale == -12345.f)) {
-    const float4 bz = *reinterpret_cast<const float4*>(sbias + nb);
+    const float4 bz = bias_regs ? make_float4((*bias_regs)[0], (*bias_regs)[1], (*bias_regs)[2], (*bias_regs)[3])
+                                : *reinterpret_cast<const float4*>(sbias + nb);
     const bool odd = fi & 1;
     unsigned off, pitch;
     bool planes;                                     // split the values and store fp16 planes (else fp32)
@@ -560,7 +562,7 @@ __device__ __forceinline__ void x2_tile_epilogue(f32x4 (&acc)[4][4], int t, int 
     [[maybe_unused]] const float* srow = nullptr;
     if constexpr (EPI == EPI_GELU_LN) {
       c1z = *reinterpret_cast<const float4*>(sbias + N + nb);
-      srow = reinterpret_cast<const float*>(smem + XROWSTAT + (ti & 1) * (XBM * 8)) + (wr * 64 + 4 * fg) * 2;
+      srow = reinterpret_cast<const float*>(smem + XROWSTAT + (ti & 1) * (XBM * 8)) + rs_row * 2;
     }
     auto value = [&](int mi, int r, int e) {
       const float bze = e == 0 ? bz.x : e == 1 ? bz.y : e == 2 ? bz.z : bz.w;
@@ -690,11 +692,21 @@ __device__ __forceinline__ void x2_tile_epilogue(f32x4 (&acc)[4][4], int t, int 
   }
 }
 
+template <int EPI, int TAG>
+__device__ __forceinline__ void x2_tile_epilogue(f32x4 (&acc)[4][4], int t, int ti, int tiles_n, int M, int N, int wr, int wc,
+                                                 int fi, int fg, int lane, float unscale, float oscale, float* __restrict__ outf,
+                                                 f16* __restrict__ out2, float* __restrict__ aux, unsigned* __restrict__ flag,
+                                                 const float* sbias, char* smem) {
+  x2_epilogue_at<EPI, TAG>(acc, (t / tiles_n) * XBM + wr * 64 + 4 * fg, (t % tiles_n) * XBN + wc * 64 + 4 * fi, ti, M, N,
+                           wr * 64 + 4 * fg, fi, lane, unscale, oscale, outf, out2, aux, flag, sbias, smem);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // PING-PONG form of the same Linear: the two compute waves of a SIMD work half a k-step apart.
 //
 // Measured on the kernel above with its loads AND its epilogue compiled out (gpurun c7, profiles/r04_gemm_probes.md): 463 us for
-// the qkv shape at M = 128,960 = 1.22 us = 2500 cycles per k-step, of which the matrix pipe needs 96 MFMAs x 16 = 1536.  All
+// the qkv shape at M = 128,960 = 1.22 us per k-step, of which the matrix pipe needs 96 MFMAs x 16 = 1536 cycles (0.85 us at the 1.8 GHz
+// the chip holds here).  All
 // eight compute waves pass the k-step's barrier together, all read their fragments from LDS together (the pipe idles), then
 // both waves of every SIMD push their 48 MFMAs through the one pipe together: the pipe is never fed during the read phase.
 // Here the compute waves form two teams -- X = waves 0..3, Y = waves 4..7: one wave of each per SIMD (waves go to SIMDs round
@@ -856,6 +868,204 @@ __global__ __launch_bounds__(768) void gemm_f16x2_pp_kernel(const f16* __restric
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (++ks == NK) { ks = 0; ++ti; }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// WIDE form of the same Linear: 256 x 256 tile, eight waves of 256 registers, no loader waves.
+//
+// An experiment (profiles/r04_gemm_probes.md section 4): per MFMA a 64 x 128 register tile per wave (128 accumulator registers,
+// 64 for the eight W fragments it keeps for the whole k-step) reads 0.75 x the LDS bytes of the kernel at the top of this file,
+// receives 0.67 x the LDS-DMA bytes, fetches A half as often and passes half as many barriers.  That needs the 256 registers
+// of a two-waves-per-SIMD workgroup, so nothing is left for loader waves: every wave issues its own share of the k-step's
+// LDS-DMA (4 A pieces + 4 W pieces of 8 rows) in inline assembly and waits for it with counted vmcnt; the epilogue's
+// stores pass through the same counter and are counted with it (x2_epilogue_at issues exactly 16 stores per 64 x 64
+// block of a full tile).  MEASURED: ties with the kernel at the top within 3 % as built, without loads, without epilogue
+// and without both -- the Linear's time is its MFMA count at the clock the power budget allows, not its LDS traffic.
+// Kept behind D3DP_X2_WIDE=1 (and epi | 4096 of d3dp_op_linear_x2), off.
+//   LDS: A ring 3 x 32 KiB at 0, W ring 2 x 32 KiB at 96 KiB = 160 KiB; the bias is read from global memory.
+//   per k-step g:  wait own A(g), W(g) | barrier | issue W(g+1) -> W slot of g-1, A(g+2) -> A slot of g-1 | 96 MFMAs
+// Requires N % 256 == 0 and K % 32 == 0.  The products meet every accumulator in the order of the plain kernel
+// (k ascending; ah.wl, al.wh, ah.wh): results are bit-identical to it.
+constexpr int WBN = 256;
+constexpr int WA_STAGES = 3, WW_STAGES = 2;
+constexpr int WW_BYTES = WBN * 128;                  // 32 KiB
+constexpr int WW_BASE = WA_STAGES * XA_BYTES;        // 96 KiB
+constexpr int WLDS = WW_BASE + WW_STAGES * WW_BYTES; // 160 KiB
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"          // (the expected "clobber list contains reserved registers" note for m0)
+// one LDS-DMA wave-instruction in the  uniform base + 32-bit lane offset  form: lane l's 16 bytes at base + off -> LDS
+// bytes [lds + 16 l, +16).  Inline assembly for the reasons given at lds_dma16 in attention.hip: the builtin makes the
+// compiler turn every vector-memory wait of the kernel into vmcnt(0).
+__device__ __forceinline__ void wide_dma16(unsigned off, const char* base, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+// 16-byte global load the compiler does not track (it would wait for it with vmcnt(0) counted without the LDS-DMA operations
+// around it); the caller waits with wide_wait_vmcnt and passes the registers through wide_settle.
+__device__ __forceinline__ f32x4 wide_gload16(const float* p) {
+  f32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ void wide_settle(f32x4& r) { asm volatile("" : "+v"(r)); }
+template <int V>
+__device__ __forceinline__ void wide_wait_vmcnt() { __builtin_amdgcn_s_waitcnt((V & 15) | (7 << 4) | (15 << 8) | ((V >> 4) << 14)); }
+
+template <int EPI, int TAG>
+__global__ __launch_bounds__(512) void gemm_f16x2_wide_kernel(const f16* __restrict__ A2, const f16* __restrict__ W2,
+                                                              const float* __restrict__ bias, float unscale, float oscale,
+                                                              float* __restrict__ outf, f16* __restrict__ out2,
+                                                              float* __restrict__ aux, unsigned* __restrict__ flag, int M,
+                                                              int N, int K, int tiles_n, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int G = gridDim.x;
+  const int L = xcd_remap(blockIdx.x, G);
+  const int n_my = (total_tiles - L + G - 1) / G;      // tiles L, L+G, ...
+  const int NK = K / XBK;
+  const int gtot = n_my * NK;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int lr = lane >> 3, lq = lane & 7;             // loader role: row within an 8-row piece, physical 16-byte slot
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)LPTR(smem);
+  const unsigned rowbytes = (unsigned)K * 4;           // one operand row: K x (hi | lo) fp16
+
+  // ---- this wave's share of the loads: pieces 4 wave .. 4 wave + 3 of the A slab and of the W slab
+  unsigned voffW[4], voffA[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + lr;                            // LDS row of the W slab
+    const int wrow = (row & ~63) + colperm(row & 63);                   // output column (inside the tile) it carries
+    voffW[i] = (unsigned)wrow * rowbytes + swz128(row, lq) * 16;        // (N % 256 == 0: no clamp)
+  }
+  int tiA = 0, ksA = 0, slotA = 0, tiW = 0, ksW = 0, slotW = 0;         // (tile, k-step, ring slot) of the next slab to issue
+  const char* baseA = nullptr;
+  const char* baseW = nullptr;
+  auto issueA = [&]() {
+    if (ksA == 0) {
+      const int t = L + tiA * G;
+      const int m0 = (t / tiles_n) * XBM;
+      baseA = reinterpret_cast<const char*>(A2) + (size_t)m0 * rowbytes;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + lr;
+        voffA[i] = (unsigned)min(row, M - 1 - m0) * rowbytes + swz128(row, lq) * 16;
+      }
+    }
+    const char* b = baseA + ksA * (4 * XBK);           // one k-step of a row = 64 fp16 = 128 B
+    const unsigned dst = lds0 + slotA * XA_BYTES + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (!(D3DP_X2_PROBE & 1) || unscale == -12345.f) wide_dma16(voffA[i], b, dst + i * 1024);
+    if (++ksA == NK) { ksA = 0; ++tiA; }
+    slotA = (slotA == WA_STAGES - 1) ? 0 : slotA + 1;
+  };
+  auto issueW = [&]() {
+    if (ksW == 0) {
+      const int t = L + tiW * G;
+      baseW = reinterpret_cast<const char*>(W2) + (size_t)((t % tiles_n) * WBN) * rowbytes;
+    }
+    const char* b = baseW + ksW * (4 * XBK);
+    const unsigned dst = lds0 + WW_BASE + slotW * WW_BYTES + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (!(D3DP_X2_PROBE & 1) || unscale == -12345.f) wide_dma16(voffW[i], b, dst + i * 1024);
+    if (++ksW == NK) { ksW = 0; ++tiW; }
+    slotW ^= 1;
+  };
+
+  // per-lane fragment offsets (the swizzle depends on the lane only: rows advance in multiples of 16; lo plane = offset ^ 64)
+  const int offA = (wr * 64 + fi) * 128 + swz128(fi, fg) * 16, offAl = offA ^ 64;
+  const int offW = WW_BASE + (wc * 128 + fi) * 128 + swz128(fi, fg) * 16, offWl = offW ^ 64;
+  f32x4 acc[2][4][4];                                  // [column half][mi][ni]: two 64 x 64 blocks as the epilogue wants them
+
+  if (gtot > 0) { issueA(); issueW(); }
+  if (gtot > 1) issueA();
+  int g = 0, cslotA = 0, cslotW = 0;
+  bool after_full_tile = false;                        // the previous k-step ended with the 32 stores of a full tile
+#pragma unroll 1
+  for (int ti = 0; ti < n_my; ++ti) {
+    const int t = L + ti * G;
+    const int m0 = (t / tiles_n) * XBM, nb0 = (t % tiles_n) * WBN + wc * 128 + 4 * fi;   // (nb0: this lane's first column)
+    f32x4 bz[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ks = 0; ks < NK; ++ks, ++g) {
+      // own loads of slab g landed; younger operations that may stay in flight: A(g+1) (4) and, right behind a full
+      // tile's epilogue, its 32 stores.  (Behind a partial tile the number of stores issued is not known: the strict
+      // count is always safe -- the stores are the youngest operations.)
+      if (g + 1 >= gtot) wide_wait_vmcnt<0>();
+      else if (after_full_tile) wide_wait_vmcnt<36>();
+      else wide_wait_vmcnt<4>();
+      after_full_tile = false;
+      __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): this wave has read everything it wanted from the old slots
+      X2_BARRIER();
+      if (g + 1 < gtot) issueW();                      // into the slots of k-step g-1: every wave has passed barrier g
+      if (g + 2 < gtot) issueA();
+      if (ks == NK - 1) {                              // the tile's bias, a k-step ahead of its use (youngest operations)
+        bz[0] = wide_gload16(bias + nb0);
+        bz[1] = wide_gload16(bias + nb0 + 64);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const char* sa = smem + cslotA * XA_BYTES;
+      const char* sw = smem + cslotW * WW_BYTES;
+      cslotA = (cslotA == WA_STAGES - 1) ? 0 : cslotA + 1;
+      cslotW ^= 1;
+      f16x8 wf[8][2], ah[2], al[2];
+      ah[0] = *reinterpret_cast<const f16x8*>(sa + offA);
+      al[0] = *reinterpret_cast<const f16x8*>(sa + offAl);
+#pragma unroll
+      for (int nj = 0; nj < 8; ++nj) {
+        wf[nj][1] = *reinterpret_cast<const f16x8*>(sw + offWl + nj * 2048);
+        wf[nj][0] = *reinterpret_cast<const f16x8*>(sw + offW + nj * 2048);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int b = mi & 1;
+        if (mi < 3) {                                  // next row block's fragments while this one multiplies
+          ah[b ^ 1] = *reinterpret_cast<const f16x8*>(sa + offA + (mi + 1) * 2048);
+          al[b ^ 1] = *reinterpret_cast<const f16x8*>(sa + offAl + (mi + 1) * 2048);
+        }
+        if (mi == 0) {
+          // column-major through the first row block: its first MFMAs need 4 of the 18 fragment reads, not 10
+#pragma unroll
+          for (int nj = 0; nj < 8; ++nj) {
+            f32x4& c = acc[nj >> 2][0][nj & 3];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], wf[nj][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[0], wf[nj][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], wf[nj][0], c, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int nj = 0; nj < 8; ++nj)
+            acc[nj >> 2][mi][nj & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], wf[nj][1], acc[nj >> 2][mi][nj & 3], 0, 0, 0);
+#pragma unroll
+          for (int nj = 0; nj < 8; ++nj)
+            acc[nj >> 2][mi][nj & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[b], wf[nj][0], acc[nj >> 2][mi][nj & 3], 0, 0, 0);
+#pragma unroll
+          for (int nj = 0; nj < 8; ++nj)
+            acc[nj >> 2][mi][nj & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[b], wf[nj][0], acc[nj >> 2][mi][nj & 3], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // everything this wave has in flight was issued a k-step ago or earlier: the loads of the next two k-steps and the bias
+    wide_wait_vmcnt<0>();
+    wide_settle(bz[0]);
+    wide_settle(bz[1]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      x2_epilogue_at<EPI, TAG>(acc[h], m0 + wr * 64 + 4 * fg, nb0 + h * 64, ti, M, N, 0, fi, lane, unscale, oscale, outf, out2,
+                               aux, flag, bias, smem, &bz[h]);
+    after_full_tile = m0 + XBM <= M;
   }
 }
 
@@ -1557,8 +1767,23 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
                        outf, (f16*)out2, M, N, K, tn, tm, Q);
     return 0;
   }
+  if (pingpong == 2 && N % WBN == 0 && (epi == EPI_BIAS || epi == EPI_QKV_PACK || epi == EPI_GELU || epi == EPI_RESID)) {
+    static const KernT wides[4] = {gemm_f16x2_wide_kernel<EPI_BIAS, 0>, gemm_f16x2_wide_kernel<EPI_BIAS, 1>,
+                                   gemm_f16x2_wide_kernel<EPI_GELU, 0>, gemm_f16x2_wide_kernel<EPI_RESID, 0>};
+    static PerDeviceOnce once_wide;
+    if (once_wide.get([&](int) {
+          for (int k = 0; k < 4; ++k)
+            if (d3dp_lds_opt_in(reinterpret_cast<const void*>(wides[k]), WLDS) < 0) return -3;
+          return 1;
+        }) < 0) return -3;
+    const int tw = N / WBN, totw = tm * tw;
+    const KernT kern = wides[epi == EPI_GELU ? 2 : epi == EPI_RESID ? 3 : epi == EPI_QKV_PACK ? 1 : 0];
+    hipLaunchKernelGGL(kern, dim3(totw < cus ? totw : cus), dim3(512), WLDS, st, (const f16*)A2, (const f16*)W2, bias, unscale,
+                       oscale, outf, (f16*)out2, aux, flag, M, N, K, tw, totw);
+    return 0;
+  }
   const int total = tm * tn, grid = total < cus ? total : cus;
-  if (pingpong && (epi == EPI_BIAS || epi == EPI_QKV_PACK || epi == EPI_GELU || epi == EPI_RESID)) {
+  if (pingpong == 1 && (epi == EPI_BIAS || epi == EPI_QKV_PACK || epi == EPI_GELU || epi == EPI_RESID)) {
     static const KernT pps[4] = {gemm_f16x2_pp_kernel<EPI_BIAS, 0>, gemm_f16x2_pp_kernel<EPI_BIAS, 1>,
                                  gemm_f16x2_pp_kernel<EPI_GELU, 0>, gemm_f16x2_pp_kernel<EPI_RESID, 0>};
     static PerDeviceOnce once_pp;

@@ -293,8 +293,10 @@ int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream);
  * epi | 2048: the PING-PONG form of the kernel (two wave teams half a k-step apart: one reads its fragments from LDS while
  * the other owns the matrix pipe); same arithmetic in the same order: bit-identical results.  An experiment kept behind
  * D3DP_X2_PP=1: measured slightly slower.
+ * epi | 4096 (epi 0, 1, 2, 4; N % 256 == 0, else the default kernel runs): the WIDE form (256 x 256 tile, eight waves that
+ * load for themselves); bit-identical results.  An experiment kept behind D3DP_X2_WIDE=1: measured equal.
  * Test-only environment switches read by the library:
- * D3DP_X2_PP=1 (the ping-pong form of the EXACT Linear), D3DP_X2_SKEW=1|2|4 (the skewed schedule above for the denoiser's qkv / fc1 Linears; measured slower, off by default), D3DP_EXACT_IMPL=bf16x3|f32 and D3DP_NO_FOLD=1 (cross-check implementations of EXACT mode), D3DP_FOLD_LN=1 (norm2 folded into
+ * D3DP_X2_PP=1 / D3DP_X2_WIDE=1 (the ping-pong / wide form of the EXACT Linear), D3DP_X2_SKEW=1|2|4 (the skewed schedule above for the denoiser's qkv / fc1 Linears; measured slower, off by default), D3DP_EXACT_IMPL=bf16x3|f32 and D3DP_NO_FOLD=1 (cross-check implementations of EXACT mode), D3DP_FOLD_LN=1 (norm2 folded into
  * the proj / fc1 Linears; measured no faster than the row kernel and left off) -- all read in d3dp_create. */
 int d3dp_op_split2(const float* src, void* dst, size_t n, float scale, void* stream);
 int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* bias, float w_scale, void* out, int32_t M,

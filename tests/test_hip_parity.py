@@ -267,6 +267,35 @@ def test_linear_split_f16_pingpong_is_bit_identical(lib, M, N, K, epi):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(70000, 1536, 512, 4), (4131, 1024, 512, 1), (66000, 512, 1024, 2), (129, 256, 64, 0),
+                                       (1000, 512, 512, 2), (300, 1536, 512, 4), (25000, 1024, 512, 1), (256, 512, 128, 0),
+                                       (128960, 1536, 512, 4)])
+def test_linear_split_f16_wide_is_bit_identical(lib, M, N, K, epi):
+    """The wide form of the EXACT Linear (gemm_x2.hip: 256 x 256 tiles, every wave loads its own share by LDS-DMA and counts
+    its epilogue stores into the same vmcnt) meets every accumulator with the products of the plain kernel in its order:
+    every epilogue's output equals the plain kernel's bit for bit -- at the full size too, where each workgroup walks eleven
+    or twelve tiles and every counted wait is exercised."""
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    A = (torch.randn(M, K, generator=g) * 2).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    x0 = torch.randn(M, N, generator=g).cuda()
+    A2 = torch.empty(2, M, K, dtype=torch.float16, device="cuda")
+    W2 = torch.empty(2, N, K, dtype=torch.float16, device="cuda")
+    w_scale = 2.0 ** (13 - int(np.floor(np.log2(W.abs().max().item()))))
+    _lib.check(lib.d3dp_op_split2(A.data_ptr(), A2.data_ptr(), M * K, 16.0, stream()))
+    _lib.check(lib.d3dp_op_split2(W.data_ptr(), W2.data_ptr(), N * K, w_scale, stream()))
+    outs = []
+    for flag in (0, 4096, 4096):
+        out = x0.clone() if epi == 2 else torch.full((M, N), float("nan"), device="cuda")
+        _lib.check(lib.d3dp_op_linear_x2(epi | flag, A2.data_ptr(), W2.data_ptr(), bias.data_ptr(), w_scale, out.data_ptr(), M, N,
+                                         K, stream()), "d3dp_op_linear_x2")
+        torch.cuda.synchronize()
+        outs.append(out.view(torch.int32).cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[2])
+
+
 def test_skewed_schedule_end_to_end_keeps_parity_and_batch_invariance(monkeypatch):
     """D3DP_X2_SKEW=4 (the experiment of gemm_x2.hip kept behind a switch: measured slower, off by default) through the whole
     denoiser: every sequence is padded to a multiple of 64 rows, so a token's summation order depends on its index in its

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--x2", action="store_true", help="EXACT-mode split-fp16 kernel (two planes per operand, three passes)")
     ap.add_argument("--real-epi", action="store_true", help="--x2: the epilogues the denoiser launches (qkv: packed rows, proj / fc2: x += ..., fc1: GELU planes)")
     ap.add_argument("--pp", action="store_true", help="--x2: the ping-pong form of the kernel (epi | 2048)")
+    ap.add_argument("--wide", action="store_true", help="--x2: the 256 x 256 tile form of the kernel (epi | 4096)")
     ap.add_argument("--skew", type=int, default=0, help="--x2 --real-epi: D of the skewed schedule for qkv and fc1 (0 = plain)")
     ap.add_argument("--check", action="store_true", help="compare each result with torch (fp32 matmul of the bf16 operands)")
     ap.add_argument("--cache", default="hot", choices=["hot", "cold", "produced"],
@@ -42,6 +43,8 @@ def main():
                 epi = {"qkv": 4 | (a.skew << 8), "proj": 2, "fc1": 1 | (a.skew << 8), "fc2": 2}.get(name, epi)
             if a.pp:
                 epi |= 2048
+            if a.wide:
+                epi |= 4096
             A = torch.randn(M, K, device="cuda")
             W = torch.randn(N, K, device="cuda") / K ** 0.5
             A2 = torch.empty(2, M, K, dtype=torch.float16, device="cuda")
