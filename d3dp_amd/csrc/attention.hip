@@ -763,6 +763,21 @@ __device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt((V & 1
 //         P.V (q(p+1) requested on the way), store O  barrier 3     (every wave is done with the V image)  issue V(p+1)
 // The vmcnt(2 PER) at the top is exact: vector memory operations of a wave retire in order and the 2 PER youngest are
 // the V pieces.
+// measurement build (-DD3DP_ATTN_STAMP=1): s_memtime at the phase boundaries of the first 16 problems of workgroups 0..3,
+// every wave's lane 0 -> d3dp_attn_stamps[wg][wave][problem][8] (read back by d3dp_debug_attn_stamps)
+#ifndef D3DP_ATTN_STAMP
+#define D3DP_ATTN_STAMP 0
+#endif
+#if D3DP_ATTN_STAMP
+__device__ unsigned long long d3dp_attn_stamps[4 * 8 * 16 * 8];
+#define ATTN_STAMP(k)                                                                                          \
+  do {                                                                                                         \
+    if (blockIdx.x < 4 && iter < 16 && lane == 0)                                                              \
+      d3dp_attn_stamps[((blockIdx.x * 8 + wave) * 16 + iter) * 8 + (k)] = __builtin_readcyclecounter();        \
+  } while (0)
+#else
+#define ATTN_STAMP(k) do { } while (0)
+#endif
 template <int NKT, int OUTS, bool MASK_ANY_TILE>
 __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
                                                                SeqMap map, int C, int heads, size_t plane_elems,
@@ -839,9 +854,13 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
   issue_kv(row0, head, 0);
   load_q_raw(row0, head);
   issue_kv(row0, head, 1);
-  for (;;) {
+  [[maybe_unused]] int iter = 0;
+  for (;; ++iter) {
+    ATTN_STAMP(0);
     wait_vmcnt<2 * PER>();
+    ATTN_STAMP(1);
     __builtin_amdgcn_s_barrier();                      // 1: the K image of problem p is complete
+    ATTN_STAMP(2);
     f16x8 ph[TPW][NKT / 2], pl[TPW][NKT / 2];
     float denom[TPW];
     // (fragment bases re-derived per phase from the opaque lane id: the four V bases are not live during the scores)
@@ -882,8 +901,11 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
       }
     }
     }
+    ATTN_STAMP(3);
     wait_vmcnt<0>();
+    ATTN_STAMP(4);
     __builtin_amdgcn_s_barrier();                      // 2: V image complete; nobody reads the K image any more
+    ATTN_STAMP(5);
     const int pn = p + gridDim.x;
     const bool has_next = pn < n_prob;
     int head_n = 0;
@@ -913,7 +935,9 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
     }
     if (!has_next) break;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ATTN_STAMP(6);
     __builtin_amdgcn_s_barrier();                      // 3: nobody reads the V image any more
+    ATTN_STAMP(7);
     issue_kv(row0_n, head_n, 1);
     p = pn; row0 = row0_n; head = head_n;
   }
@@ -1298,3 +1322,9 @@ int d3dp_launch_attn_spatial_bf16(const void* qkv, void* out, int n_seq, SeqMap 
                      n_prob, map, C, heads);
   return 0;
 }
+
+#if D3DP_ATTN_STAMP
+extern "C" int d3dp_debug_attn_stamps(unsigned long long* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(d3dp_attn_stamps), sizeof(unsigned long long) * 4 * 8 * 16 * 8);
+}
+#endif

@@ -8,6 +8,8 @@
 //                     (position-embedding and time-embedding grads), embedding / head / time-MLP backward.
 // DropPath (timm semantics: per-sample mask in {0, 1/keep}) enters as an optional per-sample scale of the branch
 // output: sample = token / J for spatial blocks ((b f) n c), = (b, n) for temporal blocks ((b n) f c).
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -573,10 +575,259 @@ int d3dp_train_transpose_pad(const float* in, float* out, int R, int C, int Rpad
 }
 size_t d3dp_train_attn_stats_bytes(int n_seq, int n_tok, int heads) { return (size_t)n_seq * heads * n_tok * sizeof(AttnStats); }
 
+// ------------------------------------------------------------------------------------------------
+// Attention backward on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 fma chains), head dim 64, sequences of
+// up to 256 tokens (the temporal axis: 243 frames).  The two kernels above spend 13 ms of the configs[4] step on the VALU;
+// the same five products per (sequence, head) cost the fp32 matrix pipe 37.8 MFLOP = 148 k cycles of one CU.
+//   pass Q : K, V in LDS; one 16-query tile per wave.  S^T = K Q^T and dP^T = V dO^T as MFMA tiles [key][query] (the layout
+//            of attention.hip's forward kernel), two-pass softmax in registers, dS^T = P^T (dP^T - D) / 8 per key tile and
+//            dQ^T += K^T dS^T straight from the registers that hold it.  Writes (row max, denominator, D) per query.
+//   pass KV: Q, dO and the statistics in LDS; one 16-key tile per wave with its K / V fragments in registers.  S = Q K^T and
+//            dP = dO V^T as tiles [query][key], P from the stored statistics, dV^T += dO^T P and dK^T += Q^T dS.
+// A workgroup = four waves = four consecutive tiles of one problem (grid = problems x ceil(tiles / 4)): with one
+// 139-KiB workgroup per CU, 544 problems of 16 tiles each would quantise to three rounds of 256; 2,176 quarter problems
+// to 8.5 quarter rounds.  LDS rows: 68 floats (row-pattern fragments = four ds_read_b128 per 16 contraction steps;
+// column-pattern fragments conflict-free ds_read_b32).
+// ------------------------------------------------------------------------------------------------
+constexpr int LDB = 68;
+using f32x4m = float __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void bwd_stage_rows(float* dst, const float* src0, size_t row_stride, int n, int NK, int tid) {
+  for (int idx = tid; idx < NK * 16; idx += 256) {
+    const int row = idx >> 4, c4 = (idx & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < n) v = *reinterpret_cast<const float4*>(src0 + (size_t)row * row_stride + c4);
+    *reinterpret_cast<float4*>(dst + row * LDB + c4) = v;
+  }
+}
+// 16 contraction steps of two independent tiles: acc_a += A_a[fi][16 fg + kk] b_a[kk], the same for b
+__device__ __forceinline__ void bwd_chain2(const float* ra, const float* rb, const float (&ba)[16], const float (&bb)[16],
+                                           f32x4m& a, f32x4m& b) {
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    a = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[kk], ba[kk], a, 0, 0, 0);
+    b = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[kk], bb[kk], b, 0, 0, 0);
+  }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256, 1) void attn_bwd_q_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                                 const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                                 AttnStats* __restrict__ stats, SeqMap map, int C, int heads,
+                                                                 int groups) {
+  constexpr int NK = 16 * NKT;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* KS = reinterpret_cast<float*>(smem_raw);
+  float* VS = KS + NK * LDB;
+  const int n = map.n_tok;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int prob = blockIdx.x / groups, group = blockIdx.x % groups;
+  const int seq = prob / heads, head = prob % heads;
+  const int base = (seq / map.inner) * map.outer_stride + (seq % map.inner) * map.inner_stride;
+  const int ts = map.tok_stride;
+  const size_t ld = (size_t)3 * C;
+  const float* qbase = qkv + (size_t)base * ld + (size_t)head * 64;
+  bwd_stage_rows(KS, qbase + C, (size_t)ts * ld, n, NK, tid);
+  bwd_stage_rows(VS, qbase + 2 * C, (size_t)ts * ld, n, NK, tid);
+  __syncthreads();
+  const int qt = group * 4 + wave;
+  if (qt * 16 >= n) return;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int q = qt * 16 + fi;
+  const size_t tok = (size_t)(base + min(q, n - 1) * ts);
+  float qv[16], gv[16];
+  float D = 0.f;
+  {
+    const float* qs = qkv + tok * ld + head * 64 + fg * 16;
+    const float* gs = dout + tok * C + head * 64 + fg * 16;
+    const float* os = o + tok * C + head * 64 + fg * 16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(qs + c * 4);
+      const float4 g = *reinterpret_cast<const float4*>(gs + c * 4);
+      const float4 ov = *reinterpret_cast<const float4*>(os + c * 4);
+      qv[c * 4] = a.x; qv[c * 4 + 1] = a.y; qv[c * 4 + 2] = a.z; qv[c * 4 + 3] = a.w;
+      gv[c * 4] = g.x; gv[c * 4 + 1] = g.y; gv[c * 4 + 2] = g.z; gv[c * 4 + 3] = g.w;
+      D = fmaf(g.x, ov.x, D); D = fmaf(g.y, ov.y, D); D = fmaf(g.z, ov.z, D); D = fmaf(g.w, ov.w, D);
+    }
+  }
+  D += __shfl_xor(D, 16, 64);
+  D += __shfl_xor(D, 32, 64);
+  // S^T[key = 16 t + 4 fg + r][query fi], two key tiles (two accumulator chains) at a time
+  f32x4m s[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; t += 2) {
+    f32x4m a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    bwd_chain2(KS + (t * 16 + fi) * LDB + fg * 16, KS + ((t + 1) * 16 + fi) * LDB + fg * 16, qv, qv, a, b);
+    s[t] = a; s[t + 1] = b;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    if (16 * (t + 1) > n) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * t + 4 * fg + r >= n) s[t][r] = -INFINITY;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float cexp = 0.125f * 1.44269504088896340736f;
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[t][r] = exp2f((s[t][r] - mx) * cexp);
+      sum += s[t][r];
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float pscale = 0.125f / sum;                   // P / 8: dS = P (dP - D) / sqrt(64)
+  f32x4m dq[4];
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) dq[dn] = (f32x4m){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NKT; t += 2) {
+    f32x4m da = {0.f, 0.f, 0.f, 0.f}, db = da;          // dP^T of key tiles t, t + 1
+    bwd_chain2(VS + (t * 16 + fi) * LDB + fg * 16, VS + ((t + 1) * 16 + fi) * LDB + fg * 16, gv, gv, da, db);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const f32x4m dp = u ? db : da;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ds = s[t + u][r] * pscale * (dp[r] - D);
+        const float* kr = KS + ((t + u) * 16 + 4 * fg + r) * LDB + fi;      // K[key][dn * 16 + fi]
+#pragma unroll
+        for (int dn = 0; dn < 4; ++dn) dq[dn] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[dn * 16], ds, dq[dn], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (q < n) {
+    float* dst = dqkv + tok * ld + head * 64 + fg * 4;                      // dQ^T[d = dn * 16 + 4 fg + i][query fi]
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn)
+      *reinterpret_cast<float4*>(dst + dn * 16) = make_float4(dq[dn][0], dq[dn][1], dq[dn][2], dq[dn][3]);
+    if (fg == 0) stats[(size_t)prob * n + q] = AttnStats{mx, sum, D};       // (raw row max, denominator: private to pass KV)
+  }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256, 1) void attn_bwd_kv_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                  float* __restrict__ dqkv, const AttnStats* __restrict__ stats,
+                                                                  SeqMap map, int C, int heads, int groups) {
+  constexpr int NK = 16 * NKT;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* QS = reinterpret_cast<float*>(smem_raw);
+  float* GS = QS + NK * LDB;
+  float* ST = GS + NK * LDB;                           // [NK][4]: row max, 1 / (8 denominator), D, -
+  const int n = map.n_tok;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int prob = blockIdx.x / groups, group = blockIdx.x % groups;
+  const int seq = prob / heads, head = prob % heads;
+  const int base = (seq / map.inner) * map.outer_stride + (seq % map.inner) * map.inner_stride;
+  const int ts = map.tok_stride;
+  const size_t ld = (size_t)3 * C;
+  bwd_stage_rows(QS, qkv + (size_t)base * ld + (size_t)head * 64, (size_t)ts * ld, n, NK, tid);
+  bwd_stage_rows(GS, dout + (size_t)base * C + (size_t)head * 64, (size_t)ts * C, n, NK, tid);
+  for (int i = tid; i < NK; i += 256) {
+    // rows >= n: Q and dO rows are zero, so whatever finite P and dS they get contributes nothing
+    float4 v = make_float4(0.f, 0.125f, 0.f, 0.f);
+    if (i < n) {
+      const AttnStats a = stats[(size_t)prob * n + i];
+      v = make_float4(a.m, 0.125f / a.l, a.D, 0.f);
+    }
+    *reinterpret_cast<float4*>(ST + i * 4) = v;
+  }
+  __syncthreads();
+  const int kt = group * 4 + wave;
+  if (kt * 16 >= n) return;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int key = kt * 16 + fi;
+  const size_t tok = (size_t)(base + min(key, n - 1) * ts);
+  float kv[16], vv[16];
+  {
+    const float* ks = qkv + tok * ld + C + head * 64 + fg * 16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float4 a = *reinterpret_cast<const float4*>(ks + c * 4);
+      float4 b = *reinterpret_cast<const float4*>(ks + C + c * 4);
+      if (key >= n) { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+      kv[c * 4] = a.x; kv[c * 4 + 1] = a.y; kv[c * 4 + 2] = a.z; kv[c * 4 + 3] = a.w;
+      vv[c * 4] = b.x; vv[c * 4 + 1] = b.y; vv[c * 4 + 2] = b.z; vv[c * 4 + 3] = b.w;
+    }
+  }
+  const float cexp = 0.125f * 1.44269504088896340736f;
+  f32x4m dk[4], dv[4];
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) { dk[dn] = (f32x4m){0.f, 0.f, 0.f, 0.f}; dv[dn] = dk[dn]; }
+#pragma unroll 2
+  for (int t = 0; t < NKT; ++t) {
+    // S[query = 16 t + 4 fg + i][key fi] and dP of the same tile: two accumulator chains
+    f32x4m sa = {0.f, 0.f, 0.f, 0.f}, da = sa;
+    bwd_chain2(QS + (t * 16 + fi) * LDB + fg * 16, GS + (t * 16 + fi) * LDB + fg * 16, kv, vv, sa, da);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = t * 16 + 4 * fg + i;
+      const float4 a = *reinterpret_cast<const float4*>(ST + row * 4);
+      const float p8 = exp2f((sa[i] - a.x) * cexp) * a.y;               // P / 8
+      const float ds = p8 * (da[i] - a.z);
+      const float p = p8 * 8.0f;
+      const float* gr = GS + row * LDB + fi;                             // dO[query][dn * 16 + fi]
+      const float* qr = QS + row * LDB + fi;
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) {
+        dv[dn] = __builtin_amdgcn_mfma_f32_16x16x4f32(gr[dn * 16], p, dv[dn], 0, 0, 0);
+        dk[dn] = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[dn * 16], ds, dk[dn], 0, 0, 0);
+      }
+    }
+  }
+  if (key < n) {
+    float* dst = dqkv + tok * ld + C + head * 64 + fg * 4;                // d{K,V}^T[d = dn * 16 + 4 fg + i][key fi]
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) {
+      *reinterpret_cast<float4*>(dst + dn * 16) = make_float4(dk[dn][0], dk[dn][1], dk[dn][2], dk[dn][3]);
+      *reinterpret_cast<float4*>(dst + C + dn * 16) = make_float4(dv[dn][0], dv[dn][1], dv[dn][2], dv[dn][3]);
+    }
+  }
+}
+
+template <int NKT>
+static int launch_attn_bwd_mfma(const float* qkv, const float* o, const float* dout, float* dqkv, void* stats, int n_seq,
+                                SeqMap map, int C, int heads, hipStream_t st) {
+  constexpr int NK = 16 * NKT;
+  const size_t lds_q = (size_t)2 * NK * LDB * 4, lds_kv = lds_q + (size_t)NK * 16;
+  static PerDeviceOnce once;
+  if (once.get([&](int) {
+        return d3dp_lds_opt_in(reinterpret_cast<const void*>(attn_bwd_q_mfma_kernel<NKT>), 160 * 1024) < 0 ? -3
+               : d3dp_lds_opt_in(reinterpret_cast<const void*>(attn_bwd_kv_mfma_kernel<NKT>), 160 * 1024);
+      }) < 0) return -3;
+  const int tiles = (map.n_tok + 15) / 16, groups = (tiles + 3) / 4;
+  hipLaunchKernelGGL((attn_bwd_q_mfma_kernel<NKT>), dim3(n_seq * heads * groups), dim3(256), lds_q, st, qkv, o, dout, dqkv,
+                     (AttnStats*)stats, map, C, heads, groups);
+  hipLaunchKernelGGL((attn_bwd_kv_mfma_kernel<NKT>), dim3(n_seq * heads * groups), dim3(256), lds_kv, st, qkv, dout, dqkv,
+                     (const AttnStats*)stats, map, C, heads, groups);
+  return 0;
+}
+
 template <int HD>
 static int launch_attn_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, void* stats, int n_seq,
                            SeqMap map, int C, int heads, hipStream_t st) {
   const int n = map.n_tok;
+  if constexpr (HD == 64) {
+    // long sequences (the temporal axis) on the fp32 matrix cores; D3DP_TRAIN_ATTN_BWD=valu keeps the kernels below (cross-check)
+    const char* e = getenv("D3DP_TRAIN_ATTN_BWD");     // (read per call: the tests switch it between two steps)
+    const bool valu = e && e[0] == 'v';
+    if (!valu && n > 32 && n <= 256 && C % 4 == 0) {
+      if (n <= 64) return launch_attn_bwd_mfma<4>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
+      if (n <= 128) return launch_attn_bwd_mfma<8>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
+      return launch_attn_bwd_mfma<16>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
+    }
+  }
   const size_t lds_q = (size_t)2 * n * (HD + 4) * 4;
   const size_t lds_kv = lds_q + (size_t)n * sizeof(AttnStats);
   if (lds_kv > 160 * 1024 || n > 256) return -2;

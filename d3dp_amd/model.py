@@ -451,10 +451,13 @@ class MixSTE2(nn.Module):
 
     def train_arithmetic(self) -> str:
         """What the training step's Linears run on (bench.py reports it next to the step time)."""
+        attn = "fp32 attention (temporal axis: fp32 MFMA forward and backward; spatial axis: VALU)"
+        if os.environ.get("D3DP_TRAIN_ATTN_BWD", "")[:1] == "v":
+            attn = "fp32 attention (temporal forward on fp32 MFMA, backward on the VALU: D3DP_TRAIN_ATTN_BWD=valu)"
         if os.environ.get("D3DP_TRAIN_IMPL") == "f32":
-            return "fp32 MFMA Linears (D3DP_TRAIN_IMPL=f32), fp32 VALU attention"
+            return "fp32 MFMA Linears (D3DP_TRAIN_IMPL=f32), " + attn
         return ("split-fp16 Linears (forward, dgrad, split-K wgrad: three fp16-MFMA passes, fp32 accumulate, device-side operand "
-                "scales), fp32 VALU attention")
+                "scales), " + attn)
 
     # -- profiling passthrough --------------------------------------------------------------------
     def profile_enable(self, on: bool = True):

@@ -1056,6 +1056,41 @@ def test_training_step_config5_vs_oracle_autograd():
     print(f"config-5: worst relative gradient error over {len(po)} parameters: {worst[1]:.2e} ({worst[0]})")
 
 
+@pytest.mark.parametrize("Fr", [40, 81, 243])
+def test_attention_backward_on_matrix_cores_matches_the_valu_kernels(monkeypatch, Fr):
+    """Sequences longer than 32 tokens take the fp32-MFMA attention backward (train.hip attn_bwd_{q,kv}_mfma_kernel: 4, 8
+    or 16 key tiles); D3DP_TRAIN_ATTN_BWD=valu keeps the two-threads-per-row VALU kernels.  Both are fp32 arithmetic in a
+    different summation order: every parameter gradient of a training step agrees to fp32 noise."""
+    B, cs, dep = 2, 512, 2
+    args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
+    sd = make_state_dict(11, cs, dep, Fr)
+    m = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=True)
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda().train()
+    x2d = torch.from_numpy(synthetic_inputs_2d(911, B, Fr)).cuda()
+    gt = torch.from_numpy(synthetic_noise(912, (B, Fr, 17, 3))) * 0.3
+    gt[:, :, 0] = 0
+    gt = gt.cuda()
+    t = torch.tensor([[30], [700]], dtype=torch.long)
+    noise = torch.from_numpy(synthetic_noise(913, (B, Fr, 17, 3)))
+    grads = []
+    for impl in ("valu", "mfma"):
+        monkeypatch.setenv("D3DP_TRAIN_ATTN_BWD", impl)
+        m.zero_grad(set_to_none=True)
+        pred = m(x2d, gt, t=t, noise=noise, droppath={})
+        loss = torch.mean(torch.norm(pred - gt, dim=-1))
+        loss.backward(loss.clone().detach())
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.double().cpu() for k, p in m.pose_estimator.named_parameters()})
+    worst = 0.0
+    for k in grads[0]:
+        err = (grads[0][k] - grads[1][k]).norm().item() / max(grads[0][k].norm().item(), 1e-30)
+        worst = max(worst, err)
+        assert err < 2e-5, (k, err)
+    assert any(not torch.equal(grads[0][k], grads[1][k]) for k in grads[0])   # (the switch did select another kernel)
+    print(f"attention backward, F={Fr}: MFMA vs VALU kernels, worst relative gradient difference {worst:.2e}")
+
+
 def test_bench_launches_its_own_ranks_when_two_gpus_are_visible():
     """`python bench.py --gpus 2` outside a torchrun job re-executes itself as 2 RCCL ranks, checks that the 2-rank
     run on sliced global noise reproduces the 1-rank H=2*H_local run bit for bit, and reports the world size and the
