@@ -917,6 +917,8 @@ struct TrainLayout {
   size_t xn, y, hid, dA, dB, dC, dqkv, dh, z, At, Xt, Wt, dtemb, stats;
   // split-fp16 operands of the training Linears (X2Train below): row form [rows][2 K] and transposed form [features][2 Tp]
   size_t op_a, op_w, op_at, op_xt, part, slots;
+  size_t x_cols, x_block;           // every Linear's activation operand, transposed form [K][2 Tp], kept from the forward pass for wgrad
+  size_t w_rows, w_cols, w_block;   // every weight's split operands (row form / transposed form), prepared once per step: w_block floats per block
   size_t Tp_max;                    // columns (tokens, padded) of a transposed operand row
   size_t total_floats;
 };
@@ -951,6 +953,11 @@ TrainLayout train_layout(const d3dp_cfg& g, int B) {
     L.op_xt = take(kmax * L.Tp_max);                 // X^T:  [K][2 Tp] fp16
     L.part = take((size_t)(1024 + 64) * 256 * 128);  // split-K partial products: at most ~ (CUs + tiles) output tiles
     L.slots = take(2 * 8192);                        // absmax words | 1 / scale per operand
+    L.w_block = 4 * L.C * L.C + 2 * L.Hd * L.C;      // qkv | proj | fc1 | fc2 of one block ([N][2 K] fp16 = N K floats each)
+    L.x_block = (3 * L.C + L.Hd) * L.Tp_max;         // qkv | proj | fc1 | fc2 inputs of one block
+    L.x_cols = take(L.x_block * 2 * g.depth);
+    L.w_rows = take(L.w_block * 2 * g.depth);
+    L.w_cols = take(L.w_block * 2 * g.depth);
   }
   L.total_floats = off;
   return L;
@@ -977,12 +984,22 @@ struct X2Train {
   float* ws;
   const TrainLayout& L;
   int n_cu;
-  int next = 0;                                        // next absmax / unscale slot
+  // absmax / unscale slots: the forward pass owns slots 2 l (activation operand) and 2 l + 1 (weight) of its Linear l = 4 block
+  // + {qkv, proj, fc1, fc2} and leaves them for the backward pass of the same step, whose wgrad / dgrad read the same
+  // tensors (the saved or bitwise-recomputed activations, the same weights): 128 of the step's 320 absmax launches are not
+  // repeated.  (A scale leaves a factor 4 of headroom below the fp16 range, so the last-bit differences between the two
+  // LayerNorm kernels that produce norm2's output in the two passes cannot matter.)  The backward pass allocates its own
+  // (the gradients) from kBwdSlot0.
+  static constexpr int kBwdSlot0 = 4096;
+  int next = 0;
   unsigned* amax() const { return reinterpret_cast<unsigned*>(ws + L.slots); }
   float* uns() const { return ws + L.slots + 8192; }
-  int begin() { next = 0; return hipMemsetAsync(ws + L.slots, 0, 8192 * 4, st) == hipSuccess ? 0 : -3; }
-  int slot_for(const float* src, size_t n) {           // absmax of a tensor into a fresh slot
-    if (next >= 8192) return -1;
+  int begin(bool forward_pass) {
+    next = forward_pass ? 0 : kBwdSlot0;
+    return hipMemsetAsync(ws + L.slots + next, 0, (size_t)kBwdSlot0 * 4, st) == hipSuccess ? 0 : -3;
+  }
+  int slot_for(const float* src, size_t n) {           // absmax of a tensor into a fresh slot of the backward range
+    if (next < kBwdSlot0 || next >= 8192) return -1;
     d3dp_launch_absmax(src, n, amax() + next, st);
     return next++;
   }
@@ -992,36 +1009,89 @@ struct X2Train {
   void cols(const float* src, int R, int C, int Rpad, void* dst, int slot) {   // [R][C] -> [C][2 Rpad]
     d3dp_launch_split2_t_dyn(src, dst, R, C, Rpad, amax() + slot, uns() + slot, st);
   }
-  // out[T, N] = A[T, K] W[N, K]^T + bias
-  int forward(const float* A, const float* W, const float* bias, float* out, int T, int N, int K) {
-    const int sa = slot_for(A, (size_t)T * K), sw = slot_for(W, (size_t)N * K);
-    if (sa < 0 || sw < 0) return -1;
-    rows(A, T, K, ws + L.op_a, sa);
-    rows(W, N, K, ws + L.op_w, sw);
-    return d3dp_launch_linear_f16x2_dyn(ws + L.op_a, ws + L.op_w, bias, uns() + sa, uns() + sw, out, T, N, K, 1, st);
+  // Every weight's absmax, row form and transposed form in three launches at the start of the forward pass (up to 64
+  // Linears: depth <= 8; deeper models prepare each weight where it is used).  woff(l): float offset of Linear l's operands
+  // inside the w_rows / w_cols regions.
+  bool batched = false;
+  size_t xoff(int l) const { return (size_t)(l >> 2) * L.x_block + (size_t)(l & 3) * L.C * L.Tp_max; }
+  size_t woff(int l) const {
+    const size_t CC = L.C * L.C, j = (size_t)(l & 3);
+    return (size_t)(l >> 2) * L.w_block + (j == 0 ? 0 : j == 1 ? 3 * CC : j == 2 ? 4 * CC : 4 * CC + L.Hd * L.C);
   }
-  // dX[T, K] = dY[T, N] W[N, K]   (sdy: the absmax slot of dY, shared with wgrad)
-  int dgrad(const float* dY, int sdy, const float* W, float* dX, int T, int N, int K) {
-    const int sw = slot_for(W, (size_t)N * K);
-    if (sw < 0) return -1;
-    rows(dY, T, N, ws + L.op_a, sdy);
-    cols(W, N, K, N, ws + L.op_w, sw);                 // W^T: [K][2 N]  (N % 32 == 0: the model's widths)
-    return d3dp_launch_linear_f16x2_dyn(ws + L.op_a, ws + L.op_w, nullptr, uns() + sdy, uns() + sw, dX, T, K, N, 1, st);
+  int prepare_weights(const d3dp_ctx* c) {
+    const int nl = 8 * c->cfg.depth;
+    batched = nl <= D3DP_WPREP_MAX;
+    if (!batched) return 0;
+    D3dpWPrepTable tb{};
+    tb.n = nl;
+    const int C = (int)L.C, Hd = (int)L.Hd;
+    for (int l = 0; l < nl; ++l) {
+      const int blk = l >> 2, j = l & 3;
+      const BlockDev& w = (blk & 1) ? c->tte[blk >> 1] : c->ste[blk >> 1];
+      const void* p = j == 0 ? w.qkv_w : j == 1 ? w.proj_w : j == 2 ? w.fc1_w : w.fc2_w;
+      tb.it[l] = D3dpWPrepItem{(const float*)p, j == 0 ? 3 * C : j == 2 ? Hd : C, j == 3 ? Hd : C, 2 * l + 1, 0, woff(l)};
+    }
+    return d3dp_launch_wprep(tb, ws + L.w_rows, ws + L.w_cols, amax(), uns(), st);
   }
-  // dW[N, K] = dY[T, N]^T X[T, K]
-  int wgrad(const float* dY, int sdy, const float* X, float* dW, int T, int N, int K) {
-    const int sx = slot_for(X, (size_t)T * K);
-    if (sx < 0) return -1;
+  // out[T, N] = A[T, K] W[N, K]^T + bias     (l: the Linear's index, see the slots above)
+  int forward(int l, const float* A, const float* W, const float* bias, float* out, int T, int N, int K) {
+    const int sa = 2 * l, sw = 2 * l + 1;
+    if (l < 0 || sw >= kBwdSlot0) return -1;
+    d3dp_launch_absmax(A, (size_t)T * K, amax() + sa, st);
+    {
+      // row form for this product and, in the same pass, the transposed form the wgrad of this Linear will want: the
+      // backward pass then neither recomputes this activation (LayerNorm / GELU outputs) nor reads it again
+      int Z, Tp;
+      wgrad_split(T, N, K, Z, Tp);
+      if ((size_t)Tp > L.Tp_max) return -1;
+      const int r = d3dp_launch_dyprep(A, ws + L.op_a, ws + L.x_cols + xoff(l), nullptr, T, K, Tp, amax() + sa, uns() + sa, st);
+      if (r) return r;
+    }
+    const float* w2 = ws + L.op_w;
+    if (batched) w2 = ws + L.w_rows + woff(l);
+    else {
+      d3dp_launch_absmax(W, (size_t)N * K, amax() + sw, st);
+      rows(W, N, K, ws + L.op_w, sw);
+    }
+    return d3dp_launch_linear_f16x2_dyn(ws + L.op_a, w2, bias, uns() + sa, uns() + sw, out, T, N, K, 1, st);
+  }
+  // dX[T, K] = dY[T, N] W[N, K]   (sdy: the absmax slot of dY, shared with wgrad; l: the forward Linear whose W this is)
+  int dgrad(int l, const float* dY, int sdy, const float* W, float* dX, int T, int N, int K) {
+    const int sw = 2 * l + 1;
+    if (!dy_ready) rows(dY, T, N, ws + L.op_a, sdy);
+    const float* wt = ws + L.op_w;
+    if (batched) wt = ws + L.w_cols + woff(l);         // (prepared by the forward pass of this step)
+    else cols(W, N, K, N, ws + L.op_w, sw);            // W^T: [K][2 N]  (N % 32 == 0: the model's widths)
+    return d3dp_launch_linear_f16x2_dyn(ws + L.op_a, wt, nullptr, uns() + sdy, uns() + sw, dX, T, K, N, 1, st);
+  }
+  // split count / padded token count of the wgrad product dW[N, K] = dY^T X
+  void wgrad_split(int T, int N, int K, int& Z, int& Tp) const {
     const int tiles = ((N + 255) / 256) * ((K + 127) / 128);
     const int nk = (T + 31) / 32;
-    int Z = std::max(1, std::min(std::min(n_cu / tiles, 64), nk / 4));
+    Z = std::max(1, std::min(std::min(n_cu / tiles, 64), nk / 4));
     const int nkz = (nk + Z - 1) / Z;
-    const int Tp = Z * nkz * 32;
+    Tp = Z * nkz * 32;
+  }
+  // everything the backward pass of Linear [N, K] needs from its dY in one pass: row form -> op_a (dgrad), transposed form
+  // -> op_at (wgrad), the bias gradient += column sums.  `dy_ready` then tells dgrad / wgrad not to build them again.
+  bool dy_ready = false;
+  int prep_dy(const float* dY, int sdy, float* dbias, int T, int N, int K) {
+    int Z, Tp;
+    wgrad_split(T, N, K, Z, Tp);
+    if ((size_t)Tp > L.Tp_max) return -1;
+    dy_ready = true;
+    return d3dp_launch_dyprep(dY, ws + L.op_a, ws + L.op_at, dbias, T, N, Tp, amax() + sdy, uns() + sdy, st);
+  }
+  // dW[N, K] = dY[T, N]^T X[T, K]   (X: the activation operand of forward Linear l)
+  int wgrad(int l, const float* dY, int sdy, const float* X, float* dW, int T, int N, int K) {
+    const int sx = 2 * l;
+    int Z, Tp;
+    wgrad_split(T, N, K, Z, Tp);
     if ((size_t)Tp > L.Tp_max || (size_t)Z * N * K > (size_t)(1024 + 64) * 256 * 128) return -1;
-    cols(dY, T, N, Tp, ws + L.op_at, sdy);             // dY^T: [N][2 Tp]
-    cols(X, T, K, Tp, ws + L.op_xt, sx);               // X^T:  [K][2 Tp]
-    const int r = d3dp_launch_linear_f16x2_dyn(ws + L.op_at, ws + L.op_xt, nullptr, uns() + sdy, uns() + sx, ws + L.part, N, K,
-                                               Tp, Z, st);
+    if (!dy_ready) cols(dY, T, N, Tp, ws + L.op_at, sdy);   // dY^T: [N][2 Tp]
+    (void)X;                                           // X^T [K][2 Tp]: left by the forward pass of this step
+    const int r = d3dp_launch_linear_f16x2_dyn(ws + L.op_at, ws + L.x_cols + xoff(l), nullptr, uns() + sdy, uns() + sx,
+                                               ws + L.part, N, K, Tp, Z, st);
     if (r) return r;
     d3dp_launch_sum_partials(ws + L.part, dW, (size_t)N * K, Z, st);
     return 0;
@@ -1052,9 +1122,12 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
   float *xn = ws + L.xn, *y = ws + L.y, *hid = ws + L.hid;
   X2Train x2{st, ws, L, c->n_cu};
   const bool use_x2 = c->train_x2 && C % 32 == 0 && Hd % 32 == 0;
-  if (use_x2) LAUNCH_TRY(x2.begin());
-  auto lin = [&](const float* A, const float* W, const float* bias, float* out, int M, int N, int K) {
-    return use_x2 ? x2.forward(A, W, bias, out, M, N, K) : lin32(A, W, bias, out, M, N, K, st);
+  if (use_x2) {
+    LAUNCH_TRY(x2.begin(true));
+    LAUNCH_TRY(x2.prepare_weights(c));
+  }
+  auto lin = [&](int l, const float* A, const float* W, const float* bias, float* out, int M, int N, int K) {
+    return use_x2 ? x2.forward(l, A, W, bias, out, M, N, K) : lin32(A, W, bias, out, M, N, K, st);
   };
   LAUNCH_TRY(d3dp_launch_time_mlp(t, c->freq, c->t1w, c->t1b, c->t3w, c->t3b, ws + L.temb, B, C, st));
   float* slab0 = ws + L.saved0;
@@ -1064,17 +1137,17 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     const int kind = blk & 1, d = blk >> 1;
     const BlockDev& w = kind ? c->tte[d] : c->ste[d];
     float* S = ws + L.saved0 + (size_t)blk * L.saved_stride;
-    LAUNCH_TRY(lin(xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C));
+    LAUNCH_TRY(lin(4 * blk, xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C));
     if (kind == 0) LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * F, spatial_map(F, J), C, g.heads, st));
     else if (use_x2 && C / g.heads == 64)                // temporal axis on the fp32 matrix cores (bitwise an fp32 fmaf chain per
       LAUNCH_TRY(d3dp_launch_attn_temporal_f32(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st));   // product)
     else LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st));
-    LAUNCH_TRY(lin(S + L.o_att, (const float*)w.proj_w, w.proj_b, y, T, C, C));
+    LAUNCH_TRY(lin(4 * blk + 1, S + L.o_att, (const float*)w.proj_w, w.proj_b, y, T, C, C));
     LAUNCH_TRY(d3dp_train_add_mask_ln(S + L.o_xin, y, mask_ptr(masks, g, B, blk, 0), kind, F, J, w.n2w, w.n2b, g.eps_block,
                                       S + L.o_xmid, xn, T, C, st));
-    LAUNCH_TRY(lin(xn, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C));
+    LAUNCH_TRY(lin(4 * blk + 2, xn, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C));
     LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, st));
-    LAUNCH_TRY(lin(hid, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd));
+    LAUNCH_TRY(lin(4 * blk + 3, hid, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd));
     LAUNCH_TRY(d3dp_train_add_mask_ln(S + L.o_xmid, y, mask_ptr(masks, g, B, blk, 1), kind, F, J, nullptr, nullptr,
                                       g.eps_block, S + L.o_xout, nullptr, T, C, st));
     // shared norm -> next block's input (or x_final)
@@ -1134,23 +1207,30 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
 
   X2Train x2{st, ws, L, c->n_cu};
   const bool use_x2 = c->train_x2 && C % 32 == 0 && Hd % 32 == 0;
-  if (use_x2) LAUNCH_TRY(x2.begin());
+  if (use_x2) {
+    LAUNCH_TRY(x2.begin(false));
+    x2.batched = 8 * g.depth <= D3DP_WPREP_MAX;          // (the forward pass of this step left the weight operands in place)
+  }
   int sdy = -1;                                          // absmax slot of the dY the next wgrad / dgrad pair shares
   // wgrad: dW[N, K] = dY[T, N]^T X[T, K]  (fp32 path: both operands transposed to [*, Tpad], zero padded)
-  auto wgrad = [&](const float* dY, int N, const float* X, int K, float* dW) -> int {
+  // (dbias: the Linear's bias gradient = column sums of dY, accumulated)
+  auto wgrad = [&](int l, const float* dY, int N, const float* X, int K, float* dW, float* dbias) -> int {
+    int r;
     if (use_x2) {
       sdy = x2.slot_for(dY, (size_t)T * N);
-      return sdy < 0 ? -1 : x2.wgrad(dY, sdy, X, dW, T, N, K);
+      if (sdy < 0) return -1;
+      if ((r = x2.prep_dy(dY, sdy, dbias, T, N, K))) return r;
+      return x2.wgrad(l, dY, sdy, X, dW, T, N, K);
     }
-    int r;
+    if ((r = d3dp_train_colsum(dY, dbias, T, N, st))) return r;
     if ((r = d3dp_train_transpose_pad(dY, At, T, N, Tp, st))) return r;
     if ((r = d3dp_train_transpose_pad(X, Xt, T, K, Tp, st))) return r;
     if (hipMemsetAsync(dW, 0, (size_t)N * K * 4, st) != hipSuccess) return -3;
     return d3dp_launch_linear_f32_splitk(At, Xt, dW, N, K, Tp, st);       // contraction over tokens: split-K
   };
   // dgrad: dX[T, K] = dY[T, N] W[N, K]   (W transposed to [K, N])
-  auto dgrad = [&](const float* dY, int N, const float* W, int K, float* dX) -> int {
-    if (use_x2) return sdy < 0 ? -1 : x2.dgrad(dY, sdy, W, dX, T, N, K);     // (always right behind the wgrad of the same dY)
+  auto dgrad = [&](int l, const float* dY, int N, const float* W, int K, float* dX) -> int {
+    if (use_x2) return sdy < 0 ? -1 : x2.dgrad(l, dY, sdy, W, dX, T, N, K);  // (always right behind the wgrad of the same dY)
     int r;
     if ((r = d3dp_train_transpose_pad(W, Wt, N, K, N, st))) return r;
     return lin32(dY, Wt, zb, dX, T, K, N, st);
@@ -1175,28 +1255,24 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     LAUNCH_TRY(d3dp_train_ln_bwd(dA, S + L.o_xout, snw, g.eps_block, nullptr, dB, gsnw, gsnb, T, C, st));
     // ---- MLP branch ----
     LAUNCH_TRY(d3dp_train_scale_mask(dB, mask_ptr(masks, g, B, blk, 1), kind, F, J, dC, T, C, st));        // dy2
-    LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, st));
-    LAUNCH_TRY(wgrad(dC, C, hid, Hd, G(gw.fc2_w)));
-    LAUNCH_TRY(d3dp_train_colsum(dC, G(gw.fc2_b), T, C, st));
-    LAUNCH_TRY(dgrad(dC, C, (const float*)w.fc2_w, Hd, dh));                                               // d hidden
+    if (!use_x2) LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, st));   // (x2: wgrad reads the forward pass' operand)
+    LAUNCH_TRY(wgrad(4 * blk + 3, dC, C, hid, Hd, G(gw.fc2_w), G(gw.fc2_b)));
+    LAUNCH_TRY(dgrad(4 * blk + 3, dC, C, (const float*)w.fc2_w, Hd, dh));                                               // d hidden
     LAUNCH_TRY(d3dp_train_gelu_bwd(dh, S + L.o_hpre, dh, (size_t)T * Hd, st));                             // d h_pre
-    LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xmid, w.n2w, w.n2b, g.eps_block, nullptr, F, J, xn, T, C, st));   // xn2
-    LAUNCH_TRY(wgrad(dh, Hd, xn, C, G(gw.fc1_w)));
-    LAUNCH_TRY(d3dp_train_colsum(dh, G(gw.fc1_b), T, Hd, st));
-    LAUNCH_TRY(dgrad(dh, Hd, (const float*)w.fc1_w, C, dC));                                               // d xn2
+    if (!use_x2) LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xmid, w.n2w, w.n2b, g.eps_block, nullptr, F, J, xn, T, C, st));   // xn2
+    LAUNCH_TRY(wgrad(4 * blk + 2, dh, Hd, xn, C, G(gw.fc1_w), G(gw.fc1_b)));
+    LAUNCH_TRY(dgrad(4 * blk + 2, dh, Hd, (const float*)w.fc1_w, C, dC));                                               // d xn2
     LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xmid, w.n2w, g.eps_block, dB, dA, G(gw.norm2_w), G(gw.norm2_b), T, C, st));
     // dA = d x_mid
     // ---- attention branch ----
     LAUNCH_TRY(d3dp_train_scale_mask(dA, mask_ptr(masks, g, B, blk, 0), kind, F, J, dC, T, C, st));        // dy1
-    LAUNCH_TRY(wgrad(dC, C, S + L.o_att, C, G(gw.proj_w)));
-    LAUNCH_TRY(d3dp_train_colsum(dC, G(gw.proj_b), T, C, st));
-    LAUNCH_TRY(dgrad(dC, C, (const float*)w.proj_w, C, dB));                                               // d att
+    LAUNCH_TRY(wgrad(4 * blk + 1, dC, C, S + L.o_att, C, G(gw.proj_w), G(gw.proj_b)));
+    LAUNCH_TRY(dgrad(4 * blk + 1, dC, C, (const float*)w.proj_w, C, dB));                                               // d att
     if (kind == 0) LAUNCH_TRY(d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * F, spatial_map(F, J), C, g.heads, st));
     else LAUNCH_TRY(d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * J, temporal_map(F, J), C, g.heads, st));
-    LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xin, w.n1w, w.n1b, g.eps_block, nullptr, F, J, xn, T, C, st));    // xn1
-    LAUNCH_TRY(wgrad(dqkv, 3 * C, xn, C, G(gw.qkv_w)));
-    LAUNCH_TRY(d3dp_train_colsum(dqkv, G(gw.qkv_b), T, 3 * C, st));
-    LAUNCH_TRY(dgrad(dqkv, 3 * C, (const float*)w.qkv_w, C, dC));                                          // d xn1
+    if (!use_x2) LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xin, w.n1w, w.n1b, g.eps_block, nullptr, F, J, xn, T, C, st));    // xn1
+    LAUNCH_TRY(wgrad(4 * blk, dqkv, 3 * C, xn, C, G(gw.qkv_w), G(gw.qkv_b)));
+    LAUNCH_TRY(dgrad(4 * blk, dqkv, 3 * C, (const float*)w.qkv_w, C, dC));                                          // d xn1
     LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xin, w.n1w, g.eps_block, dA, dB, G(gw.norm1_w), G(gw.norm1_b), T, C, st));
     // dB = d x_in of this block = gradient w.r.t. the previous shared norm's output
     std::swap(dA, dB);

@@ -1592,6 +1592,124 @@ __global__ __launch_bounds__(256) void split2h_t_dyn_kernel(const float* __restr
   }
 }
 
+// One pass over a gradient dY [R][C] (fp32) for everything the backward pass of a Linear needs from it: the row form
+// [R][2 C] (dgrad's operand), the transposed form [C][2 Rpad] (wgrad's operand; rows R .. Rpad - 1 zero) and the column
+// sums (the bias gradient, += into colsum).  As three kernels (split2h_dyn, split2h_t_dyn, colsum) the same tensor was
+// read three times: 67 us per Linear of the configs[4] step.  32 x 32 tiles through LDS; blockIdx.y = column tile, a
+// workgroup strides over the row tiles and keeps its columns' sums in registers: gridDim.x atomics per column.
+// C % 32 == 0, Rpad % 32 == 0.
+__global__ __launch_bounds__(256) void dyprep_kernel(const float* __restrict__ s, f16* __restrict__ drow, f16* __restrict__ dcol,
+                                                     float* __restrict__ colsum, int R, int C, int Rpad,
+                                                     const unsigned* __restrict__ amax, float* __restrict__ unscale) {
+  __shared__ float tile[32][33];
+  __shared__ float csum[8][32];
+  const float sc = dyn_scale(amax[0]);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) unscale[0] = 1.0f / sc;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  float acc = 0.f;
+  for (int rt = blockIdx.x; rt < Rpad / 32; rt += gridDim.x) {
+    const int r0 = rt * 32;
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+      const int r = r0 + k;
+      const float v = r < R ? s[(size_t)r * C + c0 + tx] : 0.f;
+      acc += v;
+      const float vs = v * sc;
+      tile[k][tx] = vs;
+      if (r < R) {                                       // row form: the 128-byte h2i block of row r, columns c0 .. c0 + 31
+        f16 a, b;
+        split2h_scaled(vs, a, b);
+        f16* blk = drow + (size_t)r * 2 * C + (size_t)blockIdx.y * 64;
+        blk[tx] = a;
+        blk[32 + tx] = b;
+      }
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {                   // transposed form: destination row c0 + k, source rows r0 .. r0 + 31
+      f16 a, b;
+      split2h_scaled(tile[tx][k], a, b);
+      f16* blk = dcol + (size_t)(c0 + k) * 2 * Rpad + (size_t)rt * 64;
+      blk[tx] = a;
+      blk[32 + tx] = b;
+    }
+  }
+  if (colsum) {
+    csum[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t += csum[j][tx];
+      atomicAdd(colsum + c0 + tx, t);
+    }
+  }
+}
+
+// ---- the training step's weight operands, all Linears of the model in three launches ------------------------------------
+// (per-weight launches of absmax / split2h_dyn / split2h_t_dyn: 192 launches of 5 - 6 us for 100 MB of weights per step)
+// blockIdx.y = the weight; a workgroup row strides over that weight only.
+__global__ __launch_bounds__(256) void wprep_absmax_kernel(D3dpWPrepTable tb, unsigned* __restrict__ amax) {
+  __shared__ float part[4];
+  const D3dpWPrepItem it = tb.it[blockIdx.y];
+  const size_t n4 = (size_t)it.N * it.K / 4, stride = (size_t)gridDim.x * blockDim.x;
+  const float4* s4 = reinterpret_cast<const float4*>(it.w);
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = s4[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(amax + it.slot, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
+}
+// rows form [N][2 K] (the forward operand) of every weight: the loop of split2h_dyn_kernel
+__global__ __launch_bounds__(256) void wprep_rows_kernel(D3dpWPrepTable tb, f16* __restrict__ base, const unsigned* __restrict__ amax,
+                                                         float* __restrict__ unscale) {
+  const D3dpWPrepItem it = tb.it[blockIdx.y];
+  const float sc = dyn_scale(amax[it.slot]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) unscale[it.slot] = 1.0f / sc;
+  f16* d = base + 2 * it.off;
+  const int G8 = it.K / 8;
+  const size_t n = (size_t)it.N * G8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / G8;
+    const int c = (int)(i - r * G8) * 8;
+    const float4 a = *reinterpret_cast<const float4*>(it.w + r * it.K + c), b = *reinterpret_cast<const float4*>(it.w + r * it.K + c + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    f16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { f16 h, l; split2h_scaled(v[e] * sc, h, l); hi[e] = h; lo[e] = l; }
+    f16* row = d + r * 2 * (size_t)it.K + h2i_col(c);
+    *reinterpret_cast<f16x8*>(row) = hi;
+    *reinterpret_cast<f16x8*>(row + kH2iLo) = lo;
+  }
+}
+// transposed form [K][2 N] (the dgrad operand) of every weight: the tiles of split2h_t_dyn_kernel, strided over by a
+// workgroup row (N % 32 == 0, K % 32 == 0)
+__global__ __launch_bounds__(256) void wprep_cols_kernel(D3dpWPrepTable tb, f16* __restrict__ base, const unsigned* __restrict__ amax) {
+  __shared__ float tile[32][33];
+  const D3dpWPrepItem it = tb.it[blockIdx.y];
+  const float sc = dyn_scale(amax[it.slot]);
+  f16* d = base + 2 * it.off;
+  const int tr = it.N / 32, tc = it.K / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int tI = blockIdx.x; tI < tr * tc; tI += gridDim.x) {
+    const int r0 = (tI / tc) * 32, c0 = (tI % tc) * 32;
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) tile[k][tx] = it.w[(size_t)(r0 + k) * it.K + c0 + tx] * sc;
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+      f16 a, b;
+      split2h_scaled(tile[tx][k], a, b);
+      f16* blk = d + (size_t)(c0 + k) * 2 * it.N + (size_t)(r0 / 32) * 64;
+      blk[tx] = a;
+      blk[32 + tx] = b;
+    }
+  }
+}
+
 // out[i] = sum_z part[z n + i] in the order z = 0, 1, ... (the deterministic end of a split-K product)
 __global__ void sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int Z) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -1623,11 +1741,14 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ s
   float m = 0.f;
   const size_t n4 = n / 4;
   const float4* s4 = reinterpret_cast<const float4*>(s);   // (operands are 16-byte aligned: whole tensors)
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const float4 v = s4[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  auto amax4 = [](const float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); };
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {         // four independent 16-byte loads in flight per thread
+    const float4 v0 = s4[i], v1 = s4[i + stride], v2 = s4[i + 2 * stride], v3 = s4[i + 3 * stride];
+    m = fmaxf(m, fmaxf(fmaxf(amax4(v0), amax4(v1)), fmaxf(amax4(v2), amax4(v3))));
   }
-  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(s[i]));
+  for (; i < n4; i += stride) m = fmaxf(m, amax4(s4[i]));
+  for (size_t j = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) m = fmaxf(m, fabsf(s[j]));
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
   __syncthreads();
@@ -1863,6 +1984,23 @@ void d3dp_launch_split2_t_dyn(const float* src, void* dst, int R, int C, int Rpa
                               hipStream_t st) {
   hipLaunchKernelGGL(split2h_t_dyn_kernel, dim3(Rpad / 32, (C + 31) / 32), dim3(256), 0, st, src, (f16*)dst, R, C, Rpad, amax,
                      unscale);
+}
+
+int d3dp_launch_dyprep(const float* src, void* drow, void* dcol, float* colsum, int R, int C, int Rpad, const unsigned* amax,
+                       float* unscale, hipStream_t st) {
+  if (C % 32 != 0 || Rpad % 32 != 0 || Rpad < R) return -1;
+  hipLaunchKernelGGL(dyprep_kernel, dim3(32, C / 32), dim3(256), 0, st, src, (f16*)drow, (f16*)dcol, colsum, R, C, Rpad, amax, unscale);
+  return 0;
+}
+
+int d3dp_launch_wprep(const D3dpWPrepTable& tb, void* rows_base, void* cols_base, unsigned* amax, float* unscale, hipStream_t st) {
+  if (tb.n < 1 || tb.n > D3DP_WPREP_MAX) return -1;
+  for (int i = 0; i < tb.n; ++i)
+    if (tb.it[i].N % 32 != 0 || tb.it[i].K % 32 != 0) return -1;
+  hipLaunchKernelGGL(wprep_absmax_kernel, dim3(16, tb.n), dim3(256), 0, st, tb, amax);
+  hipLaunchKernelGGL(wprep_rows_kernel, dim3(32, tb.n), dim3(256), 0, st, tb, (f16*)rows_base, (const unsigned*)amax, unscale);
+  hipLaunchKernelGGL(wprep_cols_kernel, dim3(32, tb.n), dim3(256), 0, st, tb, (f16*)cols_base, (const unsigned*)amax);
+  return 0;
 }
 
 void d3dp_launch_sum_partials(const float* part, float* out, size_t n, int Z, hipStream_t st) {

@@ -85,6 +85,15 @@ void d3dp_launch_split2_dyn(const float* src, void* dst, int R, int C, int Cpad,
 void d3dp_launch_split2_t_dyn(const float* src, void* dst, int R, int C, int Rpad, const unsigned* amax, float* unscale,
                               hipStream_t st);
 // out[i] = sum over z of part[z n + i], z ascending
+// dY [R][C] -> row form [R][2 C], transposed form [C][2 Rpad] and colsum[c] += sum_r dY[r][c] in one pass (gemm_x2.hip)
+int d3dp_launch_dyprep(const float* src, void* drow, void* dcol, float* colsum, int R, int C, int Rpad, const unsigned* amax,
+                       float* unscale, hipStream_t st);
+// the training step's weight operands in three launches (gemm_x2.hip): absmax -> slot, rows form [N][2 K] at rows_base + 2 off
+// halves, transposed form [K][2 N] at cols_base + 2 off halves, unscale[slot] = 1 / scale
+constexpr int D3DP_WPREP_MAX = 64;
+struct D3dpWPrepItem { const float* w; int N, K, slot, pad; size_t off; };
+struct D3dpWPrepTable { D3dpWPrepItem it[D3DP_WPREP_MAX]; int n; };
+int d3dp_launch_wprep(const D3dpWPrepTable& tb, void* rows_base, void* cols_base, unsigned* amax, float* unscale, hipStream_t st);
 void d3dp_launch_sum_partials(const float* part, float* out, size_t n, int Z, hipStream_t st);
 void d3dp_launch_absmax(const float* src, size_t n, unsigned* out, hipStream_t st);
 // flag[0] |= 1 if any of x[0..n) is inf / nan

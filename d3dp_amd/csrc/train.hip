@@ -86,22 +86,40 @@ __global__ __launch_bounds__(256) void ln_pos_kernel(const float* __restrict__ x
 
 // ---- LayerNorm backward: dx (+= dres), dgamma/dbeta accumulated with atomics ------------------------------------
 //   xhat = (x - mean) rstd ; g = dy * gamma ; dx = rstd (g - mean(g) - xhat mean(g xhat))  [+ dres]
+// A lane owns the columns (g 64 + lane) 4 .. + 3 of a row (16-byte accesses) when C % 256 == 0, else i 64 + lane.
 template <int C>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ w, float eps,
                                                      const float* __restrict__ dres, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int T) {
   constexpr int NV = C / 64;
+  constexpr bool V4 = NV % 4 == 0;
   __shared__ float sg[4][C], sb[4][C];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float ag[NV], ab[NV];
+  auto col = [&](int i) { return V4 ? ((i >> 2) * 64 + lane) * 4 + (i & 3) : i * 64 + lane; };
+  auto load_row = [&](const float* p, float (&v)[NV]) {
+    if constexpr (V4) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+      for (int g = 0; g < NV / 4; ++g) {
+        const float4 a = *reinterpret_cast<const float4*>(p + (g * 64 + lane) * 4);
+        v[g * 4] = a.x; v[g * 4 + 1] = a.y; v[g * 4 + 2] = a.z; v[g * 4 + 3] = a.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = p[i * 64 + lane];
+    }
+  };
+  float ag[NV], ab[NV], wl[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { ag[i] = 0.f; ab[i] = 0.f; wl[i] = w[col(i)]; }
   for (int tok = blockIdx.x * 4 + wv; tok < T; tok += gridDim.x * 4) {
-    float v[NV], g[NV];
+    float v[NV], g[NV], d[NV], r0[NV];
+    load_row(x + (size_t)tok * C, v);
+    load_row(dy + (size_t)tok * C, d);
+    if (dres) load_row(dres + (size_t)tok * C, r0);
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) { v[i] = x[(size_t)tok * C + i * 64 + lane]; s += v[i]; }
+    for (int i = 0; i < NV; ++i) s += v[i];
     const float mean = wave_sum(s) * (1.0f / C);
     float q = 0.f;
 #pragma unroll
@@ -110,27 +128,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     float sg1 = 0.f, sg2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = i * 64 + lane;
-      const float d = dy[(size_t)tok * C + c];
       v[i] *= rstd;                    // xhat
-      g[i] = d * w[c];
+      g[i] = d[i] * wl[i];
       sg1 += g[i];
       sg2 = fmaf(g[i], v[i], sg2);
-      ag[i] = fmaf(d, v[i], ag[i]);
-      ab[i] += d;
+      ag[i] = fmaf(d[i], v[i], ag[i]);
+      ab[i] += d[i];
     }
     sg1 = wave_sum(sg1) * (1.0f / C);
     sg2 = wave_sum(sg2) * (1.0f / C);
+    float r[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const size_t o = (size_t)tok * C + i * 64 + lane;
-      float r = rstd * (g[i] - sg1 - v[i] * sg2);
-      if (dres) r += dres[o];
-      dx[o] = r;
+      r[i] = rstd * (g[i] - sg1 - v[i] * sg2);
+      if (dres) r[i] += r0[i];
+    }
+    float* o = dx + (size_t)tok * C;
+    if constexpr (V4) {
+#pragma unroll
+      for (int gq = 0; gq < NV / 4; ++gq)
+        *reinterpret_cast<float4*>(o + (gq * 64 + lane) * 4) = make_float4(r[gq * 4], r[gq * 4 + 1], r[gq * 4 + 2], r[gq * 4 + 3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) o[i * 64 + lane] = r[i];
     }
   }
 #pragma unroll
-  for (int i = 0; i < NV; ++i) { sg[wv][i * 64 + lane] = ag[i]; sb[wv][i * 64 + lane] = ab[i]; }
+  for (int i = 0; i < NV; ++i) { sg[wv][col(i)] = ag[i]; sb[wv][col(i)] = ab[i]; }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     atomicAdd(dgamma + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
@@ -138,20 +162,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+// (four elements per thread; n % 4 == 0: the hidden width is a multiple of 32)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n4) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) y[i] = gelu_erf(x[i]);
+  if (i >= n4) return;
+  const float4 v = reinterpret_cast<const float4*>(x)[i];
+  reinterpret_cast<float4*>(y)[i] = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
 }
 
 // dpre = dh * (Phi(x) + x phi(x))
-__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* dh, const float* __restrict__ x, float* dpre,
-                                                       size_t n) {   // dpre may alias dh
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float v = x[i];
+__device__ __forceinline__ float gelu_grad(float v) {
   const float cdf = 0.5f * (1.0f + erff(v * kInvSqrt2));
   const float pdf = kInvSqrt2Pi * expf(-0.5f * v * v);
-  dpre[i] = dh[i] * (cdf + v * pdf);
+  return cdf + v * pdf;
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* dh, const float* __restrict__ x, float* dpre,
+                                                       size_t n4) {   // dpre may alias dh
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = reinterpret_cast<const float4*>(x)[i], d = reinterpret_cast<const float4*>(dh)[i];
+  reinterpret_cast<float4*>(dpre)[i] = make_float4(d.x * gelu_grad(v.x), d.y * gelu_grad(v.y), d.z * gelu_grad(v.z), d.w * gelu_grad(v.w));
 }
 
 // out[t, :] = m[sample(t)] * in[t, :]
@@ -163,13 +193,38 @@ __global__ __launch_bounds__(256) void scale_mask_kernel(const float* __restrict
   out[i] = in[i] * (mask ? mask[sample_of(tok, axis, F, J)] : 1.0f);
 }
 
-// out[c] += sum_t in[t, c]     (bias grads)
+// out[c] += sum_t in[t, c]     (bias grads).  A thread owns four columns (one 16-byte load per row) of one row in four; the
+// four row lanes of a workgroup meet in LDS, so a column receives one atomic per workgroup (gridDim.y of them).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int T, int C) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int t = blockIdx.y; t < T; t += gridDim.y) s += in[(size_t)t * C + c];
-  atomicAdd(out + c, s);
+  __shared__ float4 part[4][64];
+  const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cg) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C) {
+    const int step = gridDim.y * 4;
+    int t = blockIdx.y * 4 + rl;
+    for (; t + 3 * step < T; t += 4 * step) {            // four independent loads in flight
+      const float4 v0 = *reinterpret_cast<const float4*>(in + (size_t)t * C + c);
+      const float4 v1 = *reinterpret_cast<const float4*>(in + (size_t)(t + step) * C + c);
+      const float4 v2 = *reinterpret_cast<const float4*>(in + (size_t)(t + 2 * step) * C + c);
+      const float4 v3 = *reinterpret_cast<const float4*>(in + (size_t)(t + 3 * step) * C + c);
+      s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+      s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; t < T; t += step) {
+      const float4 v = *reinterpret_cast<const float4*>(in + (size_t)t * C + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  part[rl][cg] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    const float4 a = part[0][cg], b = part[1][cg], d = part[2][cg], e = part[3][cg];
+    atomicAdd(out + c, (a.x + b.x) + (d.x + e.x));
+    atomicAdd(out + c + 1, (a.y + b.y) + (d.y + e.y));
+    atomicAdd(out + c + 2, (a.z + b.z) + (d.z + e.z));
+    atomicAdd(out + c + 3, (a.w + b.w) + (d.w + e.w));
+  }
 }
 
 // out[g, c] += sum over tokens of group g of in[t, c]; group: 0 -> n = t % J, 1 -> f = (t / J) % F, 2 -> b = t / (F J)
@@ -469,50 +524,69 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   if (c == 0) { atomicAdd(db, sb[0]); atomicAdd(db + 1, sb[1]); atomicAdd(db + 2, sb[2]); }
 }
 
-// ---- time MLP backward (B rows; one workgroup per batch element, atomics into the shared weight grads) -----------
+// ---- time MLP backward: one WAVE per hidden unit k of the 2C ---------------------------------------------------------
+// (mixste.py:127-139: sinusoid -> Linear(C, 2C) -> GELU -> Linear(2C, C)).  The wave keeps row k of w1 and column k of w2
+// in registers, walks the batch in order (deterministic sums, no atomics) and owns row k of dw1, column k of dw2 and
+// db1[k]; the first C / 64 waves also write db2.  (The first version ran one workgroup per batch element with strided
+// weight reads and atomics into the shared gradients: 1.0 ms of the configs[4] step for 4 MFLOP.)
+template <int C>
 __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const int64_t* __restrict__ t, const float* __restrict__ freq,
                                                            const float* __restrict__ w1, const float* __restrict__ b1,
                                                            const float* __restrict__ w2, const float* __restrict__ dtemb,
                                                            float* __restrict__ dw1, float* __restrict__ db1,
-                                                           float* __restrict__ dw2, float* __restrict__ db2, int C) {
-  extern __shared__ float sm[];            // e[C] | pre[2C] | act[2C] | dpre[2C]
-  float* e = sm;
-  float* pre = sm + C;
-  float* act = pre + 2 * C;
-  float* dpre = act + 2 * C;
-  const int b = blockIdx.x, half = C / 2;
-  const float tv = (float)t[b];
-  for (int i = threadIdx.x; i < half; i += blockDim.x) {
-    const float a = tv * freq[i];
-    e[i] = sinf(a);
-    e[half + i] = cosf(a);
+                                                           float* __restrict__ dw2, float* __restrict__ db2, int B) {
+  constexpr int NV = C / 64, HALF = C / 2;
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);     // hidden unit
+  if (k >= 2 * C) return;
+  float w1r[NV], w2c[NV], fr[NV], g1[NV], g2[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = i * 64 + lane;                         // input channel j of the sinusoid / output channel j of the MLP
+    w1r[i] = w1[(size_t)k * C + j];
+    w2c[i] = w2[(size_t)j * 2 * C + k];
+    fr[i] = freq[j < HALF ? j : j - HALF];
+    g1[i] = 0.f; g2[i] = 0.f;
   }
-  __syncthreads();
-  for (int o = threadIdx.x; o < 2 * C; o += blockDim.x) {
-    float a = 0.f;
-    for (int k = 0; k < C; ++k) a = fmaf(e[k], w1[(size_t)o * C + k], a);
-    pre[o] = a + b1[o];
-    act[o] = gelu_erf(pre[o]);
-  }
-  __syncthreads();
-  const float* dy = dtemb + (size_t)b * C;
-  for (int o = threadIdx.x; o < C; o += blockDim.x) atomicAdd(db2 + o, dy[o]);
-  for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) {
-    float dg = 0.f;
-    for (int o = 0; o < C; ++o) {
-      dg = fmaf(dy[o], w2[(size_t)o * 2 * C + k], dg);
-      atomicAdd(dw2 + (size_t)o * 2 * C + k, dy[o] * act[k]);
+  const float bias = b1[k];
+  float gb1 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float tv = (float)t[b];
+    float e[NV], dy[NV];
+    float pre = 0.f, dg = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int j = i * 64 + lane;
+      const float a = tv * fr[i];
+      e[i] = j < HALF ? sinf(a) : cosf(a);
+      dy[i] = dtemb[(size_t)b * C + j];
+      pre = fmaf(e[i], w1r[i], pre);
+      dg = fmaf(dy[i], w2c[i], dg);
     }
-    const float v = pre[k];
-    const float cdf = 0.5f * (1.0f + erff(v * kInvSqrt2));
-    const float pdf = kInvSqrt2Pi * expf(-0.5f * v * v);
-    dpre[k] = dg * (cdf + v * pdf);
-    atomicAdd(db1 + k, dpre[k]);
+    pre = wave_sum(pre) + bias;
+    dg = wave_sum(dg);
+    const float act = gelu_erf(pre);
+    const float cdf = 0.5f * (1.0f + erff(pre * kInvSqrt2));
+    const float pdf = kInvSqrt2Pi * expf(-0.5f * pre * pre);
+    const float dpre = dg * (cdf + pre * pdf);
+    gb1 += dpre;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      g1[i] = fmaf(dpre, e[i], g1[i]);
+      g2[i] = fmaf(dy[i], act, g2[i]);
+    }
   }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < 2 * C * C; idx += blockDim.x) {
-    const int o = idx / C, k = idx % C;
-    atomicAdd(dw1 + idx, dpre[o] * e[k]);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int j = i * 64 + lane;
+    dw1[(size_t)k * C + j] += g1[i];
+    dw2[(size_t)j * 2 * C + k] += g2[i];
+  }
+  if (lane == 0) db1[k] += gb1;
+  if (k < NV) {                                          // db2[j] for j = k * 64 + lane
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dtemb[(size_t)b * C + k * 64 + lane];
+    db2[k * 64 + lane] += a;
   }
 }
 
@@ -541,17 +615,21 @@ int d3dp_train_ln_pos(const float* x, const float* w, const float* b, float eps,
 }
 int d3dp_train_ln_bwd(const float* dy, const float* x, const float* w, float eps, const float* dres, float* dx,
                       float* dgamma, float* dbeta, int T, int C, hipStream_t st) {
-  const int blocks = (T + 3) / 4 < 1024 ? (T + 3) / 4 : 1024;
+  // (512 workgroups: two per CU; every workgroup ends with 2 C atomics into the shared gamma / beta gradients, which at
+  //  1024 workgroups were most of the kernel's time)
+  const int blocks = (T + 3) / 4 < 512 ? (T + 3) / 4 : 512;
   TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd_kernel<CC>), dim3(blocks), dim3(256), 0, st, dy, x, w, eps, dres, dx,
                                          dgamma, dbeta, T))
   return 0;
 }
 int d3dp_train_gelu_fwd(const float* x, float* y, size_t n, hipStream_t st) {
-  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
+  if (n % 4 != 0) return -2;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, x, y, n / 4);
   return 0;
 }
 int d3dp_train_gelu_bwd(const float* dh, const float* x, float* dpre, size_t n, hipStream_t st) {
-  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dh, x, dpre, n);
+  if (n % 4 != 0) return -2;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, dh, x, dpre, n / 4);
   return 0;
 }
 int d3dp_train_scale_mask(const float* in, const float* mask, int axis, int F, int J, float* out, int T, int C,
@@ -561,7 +639,11 @@ int d3dp_train_scale_mask(const float* in, const float* mask, int axis, int F, i
   return 0;
 }
 int d3dp_train_colsum(const float* in, float* out, int T, int C, hipStream_t st) {
-  hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, T < 512 ? T : 512), dim3(256), 0, st, in, out, T, C);
+  if (C % 4 != 0) return -2;
+  const int gx = (C + 255) / 256;
+  int gy = 512 / gx;                                     // ~512 workgroups: two per CU, gy atomics per column
+  if (gy > (T + 3) / 4) gy = (T + 3) / 4;
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy < 1 ? 1 : gy), dim3(256), 0, st, in, out, T, C);
   return 0;
 }
 int d3dp_train_groupsum(const float* in, float* out, int T, int C, int mode, int F, int J, hipStream_t st) {
@@ -584,16 +666,19 @@ size_t d3dp_train_attn_stats_bytes(int n_seq, int n_tok, int heads) { return (si
 //            dQ^T += K^T dS^T straight from the registers that hold it.  Writes (row max, denominator, D) per query.
 //   pass KV: Q, dO and the statistics in LDS; one 16-key tile per wave with its K / V fragments in registers.  S = Q K^T and
 //            dP = dO V^T as tiles [query][key], P from the stored statistics, dV^T += dO^T P and dK^T += Q^T dS.
-// A workgroup = four waves = four consecutive tiles of one problem (grid = problems x ceil(tiles / 4)): with one
-// 139-KiB workgroup per CU, 544 problems of 16 tiles each would quantise to three rounds of 256; 2,176 quarter problems
-// to 8.5 quarter rounds.  LDS rows: 68 floats (row-pattern fragments = four ds_read_b128 per 16 contraction steps;
+// A workgroup = eight waves = eight consecutive tiles of one problem (grid = problems x ceil(tiles / 8)): with one
+// 139-KiB workgroup per CU, 544 problems of 16 tiles each would quantise to three rounds of 256; 1,088 half problems
+// to 4.25 half rounds (four tiles per workgroup: the same rounds, but the K / V staging -- as long as a tile's MFMAs --
+// twice as often and by half as many threads: measured 300 + 325 us per temporal block instead of the 130 + 160 of
+// the MFMAs).  LDS rows: 68 floats (row-pattern fragments = four ds_read_b128 per 16 contraction steps;
 // column-pattern fragments conflict-free ds_read_b32).
 // ------------------------------------------------------------------------------------------------
 constexpr int LDB = 68;
 using f32x4m = float __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void bwd_stage_rows(float* dst, const float* src0, size_t row_stride, int n, int NK, int tid) {
-  for (int idx = tid; idx < NK * 16; idx += 256) {
+// NW = tiles (waves) per workgroup: 8 for the long sequences (two per SIMD cover each other's LDS waits), 2 for <= 32 tokens
+__device__ __forceinline__ void bwd_stage_rows(float* dst, const float* src0, size_t row_stride, int n, int NK, int tid, int nthr) {
+  for (int idx = tid; idx < NK * 16; idx += nthr) {
     const int row = idx >> 4, c4 = (idx & 15) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < n) v = *reinterpret_cast<const float4*>(src0 + (size_t)row * row_stride + c4);
@@ -610,8 +695,8 @@ __device__ __forceinline__ void bwd_chain2(const float* ra, const float* rb, con
   }
 }
 
-template <int NKT>
-__global__ __launch_bounds__(256, 1) void attn_bwd_q_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+template <int NKT, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_q_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                                  const float* __restrict__ dout, float* __restrict__ dqkv,
                                                                  AttnStats* __restrict__ stats, SeqMap map, int C, int heads,
                                                                  int groups) {
@@ -627,10 +712,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_q_mfma_kernel(const float* __
   const int ts = map.tok_stride;
   const size_t ld = (size_t)3 * C;
   const float* qbase = qkv + (size_t)base * ld + (size_t)head * 64;
-  bwd_stage_rows(KS, qbase + C, (size_t)ts * ld, n, NK, tid);
-  bwd_stage_rows(VS, qbase + 2 * C, (size_t)ts * ld, n, NK, tid);
+  bwd_stage_rows(KS, qbase + C, (size_t)ts * ld, n, NK, tid, NW * 64);
+  bwd_stage_rows(VS, qbase + 2 * C, (size_t)ts * ld, n, NK, tid, NW * 64);
   __syncthreads();
-  const int qt = group * 4 + wave;
+  const int qt = group * NW + wave;
   if (qt * 16 >= n) return;
   const int fi = lane & 15, fg = lane >> 4;
   const int q = qt * 16 + fi;
@@ -716,8 +801,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_q_mfma_kernel(const float* __
   }
 }
 
-template <int NKT>
-__global__ __launch_bounds__(256, 1) void attn_bwd_kv_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+template <int NKT, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_kv_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                   float* __restrict__ dqkv, const AttnStats* __restrict__ stats,
                                                                   SeqMap map, int C, int heads, int groups) {
   constexpr int NK = 16 * NKT;
@@ -732,9 +817,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_mfma_kernel(const float* _
   const int base = (seq / map.inner) * map.outer_stride + (seq % map.inner) * map.inner_stride;
   const int ts = map.tok_stride;
   const size_t ld = (size_t)3 * C;
-  bwd_stage_rows(QS, qkv + (size_t)base * ld + (size_t)head * 64, (size_t)ts * ld, n, NK, tid);
-  bwd_stage_rows(GS, dout + (size_t)base * C + (size_t)head * 64, (size_t)ts * C, n, NK, tid);
-  for (int i = tid; i < NK; i += 256) {
+  bwd_stage_rows(QS, qkv + (size_t)base * ld + (size_t)head * 64, (size_t)ts * ld, n, NK, tid, NW * 64);
+  bwd_stage_rows(GS, dout + (size_t)base * C + (size_t)head * 64, (size_t)ts * C, n, NK, tid, NW * 64);
+  for (int i = tid; i < NK; i += NW * 64) {
     // rows >= n: Q and dO rows are zero, so whatever finite P and dS they get contributes nothing
     float4 v = make_float4(0.f, 0.125f, 0.f, 0.f);
     if (i < n) {
@@ -744,7 +829,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_mfma_kernel(const float* _
     *reinterpret_cast<float4*>(ST + i * 4) = v;
   }
   __syncthreads();
-  const int kt = group * 4 + wave;
+  const int kt = group * NW + wave;
   if (kt * 16 >= n) return;
   const int fi = lane & 15, fg = lane >> 4;
   const int key = kt * 16 + fi;
@@ -799,17 +884,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_mfma_kernel(const float* _
 template <int NKT>
 static int launch_attn_bwd_mfma(const float* qkv, const float* o, const float* dout, float* dqkv, void* stats, int n_seq,
                                 SeqMap map, int C, int heads, hipStream_t st) {
-  constexpr int NK = 16 * NKT;
+  constexpr int NK = 16 * NKT, NW = NKT <= 2 ? 2 : 8;
   const size_t lds_q = (size_t)2 * NK * LDB * 4, lds_kv = lds_q + (size_t)NK * 16;
   static PerDeviceOnce once;
   if (once.get([&](int) {
-        return d3dp_lds_opt_in(reinterpret_cast<const void*>(attn_bwd_q_mfma_kernel<NKT>), 160 * 1024) < 0 ? -3
-               : d3dp_lds_opt_in(reinterpret_cast<const void*>(attn_bwd_kv_mfma_kernel<NKT>), 160 * 1024);
+        return d3dp_lds_opt_in(reinterpret_cast<const void*>(attn_bwd_q_mfma_kernel<NKT, NW>), 160 * 1024) < 0 ? -3
+               : d3dp_lds_opt_in(reinterpret_cast<const void*>(attn_bwd_kv_mfma_kernel<NKT, NW>), 160 * 1024);
       }) < 0) return -3;
-  const int tiles = (map.n_tok + 15) / 16, groups = (tiles + 3) / 4;
-  hipLaunchKernelGGL((attn_bwd_q_mfma_kernel<NKT>), dim3(n_seq * heads * groups), dim3(256), lds_q, st, qkv, o, dout, dqkv,
+  const int tiles = (map.n_tok + 15) / 16, groups = (tiles + NW - 1) / NW;
+  hipLaunchKernelGGL((attn_bwd_q_mfma_kernel<NKT, NW>), dim3(n_seq * heads * groups), dim3(NW * 64), lds_q, st, qkv, o, dout, dqkv,
                      (AttnStats*)stats, map, C, heads, groups);
-  hipLaunchKernelGGL((attn_bwd_kv_mfma_kernel<NKT>), dim3(n_seq * heads * groups), dim3(256), lds_kv, st, qkv, dout, dqkv,
+  hipLaunchKernelGGL((attn_bwd_kv_mfma_kernel<NKT, NW>), dim3(n_seq * heads * groups), dim3(NW * 64), lds_kv, st, qkv, dout, dqkv,
                      (const AttnStats*)stats, map, C, heads, groups);
   return 0;
 }
@@ -819,10 +904,11 @@ static int launch_attn_bwd(const float* qkv, const float* o, const float* dout, 
                            SeqMap map, int C, int heads, hipStream_t st) {
   const int n = map.n_tok;
   if constexpr (HD == 64) {
-    // long sequences (the temporal axis) on the fp32 matrix cores; D3DP_TRAIN_ATTN_BWD=valu keeps the kernels below (cross-check)
+    // head dim 64 on the fp32 matrix cores; D3DP_TRAIN_ATTN_BWD=valu keeps the kernels below (cross-check)
     const char* e = getenv("D3DP_TRAIN_ATTN_BWD");     // (read per call: the tests switch it between two steps)
     const bool valu = e && e[0] == 'v';
-    if (!valu && n > 32 && n <= 256 && C % 4 == 0) {
+    if (!valu && n <= 256 && C % 4 == 0) {
+      if (n <= 32) return launch_attn_bwd_mfma<2>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
       if (n <= 64) return launch_attn_bwd_mfma<4>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
       if (n <= 128) return launch_attn_bwd_mfma<8>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
       return launch_attn_bwd_mfma<16>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
@@ -870,7 +956,7 @@ int d3dp_train_head_bwd(const float* g, const float* z, const float* w, float* d
 int d3dp_train_time_mlp_bwd(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2,
                             const float* dtemb, float* dw1, float* db1, float* dw2, float* db2, int B, int C,
                             hipStream_t st) {
-  hipLaunchKernelGGL(time_mlp_bwd_kernel, dim3(B), dim3(256), (size_t)7 * C * sizeof(float), st, t, freq, w1, b1, w2, dtemb,
-                     dw1, db1, dw2, db2, C);
+  TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((time_mlp_bwd_kernel<CC>), dim3((2 * C + 3) / 4), dim3(256), 0, st, t, freq, w1, b1,
+                                         w2, dtemb, dw1, db1, dw2, db2, B))
   return 0;
 }

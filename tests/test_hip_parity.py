@@ -1056,10 +1056,10 @@ def test_training_step_config5_vs_oracle_autograd():
     print(f"config-5: worst relative gradient error over {len(po)} parameters: {worst[1]:.2e} ({worst[0]})")
 
 
-@pytest.mark.parametrize("Fr", [40, 81, 243])
+@pytest.mark.parametrize("Fr", [9, 40, 81, 243])
 def test_attention_backward_on_matrix_cores_matches_the_valu_kernels(monkeypatch, Fr):
-    """Sequences longer than 32 tokens take the fp32-MFMA attention backward (train.hip attn_bwd_{q,kv}_mfma_kernel: 4, 8
-    or 16 key tiles); D3DP_TRAIN_ATTN_BWD=valu keeps the two-threads-per-row VALU kernels.  Both are fp32 arithmetic in a
+    """Head-dim-64 attention takes the fp32-MFMA backward (train.hip attn_bwd_{q,kv}_mfma_kernel: 2, 4, 8 or 16 key tiles --
+    the spatial axis' 17 joints and F = 9 frames use 2); D3DP_TRAIN_ATTN_BWD=valu keeps the two-threads-per-row VALU kernels.  Both are fp32 arithmetic in a
     different summation order: every parameter gradient of a training step agrees to fp32 noise."""
     B, cs, dep = 2, 512, 2
     args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
