@@ -1091,9 +1091,14 @@ int launch_temporal_x2(const void* qkv, void* out, int n_seq, SeqMap map, int C,
 // ------------------------------------------------------------------------------------------------
 constexpr int LDKF = 65, LDVF = 68;
 
+// A workgroup = eight waves = eight consecutive query tiles of one (sequence, head) problem; grid = problems x ceil(tiles / 8):
+// 544 problems of 16 tiles (the configs[4] training batch) quantise to three rounds of one 139-KiB workgroup per CU, 1,088
+// half problems to 4.25 half rounds, and two waves per SIMD cover each other's LDS waits (four waves walking four tiles each:
+// 178 us per launch).
+constexpr int TF32_WAVES = 8;
 template <int NKT, int OUTS>
-__global__ __launch_bounds__(256, 1) void attn_temporal_f32_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
-                                                                SeqMap map, int C, int heads, size_t plane) {
+__global__ __launch_bounds__(TF32_WAVES * 64) void attn_temporal_f32_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
+                                                                         SeqMap map, int C, int heads, size_t plane, int groups) {
   constexpr int NK = 16 * NKT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* KS = reinterpret_cast<float*>(smem);
@@ -1101,7 +1106,8 @@ __global__ __launch_bounds__(256, 1) void attn_temporal_f32_kernel(const float* 
   static_assert((16 * LDKF + 0) % 1 == 0, "");
   const int n = map.n_tok;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
+  const int prob = blockIdx.x / groups, group = blockIdx.x % groups;
+  const int seq = prob / heads, head = prob % heads;
   const int base = seq_base(map, seq);
   const int ts = map.tok_stride;
   const size_t ld = (size_t)3 * C;
@@ -1110,7 +1116,7 @@ __global__ __launch_bounds__(256, 1) void attn_temporal_f32_kernel(const float* 
   const int n_qt = (n + 15) >> 4;
 
   // stage K (scalar stores, stride 65) and V (float4 stores, stride 68); zero the padding rows of V
-  for (int idx = tid; idx < NK * 16; idx += 256) {
+  for (int idx = tid; idx < NK * 16; idx += TF32_WAVES * 64) {
     const int row = idx >> 4, c4 = (idx & 15) * 4;
     float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
     if (row < n) {
@@ -1124,7 +1130,7 @@ __global__ __launch_bounds__(256, 1) void attn_temporal_f32_kernel(const float* 
   }
   __syncthreads();
   const float cexp = 0.125f * 1.44269504088896340736f;
-  for (int qt = wave; qt < n_qt; qt += 4) {
+  for (int qt = group * TF32_WAVES + wave; qt < n_qt; qt = n_qt) {   // (one tile per wave)
     const int q = qt * 16 + fi;
     // contraction index of MFMA step kk for lane group g is d = 16 g + kk (K fragments use the same map)
     const float* qsrc = qbase + (size_t)min(q, n - 1) * ts * ld + fg * 16;
@@ -1224,7 +1230,9 @@ int launch_temporal_f32(const void* qkv, void* out, int n_seq, SeqMap map, int C
   auto kern = attn_temporal_f32_kernel<NKT, OUTS>;
   static PerDeviceOnce once;                          // (one per template instantiation = per kernel)
   if (once.get([&](int) { return d3dp_lds_opt_in(reinterpret_cast<const void*>(kern), 160 * 1024); }) < 0) return -3;
-  hipLaunchKernelGGL(kern, dim3(n_seq * heads), dim3(256), lds, st, (const float*)qkv, out, map, C, heads, plane);
+  const int groups = ((map.n_tok + 15) / 16 + TF32_WAVES - 1) / TF32_WAVES;
+  hipLaunchKernelGGL(kern, dim3(n_seq * heads * groups), dim3(TF32_WAVES * 64), lds, st, (const float*)qkv, out, map, C, heads, plane,
+                     groups);
   return 0;
 }
 

@@ -998,6 +998,7 @@ struct X2Train {
     next = forward_pass ? 0 : kBwdSlot0;
     return hipMemsetAsync(ws + L.slots + next, 0, (size_t)kBwdSlot0 * 4, st) == hipSuccess ? 0 : -3;
   }
+  int take() { return (next < kBwdSlot0 || next >= 8192) ? -1 : next++; }   // a fresh slot of the backward range for a producer kernel to fill
   int slot_for(const float* src, size_t n) {           // absmax of a tensor into a fresh slot of the backward range
     if (next < kBwdSlot0 || next >= 8192) return -1;
     d3dp_launch_absmax(src, n, amax() + next, st);
@@ -1033,11 +1034,36 @@ struct X2Train {
     }
     return d3dp_launch_wprep(tb, ws + L.w_rows, ws + L.w_cols, amax(), uns(), st);
   }
+  // out[T, N] = A2 . W2^T (+ bias) with T = 256 q + rem rows.  The persistent kernel works in rounds of n_cu tiles of 256 x 128;
+  // the configs[4] batch has T = 16,524 = 64 x 256 + 140, so every forward / dgrad product had ONE row of tiles too many for
+  // a whole number of rounds (fc2: 260 tiles on 256 CUs = two rounds for 1.02 rounds of work).  When the remainder rows cost a round of their own they go to a second
+  // launch as a split-K product (Z chunks of the contraction: tn Z short work items instead of tn long ones) whose partial
+  // sums are added in a fixed order.
+  int gemm(const float* A2, const float* W2, const float* bias, const float* ua, const float* uw, float* out, int T, int N,
+           int K) {
+    const int tn = (N + 127) / 128, q = T / 256, rem = T - q * 256;
+    const int rounds_all = ((q + (rem ? 1 : 0)) * tn + n_cu - 1) / n_cu, rounds_full = (q * tn + n_cu - 1) / n_cu;
+    const int nk = K / 32;
+    int Z = 1;
+    for (int z = 2; z <= 16; ++z)
+      if (nk % z == 0) Z = z;
+    // (measured: a last round of a few tiles runs its k-steps at 0.75 us -- few CUs active, full clock -- against 1.4 us in a
+    //  full round, so for 16 k-steps it costs 12 us, what the second launch and the sum cost too: split from 32 k-steps on)
+    if (rem == 0 || q == 0 || rounds_all == rounds_full || Z == 1 || nk < 32 || (size_t)Z * rem * N > (size_t)(1024 + 64) * 256 * 128)
+      return d3dp_launch_linear_f16x2_dyn(A2, W2, bias, ua, uw, out, T, N, K, 1, st);
+    int r = d3dp_launch_linear_f16x2_dyn(A2, W2, bias, ua, uw, out, q * 256, N, K, 1, st);
+    if (r) return r;
+    r = d3dp_launch_linear_f16x2_dyn(A2 + (size_t)q * 256 * K, W2, nullptr, ua, uw, ws + L.part, rem, N, K, Z, st);   // (a row = 2 K fp16 = K floats)
+    if (r) return r;
+    d3dp_launch_sum_partials_bias(ws + L.part, bias, out + (size_t)q * 256 * N, (size_t)rem * N, N, Z, st);
+    return 0;
+  }
   // out[T, N] = A[T, K] W[N, K]^T + bias     (l: the Linear's index, see the slots above)
-  int forward(int l, const float* A, const float* W, const float* bias, float* out, int T, int N, int K) {
+  // (a_amax_ready: the kernel that produced A already left its absmax in slot 2 l)
+  int forward(int l, const float* A, const float* W, const float* bias, float* out, int T, int N, int K, bool a_amax_ready = false) {
     const int sa = 2 * l, sw = 2 * l + 1;
     if (l < 0 || sw >= kBwdSlot0) return -1;
-    d3dp_launch_absmax(A, (size_t)T * K, amax() + sa, st);
+    if (!a_amax_ready) d3dp_launch_absmax(A, (size_t)T * K, amax() + sa, st);
     {
       // row form for this product and, in the same pass, the transposed form the wgrad of this Linear will want: the
       // backward pass then neither recomputes this activation (LayerNorm / GELU outputs) nor reads it again
@@ -1053,7 +1079,7 @@ struct X2Train {
       d3dp_launch_absmax(W, (size_t)N * K, amax() + sw, st);
       rows(W, N, K, ws + L.op_w, sw);
     }
-    return d3dp_launch_linear_f16x2_dyn(ws + L.op_a, w2, bias, uns() + sa, uns() + sw, out, T, N, K, 1, st);
+    return gemm(ws + L.op_a, w2, bias, uns() + sa, uns() + sw, out, T, N, K);
   }
   // dX[T, K] = dY[T, N] W[N, K]   (sdy: the absmax slot of dY, shared with wgrad; l: the forward Linear whose W this is)
   int dgrad(int l, const float* dY, int sdy, const float* W, float* dX, int T, int N, int K) {
@@ -1062,7 +1088,7 @@ struct X2Train {
     const float* wt = ws + L.op_w;
     if (batched) wt = ws + L.w_cols + woff(l);         // (prepared by the forward pass of this step)
     else cols(W, N, K, N, ws + L.op_w, sw);            // W^T: [K][2 N]  (N % 32 == 0: the model's widths)
-    return d3dp_launch_linear_f16x2_dyn(ws + L.op_a, wt, nullptr, uns() + sdy, uns() + sw, dX, T, K, N, 1, st);
+    return gemm(ws + L.op_a, wt, nullptr, uns() + sdy, uns() + sw, dX, T, K, N);
   }
   // split count / padded token count of the wgrad product dW[N, K] = dY^T X
   void wgrad_split(int T, int N, int K, int& Z, int& Tp) const {
@@ -1126,8 +1152,8 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     LAUNCH_TRY(x2.begin(true));
     LAUNCH_TRY(x2.prepare_weights(c));
   }
-  auto lin = [&](int l, const float* A, const float* W, const float* bias, float* out, int M, int N, int K) {
-    return use_x2 ? x2.forward(l, A, W, bias, out, M, N, K) : lin32(A, W, bias, out, M, N, K, st);
+  auto lin = [&](int l, const float* A, const float* W, const float* bias, float* out, int M, int N, int K, bool a_amax_ready = false) {
+    return use_x2 ? x2.forward(l, A, W, bias, out, M, N, K, a_amax_ready) : lin32(A, W, bias, out, M, N, K, st);
   };
   LAUNCH_TRY(d3dp_launch_time_mlp(t, c->freq, c->t1w, c->t1b, c->t3w, c->t3b, ws + L.temb, B, C, st));
   float* slab0 = ws + L.saved0;
@@ -1146,8 +1172,8 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     LAUNCH_TRY(d3dp_train_add_mask_ln(S + L.o_xin, y, mask_ptr(masks, g, B, blk, 0), kind, F, J, w.n2w, w.n2b, g.eps_block,
                                       S + L.o_xmid, xn, T, C, st));
     LAUNCH_TRY(lin(4 * blk + 2, xn, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C));
-    LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, st));
-    LAUNCH_TRY(lin(4 * blk + 3, hid, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd));
+    LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, use_x2 ? x2.amax() + 2 * (4 * blk + 3) : nullptr, st));
+    LAUNCH_TRY(lin(4 * blk + 3, hid, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd, true));
     LAUNCH_TRY(d3dp_train_add_mask_ln(S + L.o_xmid, y, mask_ptr(masks, g, B, blk, 1), kind, F, J, nullptr, nullptr,
                                       g.eps_block, S + L.o_xout, nullptr, T, C, st));
     // shared norm -> next block's input (or x_final)
@@ -1214,10 +1240,11 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
   int sdy = -1;                                          // absmax slot of the dY the next wgrad / dgrad pair shares
   // wgrad: dW[N, K] = dY[T, N]^T X[T, K]  (fp32 path: both operands transposed to [*, Tpad], zero padded)
   // (dbias: the Linear's bias gradient = column sums of dY, accumulated)
-  auto wgrad = [&](int l, const float* dY, int N, const float* X, int K, float* dW, float* dbias) -> int {
+  // (pre_slot >= 0: the kernel that produced dY left its absmax there)
+  auto wgrad = [&](int l, const float* dY, int N, const float* X, int K, float* dW, float* dbias, int pre_slot = -1) -> int {
     int r;
     if (use_x2) {
-      sdy = x2.slot_for(dY, (size_t)T * N);
+      sdy = pre_slot >= 0 ? pre_slot : x2.slot_for(dY, (size_t)T * N);
       if (sdy < 0) return -1;
       if ((r = x2.prep_dy(dY, sdy, dbias, T, N, K))) return r;
       return x2.wgrad(l, dY, sdy, X, dW, T, N, K);
@@ -1254,19 +1281,30 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     // shared norm backward: dB = d x_out
     LAUNCH_TRY(d3dp_train_ln_bwd(dA, S + L.o_xout, snw, g.eps_block, nullptr, dB, gsnw, gsnb, T, C, st));
     // ---- MLP branch ----
-    LAUNCH_TRY(d3dp_train_scale_mask(dB, mask_ptr(masks, g, B, blk, 1), kind, F, J, dC, T, C, st));        // dy2
-    if (!use_x2) LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, st));   // (x2: wgrad reads the forward pass' operand)
-    LAUNCH_TRY(wgrad(4 * blk + 3, dC, C, hid, Hd, G(gw.fc2_w), G(gw.fc2_b)));
+    auto fresh = [&](int& slot) -> unsigned* {             // a slot for the producer of the next dY (split-fp16 path only)
+      slot = use_x2 ? x2.take() : -1;
+      return slot >= 0 ? x2.amax() + slot : nullptr;
+    };
+    int ps = -1;
+    unsigned* pa = fresh(ps);
+    if (use_x2 && ps < 0) return fail(D3DP_ESTATE, "d3dp_train_backward: out of operand slots");
+    LAUNCH_TRY(d3dp_train_scale_mask(dB, mask_ptr(masks, g, B, blk, 1), kind, F, J, dC, T, C, pa, st));    // dy2
+    if (!use_x2) LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, nullptr, st));   // (x2: wgrad reads the forward pass' operand)
+    LAUNCH_TRY(wgrad(4 * blk + 3, dC, C, hid, Hd, G(gw.fc2_w), G(gw.fc2_b), ps));
     LAUNCH_TRY(dgrad(4 * blk + 3, dC, C, (const float*)w.fc2_w, Hd, dh));                                               // d hidden
-    LAUNCH_TRY(d3dp_train_gelu_bwd(dh, S + L.o_hpre, dh, (size_t)T * Hd, st));                             // d h_pre
+    pa = fresh(ps);
+    if (use_x2 && ps < 0) return fail(D3DP_ESTATE, "d3dp_train_backward: out of operand slots");
+    LAUNCH_TRY(d3dp_train_gelu_bwd(dh, S + L.o_hpre, dh, (size_t)T * Hd, pa, st));                         // d h_pre
     if (!use_x2) LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xmid, w.n2w, w.n2b, g.eps_block, nullptr, F, J, xn, T, C, st));   // xn2
-    LAUNCH_TRY(wgrad(4 * blk + 2, dh, Hd, xn, C, G(gw.fc1_w), G(gw.fc1_b)));
+    LAUNCH_TRY(wgrad(4 * blk + 2, dh, Hd, xn, C, G(gw.fc1_w), G(gw.fc1_b), ps));
     LAUNCH_TRY(dgrad(4 * blk + 2, dh, Hd, (const float*)w.fc1_w, C, dC));                                               // d xn2
     LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xmid, w.n2w, g.eps_block, dB, dA, G(gw.norm2_w), G(gw.norm2_b), T, C, st));
     // dA = d x_mid
     // ---- attention branch ----
-    LAUNCH_TRY(d3dp_train_scale_mask(dA, mask_ptr(masks, g, B, blk, 0), kind, F, J, dC, T, C, st));        // dy1
-    LAUNCH_TRY(wgrad(4 * blk + 1, dC, C, S + L.o_att, C, G(gw.proj_w), G(gw.proj_b)));
+    pa = fresh(ps);
+    if (use_x2 && ps < 0) return fail(D3DP_ESTATE, "d3dp_train_backward: out of operand slots");
+    LAUNCH_TRY(d3dp_train_scale_mask(dA, mask_ptr(masks, g, B, blk, 0), kind, F, J, dC, T, C, pa, st));    // dy1
+    LAUNCH_TRY(wgrad(4 * blk + 1, dC, C, S + L.o_att, C, G(gw.proj_w), G(gw.proj_b), ps));
     LAUNCH_TRY(dgrad(4 * blk + 1, dC, C, (const float*)w.proj_w, C, dB));                                               // d att
     if (kind == 0) LAUNCH_TRY(d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * F, spatial_map(F, J), C, g.heads, st));
     else LAUNCH_TRY(d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * J, temporal_map(F, J), C, g.heads, st));

@@ -35,6 +35,25 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // libm's branching erff: 21 VALU instructions instead of 41 per element in the EXACT fc1 epilogue, where they run with
 // the matrix pipes idle.  Coefficients: the single-precision erf of Eigen / XLA; measured against fp64 on N(0,1) inputs
 // (tools/erf_check.py): mean |error| of the GELU 2.2e-8, max 6.1e-7 -- torch's own fp32 GELU has 1.8e-8 and 9.9e-7.
+// erf(z) by the same rational (z clamped to [-4, 4], where |erf| = 1 in fp32)
+__device__ __forceinline__ float erf_rational(float zin) {
+  const float z = __builtin_amdgcn_fmed3f(zin, -4.0f, 4.0f), z2 = z * z;
+  float p = -2.72614225801306e-10f;
+  p = fmaf(p, z2, 2.77068142495902e-08f);
+  p = fmaf(p, z2, -2.10102402082508e-06f);
+  p = fmaf(p, z2, -5.69250639462346e-05f);
+  p = fmaf(p, z2, -7.34990630326855e-04f);
+  p = fmaf(p, z2, -2.95459980854025e-03f);
+  p = fmaf(p, z2, -1.60960333262415e-02f) * z;
+  float q = -1.45660718464996e-05f;
+  q = fmaf(q, z2, -2.13374055278905e-04f);
+  q = fmaf(q, z2, -1.68282697438203e-03f);
+  q = fmaf(q, z2, -7.37332916720468e-03f);
+  q = fmaf(q, z2, -1.42647390514189e-02f);
+  const float r = __builtin_amdgcn_rcpf(q);
+  const float e = p * r;
+  return fmaf(fmaf(-q, e, p), r, e);                   // one Newton step on the quotient
+}
 __device__ __forceinline__ float gelu_erf_rational(float x) {
   const float z = __builtin_amdgcn_fmed3f(x * 0.70710678118654752440f, -4.0f, 4.0f), z2 = z * z;
   float p = -2.72614225801306e-10f;

@@ -1719,6 +1719,16 @@ __global__ void sum_partials_kernel(const float* __restrict__ part, float* __res
   }
 }
 
+// out[r][c] = sum_z part[z][r][c] + bias[c]   (the split-K remainder rows of a training Linear; bias may be null)
+__global__ void sum_partials_bias_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
+                                         size_t n, int N, int Z) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float a = part[i];
+    for (int z = 1; z < Z; ++z) a += part[(size_t)z * n + i];
+    out[i] = bias ? a + bias[i % N] : a;
+  }
+}
+
 // src[i] * scale -> h2i layout (common.h): blocks of 32 elements, dst[64 b .. 64 b + 31] = hi, dst[64 b + 32 .. 64 b + 63] = lo
 // of elements 32 b .. 32 b + 31 (n % 32 == 0; any row length that is a multiple of 32)
 __global__ void split2h_kernel(const float* __restrict__ s, f16* __restrict__ d, size_t n, float scale) {
@@ -2003,6 +2013,10 @@ int d3dp_launch_wprep(const D3dpWPrepTable& tb, void* rows_base, void* cols_base
   return 0;
 }
 
+void d3dp_launch_sum_partials_bias(const float* part, const float* bias, float* out, size_t n, int N, int Z, hipStream_t st) {
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(sum_partials_bias_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, part, bias, out, n, N, Z);
+}
 void d3dp_launch_sum_partials(const float* part, float* out, size_t n, int Z, hipStream_t st) {
   const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, part, out, n, Z);

@@ -95,6 +95,7 @@ struct D3dpWPrepItem { const float* w; int N, K, slot, pad; size_t off; };
 struct D3dpWPrepTable { D3dpWPrepItem it[D3DP_WPREP_MAX]; int n; };
 int d3dp_launch_wprep(const D3dpWPrepTable& tb, void* rows_base, void* cols_base, unsigned* amax, float* unscale, hipStream_t st);
 void d3dp_launch_sum_partials(const float* part, float* out, size_t n, int Z, hipStream_t st);
+void d3dp_launch_sum_partials_bias(const float* part, const float* bias, float* out, size_t n, int N, int Z, hipStream_t st);
 void d3dp_launch_absmax(const float* src, size_t n, unsigned* out, hipStream_t st);
 // flag[0] |= 1 if any of x[0..n) is inf / nan
 void d3dp_launch_nonfinite_flag(const float* x, size_t n, unsigned* flag, hipStream_t st);
@@ -172,10 +173,11 @@ int d3dp_train_ln_pos(const float* x, const float* w, const float* b, float eps,
                       int T, int C, hipStream_t st);
 int d3dp_train_ln_bwd(const float* dy, const float* x, const float* w, float eps, const float* dres, float* dx,
                       float* dgamma, float* dbeta, int T, int C, hipStream_t st);
-int d3dp_train_gelu_fwd(const float* x, float* y, size_t n, hipStream_t st);
-int d3dp_train_gelu_bwd(const float* dh, const float* x, float* dpre, size_t n, hipStream_t st);
+// (amax: optional absmax slot of the result, see train.hip block_amax_commit)
+int d3dp_train_gelu_fwd(const float* x, float* y, size_t n, unsigned* amax, hipStream_t st);
+int d3dp_train_gelu_bwd(const float* dh, const float* x, float* dpre, size_t n, unsigned* amax, hipStream_t st);
 int d3dp_train_scale_mask(const float* in, const float* mask, int axis, int F, int J, float* out, int T, int C,
-                          hipStream_t st);
+                          unsigned* amax, hipStream_t st);
 int d3dp_train_colsum(const float* in, float* out, int T, int C, hipStream_t st);
 int d3dp_train_groupsum(const float* in, float* out, int T, int C, int mode, int F, int J, hipStream_t st);
 int d3dp_train_transpose_pad(const float* in, float* out, int R, int C, int Rpad, hipStream_t st);

@@ -162,35 +162,68 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
+// The three elementwise producers of split operands (the fc2 input, the two kinds of dY) also leave their result's absmax in a
+// slot of the training step (as absmax_kernel: bit pattern of a non-negative float, one atomic per workgroup; amax may be
+// null): grid-stride over 16-byte groups so that a launch has at most 512 workgroups = 512 atomics.
+__device__ __forceinline__ void block_amax_commit(float m, unsigned* amax) {
+  __shared__ float part_amax[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) part_amax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0 && amax)
+    atomicMax(amax, __float_as_uint(fmaxf(fmaxf(part_amax[0], part_amax[1]), fmaxf(part_amax[2], part_amax[3]))));
+}
+__device__ __forceinline__ float amax4f(const float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+
 // (four elements per thread; n % 4 == 0: the hidden width is a multiple of 32)
-__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n4) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  const float4 v = reinterpret_cast<const float4*>(x)[i];
-  reinterpret_cast<float4*>(y)[i] = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n4,
+                                                       unsigned* __restrict__ amax) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    // (the rational erf of the inference epilogue: fp32-class, half the instructions of libm's erff -- these two kernels
+    //  are VALU-bound)
+    const float4 r = make_float4(gelu_erf_rational(v.x), gelu_erf_rational(v.y), gelu_erf_rational(v.z), gelu_erf_rational(v.w));
+    reinterpret_cast<float4*>(y)[i] = r;
+    m = fmaxf(m, amax4f(r));
+  }
+  block_amax_commit(m, amax);
 }
 
 // dpre = dh * (Phi(x) + x phi(x))
 __device__ __forceinline__ float gelu_grad(float v) {
-  const float cdf = 0.5f * (1.0f + erff(v * kInvSqrt2));
-  const float pdf = kInvSqrt2Pi * expf(-0.5f * v * v);
-  return cdf + v * pdf;
+  const float cdf = fmaf(0.5f, erf_rational(v * kInvSqrt2), 0.5f);
+  const float pdf = kInvSqrt2Pi * __builtin_amdgcn_exp2f(v * v * -0.72134752044448170368f);   // exp(-v^2 / 2) = 2^(-v^2 log2(e) / 2)
+  return fmaf(v, pdf, cdf);
 }
-__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* dh, const float* __restrict__ x, float* dpre,
-                                                       size_t n4) {   // dpre may alias dh
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  const float4 v = reinterpret_cast<const float4*>(x)[i], d = reinterpret_cast<const float4*>(dh)[i];
-  reinterpret_cast<float4*>(dpre)[i] = make_float4(d.x * gelu_grad(v.x), d.y * gelu_grad(v.y), d.z * gelu_grad(v.z), d.w * gelu_grad(v.w));
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* dh, const float* __restrict__ x, float* dpre, size_t n4,
+                                                       unsigned* __restrict__ amax) {   // dpre may alias dh
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i], d = reinterpret_cast<const float4*>(dh)[i];
+    const float4 r = make_float4(d.x * gelu_grad(v.x), d.y * gelu_grad(v.y), d.z * gelu_grad(v.z), d.w * gelu_grad(v.w));
+    reinterpret_cast<float4*>(dpre)[i] = r;
+    m = fmaxf(m, amax4f(r));
+  }
+  block_amax_commit(m, amax);
 }
 
-// out[t, :] = m[sample(t)] * in[t, :]
+// out[t, :] = m[sample(t)] * in[t, :]     (C % 4 == 0)
 __global__ __launch_bounds__(256) void scale_mask_kernel(const float* __restrict__ in, const float* __restrict__ mask,
-                                                         int axis, int F, int J, float* __restrict__ out, int T, int C) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)T * C) return;
-  const int tok = (int)(i / C);
-  out[i] = in[i] * (mask ? mask[sample_of(tok, axis, F, J)] : 1.0f);
+                                                         int axis, int F, int J, float* __restrict__ out, int T, int C,
+                                                         unsigned* __restrict__ amax) {
+  const size_t n4 = (size_t)T * C / 4;
+  const int C4 = C / 4;
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const int tok = (int)(i / C4);
+    const float k = mask ? mask[sample_of(tok, axis, F, J)] : 1.0f;
+    const float4 v = reinterpret_cast<const float4*>(in)[i];
+    const float4 r = make_float4(v.x * k, v.y * k, v.z * k, v.w * k);
+    reinterpret_cast<float4*>(out)[i] = r;
+    m = fmaxf(m, amax4f(r));
+  }
+  block_amax_commit(m, amax);
 }
 
 // out[c] += sum_t in[t, c]     (bias grads).  A thread owns four columns (one 16-byte load per row) of one row in four; the
@@ -622,20 +655,21 @@ int d3dp_train_ln_bwd(const float* dy, const float* x, const float* w, float eps
                                          dgamma, dbeta, T))
   return 0;
 }
-int d3dp_train_gelu_fwd(const float* x, float* y, size_t n, hipStream_t st) {
-  if (n % 4 != 0) return -2;
-  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, x, y, n / 4);
+static unsigned ew_blocks(size_t n4) { return (unsigned)((n4 + 255) / 256 < 512 ? (n4 + 255) / 256 : 512); }
+int d3dp_train_gelu_fwd(const float* x, float* y, size_t n, unsigned* amax, hipStream_t st) {
+  if (n % 4 != 0 || n == 0) return -2;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, st, x, y, n / 4, amax);
   return 0;
 }
-int d3dp_train_gelu_bwd(const float* dh, const float* x, float* dpre, size_t n, hipStream_t st) {
-  if (n % 4 != 0) return -2;
-  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, dh, x, dpre, n / 4);
+int d3dp_train_gelu_bwd(const float* dh, const float* x, float* dpre, size_t n, unsigned* amax, hipStream_t st) {
+  if (n % 4 != 0 || n == 0) return -2;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, st, dh, x, dpre, n / 4, amax);
   return 0;
 }
-int d3dp_train_scale_mask(const float* in, const float* mask, int axis, int F, int J, float* out, int T, int C,
+int d3dp_train_scale_mask(const float* in, const float* mask, int axis, int F, int J, float* out, int T, int C, unsigned* amax,
                           hipStream_t st) {
-  const size_t n = (size_t)T * C;
-  hipLaunchKernelGGL(scale_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, mask, axis, F, J, out, T, C);
+  if (C % 4 != 0 || T < 1) return -2;
+  hipLaunchKernelGGL(scale_mask_kernel, dim3(ew_blocks((size_t)T * C / 4)), dim3(256), 0, st, in, mask, axis, F, J, out, T, C, amax);
   return 0;
 }
 int d3dp_train_colsum(const float* in, float* out, int T, int C, hipStream_t st) {
