@@ -1208,7 +1208,16 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
   float* ws = (float*)workspace;
   const int T = (int)L.T, Tp = (int)L.Tpad, C = g.channels, F = g.frames, J = g.joints, Hd = g.hidden;
   auto G = [](const float* p) { return const_cast<float*>(p); };
-  auto zero = [&](const float* p, size_t n) { return hipMemsetAsync(G(p), 0, n * 4, st); };
+  // (one launch for all the small gradient buffers: ~150 memset launches per step otherwise; buffers that do not fit the
+  //  table -- more than 192 of them, or one of 4 Gi elements -- fall back to a memset each)
+  D3dpZeroTable ztab{};
+  auto zero = [&](const float* p, size_t n) -> hipError_t {
+    if (ztab.count < D3DP_ZERO_MAX && n < ((size_t)1 << 32)) {
+      ztab.p[ztab.count] = G(p); ztab.n[ztab.count] = (unsigned)n; ++ztab.count;
+      return hipSuccess;
+    }
+    return hipMemsetAsync(G(p), 0, n * 4, st);
+  };
   // ---- zero every gradient buffer -------------------------------------------------------------------------------
   const size_t CC = (size_t)C * C;
   HIP_TRY(zero(grads->spatial_pos, (size_t)J * C)); HIP_TRY(zero(grads->temporal_pos, (size_t)F * C));
@@ -1226,7 +1235,8 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
       HIP_TRY(zero(b.qkv_b, 3 * (size_t)C)); HIP_TRY(zero(b.proj_b, C)); HIP_TRY(zero(b.fc1_b, Hd)); HIP_TRY(zero(b.fc2_b, C));
       // weight matrices are written (not accumulated) by their wgrad GEMM
     }
-  HIP_TRY(hipMemsetAsync(ws + L.zero_bias, 0, 4 * (size_t)C * 4, st));
+  HIP_TRY(zero(ws + L.zero_bias, 4 * (size_t)C));
+  if (ztab.count) LAUNCH_TRY(d3dp_train_zero_many(ztab, st));
   const float* zb = ws + L.zero_bias;
   float *xn = ws + L.xn, *hid = ws + L.hid, *dA = ws + L.dA, *dB = ws + L.dB, *dC = ws + L.dC, *dqkv = ws + L.dqkv,
         *dh = ws + L.dh, *At = ws + L.At, *Xt = ws + L.Xt, *Wt = ws + L.Wt;

@@ -1601,47 +1601,54 @@ __global__ __launch_bounds__(256) void split2h_t_dyn_kernel(const float* __restr
 __global__ __launch_bounds__(256) void dyprep_kernel(const float* __restrict__ s, f16* __restrict__ drow, f16* __restrict__ dcol,
                                                      float* __restrict__ colsum, int R, int C, int Rpad,
                                                      const unsigned* __restrict__ amax, float* __restrict__ unscale) {
+  // A thread owns FOUR elements of a tile in either direction: one 16-byte load and two 8-byte stores (4 hi, 4 lo) for the
+  // row form, four LDS reads and two 8-byte stores for the transposed form (the first version moved every fp16 with its own
+  // 2-byte store: store-issue-bound at 4 TB/s).
   __shared__ float tile[32][33];
-  __shared__ float csum[8][32];
+  __shared__ float csum[32][33];
   const float sc = dyn_scale(amax[0]);
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) unscale[0] = 1.0f / sc;
   const int c0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  float acc = 0.f;
+  const int tr = threadIdx.x >> 3, tq = (threadIdx.x & 7) * 4;   // phase 1: source row tr, columns tq .. tq + 3; phase 2: source column tr, rows tq .. tq + 3
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto split4 = [](const float (&v)[4], f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f16 h, l; split2h_scaled(v[e], h, l); hi[e] = h; lo[e] = l; }
+  };
   for (int rt = blockIdx.x; rt < Rpad / 32; rt += gridDim.x) {
-    const int r0 = rt * 32;
+    const int r = rt * 32 + tr;
     __syncthreads();
-    for (int k = ty; k < 32; k += 8) {
-      const int r = r0 + k;
-      const float v = r < R ? s[(size_t)r * C + c0 + tx] : 0.f;
-      acc += v;
-      const float vs = v * sc;
-      tile[k][tx] = vs;
-      if (r < R) {                                       // row form: the 128-byte h2i block of row r, columns c0 .. c0 + 31
-        f16 a, b;
-        split2h_scaled(vs, a, b);
-        f16* blk = drow + (size_t)r * 2 * C + (size_t)blockIdx.y * 64;
-        blk[tx] = a;
-        blk[32 + tx] = b;
-      }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < R) v = *reinterpret_cast<const float4*>(s + (size_t)r * C + c0 + tq);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    const float vs[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+    tile[tr][tq] = vs[0]; tile[tr][tq + 1] = vs[1]; tile[tr][tq + 2] = vs[2]; tile[tr][tq + 3] = vs[3];
+    if (r < R) {                                         // row form: the 128-byte h2i block of row r, columns c0 .. c0 + 31
+      f16x4 hi, lo;
+      split4(vs, hi, lo);
+      f16* blk = drow + (size_t)r * 2 * C + (size_t)blockIdx.y * 64 + tq;
+      *reinterpret_cast<f16x4*>(blk) = hi;
+      *reinterpret_cast<f16x4*>(blk + 32) = lo;
     }
     __syncthreads();
-    for (int k = ty; k < 32; k += 8) {                   // transposed form: destination row c0 + k, source rows r0 .. r0 + 31
-      f16 a, b;
-      split2h_scaled(tile[tx][k], a, b);
-      f16* blk = dcol + (size_t)(c0 + k) * 2 * Rpad + (size_t)rt * 64;
-      blk[tx] = a;
-      blk[32 + tx] = b;
+    {                                                    // transposed form: destination row c0 + tr, source rows rt 32 + tq .. + 3
+      const float t4[4] = {tile[tq][tr], tile[tq + 1][tr], tile[tq + 2][tr], tile[tq + 3][tr]};
+      f16x4 hi, lo;
+      split4(t4, hi, lo);
+      f16* blk = dcol + (size_t)(c0 + tr) * 2 * Rpad + (size_t)rt * 64 + tq;
+      *reinterpret_cast<f16x4*>(blk) = hi;
+      *reinterpret_cast<f16x4*>(blk + 32) = lo;
     }
   }
   if (colsum) {
-    csum[ty][tx] = acc;
     __syncthreads();
-    if (ty == 0) {
+    csum[tr][tq] = acc.x; csum[tr][tq + 1] = acc.y; csum[tr][tq + 2] = acc.z; csum[tr][tq + 3] = acc.w;
+    __syncthreads();
+    if (threadIdx.x < 32) {
       float t = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) t += csum[j][tx];
-      atomicAdd(colsum + c0 + tx, t);
+#pragma unroll 8
+      for (int j = 0; j < 32; ++j) t += csum[j][threadIdx.x];
+      atomicAdd(colsum + c0 + threadIdx.x, t);
     }
   }
 }

@@ -179,6 +179,10 @@ int d3dp_train_gelu_bwd(const float* dh, const float* x, float* dpre, size_t n, 
 int d3dp_train_scale_mask(const float* in, const float* mask, int axis, int F, int J, float* out, int T, int C,
                           unsigned* amax, hipStream_t st);
 int d3dp_train_colsum(const float* in, float* out, int T, int C, hipStream_t st);
+// zero up to D3DP_ZERO_MAX fp32 buffers in one launch (the small gradient buffers of a backward pass)
+constexpr int D3DP_ZERO_MAX = 192;
+struct D3dpZeroTable { float* p[D3DP_ZERO_MAX]; unsigned n[D3DP_ZERO_MAX]; int count; };
+int d3dp_train_zero_many(const D3dpZeroTable& tb, hipStream_t st);
 int d3dp_train_groupsum(const float* in, float* out, int T, int C, int mode, int F, int J, hipStream_t st);
 int d3dp_train_transpose_pad(const float* in, float* out, int R, int C, int Rpad, hipStream_t st);
 size_t d3dp_train_attn_stats_bytes(int n_seq, int n_tok, int heads);

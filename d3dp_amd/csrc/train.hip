@@ -226,6 +226,12 @@ __global__ __launch_bounds__(256) void scale_mask_kernel(const float* __restrict
   block_amax_commit(m, amax);
 }
 
+__global__ __launch_bounds__(256) void zero_many_kernel(D3dpZeroTable tb) {
+  float* p = tb.p[blockIdx.y];
+  const unsigned n = tb.n[blockIdx.y];
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0.f;
+}
+
 // out[c] += sum_t in[t, c]     (bias grads).  A thread owns four columns (one 16-byte load per row) of one row in four; the
 // four row lanes of a workgroup meet in LDS, so a column receives one atomic per workgroup (gridDim.y of them).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int T, int C) {
@@ -670,6 +676,11 @@ int d3dp_train_scale_mask(const float* in, const float* mask, int axis, int F, i
                           hipStream_t st) {
   if (C % 4 != 0 || T < 1) return -2;
   hipLaunchKernelGGL(scale_mask_kernel, dim3(ew_blocks((size_t)T * C / 4)), dim3(256), 0, st, in, mask, axis, F, J, out, T, C, amax);
+  return 0;
+}
+int d3dp_train_zero_many(const D3dpZeroTable& tb, hipStream_t st) {
+  if (tb.count < 1 || tb.count > D3DP_ZERO_MAX) return -1;
+  hipLaunchKernelGGL(zero_many_kernel, dim3(4, tb.count), dim3(256), 0, st, tb);
   return 0;
 }
 int d3dp_train_colsum(const float* in, float* out, int T, int C, hipStream_t st) {
