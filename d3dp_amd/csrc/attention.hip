@@ -639,29 +639,59 @@ __device__ __forceinline__ void attn_scores_x2_pair(const FragBases& fb, int pla
     k[2] = *reinterpret_cast<const f16x8*>(fb.k0 + t * 2048);           // hi
     k[3] = *reinterpret_cast<const f16x8*>(fb.k1 + t * 2048);
   };
-  // (no register prefetch of the next pair's fragments here, unlike attn_scores_x2: s0 + s1 already hold 128 registers, and
-  //  the four chains leave the scheduler room to start a pair's MFMAs as its first fragments land)
+  // No registers are left for a prefetch of the next pair's fragments (s0 + s1 hold 128).  -DD3DP_ATTN_KPIPE=1 is the
+  // prefetch that needs none -- a pair's lo fragments are dead after its first eight MFMAs and its hi fragments after its
+  // last, so the next pair's are requested into the same registers behind MFMA 8 and MFMA 24 instead of all eight in front
+  // of the pair's MFMAs, where the compiler puts them.  Measured (gpurun a2, interleaved): no difference (625 against
+  // 626 us for the micro-benchmark's repack + kernel) -- the other wave of the SIMD already covers those LDS round trips.
+#ifndef D3DP_ATTN_KPIPE
+#define D3DP_ATTN_KPIPE 0
+#endif
   f16x8 kc[2][4];
-#pragma unroll
-  for (int t = 0; t < NKT; t += 2) {
-    read_k(t, kc[0]);
-    read_k(t + 1, kc[1]);
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, b0 = a0, a1 = a0, b1 = a0;
-    // K fragment index / query operand of the six product terms: Kl.Qh (d 0..31, 32..63), Kh.Ql, Kh.Qh
 #define X2_PAIR_TERM(KI, Q, D)                                                                  \
     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][KI], Q[0][D], a0, 0, 0, 0);               \
     b0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][KI], Q[0][D], b0, 0, 0, 0);               \
     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][KI], Q[1][D], a1, 0, 0, 0);               \
     b1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][KI], Q[1][D], b1, 0, 0, 0);
+  auto read_lo = [&](int t, f16x8 (&k)[4]) {
+    k[0] = *reinterpret_cast<const f16x8*>(fb.k0 + plane + t * 2048);
+    k[1] = *reinterpret_cast<const f16x8*>(fb.k1 + plane + t * 2048);
+  };
+  auto read_hi = [&](int t, f16x8 (&k)[4]) {
+    k[2] = *reinterpret_cast<const f16x8*>(fb.k0 + t * 2048);
+    k[3] = *reinterpret_cast<const f16x8*>(fb.k1 + t * 2048);
+  };
+#if D3DP_ATTN_KPIPE
+  read_k(0, kc[0]);
+  read_k(1, kc[1]);
+#endif
+#pragma unroll
+  for (int t = 0; t < NKT; t += 2) {
+#if !D3DP_ATTN_KPIPE
+    read_k(t, kc[0]);
+    read_k(t + 1, kc[1]);
+#endif
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, b0 = a0, a1 = a0, b1 = a0;
+    // K fragment index / query operand of the six product terms: Kl.Qh (d 0..31, 32..63), Kh.Ql, Kh.Qh
     X2_PAIR_TERM(0, qh, 0)
     X2_PAIR_TERM(1, qh, 1)
+#if D3DP_ATTN_KPIPE
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < NKT) { read_lo(t + 2, kc[0]); read_lo(t + 3, kc[1]); }
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     X2_PAIR_TERM(2, ql, 0)
     X2_PAIR_TERM(3, ql, 1)
     X2_PAIR_TERM(2, qh, 0)
     X2_PAIR_TERM(3, qh, 1)
-#undef X2_PAIR_TERM
+#if D3DP_ATTN_KPIPE
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < NKT) { read_hi(t + 2, kc[0]); read_hi(t + 3, kc[1]); }
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     s0[t] = a0; s0[t + 1] = b0; s1[t] = a1; s1[t + 1] = b1;
   }
+#undef X2_PAIR_TERM
   softmax_split_x2<NKT, MASK_ANY_TILE>(s0, n, lane, ph[0], pl[0], denom[0], cexp);
   softmax_split_x2<NKT, MASK_ANY_TILE>(s1, n, lane, ph[1], pl[1], denom[1], cexp);
 }

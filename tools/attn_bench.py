@@ -14,21 +14,25 @@ def main():
     ap.add_argument("--seqs", type=int, default=15)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--which", default="temporal,spatial")
+    ap.add_argument("--exact", action="store_true", help="the EXACT-mode (split-fp16) kernels on fp32 rows (impl 2) instead of the bf16 ones")
     a = ap.parse_args()
     lib = _lib.load()
     F, J, C, heads = 243, 17, 512, 8
     T = a.seqs * F * J
-    qkv = torch.randn(T, 3 * C, device="cuda").to(torch.bfloat16)
-    out = torch.empty(T, C, device="cuda", dtype=torch.bfloat16)
+    qkv = torch.randn(T, 3 * C, device="cuda")
+    out = torch.empty(T, C, device="cuda")
+    if not a.exact:
+        qkv, out = qkv.to(torch.bfloat16), out.to(torch.bfloat16)
+    act, impl = (0, 2) if a.exact else (1, 1)
     st = torch.cuda.current_stream().cuda_stream
     for name in a.which.split(","):
         axis = 1 if name == "temporal" else 0
         for _ in range(2):
-            _lib.check(lib.d3dp_op_attention(1, 1, axis, qkv.data_ptr(), out.data_ptr(), a.seqs, F, J, C, heads, st))
+            _lib.check(lib.d3dp_op_attention(act, impl, axis, qkv.data_ptr(), out.data_ptr(), a.seqs, F, J, C, heads, st))
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.iters)]
         for e0, e1 in evs:
             e0.record()
-            _lib.check(lib.d3dp_op_attention(1, 1, axis, qkv.data_ptr(), out.data_ptr(), a.seqs, F, J, C, heads, st))
+            _lib.check(lib.d3dp_op_attention(act, impl, axis, qkv.data_ptr(), out.data_ptr(), a.seqs, F, J, C, heads, st))
             e1.record()
         torch.cuda.synchronize()
         ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
