@@ -21,6 +21,17 @@
 #ifndef D3DP_ATTN_PAIR
 #define D3DP_ATTN_PAIR 1     // temporal split-fp16 kernel: both query tiles of a wave share one pass over the K image
 #endif
+// temporal split-fp16 kernel, two tiles per wave: the softmax of one tile between the matrix instructions of the other
+// (tile 0's under tile 1's scores, tile 1's under tile 0's P.V); takes precedence over D3DP_ATTN_PAIR.  Same arithmetic in
+// the same order per element: bit-identical results (the attention tests pass with it).  MEASURED (profiles/r04_attn_timeline.md):
+// the score phase loses 2 k cycles, the P.V phase gains them, and a problem takes 30.55 k cycles in either form -- the time
+// per problem is set by something both forms share, not by where the vector instructions sit.  Off.
+#ifndef D3DP_ATTN_OVERLAP
+#define D3DP_ATTN_OVERLAP 0
+#endif
+#ifndef D3DP_ATTN_OVL_SGB
+#define D3DP_ATTN_OVL_SGB 0  // > 0: ask the scheduler for this many VALU instructions behind every MFMA of an overlapped region
+#endif
 
 namespace {
 
@@ -566,6 +577,154 @@ __device__ __forceinline__ void softmax_split_x2(f32x4 (&s)[NKT], int n, int lan
   denom = sum;                                         // = 1024 x the softmax denominator
 }
 
+// ---- the same softmax in pieces, for the overlapped form of the temporal kernel (D3DP_ATTN_OVERLAP) ------------------------
+// mask + row maximum of a score row -> the exponent bias nb (p x 1024 = exp2(s cexp + nb))
+template <int NKT, bool MASK_ANY_TILE>
+__device__ __forceinline__ float x2_mask_rowmax(f32x4 (&s)[NKT], int n, int lane, float cexp) {
+  const int fg = lane >> 4;
+  if constexpr (!MASK_ANY_TILE) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (16 * (NKT - 1) + 4 * fg + r >= n) s[NKT - 1][r] = -INFINITY;
+  } else {
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * t + 4 * fg + r >= n) s[t][r] = -INFINITY;
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  return fmaf(-mx, cexp, 10.0f);
+}
+// key tiles t, t + 1 (t even) of a masked score row -> one split-fp16 B operand pair; the two partial sums continue the
+// chains of softmax_split_x2 (same order of additions: slices taken in ascending t give the same denominator bit for bit)
+__device__ __forceinline__ void x2_softmax_slice(const f32x4& sa, const f32x4& sb, float nb, float cexp, f16x8& ph, f16x8& pl,
+                                                 float (&sum2)[2]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float y = __builtin_amdgcn_exp2f(fmaf(sa[r], cexp, nb));
+    sum2[r & 1] += y;
+    const f16 h = (f16)y;
+    ph[r] = h;
+    pl[r] = (f16)fmaf(y, 1.0f, -(float)h);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float y = __builtin_amdgcn_exp2f(fmaf(sb[r], cexp, nb));
+    sum2[r & 1] += y;
+    const f16 h = (f16)y;
+    ph[4 + r] = h;
+    pl[4 + r] = (f16)fmaf(y, 1.0f, -(float)h);
+  }
+}
+__device__ __forceinline__ float x2_denominator(const float (&sum2)[2]) {
+  float sum = sum2[0] + sum2[1];
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  return sum;
+}
+// S^T of one query tile (the loop of attn_scores_x2 below); with OVL the softmax slices of ANOTHER tile's finished score row
+// `sp` ride between the MFMAs: the wave's VALU work runs in the shadow of its own matrix instructions instead of after them.
+template <int NKT, bool OVL>
+__device__ __forceinline__ void x2_scores_rows(const FragBases& fb, int plane, const f16x8 (&qh)[2], const f16x8 (&ql)[2],
+                                               f32x4 (&s)[NKT], const f32x4 (&sp)[OVL ? NKT : 1], float nbp, float cexp,
+                                               f16x8 (&php)[OVL ? NKT / 2 : 1], f16x8 (&plp)[OVL ? NKT / 2 : 1], float (&sump)[2]) {
+  auto read_k = [&](int t, f16x8 (&k)[4]) {
+    k[0] = *reinterpret_cast<const f16x8*>(fb.k0 + plane + t * 2048);   // lo, d 0..31
+    k[1] = *reinterpret_cast<const f16x8*>(fb.k1 + plane + t * 2048);   // lo, d 32..63
+    k[2] = *reinterpret_cast<const f16x8*>(fb.k0 + t * 2048);           // hi
+    k[3] = *reinterpret_cast<const f16x8*>(fb.k1 + t * 2048);
+  };
+  f16x8 kc[2][4], kn[2][2];
+  read_k(0, kc[0]);
+  read_k(1, kc[1]);
+#pragma unroll
+  for (int t = 0; t < NKT; t += 2) {
+    if (t + 2 < NKT) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        kn[j][0] = *reinterpret_cast<const f16x8*>(fb.k0 + plane + (t + 2 + j) * 2048);
+        kn[j][1] = *reinterpret_cast<const f16x8*>(fb.k1 + plane + (t + 2 + j) * 2048);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                 // (the reads stay in front of the MFMAs that cover their latency)
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][0], qh[0], a, 0, 0, 0);
+    b = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][0], qh[0], b, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][1], qh[1], a, 0, 0, 0);
+    b = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][1], qh[1], b, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][2], ql[0], a, 0, 0, 0);
+    b = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][2], ql[0], b, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][3], ql[1], a, 0, 0, 0);
+    b = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][3], ql[1], b, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][2], qh[0], a, 0, 0, 0);
+    b = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][2], qh[0], b, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[0][3], qh[1], a, 0, 0, 0);
+    b = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc[1][3], qh[1], b, 0, 0, 0);
+    if constexpr (OVL) {
+      x2_softmax_slice(sp[t], sp[t + 1], nbp, cexp, php[t >> 1], plp[t >> 1], sump);
+#if D3DP_ATTN_OVL_SGB
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {                   // one matrix instruction, then its share of the slice's vector work
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, D3DP_ATTN_OVL_SGB, 0);
+      }
+#endif
+    }
+    s[t] = a; s[t + 1] = b;
+    if (t + 2 < NKT) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        kc[j][0] = kn[j][0]; kc[j][1] = kn[j][1];
+        kc[j][2] = *reinterpret_cast<const f16x8*>(fb.k0 + (t + 2 + j) * 2048);
+        kc[j][3] = *reinterpret_cast<const f16x8*>(fb.k1 + (t + 2 + j) * 2048);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// O^T += V^T P^T of one tile (the pipeline of pv_chunks_x2) with the softmax slices of the OTHER tile's score row `sp` between
+// the MFMAs of each key chunk: chunk c of this product needs this tile's probabilities only, which are complete.
+template <int NKT, int C0>
+__device__ __forceinline__ void x2_pv_overlap_rec(const FragBases& fb, int plane, const f16x8 (&ph)[NKT / 2],
+                                                  const f16x8 (&pl)[NKT / 2], f32x4 (&o)[4], const f16x8 (&vh)[4],
+                                                  const f16x8 (&vl)[4], const f32x4 (&sp)[NKT], float nbp, float cexp,
+                                                  f16x8 (&php)[NKT / 2], f16x8 (&plp)[NKT / 2], float (&sump)[2]) {
+  f16x8 nh[4], nl[4];
+  if constexpr (C0 + 1 < NKT / 2) load_v_frags_x2<C0 + 1>(fb, plane, nh, nl);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[dn], ph[C0], o[dn], 0, 0, 0);
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dn], pl[C0], o[dn], 0, 0, 0);
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[dn], ph[C0], o[dn], 0, 0, 0);
+  x2_softmax_slice(sp[2 * C0], sp[2 * C0 + 1], nbp, cexp, php[C0], plp[C0], sump);
+#if D3DP_ATTN_OVL_SGB
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, D3DP_ATTN_OVL_SGB, 0);
+  }
+#endif
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (C0 + 1 < NKT / 2) x2_pv_overlap_rec<NKT, C0 + 1>(fb, plane, ph, pl, o, nh, nl, sp, nbp, cexp, php, plp, sump);
+}
+template <int NKT>
+__device__ __forceinline__ void x2_pv_overlap(const FragBases& fb, int plane, const f16x8 (&ph)[NKT / 2], const f16x8 (&pl)[NKT / 2],
+                                              f32x4 (&o)[4], const f32x4 (&sp)[NKT], float nbp, float cexp, f16x8 (&php)[NKT / 2],
+                                              f16x8 (&plp)[NKT / 2], float (&sump)[2]) {
+  f16x8 vh[4], vl[4];
+  load_v_frags_x2<0>(fb, plane, vh, vl);
+  x2_pv_overlap_rec<NKT, 0>(fb, plane, ph, pl, o, vh, vl, sp, nbp, cexp, php, plp, sump);
+}
+
 // Scores and softmax of one 16-query tile against NKT 16-key tiles resident in LDS.  fb: fragment bases into the K hi
 // image (the lo image is `plane` bytes further).  qh/ql: the tile's query fragments (d 0..31, 32..63), values x 16.
 // Returns the probabilities as split-fp16 B operands (x 1024) and 1024 x the softmax denominator of query (lane & 15).
@@ -895,7 +1054,36 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
     float denom[TPW];
     // (fragment bases re-derived per phase from the opaque lane id: the four V bases are not live during the scores)
     const FragBases fbk = make_frag_bases(kimg, vimg, opaque(lane));
-    if constexpr (TPW == 2 && D3DP_ATTN_PAIR) {
+    // (not with per-element masks in every key tile -- 225..240 frames on 16 key tiles: their lane masks push the overlapped
+    //  form past 256 registers; those lengths keep the paired form)
+    constexpr bool OVL = TPW == 2 && D3DP_ATTN_OVERLAP && !MASK_ANY_TILE;
+    [[maybe_unused]] f32x4 s1[OVL ? NKT : 1];          // OVL: tile 1's masked score row, turned into probabilities during tile 0's P.V
+    [[maybe_unused]] float nb1 = 0.f;
+    if constexpr (OVL) {
+      f16x8 qh[2][2], ql[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float4 qf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          settle(qr[u][i]);                            // (after the counted wait above)
+          qf[i] = make_float4(qr[u][i][0], qr[u][i][1], qr[u][i][2], qr[u][i][3]);
+        }
+        split8(qf[0], qf[1], qh[u][0], ql[u][0], sc.q);
+        split8(qf[2], qf[3], qh[u][1], ql[u][1], sc.q);
+      }
+      f32x4 s0[NKT];
+      f32x4 none_s[1];
+      f16x8 none_p[1];
+      float sum0[2] = {0.f, 0.f};
+      x2_scores_rows<NKT, false>(fbk, PLANE, qh[0], ql[0], s0, none_s, 0.f, sc.cexp, none_p, none_p, sum0);
+      const float nb0 = x2_mask_rowmax<NKT, MASK_ANY_TILE>(s0, n, lane, sc.cexp);
+      // tile 1's scores (a wave without a second tile computes them on whatever its registers hold and never stores the
+      // result) with tile 0's softmax between the MFMAs
+      x2_scores_rows<NKT, true>(fbk, PLANE, qh[1], ql[1], s1, s0, nb0, sc.cexp, ph[0], pl[0], sum0);
+      denom[0] = x2_denominator(sum0);
+      nb1 = x2_mask_rowmax<NKT, MASK_ANY_TILE>(s1, n, lane, sc.cexp);
+    } else if constexpr (TPW == 2 && D3DP_ATTN_PAIR) {
       {                                                // both query tiles of the wave in one pass over K (a wave whose second
                                                        // tile does not exist computes it on whatever its registers hold and
                                                        // never stores it: one code path, no second register allocation)
@@ -946,8 +1134,20 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
     }
     const int tok0 = seq_base(map, p / heads);
     const FragBases fb = make_frag_bases(kimg, vimg, opaque(lane));
+    if constexpr (OVL) {
+      f32x4 o[4];
 #pragma unroll
-    for (int u = 0; u < TPW; ++u) {
+      for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      float sum1[2] = {0.f, 0.f};
+      x2_pv_overlap<NKT>(fb, PLANE, ph[0], pl[0], o, s1, nb1, sc.cexp, ph[1], pl[1], sum1);
+      denom[1] = x2_denominator(sum1);
+      const int l = opaque(lane);
+      const int q = wave * 16 + (l & 15);
+      if (q < n)
+        store_o_x2<OUTS>(o, inv_scale / denom[0], out_v, (size_t)(tok0 + q * ts), C, head * 64 + (l >> 4) * 4, sc.oplane);
+    }
+#pragma unroll
+    for (int u = OVL ? 1 : 0; u < TPW; ++u) {
       // the next problem's queries: requested before the LAST tile's P.V (with two tiles the probabilities of both are
       // live during the first one's, and 32 more registers there would spill)
       if (u == TPW - 1 && has_next) load_q_raw(row0_n, head_n);

@@ -14,10 +14,11 @@ def main():
     ap.add_argument("--seqs", type=int, default=15)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--which", default="temporal,spatial")
+    ap.add_argument("--joints", type=int, default=17, help="J (temporal sequences gather rows at a stride of J token rows)")
     ap.add_argument("--exact", action="store_true", help="the EXACT-mode (split-fp16) kernels on fp32 rows (impl 2) instead of the bf16 ones")
     a = ap.parse_args()
     lib = _lib.load()
-    F, J, C, heads = 243, 17, 512, 8
+    F, J, C, heads = 243, a.joints, 512, 8
     T = a.seqs * F * J
     qkv = torch.randn(T, 3 * C, device="cuda")
     out = torch.empty(T, C, device="cuda")
