@@ -985,11 +985,9 @@ struct X2Train {
   const TrainLayout& L;
   int n_cu;
   // absmax / unscale slots: the forward pass owns slots 2 l (activation operand) and 2 l + 1 (weight) of its Linear l = 4 block
-  // + {qkv, proj, fc1, fc2} and leaves them for the backward pass of the same step, whose wgrad / dgrad read the same
-  // tensors (the saved or bitwise-recomputed activations, the same weights): 128 of the step's 320 absmax launches are not
-  // repeated.  (A scale leaves a factor 4 of headroom below the fp16 range, so the last-bit differences between the two
-  // LayerNorm kernels that produce norm2's output in the two passes cannot matter.)  The backward pass allocates its own
-  // (the gradients) from kBwdSlot0.
+  // + {qkv, proj, fc1, fc2} and leaves them -- with the operands themselves: the weights' two forms and every activation's
+  // transposed form -- for the backward pass of the same step, whose wgrad / dgrad read the same tensors: 128 of the step's
+  // 320 absmax launches are not repeated.  The backward pass allocates its own (the gradients) from kBwdSlot0.
   static constexpr int kBwdSlot0 = 4096;
   int next = 0;
   unsigned* amax() const { return reinterpret_cast<unsigned*>(ws + L.slots); }

@@ -10,7 +10,7 @@
 #   bench        the driver-style bench line (STEPS / WARMUP)
 #   stats        rocprofv3 --kernel-trace --stats of one bench step -> kernel_stats.md
 #   pmc_gemm     FETCH_SIZE / WRITE_SIZE / MFMA-busy of the qkv Linear inside the denoiser at the bench's own pass sizes
-#   pmc_step     the same counters over every kernel of one step
+#   pmc_step     the same counters over every kernel class of one step (one filtered pass per class and counter group)
 #   gemm         tools/gemm_bench.py micro-benchmark of the four Linear shapes (GEMM_ARGS)
 #   train        tools/train_bench.py
 set -u
@@ -56,15 +56,21 @@ for stage in "$@"; do
       for d in $O/pmc_*_*/; do f=$(find $d -name "*counter_collection.csv" | head -1); echo "== $d"; [ -n "$f" ] && python tools/pmc_summary.py $f gemm | grep -v "^$"; done > $O/pmc.log 2>&1
       find $O -name "*.csv" -size +10M -delete; grep -E "==|FETCH|WRITE|MFMA|GRBM" $O/pmc.log ;;
     pmc_step)
+      # One filtered pass per kernel class and counter group: rocprofv3 7.2 segfaults on this run (batch 16: 60 k dispatches)
+      # unfiltered, with an alternation in the regex, or with a regex that matches all three Linear instantiations at once.
       for mode in ${MODES:-exact}; do
         B="$R/bench.py --steps 1 --warmup 0 --no-profile --numerics $mode $QUICK"
-        ( cd /tmp
-          # (the library's own kernels only: without a filter rocprofv3 7.2 segfaults on this run at --batch 16)
-          KR="gemm|attn_|ln_kernel|ln2_kernel|embed_ln|head_kernel|time_mlp|ddim_|nonfinite"
-          timeout 500 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KR" --output-format csv -d $O/step_${mode}_f -- python $B > $O/step_${mode}_f.log 2>&1
-          timeout 500 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KR" --output-format csv -d $O/step_${mode}_w -- python $B > $O/step_${mode}_w.log 2>&1
-          timeout 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-include-regex "$KR" --output-format csv -d $O/step_${mode}_m -- python $B > $O/step_${mode}_m.log 2>&1 )
-        python tools/pmc_step_summary.py $O/step_pmc_$mode.md $(find $O/step_${mode}_f $O/step_${mode}_w $O/step_${mode}_m -name "*counter_collection.csv") > /dev/null
+        csvs=""
+        i=0
+        for rx in "f16x2_kernelILi0ELi1E" "f16x2_kernelILi2ELi0E" "f16x2_kernelILi1ELi0E" "attn_temporal_x2" "attn_spatial_x2" "ln2_kernel" "ln_kernel<" "embed_ln" "head_kernel"; do
+          i=$((i + 1))
+          for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+            t=$(echo $c | cut -d' ' -f1); d=$O/step_${mode}_${i}_$t
+            ( cd /tmp && timeout 200 rocprofv3 --pmc $c --kernel-include-regex "$rx" --output-format csv -d $d -- python $B > $d.log 2>&1 )
+            f=$(find $d -name "*counter_collection.csv" 2>/dev/null | head -1); [ -n "$f" ] && csvs="$csvs $f" || echo "no counters: $rx $t (see $d.log)"
+          done
+        done
+        python tools/pmc_step_summary.py $O/step_pmc_$mode.md $csvs > /dev/null
         head -14 $O/step_pmc_$mode.md
       done; find $O -name "*.csv" -size +20M -delete ;;
     gemm)
