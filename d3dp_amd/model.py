@@ -451,7 +451,7 @@ class MixSTE2(nn.Module):
 
     def train_arithmetic(self) -> str:
         """What the training step's Linears run on (bench.py reports it next to the step time)."""
-        attn = "fp32 attention (temporal axis: fp32 MFMA forward and backward; spatial axis: VALU)"
+        attn = "fp32 attention (fp32 MFMA: temporal forward, backward of both axes; spatial forward on the VALU)"
         if os.environ.get("D3DP_TRAIN_ATTN_BWD", "")[:1] == "v":
             attn = "fp32 attention (temporal forward on fp32 MFMA, backward on the VALU: D3DP_TRAIN_ATTN_BWD=valu)"
         if os.environ.get("D3DP_TRAIN_IMPL") == "f32":

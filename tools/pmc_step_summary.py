@@ -22,12 +22,16 @@ def main(out, *passes):
     for p in passes:
         rows = list(csv.DictReader(open(p)))
         seen = collections.Counter()
+        part = collections.defaultdict(float)
         for r in rows:
             k = short(r["Kernel_Name"])
-            tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            part[(k, r["Counter_Name"])] += float(r["Counter_Value"])
             seen[(k, r["Counter_Name"])] += 1
-        for (k, c), n in seen.items():
-            calls[k] = max(calls[k], n)
+        for (k, c), v in part.items():
+            if c in tot[k]:
+                continue          # (a kernel matched by the filter of more than one pass -- embed_ln_kernel by "ln_kernel<" -- counts once)
+            tot[k][c] = v
+            calls[k] = max(calls[k], seen[(k, c)])
     ctrs = sorted({c for v in tot.values() for c in v})
     lines = ["| kernel | dispatches | " + " | ".join(ctrs) + " |", "|---|---:|" + "---:|" * len(ctrs)]
     for k in sorted(tot, key=lambda k: -tot[k].get("GRBM_GUI_ACTIVE", tot[k].get("FETCH_SIZE", 0))):
