@@ -1091,6 +1091,42 @@ def test_attention_backward_on_matrix_cores_matches_the_valu_kernels(monkeypatch
     print(f"attention backward, F={Fr}: MFMA vs VALU kernels, worst relative gradient difference {worst:.2e}")
 
 
+def test_training_step_fp32_linears_cross_check(monkeypatch):
+    """D3DP_TRAIN_IMPL=f32 (read when the context is created) keeps the training Linears on the fp32 matrix cores -- the round-1
+    path, left in as the cross-check of the split-fp16 one with its fused operand preparation: loss and every parameter
+    gradient of one step agree between the two to fp32 noise."""
+    Fr, B, cs, dep = 27, 2, 512, 2
+    x2d = torch.from_numpy(synthetic_inputs_2d(921, B, Fr)).cuda()
+    gt = torch.from_numpy(synthetic_noise(922, (B, Fr, 17, 3))) * 0.3
+    gt[:, :, 0] = 0
+    gt = gt.cuda()
+    t = torch.tensor([[30], [700]], dtype=torch.long)
+    noise = torch.from_numpy(synthetic_noise(923, (B, Fr, 17, 3)))
+    res = []
+    for impl in ("f32", None):
+        if impl:
+            monkeypatch.setenv("D3DP_TRAIN_IMPL", impl)
+        else:
+            monkeypatch.delenv("D3DP_TRAIN_IMPL", raising=False)
+        args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
+        m = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=True)
+        m.load_state_dict(make_state_dict(13, cs, dep, Fr), strict=False)
+        m = m.cuda().train()
+        pred = m(x2d, gt, t=t, noise=noise, droppath={})
+        loss = torch.mean(torch.norm(pred - gt, dim=-1))
+        loss.backward(loss.clone().detach())
+        torch.cuda.synchronize()
+        assert ("fp32 MFMA Linears" in m.pose_estimator.train_arithmetic()) == (impl == "f32")
+        res.append((loss.item(), {k: p.grad.double().cpu() for k, p in m.pose_estimator.named_parameters()}))
+    assert abs(res[0][0] - res[1][0]) < 2e-6
+    worst = 0.0
+    for k in res[0][1]:
+        err = (res[0][1][k] - res[1][1][k]).norm().item() / max(res[0][1][k].norm().item(), 1e-30)
+        worst = max(worst, err)
+        assert err < 2e-5, (k, err)
+    print(f"training step, fp32-MFMA Linears vs split-fp16 Linears: worst relative gradient difference {worst:.2e}")
+
+
 def test_bench_launches_its_own_ranks_when_two_gpus_are_visible():
     """`python bench.py --gpus 2` outside a torchrun job re-executes itself as 2 RCCL ranks, checks that the 2-rank
     run on sliced global noise reproduces the 1-rank H=2*H_local run bit for bit, and reports the world size and the

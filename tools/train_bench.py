@@ -1,4 +1,5 @@
-"""One training step of BASELINE configs[4] (B=4, F=243, cs=512, dep=8) in a loop, for rocprofv3 --kernel-trace --stats."""
+"""One training step of BASELINE configs[4] (B=4, F=243, cs=512, dep=8) in a loop, for rocprofv3 --kernel-trace --stats.
+usage: train_bench.py [steps [batch]]"""
 import sys
 from types import SimpleNamespace
 
@@ -16,8 +17,9 @@ m = D3DP(args, KL, KR, is_train=True)
 m.load_state_dict(make_state_dict(7, 512, 8, F), strict=False)
 m = m.cuda().train()
 opt = HipAdamW(m.parameters(), lr=6e-5, weight_decay=0.1)
-x2 = torch.rand(4, F, J, 2, device="cuda") * 2 - 1
-x3 = torch.randn(4, F, J, 3, device="cuda") * 0.3
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+x2 = torch.rand(B, F, J, 2, device="cuda") * 2 - 1
+x3 = torch.randn(B, F, J, 3, device="cuda") * 0.3
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 for i in range(n + 2):
     if i == 2:
@@ -31,4 +33,5 @@ for i in range(n + 2):
     opt.step()
 b.record()
 torch.cuda.synchronize()
-print(f"train step: {a.elapsed_time(b) / n:.2f} ms")
+ms = a.elapsed_time(b) / n
+print(f"train step (B={B}): {ms:.2f} ms = {3 * B * 294.86e9 / ms / 1e9:.1f} TFLOP/s, {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB peak")
