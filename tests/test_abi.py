@@ -136,10 +136,13 @@ def test_header_is_plain_c_and_links():
         assert int(out[0]) == len(names) and int(out[1]) == _lib.ABI_VERSION
 
 
-def test_kernels_with_untracked_loads_do_not_spill(tmp_path):
+@pytest.mark.parametrize("flags", [[], ["-DD3DP_ATTN_OVERLAP=1"], ["-DD3DP_ATTN_KPIPE=1"]],
+                         ids=["default", "overlapped-softmax", "k-fragment-pipeline"])
+def test_kernels_with_untracked_loads_do_not_spill(tmp_path, flags):
     """attn_temporal_x2_kernel prefetches its queries with loads the compiler does not track (inline asm; see
     attention.hip gload16_untracked): a register spill placed right after such a load would save the register before the
-    data has arrived.  The kernel is sized to fit its 256 registers exactly -- hold the build to that."""
+    data has arrived.  The kernel is sized to fit its 256 registers exactly -- hold the build to that, for the default
+    form and for the two measured alternatives kept behind build switches."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -147,7 +150,7 @@ def test_kernels_with_untracked_loads_do_not_spill(tmp_path):
         pytest.skip("no hipcc")
     src = os.path.join(os.path.dirname(_lib.LIB_PATH), "..", "csrc", "attention.hip")
     out = str(tmp_path / "attention.s")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", *flags, "-o", out, src],
                    check=True, capture_output=True, timeout=600)
     text = open(out).read()
     sizes = re.findall(r"\.set (\S*attn_temporal_x2_kernel\S*)\.private_seg_size, (\d+)", text)
