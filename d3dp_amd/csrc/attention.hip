@@ -957,6 +957,12 @@ __device__ __forceinline__ void wait_vmcnt() { __builtin_amdgcn_s_waitcnt((V & 1
 #ifndef D3DP_ATTN_STAMP
 #define D3DP_ATTN_STAMP 0
 #endif
+// timing probes of the temporal split-fp16 kernel (results INVALID): 1 = the output stores, 2 = the query loads, 4 = the K / V
+// LDS-DMA sit behind a condition that is false at run time (the arithmetic stays)
+#ifndef D3DP_ATTN_PROBE
+#define D3DP_ATTN_PROBE 0
+#endif
+#define ATTN_PROBE_OFF(bit) (!(D3DP_ATTN_PROBE & (bit)) || sc.q == -12345.f)
 #if D3DP_ATTN_STAMP
 __device__ unsigned long long d3dp_attn_stamps[4 * 8 * 16 * 8];
 #define ATTN_STAMP(k)                                                                                          \
@@ -1007,8 +1013,10 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
       const int sw = is_v ? (((row >> 1) & 3) << 1) : ((row >> 1) & 7);
       // rows >= n: a copy of the last row (finite values; their scores are masked, their probabilities are 0)
       const char* gj = g + (unsigned)(min(row, n - 1) * ts) * (unsigned)ldb + (((l & 7) ^ sw) << 4);
-      lds_dma16(gj, img + pc * 1024);
-      lds_dma16(gj + 2 * C, img + PLANE + pc * 1024);
+      if (ATTN_PROBE_OFF(4)) {
+        lds_dma16(gj, img + pc * 1024);
+        lds_dma16(gj + 2 * C, img + PLANE + pc * 1024);
+      }
     }
   };
   // raw query fragments of the next problem.  (Not zero-initialised on purpose: the compiler would place the zeroing of
@@ -1020,7 +1028,7 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
       const int qt = wave + u * NW;
-      if (qt < n_qt) {
+      if (qt < n_qt && ATTN_PROBE_OFF(2)) {
         const int l = opaque(lane);
         const int q = qt * 16 + (l & 15);
         const float* qrow = reinterpret_cast<const float*>(row0 + (size_t)min(q, n - 1) * ts * ldb) + head * 64 + (l >> 4) * 8;
@@ -1143,7 +1151,7 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
       denom[1] = x2_denominator(sum1);
       const int l = opaque(lane);
       const int q = wave * 16 + (l & 15);
-      if (q < n)
+      if (q < n && ATTN_PROBE_OFF(1))
         store_o_x2<OUTS>(o, inv_scale / denom[0], out_v, (size_t)(tok0 + q * ts), C, head * 64 + (l >> 4) * 4, sc.oplane);
     }
 #pragma unroll
@@ -1159,7 +1167,7 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
         pv_chunks_x2<NKT, 0>(fb, PLANE, ph[u], pl[u], o);
         const int l = opaque(lane);
         const int q = qt * 16 + (l & 15);
-        if (q < n)
+        if (q < n && ATTN_PROBE_OFF(1))
           store_o_x2<OUTS>(o, inv_scale / denom[u], out_v, (size_t)(tok0 + q * ts), C, head * 64 + (l >> 4) * 4, sc.oplane);
       }
     }
