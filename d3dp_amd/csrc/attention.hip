@@ -1217,6 +1217,200 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// -DD3DP_ATTN_W16=1 (measurement build; not part of the default library): the temporal split-fp16 kernel as SIXTEEN waves
+// of at most 128 registers, one 16-query tile each, the score row in two halves of 128 keys with an online softmax --
+// the form VERDICT r3 item 3 named beside progressive DMA.  Four waves per SIMD instead of two cover each other's LDS and
+// MFMA latencies (profiles/r04_attn_timeline.md: that, not memory and not the vector-instruction count, is what the
+// two-wave form lacks); the price is the order S0, P0.V, S1, P1.V: K(p+1) can only stream in under P1.V and V(p+1) under
+// the next problem's S0, every wave reads the whole K / V image for one tile instead of two, and the probabilities of
+// the first half are formed against the first half's row maximum and rescaled (one more rounding on that half of O and
+// of the denominator: not bit-identical to the two-pass kernel).  256 keys (241..256 frames) only.
+#ifndef D3DP_ATTN_W16
+#define D3DP_ATTN_W16 0
+#endif
+#if D3DP_ATTN_W16
+// S^T of one query tile against HT key tiles, ONE key tile (four fragments, one accumulator chain of six MFMAs) at a time and
+// no register prefetch: the other three waves of the SIMD cover the fragment reads and the chain's latency, and 128
+// registers have room for neither a second tile's fragments nor a prefetch
+template <int HT>
+__device__ __forceinline__ void x2_scores_lean(const FragBases& fb, int plane, const f16x8 (&qh)[2], const f16x8 (&ql)[2],
+                                               f32x4 (&s)[HT]) {
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+    const f16x8 kl0 = *reinterpret_cast<const f16x8*>(fb.k0 + plane + t * 2048);   // lo, d 0..31
+    const f16x8 kl1 = *reinterpret_cast<const f16x8*>(fb.k1 + plane + t * 2048);   // lo, d 32..63
+    const f16x8 kh0 = *reinterpret_cast<const f16x8*>(fb.k0 + t * 2048);           // hi
+    const f16x8 kh1 = *reinterpret_cast<const f16x8*>(fb.k1 + t * 2048);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl0, qh[0], a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl1, qh[1], a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh0, ql[0], a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh1, ql[1], a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh0, qh[0], a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh1, qh[1], a, 0, 0, 0);
+    s[t] = a;
+    if (t & 1) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <int OUTS>
+__global__ __launch_bounds__(1024) void attn_temporal_x2_w16_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
+                                                                    SeqMap map, int C, int heads, size_t plane_elems,
+                                                                    int n_prob, X2Scales sc) {
+  constexpr int NKT = 16, NW = 16, NK = 256, PLANE = NK * 128, HT = NKT / 2;   // HT: key tiles per half
+  __shared__ __attribute__((aligned(16))) char kimg[2 * PLANE];
+  __shared__ __attribute__((aligned(16))) char vimg[2 * PLANE];
+  const int n = map.n_tok;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ts = map.tok_stride;
+  const size_t ldb = (size_t)12 * C;
+  const float inv_scale = sc.onorm;
+  auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
+  auto problem_row0 = [&](int p, int& head) -> const char* {
+    const int seq = p / heads;
+    head = p - seq * heads;
+    return reinterpret_cast<const char*>(qkv) + (size_t)seq_base(map, seq) * ldb;
+  };
+  auto issue_kv = [&](const char* row0, int head, int is_v) {   // pieces wave and wave + 16 of both planes: 4 LDS-DMA
+    const int l = opaque(lane);
+    const char* g = row0 + (is_v ? 8 : 4) * C + head * 128;
+    char* img = is_v ? vimg : kimg;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pc = wave + j * NW;
+      const int row = pc * 8 + (l >> 3);
+      const int sw = is_v ? (((row >> 1) & 3) << 1) : ((row >> 1) & 7);
+      const char* gj = g + (unsigned)(min(row, n - 1) * ts) * (unsigned)ldb + (((l & 7) ^ sw) << 4);
+      lds_dma16(gj, img + pc * 1024);
+      lds_dma16(gj + 2 * C, img + PLANE + pc * 1024);
+    }
+  };
+  // The queries by ORDINARY loads (a spill next to a load the compiler does not track would save stale data, and 128 registers
+  // are spill territory): requested behind K(p+1), raw in 16 registers through the last P.V, split before the output stores.
+  // The compiler waits for them with vmcnt(0), which also covers the older K(p+1) pieces -- landed long before -- and
+  // nothing younger: V(p+1) is issued after that point.
+  auto load_q = [&](const char* row0, int head, float4 (&qv)[4]) {
+    const int l = opaque(lane);
+    const int q = wave * 16 + (l & 15);
+    const float* qrow = reinterpret_cast<const float*>(row0 + (size_t)min(q, n - 1) * ts * ldb) + head * 64 + (l >> 4) * 8;
+    qv[0] = *reinterpret_cast<const float4*>(qrow);
+    qv[1] = *reinterpret_cast<const float4*>(qrow + 4);
+    qv[2] = *reinterpret_cast<const float4*>(qrow + 32);
+    qv[3] = *reinterpret_cast<const float4*>(qrow + 36);
+  };
+  auto rowmax8 = [&](const f32x4 (&s)[HT]) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    return fmaxf(mx, __shfl_xor(mx, 32, 64));
+  };
+
+  int p = blockIdx.x;
+  if (p >= n_prob) return;
+  int head;
+  const char* row0 = problem_row0(p, head);
+  issue_kv(row0, head, 0);
+  f16x8 qh[2], ql[2];
+  {
+    float4 qv[4];
+    load_q(row0, head, qv);
+    split8(qv[0], qv[1], qh[0], ql[0], sc.q);
+    split8(qv[2], qv[3], qh[1], ql[1], sc.q);
+  }
+  issue_kv(row0, head, 1);
+  for (;;) {
+    wait_vmcnt<4>();                                   // K(p) landed; the four V pieces may be in flight
+    __builtin_amdgcn_s_barrier();                      // 1: K image complete
+    f32x4 s[HT];
+    f16x8 ph[HT / 2], pl[HT / 2];
+    f32x4 o[4];
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // ---- first half: keys 0..127   (fragment bases re-derived per phase from the opaque lane id: none stays live across phases)
+    {
+      const FragBases fb = make_frag_bases(kimg, vimg, opaque(lane));
+      x2_scores_lean<HT>(fb, PLANE, qh, ql, s);
+    }
+    const float m0 = rowmax8(s);
+    float lsum[2] = {0.f, 0.f};
+    {
+      const float nb = fmaf(-m0, sc.cexp, 10.0f);
+#pragma unroll
+      for (int t = 0; t < HT; t += 2) x2_softmax_slice(s[t], s[t + 1], nb, sc.cexp, ph[t >> 1], pl[t >> 1], lsum);
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                      // 2: V image complete
+    {
+      const FragBases fb = make_frag_bases(kimg, vimg, opaque(lane));
+      pv_chunk_x2_seq<0>(fb, PLANE, ph[0], pl[0], o);
+      pv_chunk_x2_seq<1>(fb, PLANE, ph[1], pl[1], o);
+      pv_chunk_x2_seq<2>(fb, PLANE, ph[2], pl[2], o);
+      pv_chunk_x2_seq<3>(fb, PLANE, ph[3], pl[3], o);
+    }
+    // ---- second half: keys 128..255 (the tail of the last tile masked)
+    {
+      const FragBases fb = make_frag_bases(kimg + HT * 2048, vimg, opaque(lane));
+      x2_scores_lean<HT>(fb, PLANE, qh, ql, s);
+    }
+    {
+      const int fg = lane >> 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * (NKT - 1) + 4 * fg + r >= n) s[HT - 1][r] = -INFINITY;
+    }
+    const float m = fmaxf(m0, rowmax8(s));
+    __builtin_amdgcn_s_barrier();                      // 3: nobody reads the K image any more
+    const int pn = p + gridDim.x;
+    const bool has_next = pn < n_prob;
+    int head_n = 0;
+    const char* row0_n = row0;
+    float4 qn[4];
+    if (has_next) {
+      row0_n = problem_row0(pn, head_n);
+      issue_kv(row0_n, head_n, 0);
+      load_q(row0_n, head_n, qn);
+    }
+    {
+      const float resc = __builtin_amdgcn_exp2f((m0 - m) * sc.cexp);       // <= 1; exactly 1 where the first half holds the maximum
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) o[dn] *= resc;
+      lsum[0] *= resc; lsum[1] *= resc;
+      const float nb = fmaf(-m, sc.cexp, 10.0f);
+#pragma unroll
+      for (int t = 0; t < HT; t += 2) x2_softmax_slice(s[t], s[t + 1], nb, sc.cexp, ph[t >> 1], pl[t >> 1], lsum);
+    }
+    {
+      const FragBases fb = make_frag_bases(kimg, vimg + 4 * 4096, opaque(lane));
+      pv_chunk_x2_seq<0>(fb, PLANE, ph[0], pl[0], o);
+      pv_chunk_x2_seq<1>(fb, PLANE, ph[1], pl[1], o);
+      pv_chunk_x2_seq<2>(fb, PLANE, ph[2], pl[2], o);
+      pv_chunk_x2_seq<3>(fb, PLANE, ph[3], pl[3], o);
+    }
+    if (has_next) {                                    // (the current queries are dead: the next problem's take their registers)
+      split8(qn[0], qn[1], qh[0], ql[0], sc.q);
+      split8(qn[2], qn[3], qh[1], ql[1], sc.q);
+    }
+    {
+      const float denom = x2_denominator(lsum);
+      const int tok0 = seq_base(map, p / heads);
+      const int l = opaque(lane);
+      const int q = wave * 16 + (l & 15);
+      if (q < n)
+        store_o_x2<OUTS>(o, inv_scale / denom, out_v, (size_t)(tok0 + q * ts), C, head * 64 + (l >> 4) * 4, sc.oplane);
+    }
+    if (!has_next) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // 4: nobody reads the V image any more
+    issue_kv(row0_n, head_n, 1);
+    p = pn; row0 = row0_n; head = head_n;
+  }
+}
+#endif
+
 // spatial axis (<= 32 tokens per sequence): one WAVE per (sequence, head).  The K fragments of its two 16-key tiles are
 // loaded straight from the packed rows into the MFMA operand layout (lane (key, g) <- 2 x 16 contiguous bytes of each K
 // plane); only V goes through LDS (its fragments are transposed reads): a private 8 KiB image (V hi, V lo: 32 rows x
@@ -1351,6 +1545,15 @@ int launch_temporal_x2(const void* qkv, void* out, int n_seq, SeqMap map, int C,
   });
   if (n_wg < 0) return -3;
   const int n_prob = n_seq * heads;
+#if D3DP_ATTN_W16
+  if constexpr (NKT == 16) {
+    if (map.n_tok > 16 * (NKT - 1)) {
+      hipLaunchKernelGGL((attn_temporal_x2_w16_kernel<OUTS>), dim3(n_prob < n_wg ? n_prob : n_wg), dim3(1024), 0, st,
+                         (const float*)qkv, out, map, C, heads, plane, n_prob, sc);
+      return 0;
+    }
+  }
+#endif
   hipLaunchKernelGGL(kern, dim3(n_prob < n_wg ? n_prob : n_wg), dim3(NW * 64), 0, st, (const float*)qkv, out, map, C,
                      heads, plane, n_prob, sc);
   return 0;

@@ -136,8 +136,8 @@ def test_header_is_plain_c_and_links():
         assert int(out[0]) == len(names) and int(out[1]) == _lib.ABI_VERSION
 
 
-@pytest.mark.parametrize("flags", [[], ["-DD3DP_ATTN_OVERLAP=1"], ["-DD3DP_ATTN_KPIPE=1"]],
-                         ids=["default", "overlapped-softmax", "k-fragment-pipeline"])
+@pytest.mark.parametrize("flags", [[], ["-DD3DP_ATTN_OVERLAP=1"], ["-DD3DP_ATTN_KPIPE=1"], ["-DD3DP_ATTN_MIXLO=1", "-DD3DP_ATTN_W16=1"]],
+                         ids=["default", "overlapped-softmax", "k-fragment-pipeline", "mixlo+w16-kernel-compiles"])
 def test_kernels_with_untracked_loads_do_not_spill(tmp_path, flags):
     """attn_temporal_x2_kernel prefetches its queries with loads the compiler does not track (inline asm; see
     attention.hip gload16_untracked): a register spill placed right after such a load would save the register before the
