@@ -424,3 +424,23 @@ def test_skewed_linear_schedule_covers_every_tile_exactly_once(tm, tiles_n, G, N
         Q = G // tiles_n
         rg = next(r for r in range(Q) if r * tm // Q <= tile < (r + 1) * tm // Q)
         assert all(jc == jw == tile - rg * tm // Q for (_, jc, jw, _) in contrib)
+
+
+def test_step_counter_summary_counts_a_kernel_once(tmp_path):
+    """tools/pmc_step_summary.py merges one rocprofv3 counter CSV per kernel class; a kernel matched by the filters of two
+    passes (embed_ln_kernel by "ln_kernel<") must not be added twice (round 4: it was, +0.5 % on the step's HBM bytes)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pmc_step_summary", os.path.join(root, "tools", "pmc_step_summary.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    head = "Kernel_Name,Counter_Name,Counter_Value\n"
+    a = tmp_path / "a.csv"
+    b = tmp_path / "b.csv"
+    a.write_text(head + "ln_kernel<512>(float*),FETCH_SIZE,10\nln_kernel<512>(float*),FETCH_SIZE,12\nembed_ln_kernel<512>(float*),FETCH_SIZE,5\n")
+    b.write_text(head + "embed_ln_kernel<512>(float*),FETCH_SIZE,5\nembed_ln_kernel<512>(float*),WRITE_SIZE,7\n")
+    out = tmp_path / "out.md"
+    mod.main(str(out), str(a), str(b))
+    rows = {l.split("|")[1].strip().strip("`"): [c.strip() for c in l.split("|")[2:-1]] for l in out.read_text().splitlines()[2:]}
+    assert rows["ln_kernel<512>"] == ["2", "22", "0"]
+    assert rows["embed_ln_kernel<512>"] == ["1", "5", "7"]
