@@ -58,9 +58,14 @@ __device__ __forceinline__ void ld_vec(const T* p, float* v) {
 
 // OUT3: write the result as three split-bf16 planes (`plane` elements apart) instead of T -- the A operand
 // format of the bf16x3 EXACT-mode Linear.
+// Any sequence length: a thread owns the query rows row, row + TPP, ... of its problem, and K / V pass through LDS in
+// chunks of `kchunk` keys under the online softmax (one chunk = the whole sequence up to 256 tokens, which is every BASELINE
+// configuration; longer clips -- `-f 351`, reference common/arguments.py:58 -- run here instead of being refused).
+// amax (optional): absmax of the fp32 output, one atomicMax per workgroup (the training step's proj operand scale).
 template <typename T, int HD, int TPP, int OUTS>   // OUTS: 0 = T out, 3 = three split-bf16 planes, 2 = two split-fp16 planes
 __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qkv, void* __restrict__ out_v, int n_prob,
-                                                        SeqMap map, int C, int heads, size_t plane) {
+                                                        SeqMap map, int C, int heads, size_t plane, int kchunk,
+                                                        unsigned* __restrict__ amax) {
   constexpr int PPB = 256 / TPP;
   constexpr int VN = Vec16<T>::N;                 // elements per 16-byte vector
   constexpr int LDR = HD + VN;                    // padded LDS row (elements)
@@ -76,141 +81,158 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qk
   const bool live = pid < n_prob;
   const int seq = live ? pid / heads : 0, head = live ? pid % heads : 0;
   const int base = seq_base(map, seq);
-  T* Ks = smem + (size_t)lp * 2 * n * LDR;
-  T* Vs = Ks + (size_t)n * LDR;
-
-  if (live) {
-    for (int u = row; u < n * CH; u += TPP) {
-      const int j = u / CH, c = u % CH;
-      const T* src = qkv + (size_t)(base + j * map.tok_stride) * 3 * C + C + head * HD + c * VN;
-      *reinterpret_cast<float4*>(Ks + j * LDR + c * VN) = *reinterpret_cast<const float4*>(src);
-      *reinterpret_cast<float4*>(Vs + j * LDR + c * VN) = *reinterpret_cast<const float4*>(src + C);
-    }
-  }
-  __syncthreads();
-  if (!live || row >= n) return;
-
-  const size_t tok = (size_t)(base + row * map.tok_stride);
-  float q[HD], o[HD];
-#pragma unroll
-  for (int c = 0; c < CH; ++c) ld_vec<T, VN>(qkv + tok * 3 * C + head * HD + c * VN, q + c * VN);
-#pragma unroll
-  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+  T* Ks = smem + (size_t)lp * 2 * kchunk * LDR;
+  T* Vs = Ks + (size_t)kchunk * LDR;
   const float scale = 1.0f / sqrtf((float)HD);
-  float m = -INFINITY, l = 0.f;
-  // online softmax over groups of KB keys: KB independent score accumulators per pass (the dot products are latency
-  // chains; with one wave per SIMD in the 243-key configuration nothing else hides them)
-  constexpr int KB = 4;
-  for (int j0 = 0; j0 < n; j0 += KB) {
-    float sc[KB];
+  float am = 0.f;
+
+  for (int q0 = 0; q0 < n; q0 += TPP) {
+    const bool act = live && q0 + row < n;
+    const size_t tok = (size_t)(base + (act ? q0 + row : 0) * map.tok_stride);
+    float q[HD], o[HD];
 #pragma unroll
-    for (int u = 0; u < KB; ++u) sc[u] = 0.f;
+    for (int c = 0; c < CH; ++c) ld_vec<T, VN>(qkv + tok * 3 * C + head * HD + c * VN, q + c * VN);
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < n; k0 += kchunk) {
+      const int nk = min(kchunk, n - k0);
+      if (k0 > 0 || q0 > 0) __syncthreads();          // every thread is done with the chunk the images still hold
+      if (live) {
+        for (int u = row; u < nk * CH; u += TPP) {
+          const int j = u / CH, c = u % CH;
+          const T* src = qkv + (size_t)(base + (k0 + j) * map.tok_stride) * 3 * C + C + head * HD + c * VN;
+          *reinterpret_cast<float4*>(Ks + j * LDR + c * VN) = *reinterpret_cast<const float4*>(src);
+          *reinterpret_cast<float4*>(Vs + j * LDR + c * VN) = *reinterpret_cast<const float4*>(src + C);
+        }
+      }
+      __syncthreads();
+      if (!act) continue;
+      // online softmax over groups of KB keys: KB independent score accumulators per pass (the dot products are latency
+      // chains; with one wave per SIMD in the 243-key configuration nothing else hides them)
+      constexpr int KB = 4;
+      for (int j0 = 0; j0 < nk; j0 += KB) {
+        float sc[KB];
 #pragma unroll
-      for (int u = 0; u < KB; ++u) {
-        const int j = min(j0 + u, n - 1);
-        float kv[VN];
-        ld_vec<T, VN>(Ks + j * LDR + c * VN, kv);
+        for (int u = 0; u < KB; ++u) sc[u] = 0.f;
 #pragma unroll
-        for (int e = 0; e < VN; ++e) sc[u] = fmaf(q[c * VN + e], kv[e], sc[u]);
+        for (int c = 0; c < CH; ++c) {
+#pragma unroll
+          for (int u = 0; u < KB; ++u) {
+            const int j = min(j0 + u, nk - 1);
+            float kv[VN];
+            ld_vec<T, VN>(Ks + j * LDR + c * VN, kv);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) sc[u] = fmaf(q[c * VN + e], kv[e], sc[u]);
+          }
+        }
+        float gm = m;
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+          sc[u] = (j0 + u < nk) ? sc[u] * scale : -INFINITY;
+          gm = fmaxf(gm, sc[u]);
+        }
+        if (gm > m) {
+          const float f = expf(m - gm);
+          l *= f;
+#pragma unroll
+          for (int d = 0; d < HD; ++d) o[d] *= f;
+          m = gm;
+        }
+        float p[KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) { p[u] = expf(sc[u] - m); l += p[u]; }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+#pragma unroll
+          for (int u = 0; u < KB; ++u) {
+            const int j = min(j0 + u, nk - 1);
+            float vv[VN];
+            ld_vec<T, VN>(Vs + j * LDR + c * VN, vv);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) o[c * VN + e] = fmaf(p[u], vv[e], o[c * VN + e]);
+          }
+        }
       }
     }
-    float gm = m;
+    if (!act) continue;
+    const float inv = 1.0f / l;
+    if constexpr (OUTS == 2) {
+      f16* dst = reinterpret_cast<f16*>(out_v) + (size_t)tok * (2 * C);   // h2i row (common.h)
 #pragma unroll
-    for (int u = 0; u < KB; ++u) {
-      sc[u] = (j0 + u < n) ? sc[u] * scale : -INFINITY;
-      gm = fmaxf(gm, sc[u]);
-    }
-    if (gm > m) {
-      const float f = expf(m - gm);
-      l *= f;
+      for (int c = 0; c < HD / 4; ++c) {
+        f16x4 p0, p1;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) o[d] *= f;
-      m = gm;
-    }
-    float p[KB];
+        for (int e = 0; e < 4; ++e) {
+          f16 a0, a1;
+          split2h(o[c * 4 + e] * inv, a0, a1);
+          p0[e] = a0; p1[e] = a1;
+        }
+        const int hc = h2i_col(head * HD + c * 4);
+        *reinterpret_cast<f16x4*>(dst + hc) = p0;
+        *reinterpret_cast<f16x4*>(dst + hc + kH2iLo) = p1;
+      }
+    } else if constexpr (OUTS == 3) {
+      bf16* dst = reinterpret_cast<bf16*>(out_v) + tok * C + head * HD;
 #pragma unroll
-    for (int u = 0; u < KB; ++u) { p[u] = expf(sc[u] - m); l += p[u]; }
+      for (int c = 0; c < HD / 4; ++c) {
+        bf16x4 p0, p1, p2;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
+        for (int e = 0; e < 4; ++e) {
+          bf16 a0, a1, a2;
+          split3(o[c * 4 + e] * inv, a0, a1, a2);
+          p0[e] = a0; p1[e] = a1; p2[e] = a2;
+        }
+        *reinterpret_cast<bf16x4*>(dst + c * 4) = p0;
+        *reinterpret_cast<bf16x4*>(dst + plane + c * 4) = p1;
+        *reinterpret_cast<bf16x4*>(dst + 2 * plane + c * 4) = p2;
+      }
+    } else {
+      T* dst = reinterpret_cast<T*>(out_v) + tok * C + head * HD;
 #pragma unroll
-      for (int u = 0; u < KB; ++u) {
-        const int j = min(j0 + u, n - 1);
-        float vv[VN];
-        ld_vec<T, VN>(Vs + j * LDR + c * VN, vv);
+      for (int c = 0; c < CH; ++c) {
+        float r[VN];
 #pragma unroll
-        for (int e = 0; e < VN; ++e) o[c * VN + e] = fmaf(p[u], vv[e], o[c * VN + e]);
+        for (int e = 0; e < VN; ++e) { r[e] = o[c * VN + e] * inv; am = fmaxf(am, fabsf(r[e])); }
+        if constexpr (VN == 4) *reinterpret_cast<float4*>(dst + c * 4) = make_float4(r[0], r[1], r[2], r[3]);
+        else store8(reinterpret_cast<bf16*>(dst) + c * 8, r);
       }
     }
   }
-  const float inv = 1.0f / l;
-  if constexpr (OUTS == 2) {
-    f16* dst = reinterpret_cast<f16*>(out_v) + (size_t)tok * (2 * C);   // h2i row (common.h)
-#pragma unroll
-    for (int c = 0; c < HD / 4; ++c) {
-      f16x4 p0, p1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        f16 a0, a1;
-        split2h(o[c * 4 + e] * inv, a0, a1);
-        p0[e] = a0; p1[e] = a1;
-      }
-      const int hc = h2i_col(head * HD + c * 4);
-      *reinterpret_cast<f16x4*>(dst + hc) = p0;
-      *reinterpret_cast<f16x4*>(dst + hc + kH2iLo) = p1;
-    }
-  } else if constexpr (OUTS == 3) {
-    bf16* dst = reinterpret_cast<bf16*>(out_v) + tok * C + head * HD;
-#pragma unroll
-    for (int c = 0; c < HD / 4; ++c) {
-      bf16x4 p0, p1, p2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        bf16 a0, a1, a2;
-        split3(o[c * 4 + e] * inv, a0, a1, a2);
-        p0[e] = a0; p1[e] = a1; p2[e] = a2;
-      }
-      *reinterpret_cast<bf16x4*>(dst + c * 4) = p0;
-      *reinterpret_cast<bf16x4*>(dst + plane + c * 4) = p1;
-      *reinterpret_cast<bf16x4*>(dst + 2 * plane + c * 4) = p2;
-    }
-  } else {
-    T* dst = reinterpret_cast<T*>(out_v) + tok * C + head * HD;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      float r[VN];
-#pragma unroll
-      for (int e = 0; e < VN; ++e) r[e] = o[c * VN + e] * inv;
-      if constexpr (VN == 4) *reinterpret_cast<float4*>(dst + c * 4) = make_float4(r[0], r[1], r[2], r[3]);
-      else store8(reinterpret_cast<bf16*>(dst) + c * 8, r);
-    }
+  if (amax) {
+    __shared__ float part_amax[4];
+    am = wave_max(am);
+    if ((threadIdx.x & 63) == 0) part_amax[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      atomicMax(amax, __float_as_uint(fmaxf(fmaxf(part_amax[0], part_amax[1]), fmaxf(part_amax[2], part_amax[3]))));
   }
 }
 
 template <typename T, int HD, int TPP, int OUTS>
-int launch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, hipStream_t st) {
+int launch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, unsigned* amax, hipStream_t st) {
   constexpr int PPB = 256 / TPP;
   constexpr int LDR = HD + Vec16<T>::N;
   const int n_prob = n_seq * heads;
-  const size_t lds = (size_t)PPB * 2 * map.n_tok * LDR * sizeof(T);
+  const int kchunk = map.n_tok < 256 ? map.n_tok : 256;
+  const size_t lds = (size_t)PPB * 2 * kchunk * LDR * sizeof(T);
   if (lds > 160 * 1024) return -2;
   auto kern = attn_rows_kernel<T, HD, TPP, OUTS>;
   static PerDeviceOnce once;                          // (one per template instantiation = per kernel)
   if (once.get([&](int) { return d3dp_lds_opt_in(reinterpret_cast<const void*>(kern), 160 * 1024); }) < 0) return -3;
   hipLaunchKernelGGL(kern, dim3((n_prob + PPB - 1) / PPB), dim3(256), lds, st, (const T*)qkv, out, n_prob, map, C, heads,
-                     plane);
+                     plane, kchunk, amax);
   return 0;
 }
 
 template <typename T, int OUTS>
-int dispatch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, hipStream_t st) {
+int dispatch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, unsigned* amax, hipStream_t st) {
   const int hd = C / heads;
   const bool small = map.n_tok <= 32;
-  if (map.n_tok > 256) return -2;
+  if (map.n_tok < 1) return -2;
 #define ROWS_CASE(HD_)                                                                                          \
-  case HD_: return small ? launch_rows<T, HD_, 32, OUTS>(qkv, out, n_seq, map, C, heads, plane, st)             \
-                         : launch_rows<T, HD_, 256, OUTS>(qkv, out, n_seq, map, C, heads, plane, st);
+  case HD_: return small ? launch_rows<T, HD_, 32, OUTS>(qkv, out, n_seq, map, C, heads, plane, amax, st)       \
+                         : launch_rows<T, HD_, 256, OUTS>(qkv, out, n_seq, map, C, heads, plane, amax, st);
   switch (hd) {
     ROWS_CASE(64) ROWS_CASE(32) ROWS_CASE(16) ROWS_CASE(8)
     default: return -2;
@@ -1727,12 +1749,15 @@ int launch_temporal2(const void* qkv, void* out, int n_seq, SeqMap map, int C, i
 }  // namespace
 
 // act: 0 = fp32 in/out, 1 = bf16 in/out, 2 = fp32 in, split-bf16 planes out, 3 = fp32 in, split-fp16 planes out
-int d3dp_launch_attn_rows(int act, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st) {
+// (amax: fp32 output only -- its absmax, see the kernel)
+int d3dp_launch_attn_rows(int act, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, hipStream_t st,
+                          unsigned* amax) {
   const size_t plane = (size_t)n_seq * map.n_tok * C;
-  if (act == 1) return dispatch_rows<bf16, 0>(qkv, out, n_seq, map, C, heads, plane, st);
-  if (act == 2) return dispatch_rows<float, 3>(qkv, out, n_seq, map, C, heads, plane, st);
-  if (act == 3) return dispatch_rows<float, 2>(qkv, out, n_seq, map, C, heads, plane, st);
-  return dispatch_rows<float, 0>(qkv, out, n_seq, map, C, heads, plane, st);
+  if (act != 0 && amax) return -1;
+  if (act == 1) return dispatch_rows<bf16, 0>(qkv, out, n_seq, map, C, heads, plane, nullptr, st);
+  if (act == 2) return dispatch_rows<float, 3>(qkv, out, n_seq, map, C, heads, plane, nullptr, st);
+  if (act == 3) return dispatch_rows<float, 2>(qkv, out, n_seq, map, C, heads, plane, nullptr, st);
+  return dispatch_rows<float, 0>(qkv, out, n_seq, map, C, heads, plane, amax, st);
 }
 
 int d3dp_launch_attn_temporal_bf16(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,

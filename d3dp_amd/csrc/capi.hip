@@ -126,7 +126,10 @@ struct d3dp_ctx {
   bool train() const { return cfg.mode == D3DP_MODE_TRAIN; }
   bool exact() const { return !fast() && !train(); }
   bool x2() const { return exact() && exact_impl == 0; }
-  bool x2_attn() const { return x2() && cfg.channels / cfg.heads == 64; }   // split-fp16 attention kernels (head dim 64)
+  // split-fp16 attention kernels: head dim 64 and a temporal sequence that fits their LDS images (<= 256 frames: every BASELINE
+  // configuration).  Longer clips (`-f 351`, reference common/arguments.py:58, mixste.py:172) keep the split-fp16 Linears and
+  // take the chunked fp32 row kernel for both attentions (attention.hip attn_rows_kernel): slower, same tolerance.
+  bool x2_attn() const { return x2() && cfg.channels / cfg.heads == 64 && cfg.frames <= 256; }
   // proj / fc2 add into the residual stream in their epilogue (x += ...), so the row kernels read x alone
   bool fold_resid() const { return x2() && fold; }
   bool fold = true;
@@ -284,10 +287,10 @@ int attention(d3dp_ctx* c, int axis, const void* qkv, void* out, int n_bh, float
     return d3dp_launch_attn_rows(c->act(), qkv, out, n_bh * g.frames, spatial_map(g.frames, g.joints), g.channels,
                                  g.heads, st);
   }
-  if (c->fast() && g.channels / g.heads == 64)
+  if (c->fast() && g.channels / g.heads == 64 && g.frames <= 256)
     return d3dp_launch_attn_temporal_bf16(qkv, out, n_bh * g.joints, temporal_map(g.frames, g.joints), g.channels,
                                           g.heads, st);
-  if (c->exact() && g.channels / g.heads == 64)     // fp32 matrix cores
+  if (c->exact() && g.channels / g.heads == 64 && g.frames <= 256)     // fp32 matrix cores
     return d3dp_launch_attn_temporal_f32(c->act(), qkv, out, n_bh * g.joints, temporal_map(g.frames, g.joints),
                                          g.channels, g.heads, st);
   return d3dp_launch_attn_rows(c->act(), qkv, out, n_bh * g.joints, temporal_map(g.frames, g.joints), g.channels,
@@ -336,6 +339,8 @@ int run_block(d3dp_ctx* c, const BlockDev& w, int axis, float* x, void* y1, void
 extern "C" {
 
 int d3dp_abi_version(void) { return D3DP_ABI_VERSION; }
+// test hook (not part of the ABI in include/d3dp_hip.h): 1 if this library carries the experiment kernels of gemm_x2.hip
+int d3dp_debug_x2_variants(void) { return d3dp_x2_variants_built() ? 1 : 0; }
 const char* d3dp_last_error(void) { return g_err.c_str(); }
 const char* d3dp_profile_class_name(int32_t cls) {
   return (cls >= 0 && cls < D3DP_PROFILE_CLASSES) ? kClassNames[cls] : "";
@@ -344,7 +349,8 @@ const char* d3dp_profile_class_name(int32_t cls) {
 int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   if (!cfg || !out) return fail(D3DP_EINVAL, "d3dp_create: null argument");
   const d3dp_cfg& g = *cfg;
-  if (g.frames < 1 || g.frames > 256) return fail(D3DP_ENOTSUP, "frames=%d not in [1,256]", g.frames);
+  // (frames > 256: no MFMA attention kernel holds the sequence; both attentions then run the chunked fp32 row kernel)
+  if (g.frames < 1 || g.frames > 1024) return fail(D3DP_ENOTSUP, "frames=%d not in [1,1024]", g.frames);
   if (g.joints < 1 || g.joints > 32) return fail(D3DP_ENOTSUP, "joints=%d not in [1,32]", g.joints);
   if (g.channels != 64 && g.channels != 128 && g.channels != 256 && g.channels != 512)
     return fail(D3DP_ENOTSUP, "channels=%d not in {64,128,256,512}", g.channels);
@@ -364,18 +370,31 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->exact_impl = c->exact_impl_req = (xf && !strcmp(xf, "bf16x3")) ? 1 : (xf && !strcmp(xf, "f32")) ? 2 : 0;
   const char* nf = getenv("D3DP_NO_FOLD");               // cross-check: residual adds (and norm2) in the row kernels
   c->fold = !(nf && nf[0] == '1');
-  const char* sk = getenv("D3DP_X2_SKEW");               // 1, 2, 4: the skewed schedule of the EXACT qkv / fc1 Linears (0 / unset: plain)
-  if (sk && (sk[0] == '0' || sk[0] == '1' || sk[0] == '2' || sk[0] == '4') && sk[1] == 0) c->skew_d = sk[0] - '0';
   const char* ti = getenv("D3DP_TRAIN_IMPL");
   c->train_x2 = !(ti && !strcmp(ti, "f32"));
-  const char* pp = getenv("D3DP_X2_PP");
-  if (pp && (pp[0] == '0' || pp[0] == '1') && pp[1] == 0) c->pingpong = pp[0] - '0';
-  const char* wide = getenv("D3DP_X2_WIDE");           // D3DP_X2_WIDE=1: the 256 x 256 tile form (bit-identical results)
-  if (wide && wide[0] == '1' && wide[1] == 0) c->pingpong = 2;
-  const char* pd = getenv("D3DP_SEQ_PAD");
-  if (pd && (pd[0] == '0' || pd[0] == '1') && pd[1] == 0) c->pad_override = pd[0] - '0';
-  const char* nl = getenv("D3DP_FOLD_LN");               // norm2 folded into proj / fc1 instead of its own row kernel
-  c->fold_ln_on = nl && nl[0] == '1';
+  {
+    // Measurement switches of experiments that were measured and not adopted: the row-class skewed schedule
+    // (D3DP_X2_SKEW=1|2|4), the ping-pong (D3DP_X2_PP=1) and wide (D3DP_X2_WIDE=1) forms of the EXACT Linear, norm2 folded into
+    // proj / fc1 (D3DP_FOLD_LN=1), the sequence padding the skewed schedule needs (D3DP_SEQ_PAD).  Their kernels exist only in a
+    // library built with -DD3DP_X2_VARIANTS=1 (`make variants`): the product library refuses the request instead of ignoring it.
+    const char* sk = getenv("D3DP_X2_SKEW");
+    const char* pp = getenv("D3DP_X2_PP");
+    const char* wide = getenv("D3DP_X2_WIDE");
+    const char* pd = getenv("D3DP_SEQ_PAD");
+    const char* nl = getenv("D3DP_FOLD_LN");
+    int skew_d = 0, pingpong = 0, pad = -1;
+    if (sk && (sk[0] == '0' || sk[0] == '1' || sk[0] == '2' || sk[0] == '4') && sk[1] == 0) skew_d = sk[0] - '0';
+    if (pp && (pp[0] == '0' || pp[0] == '1') && pp[1] == 0) pingpong = pp[0] - '0';
+    if (wide && wide[0] == '1' && wide[1] == 0) pingpong = 2;
+    if (pd && (pd[0] == '0' || pd[0] == '1') && pd[1] == 0) pad = pd[0] - '0';
+    const bool fold_ln = nl && nl[0] == '1';
+    if ((skew_d || pingpong || pad > 0 || fold_ln) && !d3dp_x2_variants_built()) {
+      delete c;
+      return fail(D3DP_ENOTSUP, "D3DP_X2_SKEW / D3DP_X2_PP / D3DP_X2_WIDE / D3DP_SEQ_PAD / D3DP_FOLD_LN select experiment kernels that this "
+                                "library was built without (make -C d3dp_amd/csrc variants; D3DP_LIB=d3dp_amd/lib/variants/libd3dp_variants.so)");
+    }
+    c->skew_d = skew_d; c->pingpong = pingpong; c->pad_override = pad; c->fold_ln_on = fold_ln;
+  }
   HIP_TRY(hipGetDevice(&c->device));
   {
     hipDeviceProp_t prop;
@@ -417,25 +436,29 @@ int d3dp_set_weights(d3dp_ctx* c, const d3dp_weights* w, void* stream) {
   // six-pass split-bf16 implementation, which has fp32's exponent range.
   c->range_bound = 0.f;
   c->impl_fallback = false;
+  c->plan_total = -1;            // the pass plan depends on the implementation chosen below (x2-tuned or uniform passes)
   std::vector<float> blk_scale(4 * (size_t)g.depth, kActScale);      // [kind][d][s_kv, s_h]
   if (c->exact() && c->exact_impl_req == 0) {
     c->exact_impl = 0;
     const size_t nb = 2 * (size_t)g.depth;
     unsigned* dbound = nullptr;
-    HIP_TRY(hipMalloc((void**)&dbound, nb * 4 * sizeof(unsigned)));
+    HIP_TRY(hipMalloc((void**)&dbound, nb * 6 * sizeof(unsigned)));
     struct Free { unsigned* p; ~Free() { (void)hipFree(p); } } free_dbound{dbound};
-    HIP_TRY(hipMemsetAsync(dbound, 0, nb * 4 * sizeof(unsigned), st));
+    HIP_TRY(hipMemsetAsync(dbound, 0, nb * 6 * sizeof(unsigned), st));
     for (int kind = 0; kind < 2; ++kind)
       for (int d = 0; d < g.depth; ++d) {
         const d3dp_block_weights& b = (kind == 0 ? w->ste : w->tte)[d];
-        if (!b.norm1_w || !b.norm1_b || !b.qkv_w || !b.qkv_b || !b.norm2_w || !b.norm2_b || !b.fc1_w || !b.fc1_b)
+        if (!b.norm1_w || !b.norm1_b || !b.qkv_w || !b.qkv_b || !b.norm2_w || !b.norm2_b || !b.fc1_w || !b.fc1_b || !b.proj_w ||
+            !b.fc2_w)
           return fail(D3DP_EINVAL, "d3dp_set_weights: a weight pointer is null");
-        unsigned* o = dbound + ((size_t)kind * g.depth + d) * 4;
+        unsigned* o = dbound + ((size_t)kind * g.depth + d) * 6;
         d3dp_launch_rowbound(b.qkv_w, b.norm1_w, b.norm1_b, b.qkv_b, 3 * (int)C, (int)C, o, st);       // o[0] q/k/v, o[1] LN1 out
         d3dp_launch_rowbound(b.fc1_w, b.norm2_w, b.norm2_b, b.fc1_b, (int)Hd, (int)C, o + 2, st);      // o[2] hidden, o[3] LN2 out
+        d3dp_launch_absmax(b.proj_w, C * C, o + 4, st);                                                // o[4], o[5]: the two matrices
+        d3dp_launch_absmax(b.fc2_w, C * Hd, o + 5, st);                                                // no bound reads (inf check)
       }
-    std::vector<float> hb(nb * 4);
-    HIP_TRY(hipMemcpyAsync(hb.data(), dbound, nb * 4 * sizeof(float), hipMemcpyDeviceToHost, st));
+    std::vector<float> hb(nb * 6);
+    HIP_TRY(hipMemcpyAsync(hb.data(), dbound, nb * 6 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const float kSafe = 65504.0f / kActScale;           // 4094: what 2^4 holds
     auto pick = [&](float bound) {                       // largest power of two <= 2^4 with bound x scale < 65504
@@ -446,8 +469,16 @@ int d3dp_set_weights(d3dp_ctx* c, const d3dp_weights* w, void* stream) {
     float worst = 0.f;
     bool fallback = false;
     for (size_t i = 0; i < nb; ++i) {
-      const float bq = hb[4 * i], bl1 = hb[4 * i + 1], bh = hb[4 * i + 2], bl2 = hb[4 * i + 3];
-      if (!(bq < INFINITY) || !(bh < INFINITY)) return fail(D3DP_EINVAL, "d3dp_set_weights: a weight tensor holds inf/nan");
+      const float bq = hb[6 * i], bl1 = hb[6 * i + 1], bh = hb[6 * i + 2], bl2 = hb[6 * i + 3];
+      // Non-finite weights (a diverged checkpoint): ONE behaviour whichever tensor holds them -- the context moves
+      // to the split-bf16 implementation, which has fp32's range and carries inf / nan through like the reference's fp32
+      // kernels do; the output is then non-finite where the reference's is and d3dp_status reports it.  Never an error here.
+      if (!(bq < INFINITY) || !(bh < INFINITY) || !(bl1 < INFINITY) || !(bl2 < INFINITY) || !(hb[6 * i + 4] < INFINITY) ||
+          !(hb[6 * i + 5] < INFINITY)) {
+        fallback = true;
+        worst = INFINITY;
+        continue;
+      }
       worst = std::max(worst, std::max(std::max(bq, bh), std::max(bl1, bl2)));
       if (!(bl1 < kSafe) || !(bl2 < kSafe)) fallback = true;
       if (!(bq < kSafe) && !c->x2_attn()) fallback = true;
@@ -811,6 +842,9 @@ int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* 
   if (!A2 || !W2 || !bias || !out || !(w_scale > 0.f)) return fail(D3DP_EINVAL, "d3dp_op_linear_x2: bad argument");
   const int skew_d = (epi >> 8) & 7;                     // epi | (D << 8), D = 1, 2, 4: the skewed schedule (epi 1 and 4)
   const int pingpong = (epi >> 12) & 1 ? 2 : (epi >> 11) & 1;   // epi | 2048: the ping-pong form, | 4096: the wide form (bit-identical results)
+  if ((skew_d || pingpong) && !d3dp_x2_variants_built())
+    return fail(D3DP_ENOTSUP, "d3dp_op_linear_x2: epi flags %d select an experiment kernel this library was built without "
+                              "(make -C d3dp_amd/csrc variants)", epi & ~0xff);
   epi &= 255;
   if (epi == EPI_RESID_LN || epi == EPI_GELU_LN) return fail(D3DP_EINVAL, "d3dp_op_linear_x2: epilogues 5 / 6 are internal to d3dp_denoise");
   if (skew_d) {
@@ -920,8 +954,12 @@ struct TrainLayout {
   size_t x_cols, x_block;           // every Linear's activation operand, transposed form [K][2 Tp], kept from the forward pass for wgrad
   size_t w_rows, w_cols, w_block;   // every weight's split operands (row form / transposed form), prepared once per step: w_block floats per block
   size_t Tp_max;                    // columns (tokens, padded) of a transposed operand row
+  size_t red, red_floats;           // partial sums of the backward pass (LayerNorm gammas / betas, biases, embedding side),
+                                    // summed in a fixed order by d3dp_train_reduce_many at its end
   size_t total_floats;
 };
+
+constexpr int kGroupSlices = 32;     // slices of the grouped row sums (position / time embedding gradients)
 
 TrainLayout train_layout(const d3dp_cfg& g, int B) {
   TrainLayout L{};
@@ -959,6 +997,15 @@ TrainLayout train_layout(const d3dp_cfg& g, int B) {
     L.w_rows = take(L.w_block * 2 * g.depth);
     L.w_cols = take(L.w_block * 2 * g.depth);
   }
+  {
+    const size_t lnb = (size_t)D3DP_LN_BWD_BLOCKS * 2 * L.C;         // one LayerNorm call's [dgamma | dbeta] rows
+    const size_t fmax = std::max<size_t>(3 * L.C, L.Hd);
+    L.red_floats = (size_t)(6 * g.depth + 2) * lnb                   // 3 LayerNorm backward calls per block + the head's
+                   + (size_t)8 * g.depth * D3DP_DYPREP_ROWS * fmax   // bias gradients: the column sums of every dY
+                   + (size_t)512 * (3 * L.C + 4) + (size_t)D3DP_EMBED_BWD_ROWS * 5 * L.C + (size_t)512 * L.C   // head, embedding
+                   + (size_t)kGroupSlices * (g.joints + (size_t)B) * L.C + 4096;                                // spos, time embedding
+    L.red = take(L.red_floats);
+  }
   L.total_floats = off;
   return L;
 }
@@ -968,6 +1015,33 @@ const float* mask_ptr(const float* masks, const d3dp_cfg& g, int B, int blk, int
   const size_t smax = (size_t)B * std::max(g.frames, g.joints);
   return masks + ((size_t)blk * 2 + branch) * smax;
 }
+
+// The backward pass' deferred, fixed-order sums: kernels leave partial rows in the workspace's `red` region (bump-allocated
+// here), `add` records where they go, `flush` launches d3dp_train_reduce_many over what was recorded (<= D3DP_REDUCE_MAX
+// destinations per launch).  Nothing in the backward pass adds floats atomically: its gradients are bit-reproducible.
+struct Reducer {
+  float* base;
+  size_t cap, used = 0;
+  hipStream_t st;
+  D3dpReduceTable tb{};
+  int rc = 0;
+  float* take(size_t n) {
+    n = (n + 63) / 64 * 64;
+    if (used + n > cap) { rc = -1; return nullptr; }
+    float* p = base + used;
+    used += n;
+    return p;
+  }
+  void add(const float* part, float* dst, size_t n, size_t count, size_t stride, bool accumulate = false) {
+    if (!part || !dst || rc) { rc = rc ? rc : -1; return; }
+    if (tb.count == D3DP_REDUCE_MAX) flush();
+    tb.it[tb.count++] = D3dpReduceItem{part, dst, (unsigned)n, (unsigned)count, (unsigned)stride, accumulate ? 1u : 0u};
+  }
+  void flush() {
+    if (tb.count > 0 && rc == 0) rc = d3dp_train_reduce_many(tb, st);
+    tb.count = 0;
+  }
+};
 
 int lin32(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, hipStream_t st) {
   return d3dp_launch_linear_f32(EPI_BIAS, A, W, bias, out, M, N, K, st);
@@ -1097,14 +1171,15 @@ struct X2Train {
     Tp = Z * nkz * 32;
   }
   // everything the backward pass of Linear [N, K] needs from its dY in one pass: row form -> op_a (dgrad), transposed form
-  // -> op_at (wgrad), the bias gradient += column sums.  `dy_ready` then tells dgrad / wgrad not to build them again.
+  // -> op_at (wgrad), the bias gradient's partial column sums -> bias_part (D3DP_DYPREP_ROWS rows of N floats).  `dy_ready`
+  // then tells dgrad / wgrad not to build them again.
   bool dy_ready = false;
-  int prep_dy(const float* dY, int sdy, float* dbias, int T, int N, int K) {
+  int prep_dy(const float* dY, int sdy, float* bias_part, int T, int N, int K) {
     int Z, Tp;
     wgrad_split(T, N, K, Z, Tp);
     if ((size_t)Tp > L.Tp_max) return -1;
     dy_ready = true;
-    return d3dp_launch_dyprep(dY, ws + L.op_a, ws + L.op_at, dbias, T, N, Tp, amax() + sdy, uns() + sdy, st);
+    return d3dp_launch_dyprep(dY, ws + L.op_a, ws + L.op_at, bias_part, T, N, Tp, amax() + sdy, uns() + sdy, st);
   }
   // dW[N, K] = dY[T, N]^T X[T, K]   (X: the activation operand of forward Linear l)
   int wgrad(int l, const float* dY, int sdy, const float* X, float* dW, int T, int N, int K) {
@@ -1138,6 +1213,7 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
   if (!c->train()) return fail(D3DP_ESTATE, "d3dp_train_forward needs a D3DP_MODE_TRAIN context");
   if (!c->weights_set) return fail(D3DP_ESTATE, "weights not set");
   const d3dp_cfg& g = c->cfg;
+  if (g.frames > 256) return fail(D3DP_ENOTSUP, "the training step's attention backward holds a sequence in LDS: frames=%d > 256 (inference runs any clip length)", g.frames);
   const TrainLayout L = train_layout(g, B);
   if (workspace_bytes < L.total_floats * 4) return fail(D3DP_ESTATE, "train workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -1157,35 +1233,41 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
   float* slab0 = ws + L.saved0;
   LAUNCH_TRY(d3dp_launch_embed_ln(0, x2d, x3d, ws + L.temb, c->ew, c->eb, c->spos, c->ste[0].n1w, c->ste[0].n1b,
                                   g.eps_block, slab0 + L.o_xin, xn, 0, B, 1, F, J, C, st));
+  // Every Linear's activation operand arrives with its absmax already in slot 2 l, left there by the kernel that produced it
+  // (round 4 ran 64 absmax launches per step); the two exceptions are the first block's input, which the inference embedding
+  // kernel writes, and the temporal attention's output (the fp32-MFMA kernel is shared with inference).
+  auto slot = [&](int l) -> unsigned* { return use_x2 ? x2.amax() + 2 * l : nullptr; };
+  if (use_x2) d3dp_launch_absmax(xn, (size_t)T * C, slot(0), st);
   for (int blk = 0; blk < 2 * g.depth; ++blk) {
     const int kind = blk & 1, d = blk >> 1;
     const BlockDev& w = kind ? c->tte[d] : c->ste[d];
     float* S = ws + L.saved0 + (size_t)blk * L.saved_stride;
-    LAUNCH_TRY(lin(4 * blk, xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C));
-    if (kind == 0) LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * F, spatial_map(F, J), C, g.heads, st));
-    else if (use_x2 && C / g.heads == 64)                // temporal axis on the fp32 matrix cores (bitwise an fp32 fmaf chain per
+    LAUNCH_TRY(lin(4 * blk, xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C, true));
+    bool att_ready = true;
+    if (kind == 0)
+      LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * F, spatial_map(F, J), C, g.heads, st, slot(4 * blk + 1)));
+    else if (use_x2 && C / g.heads == 64 && F <= 256) {  // temporal axis on the fp32 matrix cores (bitwise an fp32 fmaf chain per
       LAUNCH_TRY(d3dp_launch_attn_temporal_f32(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st));   // product)
-    else LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st));
-    LAUNCH_TRY(lin(4 * blk + 1, S + L.o_att, (const float*)w.proj_w, w.proj_b, y, T, C, C));
+      att_ready = false;
+    } else LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st, slot(4 * blk + 1)));
+    LAUNCH_TRY(lin(4 * blk + 1, S + L.o_att, (const float*)w.proj_w, w.proj_b, y, T, C, C, att_ready));
     LAUNCH_TRY(d3dp_train_add_mask_ln(S + L.o_xin, y, mask_ptr(masks, g, B, blk, 0), kind, F, J, w.n2w, w.n2b, g.eps_block,
-                                      S + L.o_xmid, xn, T, C, st));
-    LAUNCH_TRY(lin(4 * blk + 2, xn, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C));
-    LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, use_x2 ? x2.amax() + 2 * (4 * blk + 3) : nullptr, st));
+                                      S + L.o_xmid, xn, slot(4 * blk + 2), T, C, st));
+    LAUNCH_TRY(lin(4 * blk + 2, xn, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, true));
+    LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, slot(4 * blk + 3), st));
     LAUNCH_TRY(lin(4 * blk + 3, hid, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd, true));
-    LAUNCH_TRY(d3dp_train_add_mask_ln(S + L.o_xmid, y, mask_ptr(masks, g, B, blk, 1), kind, F, J, nullptr, nullptr,
-                                      g.eps_block, S + L.o_xout, nullptr, T, C, st));
-    // shared norm -> next block's input (or x_final)
+    // the block's end in one pass: residual add, the shared norm (+ Temporal_pos_embed after the first spatial block,
+    // mixste.py:250) -> the next block's input, that block's norm1 -> its qkv operand (after the last block: the head's
+    // LayerNorm -> z)
     const bool last = blk == 2 * g.depth - 1;
     float* x_next = last ? ws + L.x_final : S + L.saved_stride + L.o_xin;
-    if (kind == 0) LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xout, c->snw, c->snb, g.eps_block, d == 0 ? c->tpos : nullptr, F, J,
-                                                x_next, T, C, st));
-    else LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xout, c->tnw, c->tnb, g.eps_block, nullptr, F, J, x_next, T, C, st));
-    if (!last) {
-      const BlockDev& wn = kind ? c->ste[d + 1] : c->tte[d];
-      LAUNCH_TRY(d3dp_train_ln_pos(x_next, wn.n1w, wn.n1b, g.eps_block, nullptr, F, J, xn, T, C, st));
-    }
+    const float *nw = c->hnw, *nb = c->hnb;
+    if (!last) { const BlockDev& wn = kind ? c->ste[d + 1] : c->tte[d]; nw = wn.n1w; nb = wn.n1b; }
+    LAUNCH_TRY(d3dp_train_add_mask_ln2(S + L.o_xmid, y, mask_ptr(masks, g, B, blk, 1), kind, F, J, kind ? c->tnw : c->snw,
+                                       kind ? c->tnb : c->snb, g.eps_block, (kind == 0 && d == 0) ? c->tpos : nullptr, nw, nb,
+                                       last ? g.eps_head : g.eps_block, S + L.o_xout, x_next, last ? ws + L.z : xn,
+                                       last ? nullptr : slot(4 * (blk + 1)), T, C, st));
   }
-  LAUNCH_TRY(d3dp_train_ln_pos(ws + L.x_final, c->hnw, c->hnb, g.eps_head, nullptr, F, J, ws + L.z, T, C, st));
   LAUNCH_TRY(d3dp_train_head_linear(ws + L.z, c->hw, c->hb, out, T, C, st));
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
@@ -1206,8 +1288,8 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
   float* ws = (float*)workspace;
   const int T = (int)L.T, Tp = (int)L.Tpad, C = g.channels, F = g.frames, J = g.joints, Hd = g.hidden;
   auto G = [](const float* p) { return const_cast<float*>(p); };
-  // (one launch for all the small gradient buffers: ~150 memset launches per step otherwise; buffers that do not fit the
-  //  table -- more than 192 of them, or one of 4 Gi elements -- fall back to a memset each)
+  // (one launch for the few gradient buffers that are still ACCUMULATED into -- the time MLP's; everything else is written:
+  //  weight matrices by their wgrad product, every other gradient by the fixed-order reduction at the end of this function)
   D3dpZeroTable ztab{};
   auto zero = [&](const float* p, size_t n) -> hipError_t {
     if (ztab.count < D3DP_ZERO_MAX && n < ((size_t)1 << 32)) {
@@ -1216,23 +1298,9 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     }
     return hipMemsetAsync(G(p), 0, n * 4, st);
   };
-  // ---- zero every gradient buffer -------------------------------------------------------------------------------
   const size_t CC = (size_t)C * C;
-  HIP_TRY(zero(grads->spatial_pos, (size_t)J * C)); HIP_TRY(zero(grads->temporal_pos, (size_t)F * C));
-  HIP_TRY(zero(grads->embed_w, (size_t)C * 5)); HIP_TRY(zero(grads->embed_b, C));
   HIP_TRY(zero(grads->time1_w, 2 * CC)); HIP_TRY(zero(grads->time1_b, 2 * C));
   HIP_TRY(zero(grads->time3_w, 2 * CC)); HIP_TRY(zero(grads->time3_b, C));
-  HIP_TRY(zero(grads->spatial_norm_w, C)); HIP_TRY(zero(grads->spatial_norm_b, C));
-  HIP_TRY(zero(grads->temporal_norm_w, C)); HIP_TRY(zero(grads->temporal_norm_b, C));
-  HIP_TRY(zero(grads->head_norm_w, C)); HIP_TRY(zero(grads->head_norm_b, C));
-  HIP_TRY(zero(grads->head_w, 3 * (size_t)C)); HIP_TRY(zero(grads->head_b, 3));
-  for (int kind = 0; kind < 2; ++kind)
-    for (int d = 0; d < g.depth; ++d) {
-      const d3dp_block_weights& b = (kind ? grads->tte : grads->ste)[d];
-      HIP_TRY(zero(b.norm1_w, C)); HIP_TRY(zero(b.norm1_b, C)); HIP_TRY(zero(b.norm2_w, C)); HIP_TRY(zero(b.norm2_b, C));
-      HIP_TRY(zero(b.qkv_b, 3 * (size_t)C)); HIP_TRY(zero(b.proj_b, C)); HIP_TRY(zero(b.fc1_b, Hd)); HIP_TRY(zero(b.fc2_b, C));
-      // weight matrices are written (not accumulated) by their wgrad GEMM
-    }
   HIP_TRY(zero(ws + L.zero_bias, 4 * (size_t)C));
   if (ztab.count) LAUNCH_TRY(d3dp_train_zero_many(ztab, st));
   const float* zb = ws + L.zero_bias;
@@ -1245,19 +1313,42 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     LAUNCH_TRY(x2.begin(false));
     x2.batched = 8 * g.depth <= D3DP_WPREP_MAX;          // (the forward pass of this step left the weight operands in place)
   }
+  Reducer red{ws + L.red, L.red_floats, 0, st};
+  const int lnrows = d3dp_train_ln_bwd_blocks(T);        // partial rows one LayerNorm-backward call leaves
+  // [dgamma | dbeta] partial rows of a LayerNorm with `calls` backward calls per step (the shared norms: one per depth), and
+  // their two destinations; call i writes rows [i lnrows, (i + 1) lnrows)
+  auto ln_part = [&](const float* dgamma, const float* dbeta, int calls) -> float* {
+    float* p = red.take((size_t)calls * lnrows * 2 * C);
+    if (p) {
+      red.add(p, G(dgamma), C, (size_t)calls * lnrows, 2 * (size_t)C);
+      red.add(p + C, G(dbeta), C, (size_t)calls * lnrows, 2 * (size_t)C);
+    }
+    return p;
+  };
+  float* part_sn = ln_part(grads->spatial_norm_w, grads->spatial_norm_b, g.depth);
+  float* part_tn = ln_part(grads->temporal_norm_w, grads->temporal_norm_b, g.depth);
+  float* part_hn = ln_part(grads->head_norm_w, grads->head_norm_b, 1);
+  if (red.rc) return fail(D3DP_ESTATE, "d3dp_train_backward: partial-sum region too small");
   int sdy = -1;                                          // absmax slot of the dY the next wgrad / dgrad pair shares
   // wgrad: dW[N, K] = dY[T, N]^T X[T, K]  (fp32 path: both operands transposed to [*, Tpad], zero padded)
-  // (dbias: the Linear's bias gradient = column sums of dY, accumulated)
+  // (dbias: the Linear's bias gradient = column sums of dY, left as partial rows and summed at the end)
   // (pre_slot >= 0: the kernel that produced dY left its absmax there)
   auto wgrad = [&](int l, const float* dY, int N, const float* X, int K, float* dW, float* dbias, int pre_slot = -1) -> int {
     int r;
     if (use_x2) {
       sdy = pre_slot >= 0 ? pre_slot : x2.slot_for(dY, (size_t)T * N);
       if (sdy < 0) return -1;
-      if ((r = x2.prep_dy(dY, sdy, dbias, T, N, K))) return r;
+      float* bp = red.take((size_t)D3DP_DYPREP_ROWS * N);
+      if (!bp) return -1;
+      red.add(bp, dbias, N, D3DP_DYPREP_ROWS, N);
+      if ((r = x2.prep_dy(dY, sdy, bp, T, N, K))) return r;
       return x2.wgrad(l, dY, sdy, X, dW, T, N, K);
     }
-    if ((r = d3dp_train_colsum(dY, dbias, T, N, st))) return r;
+    float* bp = red.take((size_t)D3DP_DYPREP_ROWS * N);
+    int rows = 0;
+    if (!bp) return -1;
+    if ((r = d3dp_train_colsum(dY, bp, &rows, D3DP_DYPREP_ROWS, T, N, st))) return r;
+    red.add(bp, dbias, N, rows, N);
     if ((r = d3dp_train_transpose_pad(dY, At, T, N, Tp, st))) return r;
     if ((r = d3dp_train_transpose_pad(X, Xt, T, K, Tp, st))) return r;
     if (hipMemsetAsync(dW, 0, (size_t)N * K * 4, st) != hipSuccess) return -3;
@@ -1270,65 +1361,116 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     if ((r = d3dp_train_transpose_pad(W, Wt, N, K, N, st))) return r;
     return lin32(dY, Wt, zb, dX, T, K, N, st);
   };
+  // a slot for the absmax the producer of the next dY leaves (split-fp16 path only)
+  auto fresh = [&](int& slot) -> unsigned* {
+    slot = use_x2 ? x2.take() : -1;
+    return slot >= 0 ? x2.amax() + slot : nullptr;
+  };
+#define D3DP_FRESH(ps, pa)                                                                              \
+  int ps = -1;                                                                                          \
+  unsigned* pa = fresh(ps);                                                                             \
+  if (use_x2 && ps < 0) return fail(D3DP_ESTATE, "d3dp_train_backward: out of operand slots");
 
-  // ---- head ------------------------------------------------------------------------------------------------------
-  LAUNCH_TRY(d3dp_train_ln_pos(ws + L.x_final, c->hnw, c->hnb, g.eps_head, nullptr, F, J, ws + L.z, T, C, st));
-  LAUNCH_TRY(d3dp_train_head_bwd(grad_out, ws + L.z, c->hw, dC, G(grads->head_w), G(grads->head_b), T, C, st));
-  LAUNCH_TRY(d3dp_train_ln_bwd(dC, ws + L.x_final, c->hnw, g.eps_head, nullptr, dA, G(grads->head_norm_w),
-                               G(grads->head_norm_b), T, C, st));
-  // dA = gradient w.r.t. the output of the last shared norm
-  for (int blk = 2 * g.depth - 1; blk >= 0; --blk) {
+  // ---- head: Linear(C, 3) backward, then its LayerNorm and the last block's shared norm in one pass --------------
+  const int nblk = 2 * g.depth;
+  {
+    float* hp = red.take((size_t)512 * (3 * C + 4));
+    int rows = 0;
+    if (!hp) return fail(D3DP_ESTATE, "d3dp_train_backward: partial-sum region too small");
+    LAUNCH_TRY(d3dp_train_head_bwd(grad_out, ws + L.z, c->hw, dC, hp, &rows, T, C, st));   // (z: left by the forward pass)
+    red.add(hp, G(grads->head_w), 3 * (size_t)C, rows, 3 * (size_t)C + 4);
+    red.add(hp + 3 * C, G(grads->head_b), 3, rows, 3 * (size_t)C + 4);
+  }
+  // dB = d x_out of the last block; its DropPath-scaled form (the fc2 dY) in dC with its absmax in slot ps
+  const float* dy = nullptr;                             // the dY of the branch about to be differentiated
+  int ps_next = -1;
+  {
+    const int lb = nblk - 1, lk = lb & 1;
+    const float* S = ws + L.saved0 + (size_t)lb * L.saved_stride;
+    const float* mk = mask_ptr(masks, g, B, lb, 1);
+    D3DP_FRESH(ps, pa)
+    LAUNCH_TRY(d3dp_train_ln_bwd(dC, ws + L.x_final, c->hnw, g.eps_head, nullptr, nullptr, S + L.o_xout, lk ? c->tnw : c->snw,
+                                 g.eps_block, dB, mk, lk, F, J, mk ? dC : nullptr, pa, part_hn,
+                                 (lk ? part_tn : part_sn) + (size_t)(lb >> 1) * lnrows * 2 * C, T, C, st));
+    dy = mk ? dC : dB;
+    ps_next = ps;
+  }
+  for (int blk = nblk - 1; blk >= 0; --blk) {
     const int kind = blk & 1, d = blk >> 1;
     const BlockDev& w = kind ? c->tte[d] : c->ste[d];
     const d3dp_block_weights& gw = (kind ? grads->tte : grads->ste)[d];
     float* S = ws + L.saved0 + (size_t)blk * L.saved_stride;
-    const float* snw = kind ? c->tnw : c->snw;
-    float* gsnw = G(kind ? grads->temporal_norm_w : grads->spatial_norm_w);
-    float* gsnb = G(kind ? grads->temporal_norm_b : grads->spatial_norm_b);
-    if (kind == 0 && d == 0) LAUNCH_TRY(d3dp_train_groupsum(dA, G(grads->temporal_pos), T, C, 1, F, J, st));
-    // shared norm backward: dB = d x_out
-    LAUNCH_TRY(d3dp_train_ln_bwd(dA, S + L.o_xout, snw, g.eps_block, nullptr, dB, gsnw, gsnb, T, C, st));
+    // here: dB = d x_out(blk), dy = its DropPath-scaled form, absmax in slot ps_next
     // ---- MLP branch ----
-    auto fresh = [&](int& slot) -> unsigned* {             // a slot for the producer of the next dY (split-fp16 path only)
-      slot = use_x2 ? x2.take() : -1;
-      return slot >= 0 ? x2.amax() + slot : nullptr;
-    };
-    int ps = -1;
-    unsigned* pa = fresh(ps);
-    if (use_x2 && ps < 0) return fail(D3DP_ESTATE, "d3dp_train_backward: out of operand slots");
-    LAUNCH_TRY(d3dp_train_scale_mask(dB, mask_ptr(masks, g, B, blk, 1), kind, F, J, dC, T, C, pa, st));    // dy2
     if (!use_x2) LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, nullptr, st));   // (x2: wgrad reads the forward pass' operand)
-    LAUNCH_TRY(wgrad(4 * blk + 3, dC, C, hid, Hd, G(gw.fc2_w), G(gw.fc2_b), ps));
-    LAUNCH_TRY(dgrad(4 * blk + 3, dC, C, (const float*)w.fc2_w, Hd, dh));                                               // d hidden
-    pa = fresh(ps);
-    if (use_x2 && ps < 0) return fail(D3DP_ESTATE, "d3dp_train_backward: out of operand slots");
-    LAUNCH_TRY(d3dp_train_gelu_bwd(dh, S + L.o_hpre, dh, (size_t)T * Hd, pa, st));                         // d h_pre
-    if (!use_x2) LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xmid, w.n2w, w.n2b, g.eps_block, nullptr, F, J, xn, T, C, st));   // xn2
-    LAUNCH_TRY(wgrad(4 * blk + 2, dh, Hd, xn, C, G(gw.fc1_w), G(gw.fc1_b), ps));
-    LAUNCH_TRY(dgrad(4 * blk + 2, dh, Hd, (const float*)w.fc1_w, C, dC));                                               // d xn2
-    LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xmid, w.n2w, g.eps_block, dB, dA, G(gw.norm2_w), G(gw.norm2_b), T, C, st));
-    // dA = d x_mid
-    // ---- attention branch ----
-    pa = fresh(ps);
-    if (use_x2 && ps < 0) return fail(D3DP_ESTATE, "d3dp_train_backward: out of operand slots");
-    LAUNCH_TRY(d3dp_train_scale_mask(dA, mask_ptr(masks, g, B, blk, 0), kind, F, J, dC, T, C, pa, st));    // dy1
-    LAUNCH_TRY(wgrad(4 * blk + 1, dC, C, S + L.o_att, C, G(gw.proj_w), G(gw.proj_b), ps));
-    LAUNCH_TRY(dgrad(4 * blk + 1, dC, C, (const float*)w.proj_w, C, dB));                                               // d att
+    LAUNCH_TRY(wgrad(4 * blk + 3, dy, C, hid, Hd, G(gw.fc2_w), G(gw.fc2_b), ps_next));
+    LAUNCH_TRY(dgrad(4 * blk + 3, dy, C, (const float*)w.fc2_w, Hd, dh));                                               // d hidden
+    {
+      D3DP_FRESH(ps, pa)
+      LAUNCH_TRY(d3dp_train_gelu_bwd(dh, S + L.o_hpre, dh, (size_t)T * Hd, pa, st));                       // d h_pre
+      if (!use_x2) LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xmid, w.n2w, w.n2b, g.eps_block, nullptr, F, J, xn, T, C, st));   // xn2
+      LAUNCH_TRY(wgrad(4 * blk + 2, dh, Hd, xn, C, G(gw.fc1_w), G(gw.fc1_b), ps));
+      LAUNCH_TRY(dgrad(4 * blk + 2, dh, Hd, (const float*)w.fc1_w, C, dC));                                             // d xn2
+    }
+    // norm2 backward + the residual: dA = d x_mid; its DropPath-scaled form (the proj dY) over dC
+    {
+      const float* mk = mask_ptr(masks, g, B, blk, 0);
+      float* pn = ln_part(gw.norm2_w, gw.norm2_b, 1);
+      D3DP_FRESH(ps, pa)
+      if (!pn) return fail(D3DP_ESTATE, "d3dp_train_backward: partial-sum region too small");
+      LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xmid, w.n2w, g.eps_block, dB, nullptr, nullptr, nullptr, 0.f, dA, mk, kind, F, J,
+                                   mk ? dC : nullptr, pa, pn, nullptr, T, C, st));
+      dy = mk ? dC : dA;
+      // ---- attention branch ----
+      LAUNCH_TRY(wgrad(4 * blk + 1, dy, C, S + L.o_att, C, G(gw.proj_w), G(gw.proj_b), ps));
+      LAUNCH_TRY(dgrad(4 * blk + 1, dy, C, (const float*)w.proj_w, C, dB));                                             // d att
+    }
     if (kind == 0) LAUNCH_TRY(d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * F, spatial_map(F, J), C, g.heads, st));
     else LAUNCH_TRY(d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * J, temporal_map(F, J), C, g.heads, st));
     if (!use_x2) LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xin, w.n1w, w.n1b, g.eps_block, nullptr, F, J, xn, T, C, st));    // xn1
     LAUNCH_TRY(wgrad(4 * blk, dqkv, 3 * C, xn, C, G(gw.qkv_w), G(gw.qkv_b)));
     LAUNCH_TRY(dgrad(4 * blk, dqkv, 3 * C, (const float*)w.qkv_w, C, dC));                                          // d xn1
-    LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xin, w.n1w, g.eps_block, dA, dB, G(gw.norm1_w), G(gw.norm1_b), T, C, st));
-    // dB = d x_in of this block = gradient w.r.t. the previous shared norm's output
-    std::swap(dA, dB);
+    float* pn1 = ln_part(gw.norm1_w, gw.norm1_b, 1);
+    if (!pn1) return fail(D3DP_ESTATE, "d3dp_train_backward: partial-sum region too small");
+    if (blk > 0) {
+      // norm1 backward + the residual (= d x_in of this block = d of the previous block's shared-norm output), then that
+      // shared norm's backward, in one pass: dB = d x_out(blk - 1) and its DropPath-scaled form over dC
+      const int pb = blk - 1, pk = pb & 1;
+      const float* Sp = ws + L.saved0 + (size_t)pb * L.saved_stride;
+      const float* mk = mask_ptr(masks, g, B, pb, 1);
+      float* g_out = pb == 0 ? ws + L.z : nullptr;       // d of Temporal_pos_embed's sum (added behind block 0's shared norm)
+      D3DP_FRESH(ps, pa)
+      LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xin, w.n1w, g.eps_block, dA, g_out, Sp + L.o_xout, pk ? c->tnw : c->snw, g.eps_block,
+                                   dB, mk, pk, F, J, mk ? dC : nullptr, pa, pn1,
+                                   (pk ? part_tn : part_sn) + (size_t)(pb >> 1) * lnrows * 2 * C, T, C, st));
+      if (g_out) LAUNCH_TRY(d3dp_train_groupsum(g_out, G(grads->temporal_pos), T, C, 1, F, J, 1, st));
+      dy = mk ? dC : dB;
+      ps_next = ps;
+    } else {
+      LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xin, w.n1w, g.eps_block, dA, nullptr, nullptr, nullptr, 0.f, dB, nullptr, 0, F, J,
+                                   nullptr, nullptr, pn1, nullptr, T, C, st));
+    }
   }
-  // ---- embedding, position and time embeddings -------------------------------------------------------------------
-  LAUNCH_TRY(d3dp_train_embed_bwd(dA, x2d, x3d, G(grads->embed_w), T, C, st));
-  LAUNCH_TRY(d3dp_train_colsum(dA, G(grads->embed_b), T, C, st));
-  LAUNCH_TRY(d3dp_train_groupsum(dA, G(grads->spatial_pos), T, C, 0, F, J, st));
-  HIP_TRY(hipMemsetAsync(ws + L.dtemb, 0, (size_t)B * C * 4, st));
-  LAUNCH_TRY(d3dp_train_groupsum(dA, ws + L.dtemb, T, C, 2, F, J, st));
+#undef D3DP_FRESH
+  // ---- embedding, position and time embeddings (dB = d of the embedded tokens) ------------------------------------
+  {
+    float* ep = red.take((size_t)D3DP_EMBED_BWD_ROWS * 5 * C);
+    float* bp = red.take((size_t)512 * C);
+    float* sp = red.take((size_t)kGroupSlices * J * C);
+    float* tp = red.take((size_t)kGroupSlices * B * C);
+    int rows = 0;
+    if (!ep || !bp || !sp || !tp) return fail(D3DP_ESTATE, "d3dp_train_backward: partial-sum region too small");
+    LAUNCH_TRY(d3dp_train_embed_bwd(dB, x2d, x3d, ep, T, C, st));
+    red.add(ep, G(grads->embed_w), 5 * (size_t)C, D3DP_EMBED_BWD_ROWS, 5 * (size_t)C);
+    LAUNCH_TRY(d3dp_train_colsum(dB, bp, &rows, 512, T, C, st));
+    red.add(bp, G(grads->embed_b), C, rows, C);
+    LAUNCH_TRY(d3dp_train_groupsum(dB, sp, T, C, 0, F, J, kGroupSlices, st));
+    red.add(sp, G(grads->spatial_pos), (size_t)J * C, kGroupSlices, (size_t)J * C);
+    LAUNCH_TRY(d3dp_train_groupsum(dB, tp, T, C, 2, F, J, kGroupSlices, st));
+    red.add(tp, ws + L.dtemb, (size_t)B * C, kGroupSlices, (size_t)B * C);
+    red.flush();                                          // (dtemb feeds the time MLP's backward below)
+  }
+  if (red.rc) return fail(D3DP_EHIP, "d3dp_train_backward: the gradient reduction failed");
   LAUNCH_TRY(d3dp_train_time_mlp_bwd(t, c->freq, c->t1w, c->t1b, c->t3w, ws + L.dtemb, G(grads->time1_w),
                                      G(grads->time1_b), G(grads->time3_w), G(grads->time3_b), B, C, st));
   HIP_TRY(hipGetLastError());

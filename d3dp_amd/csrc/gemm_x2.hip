@@ -58,6 +58,13 @@
 #ifndef D3DP_X2_PROBE
 #define D3DP_X2_PROBE 0
 #endif
+// -DD3DP_X2_VARIANTS=1 (tools/build_variant.sh variants ...; `make variants`): also build the MEASURED-NEGATIVE forms of this
+// Linear -- the ping-pong, wide (256 x 256) and row-class skewed kernels and the norm2-folding epilogues (EPI_RESID_LN /
+// EPI_GELU_LN), DESIGN.md section 7 -- behind their D3DP_X2_PP / D3DP_X2_WIDE / D3DP_X2_SKEW / D3DP_FOLD_LN switches.  The
+// product library is built without them: asking it for one fails loudly (d3dp_create: D3DP_ENOTSUP).
+#ifndef D3DP_X2_VARIANTS
+#define D3DP_X2_VARIANTS 0
+#endif
 
 // Output stores carry the nontemporal hint: the tile round's 4 MiB of output per XCD is not read again on that XCD
 // and otherwise pushes the weight matrix out of the 4 MiB L2 between rounds (FETCH_SIZE measurement in DESIGN.md).
@@ -519,6 +526,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
   }
 }
 
+#if D3DP_X2_VARIANTS
 // The tile epilogue of gemm_f16x2_kernel as a function (the ping-pong kernel below calls it from two places; the kernel above
 // keeps its own inline copy so that building without the ping-pong path reproduces its code exactly).  `acc`: this wave's
 // 64 x 64 block of tile `t`; `ti`: the workgroup's running tile index (EPI_GELU_LN's row-statistics buffer parity).
@@ -1400,6 +1408,8 @@ __global__ __launch_bounds__(768) void gemm_f16x2_skew_kernel(const f16* __restr
   }
 }
 
+#endif  // D3DP_X2_VARIANTS
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The training step's Linear (forward, dgrad and the split-K wgrad of SURVEY.md row A13) on the same three-pass split-fp16
 // scheme: out_z[M, N] = (A2 . W2^T over the k-steps of chunk z) x dynA[0] x dynW[0] (+ bias), fp32 out.
@@ -1592,63 +1602,79 @@ __global__ __launch_bounds__(256) void split2h_t_dyn_kernel(const float* __restr
   }
 }
 
-// One pass over a gradient dY [R][C] (fp32) for everything the backward pass of a Linear needs from it: the row form
-// [R][2 C] (dgrad's operand), the transposed form [C][2 Rpad] (wgrad's operand; rows R .. Rpad - 1 zero) and the column
-// sums (the bias gradient, += into colsum).  As three kernels (split2h_dyn, split2h_t_dyn, colsum) the same tensor was
-// read three times: 67 us per Linear of the configs[4] step.  32 x 32 tiles through LDS; blockIdx.y = column tile, a
-// workgroup strides over the row tiles and keeps its columns' sums in registers: gridDim.x atomics per column.
+// One pass over an fp32 matrix src [R][C] for everything the training step needs from it as a split-fp16 operand: the row
+// form [R][2 C] (a forward Linear's / dgrad's operand), the transposed form [C][2 Rpad] (wgrad's operand; rows R .. Rpad - 1
+// zero) and, for a gradient dY, its column sums (the bias gradient) -- as three kernels (split2h_dyn, split2h_t_dyn, colsum)
+// the same tensor was read three times.  blockIdx.y = a strip of 32 columns; a workgroup strides over tiles of 128 rows x 32
+// columns: FOUR 16-byte loads per thread in flight (round 4: one, on 512 workgroups -- two per CU -- which left the kernel
+// latency-bound at 3.4 TB/s), the row form leaves as 8-byte stores, the transposed form through LDS as 16-byte stores (8
+// source rows of one destination row and plane per store).  Column sums: this workgroup's rows into row blockIdx.x of
+// `colpart` (gridDim.x rows of C floats, summed in a fixed order by d3dp_train_reduce_many: no float atomics).
 // C % 32 == 0, Rpad % 32 == 0.
 __global__ __launch_bounds__(256) void dyprep_kernel(const float* __restrict__ s, f16* __restrict__ drow, f16* __restrict__ dcol,
-                                                     float* __restrict__ colsum, int R, int C, int Rpad,
+                                                     float* __restrict__ colpart, int R, int C, int Rpad,
                                                      const unsigned* __restrict__ amax, float* __restrict__ unscale) {
-  // A thread owns FOUR elements of a tile in either direction: one 16-byte load and two 8-byte stores (4 hi, 4 lo) for the
-  // row form, four LDS reads and two 8-byte stores for the transposed form (the first version moved every fp16 with its own
-  // 2-byte store: store-issue-bound at 4 TB/s).
-  __shared__ float tile[32][33];
-  __shared__ float csum[32][33];
+  __shared__ float tile[128][33];
   const float sc = dyn_scale(amax[0]);
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) unscale[0] = 1.0f / sc;
   const int c0 = blockIdx.y * 32;
-  const int tr = threadIdx.x >> 3, tq = (threadIdx.x & 7) * 4;   // phase 1: source row tr, columns tq .. tq + 3; phase 2: source column tr, rows tq .. tq + 3
+  const int tr = threadIdx.x >> 3, tj = threadIdx.x & 7, tq = tj * 4;   // phase 1: source row u 32 + tr, columns tq .. tq + 3
+  const int nblk = Rpad / 32;                           // 32-row blocks of the transposed form
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto split4 = [](const float (&v)[4], f16x4& hi, f16x4& lo) {
+  for (int rt = blockIdx.x; rt * 4 < nblk; rt += gridDim.x) {
+    float4 v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { f16 h, l; split2h_scaled(v[e], h, l); hi[e] = h; lo[e] = l; }
-  };
-  for (int rt = blockIdx.x; rt < Rpad / 32; rt += gridDim.x) {
-    const int r = rt * 32 + tr;
-    __syncthreads();
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < R) v = *reinterpret_cast<const float4*>(s + (size_t)r * C + c0 + tq);
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    const float vs[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
-    tile[tr][tq] = vs[0]; tile[tr][tq + 1] = vs[1]; tile[tr][tq + 2] = vs[2]; tile[tr][tq + 3] = vs[3];
-    if (r < R) {                                         // row form: the 128-byte h2i block of row r, columns c0 .. c0 + 31
-      f16x4 hi, lo;
-      split4(vs, hi, lo);
-      f16* blk = drow + (size_t)r * 2 * C + (size_t)blockIdx.y * 64 + tq;
-      *reinterpret_cast<f16x4*>(blk) = hi;
-      *reinterpret_cast<f16x4*>(blk + 32) = lo;
+    for (int u = 0; u < 4; ++u) {
+      const int r = rt * 128 + u * 32 + tr;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < R) v[u] = *reinterpret_cast<const float4*>(s + (size_t)r * C + c0 + tq);
+    }
+    __syncthreads();                                    // (the previous tile's transposed reads are done)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = rt * 128 + u * 32 + tr;
+      acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+      const float vs[4] = {v[u].x * sc, v[u].y * sc, v[u].z * sc, v[u].w * sc};
+      float* trow = &tile[u * 32 + tr][tq];
+      trow[0] = vs[0]; trow[1] = vs[1]; trow[2] = vs[2]; trow[3] = vs[3];
+      if (r < R) {                                       // row form: the 128-byte h2i block of row r, columns c0 .. c0 + 31
+        f16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f16 h, l; split2h_scaled(vs[e], h, l); hi[e] = h; lo[e] = l; }
+        f16* blk = drow + (size_t)r * 2 * C + (size_t)blockIdx.y * 64 + tq;
+        *reinterpret_cast<f16x4*>(blk) = hi;
+        *reinterpret_cast<f16x4*>(blk + 32) = lo;
+      }
     }
     __syncthreads();
-    {                                                    // transposed form: destination row c0 + tr, source rows rt 32 + tq .. + 3
-      const float t4[4] = {tile[tq][tr], tile[tq + 1][tr], tile[tq + 2][tr], tile[tq + 3][tr]};
-      f16x4 hi, lo;
-      split4(t4, hi, lo);
-      f16* blk = dcol + (size_t)(c0 + tr) * 2 * Rpad + (size_t)rt * 64 + tq;
-      *reinterpret_cast<f16x4*>(blk) = hi;
-      *reinterpret_cast<f16x4*>(blk + 32) = lo;
+    // transposed form: destination row c0 + tr; this thread's two (block, 8-row group) pairs of the tile's 4 x 4
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = (tj >> 2) + 2 * i, g8 = tj & 3;
+      if (rt * 4 + u < nblk) {
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          f16 h, l;
+          split2h_scaled(tile[u * 32 + g8 * 8 + e][tr], h, l);
+          hi[e] = h; lo[e] = l;
+        }
+        f16* blk = dcol + (size_t)(c0 + tr) * 2 * Rpad + (size_t)(rt * 4 + u) * 64 + g8 * 8;
+        *reinterpret_cast<f16x8*>(blk) = hi;
+        *reinterpret_cast<f16x8*>(blk + 32) = lo;
+      }
     }
   }
-  if (colsum) {
+  if (colpart) {
     __syncthreads();
-    csum[tr][tq] = acc.x; csum[tr][tq + 1] = acc.y; csum[tr][tq + 2] = acc.z; csum[tr][tq + 3] = acc.w;
+    float* cs = &tile[0][0];                             // [32][33] of the tile buffer
+    cs[tr * 33 + tq] = acc.x; cs[tr * 33 + tq + 1] = acc.y; cs[tr * 33 + tq + 2] = acc.z; cs[tr * 33 + tq + 3] = acc.w;
     __syncthreads();
     if (threadIdx.x < 32) {
       float t = 0.f;
 #pragma unroll 8
-      for (int j = 0; j < 32; ++j) t += csum[j][threadIdx.x];
-      atomicAdd(colsum + c0 + threadIdx.x, t);
+      for (int j = 0; j < 32; ++j) t += cs[j * 33 + threadIdx.x];
+      colpart[(size_t)blockIdx.x * C + c0 + threadIdx.x] = t;
     }
   }
 }
@@ -1793,6 +1819,7 @@ __global__ void rowbound_kernel(const float* __restrict__ W, const float* __rest
   }
 }
 
+#if D3DP_X2_VARIANTS
 // rowstat[m] = (mean, 1 / sqrt(var + eps)) of row m from its S slices of 64 (mean_i, M2_i): mean = avg of means,
 // M2 = sum M2_i + 64 sum (mean_i - mean)^2 (the exact pairwise update for equal counts), var = M2 / (64 S)
 __global__ void ln_combine_kernel(const float* __restrict__ sl, float* __restrict__ rowstat, int M, int S, float eps) {
@@ -1827,6 +1854,7 @@ __global__ void fold_ln_kernel(const float* __restrict__ W, const float* __restr
   if (lane == 0) { c12[n] = (float)(s2 + (double)bias[n]); c12[N + n] = (float)s1; }
 }
 
+#endif  // D3DP_X2_VARIANTS
 __global__ void nonfinite_flag_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ flag) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1845,7 +1873,10 @@ __global__ void nonfinite_flag_kernel(const float* __restrict__ x, size_t n, uns
 // register sets), and the loader / compute waves count barriers per k-step.
 // skew_d: 0 = the plain schedule; 1, 2, 4 = the row-class skewed kernel with its parked class leaving in that many k-steps
 // (EPI_QKV_PACK and EPI_GELU only; falls back to the plain kernel where the schedule does not apply: see d3dp_x2_skew_applies)
+bool d3dp_x2_variants_built() { return D3DP_X2_VARIANTS != 0; }
+
 bool d3dp_x2_skew_applies(int epi, int M, int N, int K, int skew_d, int n_cu) {
+  if (!D3DP_X2_VARIANTS) return false;
   if (skew_d != 1 && skew_d != 2 && skew_d != 4) return false;
   if (epi != EPI_QKV_PACK && epi != EPI_GELU) return false;
   const int tn = (N + XBN - 1) / XBN, tm = (M + XBM - 1) / XBM;
@@ -1875,10 +1906,18 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
   if (epi == EPI_GELU_LN && K / XBK < XNSTAGE) return -1;
   const int tm = (M + XBM - 1) / XBM, tn = (N + XBN - 1) / XBN;
   using KernT = void (*)(const f16*, const f16*, const float*, float, float, float*, f16*, float*, unsigned*, int, int, int, int, int);
+#if D3DP_X2_VARIANTS
   constexpr int NKERN = 6;
   static const KernT kerns[NKERN] = {gemm_f16x2_kernel<EPI_BIAS, 0>, gemm_f16x2_kernel<EPI_BIAS, 1>,
                                      gemm_f16x2_kernel<EPI_GELU, 0>, gemm_f16x2_kernel<EPI_RESID, 0>,
                                      gemm_f16x2_kernel<EPI_RESID_LN, 0>, gemm_f16x2_kernel<EPI_GELU_LN, 0>};
+#else
+  // the product library: the four epilogues the denoiser runs; everything else is a -DD3DP_X2_VARIANTS=1 build
+  if (epi == EPI_RESID_LN || epi == EPI_GELU_LN || skew_d != 0 || pingpong != 0) return -2;
+  constexpr int NKERN = 4;
+  static const KernT kerns[NKERN] = {gemm_f16x2_kernel<EPI_BIAS, 0>, gemm_f16x2_kernel<EPI_BIAS, 1>,
+                                     gemm_f16x2_kernel<EPI_GELU, 0>, gemm_f16x2_kernel<EPI_RESID, 0>};
+#endif
   // per DEVICE: the 156 KiB dynamic-LDS opt-in of every instantiation and the CU count (one process may drive several
   // devices: nn.DataParallel callers)
   static PerDeviceOnce once;
@@ -1888,6 +1927,8 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
     return d3dp_cu_count(dev);
   });
   if (cus < 0) return -3;
+  const int total = tm * tn, grid = total < cus ? total : cus;
+#if D3DP_X2_VARIANTS
   if (d3dp_x2_skew_applies(epi, M, N, K, skew_d, cus)) {
     using SkewT = void (*)(const f16*, const f16*, const float*, float, float, float*, f16*, int, int, int, int, int, int);
     static const SkewT skews[6] = {gemm_f16x2_skew_kernel<EPI_BIAS, 1, 1>, gemm_f16x2_skew_kernel<EPI_BIAS, 1, 2>,
@@ -1920,7 +1961,6 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
                        oscale, outf, (f16*)out2, aux, flag, M, N, K, tw, totw);
     return 0;
   }
-  const int total = tm * tn, grid = total < cus ? total : cus;
   if (pingpong == 1 && (epi == EPI_BIAS || epi == EPI_QKV_PACK || epi == EPI_GELU || epi == EPI_RESID)) {
     static const KernT pps[4] = {gemm_f16x2_pp_kernel<EPI_BIAS, 0>, gemm_f16x2_pp_kernel<EPI_BIAS, 1>,
                                  gemm_f16x2_pp_kernel<EPI_GELU, 0>, gemm_f16x2_pp_kernel<EPI_RESID, 0>};
@@ -1937,6 +1977,9 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
   }
   const KernT kern = kerns[epi == EPI_GELU ? 2 : epi == EPI_RESID ? 3 : epi == EPI_QKV_PACK ? 1 : epi == EPI_RESID_LN ? 4
                            : epi == EPI_GELU_LN ? 5 : 0];
+#else
+  const KernT kern = kerns[epi == EPI_GELU ? 2 : epi == EPI_RESID ? 3 : epi == EPI_QKV_PACK ? 1 : 0];
+#endif
   hipLaunchKernelGGL(kern, dim3(grid), dim3((XNCW + 4) * 64), XLDS, st, (const f16*)A2, (const f16*)W2, bias, unscale, oscale, outf,
                      (f16*)out2, aux, flag, M, N, K, tn, total);
   return 0;
@@ -1963,13 +2006,18 @@ void d3dp_launch_nonfinite_flag(const float* x, size_t n, unsigned* flag, hipStr
   hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, x, n, flag);
 }
 
+// (norm2 folded into proj / fc1: D3DP_X2_VARIANTS builds only; capi.hip never reaches these without one)
 void d3dp_launch_ln_combine(const float* slices, float* rowstat, int M, int C, float eps, hipStream_t st) {
+#if D3DP_X2_VARIANTS
   hipLaunchKernelGGL(ln_combine_kernel, dim3((M + 255) / 256), dim3(256), 0, st, slices, rowstat, M, (C + 63) / 64, eps);
+#endif
 }
 
 void d3dp_launch_fold_ln(const float* W, const float* gamma, const float* beta, const float* bias, float* Wp, float* c12,
                          int N, int K, hipStream_t st) {
+#if D3DP_X2_VARIANTS
   hipLaunchKernelGGL(fold_ln_kernel, dim3((N + 3) / 4), dim3(256), 0, st, W, gamma, beta, bias, Wp, c12, N, K);
+#endif
 }
 
 // ---- training-step launchers (gemm_f16x2_dyn_kernel and its operand kernels) ---------------------------------------
@@ -2003,10 +2051,11 @@ void d3dp_launch_split2_t_dyn(const float* src, void* dst, int R, int C, int Rpa
                      unscale);
 }
 
-int d3dp_launch_dyprep(const float* src, void* drow, void* dcol, float* colsum, int R, int C, int Rpad, const unsigned* amax,
+int d3dp_launch_dyprep(const float* src, void* drow, void* dcol, float* colpart, int R, int C, int Rpad, const unsigned* amax,
                        float* unscale, hipStream_t st) {
   if (C % 32 != 0 || Rpad % 32 != 0 || Rpad < R) return -1;
-  hipLaunchKernelGGL(dyprep_kernel, dim3(32, C / 32), dim3(256), 0, st, src, (f16*)drow, (f16*)dcol, colsum, R, C, Rpad, amax, unscale);
+  // D3DP_DYPREP_ROWS x C / 32 workgroups (768 at C = 512: three per CU), each with 16 KiB of loads in flight
+  hipLaunchKernelGGL(dyprep_kernel, dim3(D3DP_DYPREP_ROWS, C / 32), dim3(256), 0, st, src, (f16*)drow, (f16*)dcol, colpart, R, C, Rpad, amax, unscale);
   return 0;
 }
 

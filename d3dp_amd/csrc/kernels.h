@@ -61,6 +61,9 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
 // skew_d (1, 2, 4): the row-class skewed schedule of gemm_x2.hip for EPI_QKV_PACK / EPI_GELU -- a tile's epilogue leaves under the
 // next tile's k-loop, D k-steps per 16-row class; d3dp_x2_skew_applies says whether the launcher will use it for a shape
 bool d3dp_x2_skew_applies(int epi, int M, int N, int K, int skew_d, int n_cu);
+// whether gemm_x2.hip was built with -DD3DP_X2_VARIANTS=1 (the ping-pong / wide / skewed kernels and the norm2-folding
+// epilogues: measured-negative experiments, not part of the product library)
+bool d3dp_x2_variants_built();
 // out[0] = max over rows n of  sum_k |W[n,k]| in_k + |bias[n]|,  out[1] = max_k in_k,  in_k = sq |gamma_k| + |beta_k|: the
 // magnitude bound of a Linear fed by a LayerNorm over K channels (sq = sqrt(K - 1): |LN(x)_k| <= sq |gamma_k| + |beta_k| for
 // ANY x), as the bit patterns of non-negative floats (integer max == float max; `out` pre-zeroed)
@@ -85,8 +88,10 @@ void d3dp_launch_split2_dyn(const float* src, void* dst, int R, int C, int Cpad,
 void d3dp_launch_split2_t_dyn(const float* src, void* dst, int R, int C, int Rpad, const unsigned* amax, float* unscale,
                               hipStream_t st);
 // out[i] = sum over z of part[z n + i], z ascending
-// dY [R][C] -> row form [R][2 C], transposed form [C][2 Rpad] and colsum[c] += sum_r dY[r][c] in one pass (gemm_x2.hip)
-int d3dp_launch_dyprep(const float* src, void* drow, void* dcol, float* colsum, int R, int C, int Rpad, const unsigned* amax,
+// src [R][C] -> row form [R][2 C], transposed form [C][2 Rpad] and (colpart != null) its column sums as D3DP_DYPREP_ROWS
+// partial rows of C floats (every row written; summed by d3dp_train_reduce_many) in one pass (gemm_x2.hip)
+constexpr int D3DP_DYPREP_ROWS = 48;
+int d3dp_launch_dyprep(const float* src, void* drow, void* dcol, float* colpart, int R, int C, int Rpad, const unsigned* amax,
                        float* unscale, hipStream_t st);
 // the training step's weight operands in three launches (gemm_x2.hip): absmax -> slot, rows form [N][2 K] at rows_base + 2 off
 // halves, transposed form [K][2 N] at cols_base + 2 off halves, unscale[slot] = 1 / scale
@@ -109,8 +114,9 @@ int d3dp_launch_linear_f32(int epi, const float* A, const float* W, const float*
 //   spatial : n_tok = J, inner = 1,  outer_stride = J,   inner_stride = 0, tok_stride = 1   (s = bh*F + f)
 //   temporal: n_tok = F, inner = J,  outer_stride = F*J, inner_stride = 1, tok_stride = J   (s = bh*J + n)
 struct SeqMap { int n_tok, inner, outer_stride, inner_stride, tok_stride; };
+// (any sequence length; amax: optional absmax slot of an fp32 output, one atomicMax per workgroup)
 int d3dp_launch_attn_rows(int act_bf16, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
-                          hipStream_t st);
+                          hipStream_t st, unsigned* amax = nullptr);
 int d3dp_launch_attn_temporal_bf16(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
                                    hipStream_t st);
 int d3dp_launch_attn_temporal_f32(int act, const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads,
@@ -167,30 +173,51 @@ int d3dp_check_launch(const char* what);              // hipGetLastError -> stat
 extern "C" int d3dp_clip_count(int32_t n, int32_t F);
 
 // ---- train.hip (training step, fp32) -------------------------------------------------------------------------
+// (amax: optional absmax slot of a kernel's result -- bit pattern of a non-negative float, pre-zeroed, one atomicMax per
+//  workgroup -- so that the split-fp16 Linear that consumes the result needs no absmax pass of its own)
+// x_out = x_in + mask[sample] y ; xn = LN(x_out)
 int d3dp_train_add_mask_ln(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* w,
-                           const float* b, float eps, float* x_out, float* xn, int T, int C, hipStream_t st);
+                           const float* b, float eps, float* x_out, float* xn, unsigned* amax, int T, int C, hipStream_t st);
+// x_out = x_in + mask[sample] y ; x_next = LN_a(x_out) (+ pos[f]) ; xn = LN_b(x_next) (xn may be null: no second norm)
+int d3dp_train_add_mask_ln2(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* wa,
+                            const float* ba, float eps_a, const float* pos, const float* wb, const float* bb, float eps_b,
+                            float* x_out, float* x_next, float* xn, unsigned* amax, int T, int C, hipStream_t st);
 int d3dp_train_ln_pos(const float* x, const float* w, const float* b, float eps, const float* pos, int F, int J, float* y,
                       int T, int C, hipStream_t st);
-int d3dp_train_ln_bwd(const float* dy, const float* x, const float* w, float eps, const float* dres, float* dx,
-                      float* dgamma, float* dbeta, int T, int C, hipStream_t st);
+// LayerNorm backward, one (xa == null) or two chained LayerNorms (y = LN_b(xb), xb = LN_a(xa) (+ pos)) in one pass:
+//   g = LN_b-backward(dy) + dres (g_out: optional copy, two-norm form only);  dx = two ? LN_a-backward(g) : g;
+//   dxm (optional) = mask[sample] dx, amax (optional) its absmax -- dy and dxm may alias.
+// part_b / part_a: d3dp_train_ln_bwd_blocks(T) rows of [dgamma | dbeta] (2 C floats) per LayerNorm, to be summed in order by
+// d3dp_train_reduce_many (no float atomics anywhere in the backward pass: bit-reproducible gradients).
+constexpr int D3DP_LN_BWD_BLOCKS = 512;
+int d3dp_train_ln_bwd_blocks(int T);
+int d3dp_train_ln_bwd(const float* dy, const float* xb, const float* wb, float eps_b, const float* dres, float* g_out,
+                      const float* xa, const float* wa, float eps_a, float* dx, const float* mask, int axis, int F, int J,
+                      float* dxm, unsigned* amax, float* part_b, float* part_a, int T, int C, hipStream_t st);
+// dst[i] (+)= sum_{p < count} part[p stride + i] in a fixed order, up to D3DP_REDUCE_MAX destinations per launch
+constexpr int D3DP_REDUCE_MAX = 80;
+struct D3dpReduceItem { const float* part; float* dst; unsigned n, count, stride, accumulate; };
+struct D3dpReduceTable { D3dpReduceItem it[D3DP_REDUCE_MAX]; int count; };
+int d3dp_train_reduce_many(const D3dpReduceTable& tb, hipStream_t st);
 // (amax: optional absmax slot of the result, see train.hip block_amax_commit)
 int d3dp_train_gelu_fwd(const float* x, float* y, size_t n, unsigned* amax, hipStream_t st);
 int d3dp_train_gelu_bwd(const float* dh, const float* x, float* dpre, size_t n, unsigned* amax, hipStream_t st);
-int d3dp_train_scale_mask(const float* in, const float* mask, int axis, int F, int J, float* out, int T, int C,
-                          unsigned* amax, hipStream_t st);
-int d3dp_train_colsum(const float* in, float* out, int T, int C, hipStream_t st);
+// column sums as *rows (<= max_rows <= 512) partial rows of C floats (summed by d3dp_train_reduce_many)
+int d3dp_train_colsum(const float* in, float* part, int* rows, int max_rows, int T, int C, hipStream_t st);
 // zero up to D3DP_ZERO_MAX fp32 buffers in one launch (the small gradient buffers of a backward pass)
 constexpr int D3DP_ZERO_MAX = 192;
 struct D3dpZeroTable { float* p[D3DP_ZERO_MAX]; unsigned n[D3DP_ZERO_MAX]; int count; };
 int d3dp_train_zero_many(const D3dpZeroTable& tb, hipStream_t st);
-int d3dp_train_groupsum(const float* in, float* out, int T, int C, int mode, int F, int J, hipStream_t st);
+// grouped row sums (mode 0: per joint, 1: per frame, 2: per batch element) as `slices` partial tables of groups x C floats
+int d3dp_train_groupsum(const float* in, float* out, int T, int C, int mode, int F, int J, int slices, hipStream_t st);
 int d3dp_train_transpose_pad(const float* in, float* out, int R, int C, int Rpad, hipStream_t st);
 size_t d3dp_train_attn_stats_bytes(int n_seq, int n_tok, int heads);
 int d3dp_train_attn_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, void* stats, int n_seq,
                         SeqMap map, int C, int heads, hipStream_t st);
-int d3dp_train_embed_bwd(const float* dx, const float* x2d, const float* x3d, float* dW, int T, int C, hipStream_t st);
+constexpr int D3DP_EMBED_BWD_ROWS = 64;
+int d3dp_train_embed_bwd(const float* dx, const float* x2d, const float* x3d, float* part, int T, int C, hipStream_t st);
 int d3dp_train_head_linear(const float* z, const float* w, const float* b, float* out, int T, int C, hipStream_t st);
-int d3dp_train_head_bwd(const float* g, const float* z, const float* w, float* dz, float* dW, float* db, int T, int C,
+int d3dp_train_head_bwd(const float* g, const float* z, const float* w, float* dz, float* part, int* rows, int T, int C,
                         hipStream_t st);
 int d3dp_train_time_mlp_bwd(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2,
                             const float* dtemb, float* dw1, float* db1, float* dw2, float* db2, int B, int C,

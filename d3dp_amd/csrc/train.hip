@@ -22,82 +22,16 @@ __device__ __forceinline__ int sample_of(int tok, int axis, int F, int J) {
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
 constexpr float kInvSqrt2Pi = 0.39894228040143267794f;
 
-// ---- x_out = x_in + m[sample] * y ; optionally xn = LN(x_out) ---------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(256) void add_mask_ln_kernel(const float* __restrict__ x_in, const float* __restrict__ y,
-                                                          const float* __restrict__ mask, int axis, int F, int J,
-                                                          const float* __restrict__ w, const float* __restrict__ b,
-                                                          float eps, float* __restrict__ x_out, float* __restrict__ xn,
-                                                          int T) {
-  constexpr int NV = C / 64;
-  const int lane = threadIdx.x & 63;
-  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tok >= T) return;
-  const float m = mask ? mask[sample_of(tok, axis, F, J)] : 1.0f;
-  float v[NV];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const size_t o = (size_t)tok * C + i * 64 + lane;
-    v[i] = x_in[o] + m * y[o];
-    x_out[o] = v[i];
-    s += v[i];
+// A lane's slice of a C-channel row: NV = C / 64 values -- float4 groups at element (g 64 + lane) 4 when NV % 4 == 0 (16-byte
+// accesses), scalars at i 64 + lane otherwise.
+template <int C> struct TRow {
+  static constexpr int NV = C / 64;
+  static constexpr bool V4 = NV % 4 == 0;
+  static __device__ __forceinline__ int col(int i, int lane) {
+    if constexpr (V4) return ((i >> 2) * 64 + lane) * 4 + (i & 3);
+    else return i * 64 + lane;
   }
-  if (xn == nullptr) return;
-  const float mean = wave_sum(s) * (1.0f / C);
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = i * 64 + lane;
-    xn[(size_t)tok * C + c] = fmaf((v[i] - mean) * rstd, w[c], b[c]);
-  }
-}
-
-// ---- y = LN(x) (+ pos[f]) -----------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(256) void ln_pos_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                     const float* __restrict__ b, float eps, const float* __restrict__ pos,
-                                                     int F, int J, float* __restrict__ y, int T) {
-  constexpr int NV = C / 64;
-  const int lane = threadIdx.x & 63;
-  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tok >= T) return;
-  float v[NV];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) { v[i] = x[(size_t)tok * C + i * 64 + lane]; s += v[i]; }
-  const float mean = wave_sum(s) * (1.0f / C);
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
-  const int f = (tok / J) % F;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = i * 64 + lane;
-    float r = fmaf((v[i] - mean) * rstd, w[c], b[c]);
-    if (pos) r += pos[(size_t)f * C + c];
-    y[(size_t)tok * C + c] = r;
-  }
-}
-
-// ---- LayerNorm backward: dx (+= dres), dgamma/dbeta accumulated with atomics ------------------------------------
-//   xhat = (x - mean) rstd ; g = dy * gamma ; dx = rstd (g - mean(g) - xhat mean(g xhat))  [+ dres]
-// A lane owns the columns (g 64 + lane) 4 .. + 3 of a row (16-byte accesses) when C % 256 == 0, else i 64 + lane.
-template <int C>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                     const float* __restrict__ w, float eps,
-                                                     const float* __restrict__ dres, float* __restrict__ dx,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int T) {
-  constexpr int NV = C / 64;
-  constexpr bool V4 = NV % 4 == 0;
-  __shared__ float sg[4][C], sb[4][C];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  auto col = [&](int i) { return V4 ? ((i >> 2) * 64 + lane) * 4 + (i & 3) : i * 64 + lane; };
-  auto load_row = [&](const float* p, float (&v)[NV]) {
+  static __device__ __forceinline__ void load(const float* p, int lane, float (&v)[NV]) {
     if constexpr (V4) {
 #pragma unroll
       for (int g = 0; g < NV / 4; ++g) {
@@ -108,63 +42,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
       for (int i = 0; i < NV; ++i) v[i] = p[i * 64 + lane];
     }
-  };
-  float ag[NV], ab[NV], wl[NV];
+  }
+  static __device__ __forceinline__ void store(float* p, int lane, const float (&v)[NV]) {
+    if constexpr (V4) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) { ag[i] = 0.f; ab[i] = 0.f; wl[i] = w[col(i)]; }
-  for (int tok = blockIdx.x * 4 + wv; tok < T; tok += gridDim.x * 4) {
-    float v[NV], g[NV], d[NV], r0[NV];
-    load_row(x + (size_t)tok * C, v);
-    load_row(dy + (size_t)tok * C, d);
-    if (dres) load_row(dres + (size_t)tok * C, r0);
+      for (int g = 0; g < NV / 4; ++g)
+        *reinterpret_cast<float4*>(p + (g * 64 + lane) * 4) = make_float4(v[g * 4], v[g * 4 + 1], v[g * 4 + 2], v[g * 4 + 3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) p[i * 64 + lane] = v[i];
+    }
+  }
+  // (mean, 1 / sqrt(var + eps)) of the row a wave holds: two passes in registers
+  static __device__ __forceinline__ void stats(const float (&v)[NV], float eps, float& mean, float& rstd) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) s += v[i];
-    const float mean = wave_sum(s) * (1.0f / C);
+    mean = wave_sum(s) * (1.0f / C);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) { v[i] -= mean; q = fmaf(v[i], v[i], q); }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
-    float sg1 = 0.f, sg2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      v[i] *= rstd;                    // xhat
-      g[i] = d[i] * wl[i];
-      sg1 += g[i];
-      sg2 = fmaf(g[i], v[i], sg2);
-      ag[i] = fmaf(d[i], v[i], ag[i]);
-      ab[i] += d[i];
-    }
-    sg1 = wave_sum(sg1) * (1.0f / C);
-    sg2 = wave_sum(sg2) * (1.0f / C);
-    float r[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      r[i] = rstd * (g[i] - sg1 - v[i] * sg2);
-      if (dres) r[i] += r0[i];
-    }
-    float* o = dx + (size_t)tok * C;
-    if constexpr (V4) {
-#pragma unroll
-      for (int gq = 0; gq < NV / 4; ++gq)
-        *reinterpret_cast<float4*>(o + (gq * 64 + lane) * 4) = make_float4(r[gq * 4], r[gq * 4 + 1], r[gq * 4 + 2], r[gq * 4 + 3]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) o[i * 64 + lane] = r[i];
-    }
+    for (int i = 0; i < NV; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+    rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
   }
-#pragma unroll
-  for (int i = 0; i < NV; ++i) { sg[wv][col(i)] = ag[i]; sb[wv][col(i)] = ab[i]; }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    atomicAdd(dgamma + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
-    atomicAdd(dbeta + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
-  }
-}
+};
 
-// The three elementwise producers of split operands (the fc2 input, the two kinds of dY) also leave their result's absmax in a
-// slot of the training step (as absmax_kernel: bit pattern of a non-negative float, one atomic per workgroup; amax may be
-// null): grid-stride over 16-byte groups so that a launch has at most 512 workgroups = 512 atomics.
+// One atomic per WORKGROUP for a kernel's result absmax (bit pattern of a non-negative float; amax may be null): the row
+// kernels below walk the tokens grid-stride on at most kRowBlocks workgroups so that a launch ends with at most that many
+// same-address atomics (one per wave of a 4,131-workgroup launch cost 56 us, profiles/r04_train_step_kernel_stats.md).
+constexpr int kRowBlocks = 1024;
 __device__ __forceinline__ void block_amax_commit(float m, unsigned* amax) {
   __shared__ float part_amax[4];
   m = wave_max(m);
@@ -173,6 +78,239 @@ __device__ __forceinline__ void block_amax_commit(float m, unsigned* amax) {
   if (threadIdx.x == 0 && amax)
     atomicMax(amax, __float_as_uint(fmaxf(fmaxf(part_amax[0], part_amax[1]), fmaxf(part_amax[2], part_amax[3]))));
 }
+
+// ---- x_out = x_in + m[sample] * y ; xn = LN(x_out)  (+ absmax of xn: the fc1 operand) ------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void add_mask_ln_kernel(const float* __restrict__ x_in, const float* __restrict__ y,
+                                                          const float* __restrict__ mask, int axis, int F, int J,
+                                                          const float* __restrict__ w, const float* __restrict__ b,
+                                                          float eps, float* __restrict__ x_out, float* __restrict__ xn,
+                                                          unsigned* __restrict__ amax, int T) {
+  using R = TRow<C>;
+  constexpr int NV = R::NV;
+  const int lane = threadIdx.x & 63;
+  float wl[NV], bl[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { wl[i] = w[R::col(i, lane)]; bl[i] = b[R::col(i, lane)]; }
+  float am = 0.f;
+  for (int tok = blockIdx.x * 4 + (threadIdx.x >> 6); tok < T; tok += gridDim.x * 4) {
+    const float m = mask ? mask[sample_of(tok, axis, F, J)] : 1.0f;
+    float v[NV], yy[NV];
+    R::load(x_in + (size_t)tok * C, lane, v);
+    R::load(y + (size_t)tok * C, lane, yy);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = v[i] + m * yy[i];
+    R::store(x_out + (size_t)tok * C, lane, v);
+    float mean, rstd;
+    R::stats(v, eps, mean, rstd);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i] = fmaf((v[i] - mean) * rstd, wl[i], bl[i]); am = fmaxf(am, fabsf(v[i])); }
+    R::store(xn + (size_t)tok * C, lane, v);
+  }
+  block_amax_commit(am, amax);
+}
+
+// ---- the end of a block in ONE pass over its rows (mixste.py:113-115 second line, then :243/:250 or :257/:273):
+//   x_out = x_in + m[sample] * y ;  x_next = LN_a(x_out) (+ pos[f]) ;  xn = LN_b(x_next)  (+ absmax of xn)
+// LN_a = the shared Spatial / Temporal norm, LN_b = the next block's norm1 (the head's LayerNorm after the last block;
+// xn == nullptr: no second norm).  As three kernels (add_mask_ln, ln_pos, ln_pos) the row was written and read back twice.
+template <int C>
+__global__ __launch_bounds__(256) void add_mask_ln2_kernel(const float* __restrict__ x_in, const float* __restrict__ y,
+                                                           const float* __restrict__ mask, int axis, int F, int J,
+                                                           const float* __restrict__ wa, const float* __restrict__ ba, float eps_a,
+                                                           const float* __restrict__ pos, const float* __restrict__ wb,
+                                                           const float* __restrict__ bb, float eps_b, float* __restrict__ x_out,
+                                                           float* __restrict__ x_next, float* __restrict__ xn,
+                                                           unsigned* __restrict__ amax, int T) {
+  using R = TRow<C>;
+  constexpr int NV = R::NV;
+  const int lane = threadIdx.x & 63;
+  float wal[NV], bal[NV], wbl[NV], bbl[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = R::col(i, lane);
+    wal[i] = wa[c]; bal[i] = ba[c];
+    wbl[i] = xn ? wb[c] : 0.f; bbl[i] = xn ? bb[c] : 0.f;
+  }
+  float am = 0.f;
+  for (int tok = blockIdx.x * 4 + (threadIdx.x >> 6); tok < T; tok += gridDim.x * 4) {
+    const float m = mask ? mask[sample_of(tok, axis, F, J)] : 1.0f;
+    float v[NV], yy[NV];
+    R::load(x_in + (size_t)tok * C, lane, v);
+    R::load(y + (size_t)tok * C, lane, yy);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = v[i] + m * yy[i];
+    R::store(x_out + (size_t)tok * C, lane, v);
+    float mean, rstd;
+    R::stats(v, eps_a, mean, rstd);
+    if (pos) {
+      float pp[NV];
+      R::load(pos + (size_t)((tok / J) % F) * C, lane, pp);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { float r = fmaf((v[i] - mean) * rstd, wal[i], bal[i]); r += pp[i]; v[i] = r; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = fmaf((v[i] - mean) * rstd, wal[i], bal[i]);
+    }
+    R::store(x_next + (size_t)tok * C, lane, v);
+    if (xn) {
+      R::stats(v, eps_b, mean, rstd);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { v[i] = fmaf((v[i] - mean) * rstd, wbl[i], bbl[i]); am = fmaxf(am, fabsf(v[i])); }
+      R::store(xn + (size_t)tok * C, lane, v);
+    }
+  }
+  block_amax_commit(am, amax);
+}
+
+// ---- y = LN(x) (+ pos[f]) -- the fp32 cross-check path's recomputation of a Linear input in the backward pass -----------
+template <int C>
+__global__ __launch_bounds__(256) void ln_pos_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float eps, const float* __restrict__ pos,
+                                                     int F, int J, float* __restrict__ y, int T) {
+  using R = TRow<C>;
+  constexpr int NV = R::NV;
+  const int lane = threadIdx.x & 63;
+  float wl[NV], bl[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { wl[i] = w[R::col(i, lane)]; bl[i] = b[R::col(i, lane)]; }
+  for (int tok = blockIdx.x * 4 + (threadIdx.x >> 6); tok < T; tok += gridDim.x * 4) {
+    float v[NV];
+    R::load(x + (size_t)tok * C, lane, v);
+    float mean, rstd;
+    R::stats(v, eps, mean, rstd);
+    const int f = (tok / J) % F;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float r = fmaf((v[i] - mean) * rstd, wl[i], bl[i]);
+      if (pos) r += pos[(size_t)f * C + R::col(i, lane)];
+      v[i] = r;
+    }
+    R::store(y + (size_t)tok * C, lane, v);
+  }
+}
+
+// ---- LayerNorm backward, one LayerNorm or two chained ones per pass over the rows ------------------------------------------
+//   LN_b:  y = LN_b(xb), grad dy:   xhat = (xb - mean) rstd ; gg = dy gamma_b ;  g = rstd (gg - mean(gg) - xhat mean(gg xhat)) + dres
+//   LN_a (TWO):  xb = LN_a(xa) (+ pos):  dx = the same formula on (g, xa, gamma_a);  ONE: dx = g
+//   dxm = mask[sample] dx  (the DropPath-scaled dY of the branch below, with its absmax: the fused scale_mask pass)
+// TWO covers the pairs the forward pass chains -- the head's LayerNorm over the last shared norm, a block's norm1 over the
+// shared norm of the block before it: as two ln_bwd launches plus scale_mask the row went to memory and back twice more.
+// dgamma / dbeta: every workgroup leaves ITS sums as one row [dgamma | dbeta] of `part_b` / `part_a` (gridDim.x rows of 2 C
+// floats); d3dp_train_reduce_many adds the rows in a fixed order at the end of the backward pass -- no float atomics, so the
+// step's gradients are bit-reproducible run to run.
+// dy and dxm may alias (a wave reads its row of dy before it writes the row of dxm), hence no __restrict__ on them.
+template <int C, bool TWO>
+__global__ __launch_bounds__(256) void ln_bwd2_kernel(const float* dy, const float* __restrict__ xb, const float* __restrict__ wb,
+                                                      float eps_b, const float* __restrict__ dres, float* __restrict__ g_out,
+                                                      const float* __restrict__ xa, const float* __restrict__ wa, float eps_a,
+                                                      float* __restrict__ dx, const float* __restrict__ mask, int axis, int F, int J,
+                                                      float* dxm, unsigned* __restrict__ amax, float* __restrict__ part_b,
+                                                      float* __restrict__ part_a, int T) {
+  using R = TRow<C>;
+  constexpr int NV = R::NV;
+  __shared__ float sg[4][C], sb[4][C];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float agb[NV], abb[NV], wbl[NV];
+  [[maybe_unused]] float aga[NV], aba[NV], wal[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    agb[i] = 0.f; abb[i] = 0.f; wbl[i] = wb[R::col(i, lane)];
+    if constexpr (TWO) { aga[i] = 0.f; aba[i] = 0.f; wal[i] = wa[R::col(i, lane)]; }
+  }
+  const bool want_m = dxm != nullptr || amax != nullptr;
+  float am = 0.f;
+  for (int tok = blockIdx.x * 4 + wv; tok < T; tok += gridDim.x * 4) {
+    float v[NV], d[NV];
+    R::load(xb + (size_t)tok * C, lane, v);
+    R::load(dy + (size_t)tok * C, lane, d);
+    float mean, rstd;
+    R::stats(v, eps_b, mean, rstd);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[i] = (v[i] - mean) * rstd;                       // xhat
+      agb[i] = fmaf(d[i], v[i], agb[i]);
+      abb[i] += d[i];
+      d[i] *= wbl[i];                                    // gg
+      s1 += d[i];
+      s2 = fmaf(d[i], v[i], s2);
+    }
+    s1 = wave_sum(s1) * (1.0f / C);
+    s2 = wave_sum(s2) * (1.0f / C);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) d[i] = rstd * (d[i] - s1 - v[i] * s2);
+    if (dres) {
+      R::load(dres + (size_t)tok * C, lane, v);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) d[i] += v[i];
+    }
+    if constexpr (TWO) {
+      if (g_out) R::store(g_out + (size_t)tok * C, lane, d);
+      R::load(xa + (size_t)tok * C, lane, v);
+      R::stats(v, eps_a, mean, rstd);
+      s1 = 0.f; s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        v[i] = (v[i] - mean) * rstd;
+        aga[i] = fmaf(d[i], v[i], aga[i]);
+        aba[i] += d[i];
+        d[i] *= wal[i];
+        s1 += d[i];
+        s2 = fmaf(d[i], v[i], s2);
+      }
+      s1 = wave_sum(s1) * (1.0f / C);
+      s2 = wave_sum(s2) * (1.0f / C);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) d[i] = rstd * (d[i] - s1 - v[i] * s2);
+    }
+    R::store(dx + (size_t)tok * C, lane, d);
+    if (want_m) {
+      const float k = mask ? mask[sample_of(tok, axis, F, J)] : 1.0f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { d[i] *= k; am = fmaxf(am, fabsf(d[i])); }
+      if (dxm) R::store(dxm + (size_t)tok * C, lane, d);
+    }
+  }
+  // this workgroup's [dgamma | dbeta] rows: the four waves' sums in the order 0, 1, 2, 3
+  auto flush = [&](const float (&ag)[NV], const float (&ab)[NV], float* part) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { sg[wv][R::col(i, lane)] = ag[i]; sb[wv][R::col(i, lane)] = ab[i]; }
+    __syncthreads();
+    float* row = part + (size_t)blockIdx.x * 2 * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      row[c] = ((sg[0][c] + sg[1][c]) + sg[2][c]) + sg[3][c];
+      row[C + c] = ((sb[0][c] + sb[1][c]) + sb[2][c]) + sb[3][c];
+    }
+    __syncthreads();
+  };
+  flush(agb, abb, part_b);
+  if constexpr (TWO) flush(aga, aba, part_a);
+  if (want_m) block_amax_commit(am, amax);
+}
+
+// dst[i] (+)= sum over p < count of part[p stride + i], p ascending within each of four row groups, the groups in order: the
+// fixed-order end of every partial sum of the backward pass (LayerNorm gammas / betas, biases, the small embedding-side
+// gradients).  blockIdx.y = item; 64 columns x 4 row groups per workgroup.
+__global__ __launch_bounds__(256) void reduce_many_kernel(D3dpReduceTable tb) {
+  __shared__ float acc[4][64];
+  const D3dpReduceItem it = tb.it[blockIdx.y];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  if (blockIdx.x * 64 >= (int)it.n) return;
+  const unsigned chunk = (it.count + 3) / 4;
+  const unsigned p0 = rg * chunk, p1 = min(p0 + chunk, it.count);
+  float a = 0.f;
+  if (c < (int)it.n)
+    for (unsigned p = p0; p < p1; ++p) a += it.part[(size_t)p * it.stride + c];
+  acc[rg][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (rg == 0 && c < (int)it.n) {
+    const int l = threadIdx.x & 63;
+    const float t = ((acc[0][l] + acc[1][l]) + acc[2][l]) + acc[3][l];
+    it.dst[c] = it.accumulate ? it.dst[c] + t : t;
+  }
+}
+
 __device__ __forceinline__ float amax4f(const float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 
 // (four elements per thread; n % 4 == 0: the hidden width is a multiple of 32)
@@ -208,34 +346,17 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* dh, const fl
   block_amax_commit(m, amax);
 }
 
-// out[t, :] = m[sample(t)] * in[t, :]     (C % 4 == 0)
-__global__ __launch_bounds__(256) void scale_mask_kernel(const float* __restrict__ in, const float* __restrict__ mask,
-                                                         int axis, int F, int J, float* __restrict__ out, int T, int C,
-                                                         unsigned* __restrict__ amax) {
-  const size_t n4 = (size_t)T * C / 4;
-  const int C4 = C / 4;
-  float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    const int tok = (int)(i / C4);
-    const float k = mask ? mask[sample_of(tok, axis, F, J)] : 1.0f;
-    const float4 v = reinterpret_cast<const float4*>(in)[i];
-    const float4 r = make_float4(v.x * k, v.y * k, v.z * k, v.w * k);
-    reinterpret_cast<float4*>(out)[i] = r;
-    m = fmaxf(m, amax4f(r));
-  }
-  block_amax_commit(m, amax);
-}
-
 __global__ __launch_bounds__(256) void zero_many_kernel(D3dpZeroTable tb) {
   float* p = tb.p[blockIdx.y];
   const unsigned n = tb.n[blockIdx.y];
   for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0.f;
 }
 
-// out[c] += sum_t in[t, c]     (bias grads).  A thread owns four columns (one 16-byte load per row) of one row in four; the
-// four row lanes of a workgroup meet in LDS, so a column receives one atomic per workgroup (gridDim.y of them).
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int T, int C) {
-  __shared__ float4 part[4][64];
+// part[blockIdx.y][c] = sum over this workgroup row's tokens of in[t, c]  (gridDim.y partial rows of C floats, summed in a fixed
+// order by reduce_many_kernel).  A thread owns four columns (one 16-byte load per row) of one row in four; the four row lanes
+// of a workgroup meet in LDS.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, float* __restrict__ part, int T, int C) {
+  __shared__ float4 sh[4][64];
   const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + cg) * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -255,18 +376,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
   }
-  part[rl][cg] = s;
+  sh[rl][cg] = s;
   __syncthreads();
   if (rl == 0 && c < C) {
-    const float4 a = part[0][cg], b = part[1][cg], d = part[2][cg], e = part[3][cg];
-    atomicAdd(out + c, (a.x + b.x) + (d.x + e.x));
-    atomicAdd(out + c + 1, (a.y + b.y) + (d.y + e.y));
-    atomicAdd(out + c + 2, (a.z + b.z) + (d.z + e.z));
-    atomicAdd(out + c + 3, (a.w + b.w) + (d.w + e.w));
+    const float4 a = sh[0][cg], b = sh[1][cg], d = sh[2][cg], e = sh[3][cg];
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.y * C + c) =
+        make_float4((a.x + b.x) + (d.x + e.x), (a.y + b.y) + (d.y + e.y), (a.z + b.z) + (d.z + e.z), (a.w + b.w) + (d.w + e.w));
   }
 }
 
-// out[g, c] += sum over tokens of group g of in[t, c]; group: 0 -> n = t % J, 1 -> f = (t / J) % F, 2 -> b = t / (F J)
+// out[z][g, c] = sum over the tokens of group g that slice z of gridDim.z owns of in[t, c]; group: 0 -> n = t % J, 1 -> f = (t / J) % F,
+// 2 -> b = t / (F J).  gridDim.z partial tables of groups x C floats (gridDim.z == 1: the result itself); written, never added
+// to: the slices meet in reduce_many_kernel, in order.
 __global__ __launch_bounds__(256) void groupsum_kernel(const float* __restrict__ in, float* __restrict__ out, int T, int C,
                                                        int mode, int F, int J) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -280,7 +401,7 @@ __global__ __launch_bounds__(256) void groupsum_kernel(const float* __restrict__
   } else {
     for (int t = blockIdx.z; t < F * J; t += gridDim.z) s += in[((size_t)g * F * J + t) * C + c];
   }
-  atomicAdd(out + (size_t)g * C + c, s);
+  out[((size_t)blockIdx.z * gridDim.y + g) * C + c] = s;
 }
 
 // out[c, r] = in[r, c] for r < R, 0 for R <= r < Rpad     (in [R, C] -> out [C, Rpad])
@@ -504,9 +625,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const float* __restric
   }
 }
 
-// ---- embedding backward: dW[c, i] += sum_t dx[t, c] in5[t, i] ; in5 = (u, v, x, y, z) ----------------------------
+// ---- embedding backward: dW[c, i] = sum_t dx[t, c] in5[t, i] ; in5 = (u, v, x, y, z); gridDim.y partial tables of 5 C floats ----
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ x2d,
-                                                        const float* __restrict__ x3d, float* __restrict__ dW, int T, int C) {
+                                                        const float* __restrict__ x3d, float* __restrict__ part, int T, int C) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -519,7 +640,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     a[4] = fmaf(d, x3d[(size_t)t * 3 + 2], a[4]);
   }
 #pragma unroll
-  for (int i = 0; i < 5; ++i) atomicAdd(dW + c * 5 + i, a[i]);
+  for (int i = 0; i < 5; ++i) part[(size_t)blockIdx.y * 5 * C + c * 5 + i] = a[i];
 }
 
 // ---- head: pred[t, o] = sum_c z[t, c] W[o, c] + b[o]  (o < 3) -------------------------------------------------------
@@ -543,10 +664,11 @@ __global__ __launch_bounds__(256) void head_linear_kernel(const float* __restric
   if (lane < 3) out[(size_t)tok * 3 + lane] = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : acc[2]);
 }
 
-// dz[t, c] = sum_o g[t, o] W[o, c] ; dW[o, c] += sum_t g[t, o] z[t, c] ; db[o] += sum_t g[t, o]
+// dz[t, c] = sum_o g[t, o] W[o, c] ; dW[o, c] = sum_t g[t, o] z[t, c] ; db[o] = sum_t g[t, o]: gridDim.y partial rows of
+// 3 C + 4 floats ([dW | db, -]), summed in a fixed order by reduce_many_kernel
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ g, const float* __restrict__ z,
                                                        const float* __restrict__ w, float* __restrict__ dz,
-                                                       float* __restrict__ dW, float* __restrict__ db, int T, int C) {
+                                                       float* __restrict__ part, int T, int C) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   float a[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
@@ -558,9 +680,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     a[0] = fmaf(g0, zz, a[0]); a[1] = fmaf(g1, zz, a[1]); a[2] = fmaf(g2, zz, a[2]);
     if (c == 0) { sb[0] += g0; sb[1] += g1; sb[2] += g2; }
   }
+  float* row = part + (size_t)blockIdx.y * (3 * C + 4);
 #pragma unroll
-  for (int o = 0; o < 3; ++o) atomicAdd(dW + o * C + c, a[o]);
-  if (c == 0) { atomicAdd(db, sb[0]); atomicAdd(db + 1, sb[1]); atomicAdd(db + 2, sb[2]); }
+  for (int o = 0; o < 3; ++o) row[o * C + c] = a[o];
+  if (c == 0) { row[3 * C] = sb[0]; row[3 * C + 1] = sb[1]; row[3 * C + 2] = sb[2]; }
 }
 
 // ---- time MLP backward: one WAVE per hidden unit k of the 2C ---------------------------------------------------------
@@ -640,25 +763,52 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const int64_t* __rest
     default: return -2;                             \
   }
 
+static int row_blocks(int T) { return (T + 3) / 4 < kRowBlocks ? (T + 3) / 4 : kRowBlocks; }
 int d3dp_train_add_mask_ln(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* w,
-                           const float* b, float eps, float* x_out, float* xn, int T, int C, hipStream_t st) {
-  TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((add_mask_ln_kernel<CC>), dim3((T + 3) / 4), dim3(256), 0, st, x_in, y, mask, axis,
-                                         F, J, w, b, eps, x_out, xn, T))
+                           const float* b, float eps, float* x_out, float* xn, unsigned* amax, int T, int C, hipStream_t st) {
+  if (!w || !b || !xn) return -1;
+  TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((add_mask_ln_kernel<CC>), dim3(row_blocks(T)), dim3(256), 0, st, x_in, y, mask, axis,
+                                         F, J, w, b, eps, x_out, xn, amax, T))
+  return 0;
+}
+int d3dp_train_add_mask_ln2(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* wa,
+                            const float* ba, float eps_a, const float* pos, const float* wb, const float* bb, float eps_b,
+                            float* x_out, float* x_next, float* xn, unsigned* amax, int T, int C, hipStream_t st) {
+  if (!wa || !ba || !x_out || !x_next || (xn && (!wb || !bb))) return -1;
+  TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((add_mask_ln2_kernel<CC>), dim3(row_blocks(T)), dim3(256), 0, st, x_in, y, mask, axis,
+                                         F, J, wa, ba, eps_a, pos, wb, bb, eps_b, x_out, x_next, xn, amax, T))
   return 0;
 }
 int d3dp_train_ln_pos(const float* x, const float* w, const float* b, float eps, const float* pos, int F, int J, float* y,
                       int T, int C, hipStream_t st) {
-  TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((ln_pos_kernel<CC>), dim3((T + 3) / 4), dim3(256), 0, st, x, w, b, eps, pos, F, J,
+  TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((ln_pos_kernel<CC>), dim3(row_blocks(T)), dim3(256), 0, st, x, w, b, eps, pos, F, J,
                                          y, T))
   return 0;
 }
-int d3dp_train_ln_bwd(const float* dy, const float* x, const float* w, float eps, const float* dres, float* dx,
-                      float* dgamma, float* dbeta, int T, int C, hipStream_t st) {
-  // (512 workgroups: two per CU; every workgroup ends with 2 C atomics into the shared gamma / beta gradients, which at
-  //  1024 workgroups were most of the kernel's time)
-  const int blocks = (T + 3) / 4 < 512 ? (T + 3) / 4 : 512;
-  TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd_kernel<CC>), dim3(blocks), dim3(256), 0, st, dy, x, w, eps, dres, dx,
-                                         dgamma, dbeta, T))
+// (D3DP_LN_BWD_BLOCKS workgroups: two per CU; every workgroup ends with one partial row per LayerNorm)
+int d3dp_train_ln_bwd_blocks(int T) { return (T + 3) / 4 < D3DP_LN_BWD_BLOCKS ? (T + 3) / 4 : D3DP_LN_BWD_BLOCKS; }
+int d3dp_train_ln_bwd(const float* dy, const float* xb, const float* wb, float eps_b, const float* dres, float* g_out,
+                      const float* xa, const float* wa, float eps_a, float* dx, const float* mask, int axis, int F, int J,
+                      float* dxm, unsigned* amax, float* part_b, float* part_a, int T, int C, hipStream_t st) {
+  if (!dy || !xb || !wb || !dx || !part_b || (xa && (!wa || !part_a))) return -1;
+  const int blocks = d3dp_train_ln_bwd_blocks(T);
+  if (xa) {
+    TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd2_kernel<CC, true>), dim3(blocks), dim3(256), 0, st, dy, xb, wb, eps_b, dres,
+                                           g_out, xa, wa, eps_a, dx, mask, axis, F, J, dxm, amax, part_b, part_a, T))
+  } else {
+    TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd2_kernel<CC, false>), dim3(blocks), dim3(256), 0, st, dy, xb, wb, eps_b, dres,
+                                           nullptr, nullptr, nullptr, 0.f, dx, mask, axis, F, J, dxm, amax, part_b, nullptr, T))
+  }
+  return 0;
+}
+int d3dp_train_reduce_many(const D3dpReduceTable& tb, hipStream_t st) {
+  if (tb.count < 1 || tb.count > D3DP_REDUCE_MAX) return -1;
+  unsigned nmax = 1;
+  for (int i = 0; i < tb.count; ++i) {
+    if (!tb.it[i].part || !tb.it[i].dst || tb.it[i].n == 0) return -1;
+    nmax = tb.it[i].n > nmax ? tb.it[i].n : nmax;
+  }
+  hipLaunchKernelGGL(reduce_many_kernel, dim3((nmax + 63) / 64, tb.count), dim3(256), 0, st, tb);
   return 0;
 }
 static unsigned ew_blocks(size_t n4) { return (unsigned)((n4 + 255) / 256 < 512 ? (n4 + 255) / 256 : 512); }
@@ -672,28 +822,28 @@ int d3dp_train_gelu_bwd(const float* dh, const float* x, float* dpre, size_t n, 
   hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, st, dh, x, dpre, n / 4, amax);
   return 0;
 }
-int d3dp_train_scale_mask(const float* in, const float* mask, int axis, int F, int J, float* out, int T, int C, unsigned* amax,
-                          hipStream_t st) {
-  if (C % 4 != 0 || T < 1) return -2;
-  hipLaunchKernelGGL(scale_mask_kernel, dim3(ew_blocks((size_t)T * C / 4)), dim3(256), 0, st, in, mask, axis, F, J, out, T, C, amax);
-  return 0;
-}
 int d3dp_train_zero_many(const D3dpZeroTable& tb, hipStream_t st) {
   if (tb.count < 1 || tb.count > D3DP_ZERO_MAX) return -1;
   hipLaunchKernelGGL(zero_many_kernel, dim3(4, tb.count), dim3(256), 0, st, tb);
   return 0;
 }
-int d3dp_train_colsum(const float* in, float* out, int T, int C, hipStream_t st) {
-  if (C % 4 != 0) return -2;
+// partial rows of C floats; *rows = how many (<= max_rows <= 512)
+int d3dp_train_colsum(const float* in, float* part, int* rows, int max_rows, int T, int C, hipStream_t st) {
+  if (C % 4 != 0 || !rows || max_rows < 1) return -2;
   const int gx = (C + 255) / 256;
-  int gy = 512 / gx;                                     // ~512 workgroups: two per CU, gy atomics per column
+  int gy = 512 / gx;                                     // ~512 workgroups: two per CU
+  if (gy > max_rows) gy = max_rows;
   if (gy > (T + 3) / 4) gy = (T + 3) / 4;
-  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy < 1 ? 1 : gy), dim3(256), 0, st, in, out, T, C);
+  if (gy < 1) gy = 1;
+  *rows = gy;
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, st, in, part, T, C);
   return 0;
 }
-int d3dp_train_groupsum(const float* in, float* out, int T, int C, int mode, int F, int J, hipStream_t st) {
+// out: slices x groups x C floats (slices = 1: the sums themselves)
+int d3dp_train_groupsum(const float* in, float* out, int T, int C, int mode, int F, int J, int slices, hipStream_t st) {
   const int groups = mode == 0 ? J : (mode == 1 ? F : T / (F * J));
-  hipLaunchKernelGGL(groupsum_kernel, dim3((C + 255) / 256, groups, 8), dim3(256), 0, st, in, out, T, C, mode, F, J);
+  if (slices < 1 || groups < 1) return -1;
+  hipLaunchKernelGGL(groupsum_kernel, dim3((C + 255) / 256, groups, slices), dim3(256), 0, st, in, out, T, C, mode, F, J);
   return 0;
 }
 int d3dp_train_transpose_pad(const float* in, float* out, int R, int C, int Rpad, hipStream_t st) {
@@ -985,17 +1135,21 @@ int d3dp_train_attn_bwd(const float* qkv, const float* o, const float* dout, flo
     default: return -2;
   }
 }
-int d3dp_train_embed_bwd(const float* dx, const float* x2d, const float* x3d, float* dW, int T, int C, hipStream_t st) {
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((C + 255) / 256, 64), dim3(256), 0, st, dx, x2d, x3d, dW, T, C);
+// part: D3DP_EMBED_BWD_ROWS partial tables of 5 C floats
+int d3dp_train_embed_bwd(const float* dx, const float* x2d, const float* x3d, float* part, int T, int C, hipStream_t st) {
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((C + 255) / 256, D3DP_EMBED_BWD_ROWS), dim3(256), 0, st, dx, x2d, x3d, part, T, C);
   return 0;
 }
 int d3dp_train_head_linear(const float* z, const float* w, const float* b, float* out, int T, int C, hipStream_t st) {
   TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((head_linear_kernel<CC>), dim3((T + 3) / 4), dim3(256), 0, st, z, w, b, out, T))
   return 0;
 }
-int d3dp_train_head_bwd(const float* g, const float* z, const float* w, float* dz, float* dW, float* db, int T, int C,
+// part: *rows (<= 512) partial rows of 3 C + 4 floats ([dW | db, -])
+int d3dp_train_head_bwd(const float* g, const float* z, const float* w, float* dz, float* part, int* rows, int T, int C,
                         hipStream_t st) {
-  hipLaunchKernelGGL(head_bwd_kernel, dim3((C + 255) / 256, T < 512 ? T : 512), dim3(256), 0, st, g, z, w, dz, dW, db, T, C);
+  if (!rows) return -1;
+  *rows = T < 512 ? T : 512;
+  hipLaunchKernelGGL(head_bwd_kernel, dim3((C + 255) / 256, *rows), dim3(256), 0, st, g, z, w, dz, part, T, C);
   return 0;
 }
 int d3dp_train_time_mlp_bwd(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2,

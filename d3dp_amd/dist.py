@@ -13,8 +13,12 @@ from __future__ import annotations
 import os
 from typing import List, Optional, Sequence
 
-import torch
-import torch.distributed as dist
+# ROCr reads this flag once, at hsa_init (the process's first HIP call): it has to be in the environment BEFORE any
+# torch.cuda call, so it is exported when this module (or the package) is imported, not inside init_from_env.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch                          # noqa: E402
+import torch.distributed as dist      # noqa: E402
 
 
 RCCL_ENV = ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_SOCKET_IFNAME", "NCCL_IB_DISABLE", "RCCL_MSCCL_ENABLE",
@@ -26,8 +30,9 @@ def init_from_env(backend: Optional[str] = None, timeout_s: float = 180.0) -> tu
     Returns (rank, world_size, local_rank).  No-op for a single process.
 
     The rendezvous and the first collective are bounded by ``timeout_s`` and a failure names the environment RCCL reads:
-    on this ROCm stack cross-process device memory needs dmabuf IPC (``HSA_ENABLE_IPC_MODE_LEGACY=0``, exported here when
-    unset -- without it RCCL dies in hipIpcGetMemHandle), and a wrong MASTER_ADDR shows up as a silent hang otherwise."""
+    on this ROCm stack cross-process device memory needs dmabuf IPC (``HSA_ENABLE_IPC_MODE_LEGACY=0``, exported when this
+    module is IMPORTED if unset -- ROCr reads it at the first HIP call; without it RCCL dies in hipIpcGetMemHandle), and a
+    wrong MASTER_ADDR shows up as a silent hang otherwise."""
     import datetime
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -40,7 +45,9 @@ def init_from_env(backend: Optional[str] = None, timeout_s: float = 180.0) -> tu
         kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
         try:
             if backend == "nccl":
-                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+                    raise RuntimeError("HSA_ENABLE_IPC_MODE_LEGACY=%r: this host driver only supports dmabuf IPC (needs 0, "
+                                       "set before the process's first HIP call)" % os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
                 if torch.cuda.device_count() <= local:
                     raise RuntimeError(f"LOCAL_RANK={local} but only {torch.cuda.device_count()} device(s) visible")
                 torch.cuda.set_device(local)

@@ -68,7 +68,7 @@ class _TrainStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         x_2d, x_3d, t = ctx.saved_tensors
-        now = tuple((p.data_ptr(), p._version) for p in ctx.net.parameters())
+        now = tuple((p.data_ptr(), p._version) for p in ctx.net._weight_tensors())
         if now != ctx.versions:
             # PyTorch raises in the same situation ("one of the variables needed for gradient computation has been
             # modified by an inplace operation"): differentiating with weights the forward never saw is silently wrong
@@ -156,6 +156,11 @@ class MixSTE2(nn.Module):
         self._states_lock = threading.Lock()
         self._owns_states = True
         self._last_device: Optional[torch.device] = None
+        # Dotted names of the weights in nn.Module.parameters() order.  A DataParallel replica has NO parameters
+        # (torch/nn/parallel/replicate.py empties `_parameters` and sets the broadcast copies as plain attributes), so
+        # everything that needs "the weights of this module" resolves these names by attribute: _weight_tensors().
+        self._param_names = tuple(n for n, _ in self.named_parameters())
+        self._src_sig = None            # replicas: (data_ptr, version) of the SOURCE module's parameters at replication
 
     # -- library context ------------------------------------------------------------------------
     @property
@@ -173,7 +178,25 @@ class MixSTE2(nn.Module):
         module it was copied from and owns none of them -- dropping a replica must never free a context."""
         replica = super()._replicate_for_data_parallel()
         replica._owns_states = False
+        # What the replica's weights are copies OF: its own tensors are fresh broadcast copies on every forward (whose
+        # addresses the caching allocator recycles), so "did the weights change" can only be read off the source.
+        replica._src_sig = tuple((p.data_ptr(), p._version) for p in self._weight_tensors())
         return replica
+
+    def _weight_tensors(self) -> List[torch.Tensor]:
+        """The weight tensors in ``parameters()`` order, found by attribute -- on the module itself these ARE
+        ``list(self.parameters())``; on an nn.DataParallel replica (whose ``parameters()`` is empty) they are the
+        per-forward broadcast copies, which carry the autograd edge back to the source parameters."""
+        out = []
+        for name in self._param_names:
+            obj = self
+            for part in name.split("."):
+                obj = getattr(obj, part)
+            out.append(obj)
+        return out
+
+    def _is_replica_module(self) -> bool:
+        return bool(self.__dict__.get("_is_replica", False)) or not self.__dict__.get("_owns_states", True)
 
     def __getstate__(self):
         """copy.deepcopy / pickle: library handles do not travel; the copy starts without contexts and owns its own."""
@@ -242,9 +265,18 @@ class MixSTE2(nn.Module):
         # TRAIN mode reads the parameters' own storage (no packed copy): only a re-allocation changes anything.
         # EXACT / FAST keep packed copies, refreshed when a parameter is replaced or modified through autograd-visible
         # in-place ops; writes that bypass the version counter (p.data.mul_(), EMA code) need refresh_weights().
-        borrowed = self._mode == _lib.MODE_TRAIN and all(
-            p.device == device and p.dtype == torch.float32 and p.is_contiguous() for p in self.parameters())
-        sig = (borrowed,) + tuple((p.data_ptr(),) if borrowed else (p.data_ptr(), p._version) for p in self.parameters())
+        params = self._weight_tensors()
+        if self._is_replica_module():
+            # nn.DataParallel replica: never borrow (its tensors die with the forward), and key the packed / copied weights
+            # of this device on the SOURCE parameters -- load_state_dict and optimizer steps on the wrapped module bump
+            # their versions, so the next replica on this device re-packs (it never did).
+            borrowed = False
+            sig = ("replica", self._src_sig if self._src_sig is not None
+                   else tuple((p.data_ptr(), p._version) for p in params))
+        else:
+            borrowed = self._mode == _lib.MODE_TRAIN and len(params) > 0 and all(
+                p.device == device and p.dtype == torch.float32 and p.is_contiguous() for p in params)
+            sig = (borrowed,) + tuple((p.data_ptr(),) if borrowed else (p.data_ptr(), p._version) for p in params)
         if sig != st.weights_sig:
             self._push_weights(st, device, borrowed)
             st.weights_sig = sig
@@ -362,7 +394,7 @@ class MixSTE2(nn.Module):
                                    "inference in torch.no_grad() / call .eval())" % self.numerics)
             if self._mode == _lib.MODE_TRAIN and torch.is_grad_enabled():
                 masks = self._droppath_masks(x_3d.shape[0], x_3d.device, droppath)
-                return _TrainStep.apply(self, x_2d, x_3d, t, masks, *self.parameters())
+                return _TrainStep.apply(self, x_2d, x_3d, t, masks, *self._weight_tensors())
             return self.denoise(x_2d, x_3d[:, None], t)[:, 0]
         return self.denoise(x_2d, x_3d, t)
 
@@ -421,7 +453,8 @@ class MixSTE2(nn.Module):
 
     def _train_backward(self, x_2d, x_3d, t, masks, grad_out):
         ctx, B, dev, nbytes, x2, x3, tt = self._train_io(x_2d, x_3d, t)
-        g = {id(p): torch.empty_like(p, dtype=torch.float32) for p in self.parameters()}
+        params = self._weight_tensors()
+        g = {id(p): torch.empty_like(p, dtype=torch.float32) for p in params}
 
         def gp(p):
             return g[id(p)].data_ptr()
@@ -447,7 +480,7 @@ class MixSTE2(nn.Module):
                                                        grad_out.float().contiguous().data_ptr(), C.byref(w), B,
                                                        self._state().train_ws.data_ptr(), nbytes, _lib.current_stream()),
                        "d3dp_train_backward")
-        return [g[id(p)] for p in self.parameters()]
+        return [g[id(p)] for p in params]
 
     def train_arithmetic(self) -> str:
         """What the training step's Linears run on (bench.py reports it next to the step time)."""

@@ -48,7 +48,8 @@ enum {
                             below 65504 in magnitude.  (env D3DP_EXACT_IMPL=bf16x3 | f32: six-pass split-bf16 /
                             plain fp32-MFMA Linears, kept as cross-checks)                                        */
   D3DP_MODE_FAST = 1,    /* bf16 activations/weights into v_mfma_f32_16x16x32_bf16, fp32 accumulate/LN/softmax */
-  D3DP_MODE_TRAIN = 2,   /* fp32 weights/activations, fp32-MFMA Linears: required by d3dp_train_*; inference also works */
+  D3DP_MODE_TRAIN = 2,   /* fp32 weights and activations; Linears (forward, dgrad, wgrad) on split-fp16 operands whose scales are
+                            found on the device: required by d3dp_train_*; inference also works (fp32-MFMA Linears)          */
 };
 
 /* MixSTE2 hyper-parameters -- reference common/diffusionpose.py:123-124, common/mixste.py:142-163 */
@@ -107,10 +108,16 @@ typedef struct d3dp_ctx d3dp_ctx;
 int d3dp_abi_version(void);
 const char* d3dp_last_error(void);
 
-/* Lifetime.  Replaces: MixSTE2.__init__ (mixste.py:142-210) + .cuda() (main.py:243). */
+/* Lifetime.  Replaces: MixSTE2.__init__ (mixste.py:142-210) + .cuda() (main.py:243).
+ * Shapes: 1 <= frames <= 1024 (the split-fp16 / bf16 MFMA attention kernels hold a sequence of up to 256 frames; longer
+ * clips -- `-f 351`, common/arguments.py:58 -- run both attentions on a chunked fp32 row kernel; d3dp_train_* needs <= 256),
+ * joints <= 32, channels in {64, 128, 256, 512}, head dim in {8, 16, 32, 64}, hidden % 64 == 0 (D3DP_ENOTSUP otherwise). */
 int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out);
 int d3dp_destroy(d3dp_ctx* ctx);
-/* Replaces: load_state_dict (main.py:257).  Converts/packs weights for cfg.mode (synchronises `stream`). */
+/* Replaces: load_state_dict (main.py:257).  Converts/packs weights for cfg.mode (synchronises `stream`).
+ * Non-finite weights (a diverged checkpoint) are not an error: like the reference, the library loads them and the outputs
+ * are non-finite where the reference's are (d3dp_status reports it); an EXACT context then runs its split-bf16
+ * implementation (d3dp_exact_scales: implementation 1), which has fp32's exponent range. */
 int d3dp_set_weights(d3dp_ctx* ctx, const d3dp_weights* w, void* stream);
 /* D3DP_MODE_TRAIN only: use the caller's fp32 device buffers in place (no packed copy, no launch, no synchronisation), so
  * an optimizer step needs no re-push.  The buffers must stay allocated while the context uses them. */
@@ -134,9 +141,9 @@ int d3dp_set_weights_borrowed(d3dp_ctx* ctx, const d3dp_weights* w);
  *  - d3dp_status: *nonfinite = 1 if, since the last d3dp_status, a d3dp_denoise output held inf / nan (every call ends with a
  *    scan of its output) -- i.e. the INPUT held inf / nan or the fp32 arithmetic itself overflowed.  Synchronises the
  *    device (do not call it during stream capture); resets the flag.
- * ONE operand is outside the proof: with norm2 folded into fc1 (D3DP_FOLD_LN=1, a measurement switch, off by default) the proj
- * Linear hands fc1 the un-normalised residual stream; that epilogue checks every value it splits, exactly, at run time, and
- * reports through d3dp_status. */
+ * (In a variants build -- see d3dp_op_linear_x2 -- ONE operand is outside the proof: with norm2 folded into fc1, D3DP_FOLD_LN=1,
+ * the proj Linear hands fc1 the un-normalised residual stream; that epilogue checks every value it splits, exactly, at run
+ * time, and reports through d3dp_status.) */
 #define D3DP_SPLIT_RANGE 4094.0f
 int d3dp_exact_range_bound(const d3dp_ctx* ctx, float* bound);
 int d3dp_exact_scales(const d3dp_ctx* ctx, float* s_kv, float* s_hidden, int32_t* implementation);
@@ -286,18 +293,13 @@ int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream);
  * (N % 32 == 0 for epi 1: whole h2i blocks), N <= 2048, M * N * 4 < 2^32.  Every operand value must stay below 65504 / scale
  * in magnitude (at scale 16: |x| < 4094) -- inside d3dp_denoise the library proves and arranges that (d3dp_exact_scales);
  * a caller of this entry point owns it.
- * epi | (D << 8), D in {1, 2, 4} (epi 1 and 4 only): the row-class SKEWED schedule (an experiment kept behind D3DP_X2_SKEW:
- * gemm_x2.hip: a tile's epilogue leaves under the k-loop of the workgroup's next tile, D k-steps per 16-row class; the
- * 16-row blocks (m / 16) % 4 = c of the output sum their k-steps in the order c D, ..., K/32 - 1, 0, ..., c D - 1) -- needs
- * N % 128 == 0 and K >= 128 D (D3DP_EINVAL otherwise).
- * epi | 2048: the PING-PONG form of the kernel (two wave teams half a k-step apart: one reads its fragments from LDS while
- * the other owns the matrix pipe); same arithmetic in the same order: bit-identical results.  An experiment kept behind
- * D3DP_X2_PP=1: measured slightly slower.
- * epi | 4096 (epi 0, 1, 2, 4; N % 256 == 0, else the default kernel runs): the WIDE form (256 x 256 tile, eight waves that
- * load for themselves); bit-identical results.  An experiment kept behind D3DP_X2_WIDE=1: measured equal.
- * Test-only environment switches read by the library:
- * D3DP_X2_PP=1 / D3DP_X2_WIDE=1 (the ping-pong / wide form of the EXACT Linear), D3DP_X2_SKEW=1|2|4 (the skewed schedule above for the denoiser's qkv / fc1 Linears; measured slower, off by default), D3DP_EXACT_IMPL=bf16x3|f32 and D3DP_NO_FOLD=1 (cross-check implementations of EXACT mode), D3DP_FOLD_LN=1 (norm2 folded into
- * the proj / fc1 Linears; measured no faster than the row kernel and left off) -- all read in d3dp_create. */
+ * The product library holds ONE form of this kernel.  Three more forms (epi | (D << 8), D in {1, 2, 4}: the row-class skewed
+ * schedule; epi | 2048: ping-pong wave teams; epi | 4096: 256 x 256 tiles) and the epilogues that fold norm2 into proj / fc1
+ * were built, measured no faster and now exist only in a `make -C d3dp_amd/csrc variants` library
+ * (lib/variants/libd3dp_variants.so; tests marked `variants`): here those flags, and the environment switches D3DP_X2_SKEW,
+ * D3DP_X2_PP, D3DP_X2_WIDE, D3DP_SEQ_PAD, D3DP_FOLD_LN read by d3dp_create, fail with D3DP_ENOTSUP -- they are never ignored.
+ * Cross-check switches the product library does honour (read in d3dp_create): D3DP_EXACT_IMPL=bf16x3|f32, D3DP_NO_FOLD=1
+ * (other implementations of EXACT mode's Linears / residual adds, same tolerance), D3DP_TRAIN_IMPL=f32. */
 int d3dp_op_split2(const float* src, void* dst, size_t n, float scale, void* stream);
 int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* bias, float w_scale, void* out, int32_t M,
                       int32_t N, int32_t K, void* stream);

@@ -297,6 +297,23 @@ def fake_lib(monkeypatch):
     return lib
 
 
+def _replicate_like_torch(network):
+    """torch/nn/parallel/replicate.py for ONE replica, without devices: every module is shallow-copied by
+    `_replicate_for_data_parallel` (which empties `_parameters`), children are re-wired, and each parameter is set on the
+    replica as a plain NON-parameter attribute holding a non-leaf copy (Broadcast's output on a real box)."""
+    modules = list(network.modules())
+    idx = {m: i for i, m in enumerate(modules)}
+    copies = [m._replicate_for_data_parallel() for m in modules]
+    for m, r in zip(modules, copies):
+        for key, child in m._modules.items():
+            setattr(r, key, None if child is None else copies[idx[child]])
+        for key, param in m._parameters.items():
+            setattr(r, key, None if param is None else param * 1.0)       # non-leaf copy with an autograd edge to the source
+        for key, buf in m._buffers.items():
+            setattr(r, key, buf)
+    return copies[0]
+
+
 def test_data_parallel_replicas_never_free_the_parents_context(fake_lib):
     """VERDICT r3 weak 7 (reference caller: main.py:242-248 wraps every model in nn.DataParallel, :698 calls it).  A replica
     is a shallow copy made on every forward; it must share the per-device contexts, create the one of a new device once,
@@ -307,7 +324,7 @@ def test_data_parallel_replicas_never_free_the_parents_context(fake_lib):
     h0 = net._context(d0).value
     assert fake_lib.created == [h0] and net._ctx.value == h0
     for _ in range(3):                                     # three forwards of a 2-device DataParallel
-        r0, r1 = net._replicate_for_data_parallel(), net._replicate_for_data_parallel()
+        r0, r1 = _replicate_like_torch(net), _replicate_like_torch(net)
         assert r0._states is net._states and not r0._owns_states and net._owns_states
         assert r0._context(d0).value == h0                 # device 0: the parent's context, reused
         h1 = r1._context(d1).value                         # device 1: its own, created once
@@ -320,6 +337,46 @@ def test_data_parallel_replicas_never_free_the_parents_context(fake_lib):
     del net
     gc.collect()
     assert sorted(fake_lib.destroyed) == sorted([h0, h1])  # the owner frees each device's context exactly once
+
+
+def test_data_parallel_replicas_see_new_weights(fake_lib, monkeypatch):
+    """a replica's `parameters()` is EMPTY, so a signature built from it never changes and the packed
+    weights of a device were pushed once and never again -- main.py's flow (load the training weights into model_pos every
+    epoch, evaluate through nn.DataParallel, :242-258, :450) silently evaluated with the first epoch's weights.  The
+    signature now follows the SOURCE module's parameters; a replica re-packs exactly when they changed, from its own
+    (broadcast) tensors, and never borrows them."""
+    from d3dp_amd import model as M
+    pushes = []
+
+    def push(self, st, device, borrowed=False):
+        pushes.append((borrowed, float(self.head[1].weight.detach().reshape(-1)[0]), len(self._weight_tensors())))
+
+    monkeypatch.setattr(M.MixSTE2, "_push_weights", push)
+    for is_train in (False, True):
+        pushes.clear()
+        m = D3DP(tiny_args(), KL, KR, is_train=is_train)
+        net = m.pose_estimator
+        d0 = torch.device("cuda", 0)
+        n_params = len(list(net.parameters()))
+        r = _replicate_like_torch(m).pose_estimator
+        assert list(r.parameters()) == [] and len(r._weight_tensors()) == n_params     # what the old signature was built from
+        assert not r._owns_states and r._states is net._states
+        r._context(d0)
+        assert len(pushes) == 1 and pushes[0][0] is False and pushes[0][2] == n_params  # never borrowed on a replica
+        _replicate_like_torch(m).pose_estimator._context(d0)                           # next forward, same weights: no re-pack
+        assert len(pushes) == 1
+        with torch.no_grad():
+            net.head[1].weight.add_(1.0)                                               # optimizer step / load_state_dict
+        _replicate_like_torch(m).pose_estimator._context(d0)
+        assert len(pushes) == 2 and abs(pushes[1][1] - pushes[0][1] - 1.0) < 1e-6      # ...re-packed, from the NEW values
+        m.load_state_dict(m.state_dict())                                              # copy_ in place bumps the versions too
+        _replicate_like_torch(m).pose_estimator._context(d0)
+        assert len(pushes) == 3
+        # the weight tensors of a replica keep their autograd edge to the source parameters (multi-GPU training)
+        w = _replicate_like_torch(m).pose_estimator._weight_tensors()
+        assert all(t.grad_fn is not None for t in w) and len(w) == n_params
+        # and on the module itself they ARE its parameters, in order
+        assert all(a is b for a, b in zip(net._weight_tensors(), net.parameters()))
 
 
 def test_deepcopy_and_pickle_of_a_model_do_not_share_library_handles(fake_lib):
