@@ -98,12 +98,24 @@ def cpu_baseline(budget_s=24.0, full=False):
         times.append(one())
     torch.set_num_threads(old)
     t_k1 = sorted(times)[len(times) // 2]
-    return {"value": 1.0 / (t_k1 * 10.0), "unit": "hypothesis-clips/s", "cores": best, "kind": "port",
-            "sample": f"oracle ddim_sample_flip F=243 B=1 H=1 K=1 (2 of the unit's 20 denoiser calls), median of "
-                      f"{len(times)} runs at the best thread count = {t_k1:.3f} s; x10 DDIM steps to the K=10 unit",
-            "host_cpus": ncpu, "thread_sweep_s": {str(k): round(v, 3) for k, v in sweep.items()},
-            "gflops": 2 * flops_per_denoiser_call() / t_k1 / 1e9,
-            "full_config_run": full_config_cpu_run_live(best) if full else full_config_cpu_run()}
+    k1 = {"value": 1.0 / (t_k1 * 10.0), "unit": "hypothesis-clips/s",
+          "sample": f"oracle ddim_sample_flip F=243 B=1 H=1 K=1 (2 of the unit's 20 denoiser calls), median of "
+                    f"{len(times)} runs at the best thread count = {t_k1:.3f} s; x10 DDIM steps to the K=10 unit",
+          "gflops": 2 * flops_per_denoiser_call() / t_k1 / 1e9,
+          "note": "OPTIMISTIC for the CPU: per FLOP a real batch runs 2.3x slower (the oracle, like the reference, materialises the "
+                  "attention scores of the whole batch)"}
+    if full:
+        # the reported CPU baseline is the UN-extrapolated BASELINE configs[1] run (B=4 H=5 K=5 F=243, 58.97
+        # TFLOP: about three minutes of host CPU), rescaled by FLOP to the K=10 unit; the K=1 sample above is kept as an extra
+        fc = full_config_cpu_run_live(best)
+        return {"value": fc["k10_units_per_s"], "unit": "hypothesis-clips/s", "cores": best, "kind": "port",
+                "sample": f"oracle ddim_sample_flip over ALL of BASELINE configs[1] (F=243 B=4 H=5 K=5 flip-TTA, 58.97 TFLOP), one run, "
+                          f"{fc['seconds']:.1f} s on {best} threads, un-extrapolated; value = B H / seconds / 2 (K=5 -> K=10 units by FLOP)",
+                "host_cpus": ncpu, "thread_sweep_s": {str(k): round(v, 3) for k, v in sweep.items()}, "gflops": fc["gflops"],
+                "full_config_run": fc, "k1_sample": k1}
+    return {"value": k1["value"], "unit": "hypothesis-clips/s", "cores": best, "kind": "port", "sample": k1["sample"],
+            "host_cpus": ncpu, "thread_sweep_s": {str(k): round(v, 3) for k, v in sweep.items()}, "gflops": k1["gflops"],
+            "note": k1["note"], "full_config_run": full_config_cpu_run()}
 
 
 def full_config_cpu_run_live(threads):
@@ -331,6 +343,46 @@ def roofline_from_profile(prof, numerics, B, H, K):
     return r
 
 
+PEAK_HBM_TBS = 8.0             # HBM3E, MI355X_MICROARCH.md
+
+
+def roofline_by_kernel(prof, numerics, B, H, K):
+    """Every kernel class of the step against the roofline that bounds it (proj, fc1 and the attention
+    kernels must not hide behind the dominant qkv Linear).  GEMM classes and the temporal attention: ALGORITHMIC FLOP / HIP-event
+    time against the dense fp16 / bf16 MFMA peak; row-wise kernels and the spatial attention: ALGORITHMIC bytes (DESIGN.md
+    section 4: what the kernel must read and write once, per token row) / time against the HBM peak."""
+    T_all = 2 * B * H * F_ * J_ * K                       # token rows through each per-block kernel class, per step and block
+    nb = 2 * DEPTH
+    exact = numerics == "exact"
+    flop = {"gemm_qkv": 2 * 3 * C_ * C_ * T_all * nb, "gemm_proj": 2 * C_ * C_ * T_all * nb,
+            "gemm_fc1": 2 * 2 * C_ * C_ * T_all * nb, "gemm_fc2": 2 * 2 * C_ * C_ * T_all * nb,
+            "attn_temporal": 4 * F_ * C_ * T_all * DEPTH}
+    # bytes per token row (C = 512): EXACT activations feeding a Linear are 4 B / element (two fp16), FAST 2 B; the residual
+    # stream is fp32.  spatial attention: packed qkv row in (12 C) + planes out (4 C) in EXACT, 3 C x 2 + C x 2 in FAST.
+    a = 4 if exact else 2
+    byts = {"attn_spatial": (12 * C_ + a * C_ if exact else 8 * C_) * T_all * DEPTH,
+            "layernorm": (4 * C_ + a * C_ + (0 if exact else 2 * C_ + 4 * C_)) * T_all * nb,          # LN2: x in (+ FAST: y1 in, x out), operand out
+            "norm_pair": (8 * C_ + a * C_ + (0 if exact else 2 * C_)) * T_all * (nb - 1),            # x in / out, operand out (+ FAST: y in)
+            "embed_ln": (4 * C_ + a * C_) * T_all, "head": 4 * C_ * T_all}
+    out = {}
+    for k, (n, ms) in prof.items():
+        if ms <= 0 or n <= 0:
+            continue
+        if k in flop:
+            ach = flop[k] / (ms * 1e-3) / 1e12
+            out[k] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                      "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "ms_per_step": round(ms, 2), "launches": n,
+                      "avg_launch_us": round(ms / n * 1e3, 1)}
+        elif k in byts:
+            ach = byts[k] / (ms * 1e-3) / 1e12
+            out[k] = {"bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_TBS, "unit": "TB/s",
+                      "frac": round(ach / PEAK_HBM_TBS, 4), "ms_per_step": round(ms, 2), "launches": n,
+                      "avg_launch_us": round(ms / n * 1e3, 1)}
+        else:
+            out[k] = {"bound": "latency", "ms_per_step": round(ms, 3), "launches": n}
+    return out
+
+
 def lib_sha256():
     from d3dp_amd import _lib
     h = hashlib.sha256()
@@ -464,6 +516,59 @@ def other_configs(numerics, gen, with_cpu=True):
     return out
 
 
+def c4_consumer_1gpu(R=8, B=16, K=10, Hl=20, reps=5):
+    """BASELINE configs[3]'s exchange CONSUMER at its full size on ONE GPU (reference main.py:700-718,
+    common/loss.py:54-76): a synthetic all-gather result (R, B, K, H_local, F, 17, 3) = 1.27 GB -- what RCCL leaves on every
+    rank of the 8-GPU job -- through d3dp_jpma_gathered in place, and the 8-way winners -> combine path, both checked bit for
+    bit against d3dp_jpma on the flat (B, K, R H_local, F, 17, 3) tensor.  No collective runs here: what is timed is the kernel
+    every rank runs behind the all-gather."""
+    import torch
+    from d3dp_amd import _lib, jpma
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    gathered = torch.randn((R, B, K, Hl, F_, J_, 3), device="cuda", generator=g) * 0.3
+    x2d = torch.rand((B, F_, J_, 2), device="cuda", generator=g) * 2 - 1
+    traj, cam, gt2 = jpma_inputs(x2d, F_, "cuda")
+    tr3 = traj.reshape(B, F_, 3).contiguous()
+    agg = torch.empty((B, K, F_, J_, 3), device="cuda")
+    sel = torch.empty((B, K, F_, J_), dtype=torch.int32, device="cuda")
+
+    def ev(fn):
+        ts = []
+        for _ in range(reps + 1):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); r = fn(); b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return sorted(ts[1:])[len(ts[1:]) // 2], r
+
+    def run_gathered():
+        _lib.check(lib.d3dp_jpma_gathered(gathered.data_ptr(), tr3.data_ptr(), cam.data_ptr(), gt2.data_ptr(), 0, agg.data_ptr(),
+                                          sel.data_ptr(), 0, 0, R, B, K, Hl, F_, J_, 1, _lib.current_stream()), "d3dp_jpma_gathered")
+        return agg, sel
+
+    def run_winners():
+        wins = torch.stack([jpma.jpma_winners(gathered[r], traj, cam, gt2, h_offset=r * Hl) for r in range(R)])
+        return jpma.jpma_combine(wins)
+
+    ms_g, (agg_g, sel_g) = ev(run_gathered)
+    agg_g, sel_g = agg_g.clone(), sel_g.clone()
+    ms_w, (agg_w, sel_w) = ev(run_winners)
+    flat = gathered.permute(1, 2, 0, 3, 4, 5, 6).reshape(B, K, R * Hl, F_, J_, 3).contiguous()   # the copy the gathered form avoids
+    ms_f, (agg_f, sel_f) = ev(lambda: jpma.jpma_hip(flat, traj, cam, gt2, zero_root=True))
+    nbytes = gathered.numel() * 4
+    same = bool(torch.equal(agg_g, agg_f) and torch.equal(sel_g, sel_f) and torch.equal(agg_w, agg_f) and torch.equal(sel_w.int(), sel_f))
+    return {"workload": f"BASELINE configs[3] consumer on one GPU: gathered (R={R}, B={B}, K={K}, H_local={Hl}, F=243, 17, 3) = "
+                        f"{nbytes / 1e9:.2f} GB synthetic, H_total = {R * Hl}",
+            "jpma_gathered_ms": ms_g, "jpma_gathered_gbps": nbytes / (ms_g * 1e-3) / 1e9,
+            "jpma_gathered_frac_of_hbm_peak": nbytes / (ms_g * 1e-3) / 1e12 / PEAK_HBM_TBS,
+            "winners_x8_then_combine_ms": ms_w, "jpma_on_flat_copy_ms": ms_f,
+            "all_three_select_the_same_poses": same,
+            "what": "d3dp_jpma_gathered reads the all-gather result where RCCL leaves it (hypothesis h = r H_local + hl by stride); "
+                    "the winners path = 8 x d3dp_jpma_winners + d3dp_jpma_combine (the 12x smaller exchange); flat = d3dp_jpma after "
+                    "the permute + copy the gathered form avoids.  No collective is executed here"}
+
+
 def relaunch_under_torchrun(n):
     """`python bench.py --gpus N` outside a torchrun job: become `python -m torch.distributed.run ... bench.py <same args>`."""
     s = socket.socket()
@@ -491,11 +596,17 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (BASELINE configs[1] and the training step)")
-    ap.add_argument("--cpu-full", action="store_true", help="run the un-extrapolated BASELINE configs[1] CPU leg live (minutes)")
+    ap.add_argument("--no-cpu-full", action="store_true",
+                    help="CPU baseline from the bounded K=1 sample only (about 25 s) instead of the live, un-extrapolated BASELINE "
+                         "configs[1] run (about three minutes of host CPU), which is the default")
+    ap.add_argument("--cpu-full", action="store_true", help="(default now; kept for older command lines)")
     ap.add_argument("--dist-dry-run", type=int, default=0, metavar="N",
                     help="no GPU needed: drive the N-rank control flow of this file (self-launch, WORLD_SIZE check, shard "
                          "check, timed loop with the all-gather, MAX-reduce, multi_gpu block) over gloo with a CPU "
                          "stand-in for the sampler; the JSON line is marked dry_run and measures nothing")
+    ap.add_argument("--dry-full-size", action="store_true",
+                    help="with --dist-dry-run: keep --batch / --hyps / --ksteps and F=243, so that the exchange moves the real "
+                         "message (158.6 MB per rank at the BASELINE configs[3] shape) over gloo; needs ~6 GB of host memory per rank")
     a = ap.parse_args()
     dry = a.dist_dry_run > 0
     if dry:
@@ -515,7 +626,8 @@ def main():
     B, H, K = a.batch, a.hyps, a.ksteps
     frames = F_
     if dry:
-        B, H, K, frames = min(B, 2), min(H, 2), min(K, 2), 27
+        if not a.dry_full_size:
+            B, H, K, frames = min(B, 2), min(H, 2), min(K, 2), 27
         a.no_profile = True
     make = (lambda H_, K_, fr: DryRunSampler(H_, K_, fr)) if dry else None
 
@@ -558,7 +670,7 @@ def main():
         import torch.distributed as dist
         flag = torch.tensor([1 if sharding_ok else 0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        res["multi_gpu"] = exchange_report(local_preds, x2d, world, dev, dry)
+        res["multi_gpu"] = exchange_report(local_preds, x2d, world, dev, dry, reps=1 if (dry and a.dry_full_size) else 5)
         res["multi_gpu"].update({"sharded_equals_single_rank": bool(flag.item()),
                                  "shard_check": "F=27 B=2 H_local=2 K=2: N ranks on sliced global noise == 1 rank with H=2N, torch.equal"})
         assert bool(flag.item()), "N-rank sampling does not reproduce the 1-rank run"
@@ -570,6 +682,7 @@ def main():
         total = sum(ms for _, ms in prof.values())
         res["roofline"] = roofline_from_profile(prof, a.numerics, B, H, K)
         attach_traffic(res["roofline"], a.numerics, a.chunk_seqs, B)
+        res["roofline_by_kernel"] = roofline_by_kernel(prof, a.numerics, B, H, K)
         res["kernel_time_share"] = {k: round(ms / total, 4) for k, (_, ms) in prof.items() if ms > 0}
         res["kernel_ms_per_step"] = {k: round(ms, 3) for k, (_, ms) in prof.items() if ms > 0}
 
@@ -595,6 +708,7 @@ def main():
                 po = profile_step(mo, x2d, x2f, gen)
                 leg["roofline"] = roofline_from_profile(po, other, B, H, K)
                 attach_traffic(leg["roofline"], other, a.chunk_seqs, B)
+                leg["roofline_by_kernel"] = roofline_by_kernel(po, other, B, H, K)
                 leg["kernel_ms_per_step"] = {k: round(ms, 3) for k, (_, ms) in po.items() if ms > 0}
             res[other + "_mode"] = leg
             del mo
@@ -602,8 +716,10 @@ def main():
             res["parity"] = quick_parity()
         if not a.no_configs:
             res["configs"] = other_configs(a.numerics, gen, with_cpu=not a.no_cpu_baseline)
+            torch.cuda.empty_cache()
+            res["configs"]["c4_consumer_1gpu"] = c4_consumer_1gpu()
         if not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(full=a.cpu_full)
+            res["cpu_baseline"] = cpu_baseline(full=not a.no_cpu_full)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

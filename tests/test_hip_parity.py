@@ -1321,7 +1321,8 @@ def test_non_finite_weights_load_and_propagate():
         out = m(x2d, None, input_2d_flip=flip_2d(x2d), noise=nz)       # loads and runs: no D3DP_EINVAL
         net = m.pose_estimator
         assert net.exact_scales()[2] == "bf16x3", key
-        assert net.nonfinite_seen() or not torch.isfinite(out).all() or True   # (the clamp of the sampler may hide a NaN lane; the status word is the contract)
         want = orc.ddim_sample_flip(orc.strip_prefix(sd), orc.cosine_schedule(1000), x2d.cpu(), flip_2d(x2d).cpu(), 1, 1, dep,
                                     H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, nz)
-        assert torch.isfinite(out.cpu()).all() == torch.isfinite(want).all(), key
+        assert not torch.isfinite(want).all(), key             # the reference's output is non-finite ...
+        assert net.nonfinite_seen(), key                       # ... and the library says so about its own (d3dp_status)
+        assert out.shape == want.shape

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One parametrised driver for everything this repo runs on the GPU box (replaces the per-call scratch scripts of rounds 2-3):
-#   tools/gpu_round.sh STAGE [STAGE ...]      results under gpurun_out/$TAG/ (TAG defaults to "r04")
+#   tools/gpu_round.sh STAGE [STAGE ...]      results under gpurun_out/$TAG/ (TAG defaults to "r05")
 # stages
 #   guard        the new kernels once, small, under a short timeout (a hang here must not take the rest of the call with it);
 #                on failure the remaining stages run with D3DP_X2_SKEW=0
@@ -14,7 +14,7 @@
 #   gemm         tools/gemm_bench.py micro-benchmark of the four Linear shapes (GEMM_ARGS)
 #   train        tools/train_bench.py
 set -u
-TAG=${TAG:-r04}; R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O
+TAG=${TAG:-r05}; R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
 QUICK="--no-cpu-baseline --no-other-leg --no-parity --no-configs"
 json_line() { python -c "
@@ -25,9 +25,19 @@ print('$1', round(d['value'], 2), round(d['ms_per_step'], 1), {n: round(v) for n
 for stage in "$@"; do
   case $stage in
     guard)
-      if ! timeout 240 python -m pytest tests/test_hip_parity.py -q -x -k "skewed_schedule and 300" > $O/guard.log 2>&1; then
-        echo "guard FAILED: skewed schedule off for the rest of this call" | tee -a $O/guard.log; export D3DP_X2_SKEW=0
+      # the kernels that changed this round, small, under a short timeout: a hang here must not take the rest of the call with it
+      if ! timeout ${GUARD_TIMEOUT:-420} python -m pytest tests/test_hip_parity.py -q -x -s -k "${GUARD_K:-training_step_matches_reference or bit_reproducible or train_branch_forward}" > $O/guard.log 2>&1; then
+        echo "guard FAILED" | tee -a $O/guard.log; tail -40 $O/guard.log; exit 1
       fi; tail -5 $O/guard.log ;;
+    parity)
+      # the parity printout of the final library, kept under profiles/ 
+      timeout 1200 python -m pytest tests -m gpu -q -s -k "g3 or g4 or c2_full or c3_full or scale or config5 or longer_than_256 or bit_reproducible" > $O/parity.log 2>&1; grep -E "mm|passed|failed|error|worst" $O/parity.log | tail -40 ;;
+    variants)
+      # the tests marked `variants` against the library that carries the experiment kernels
+      D3DP_LIB=$R/d3dp_amd/lib/variants/libd3dp_variants.so timeout 900 python -m pytest tests -m "gpu and variants" -q -rs > $O/variants.log 2>&1; tail -6 $O/variants.log ;;
+    trainstats)
+      ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $O/tstats -- python $R/tools/train_bench.py ${TRAIN_ARGS:-5} > $O/train_prof.log 2>&1 )
+      db=$(find $O/tstats -name "*.db" | head -1); [ -n "$db" ] && python tools/rocprof_summary.py $db $O/train_kernel_stats.md > /dev/null; rm -rf $O/tstats; head -45 $O/train_kernel_stats.md; tail -2 $O/train_prof.log ;;
     tests)
       timeout 1500 python -m pytest tests -m gpu -q --durations=8 -rs ${PYTEST_ARGS:-} > $O/tests_full.log 2>&1; tail -30 $O/tests_full.log > $O/tests.log; tail -12 $O/tests.log ;;
     smoke)
