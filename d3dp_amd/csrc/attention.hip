@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qk
     }
   }
   if (amax) {
-    __shared__ float part_amax[4];
+    // (in the DYNAMIC allocation, behind the images: a static array would push a 160 KiB opt-in over the CU's LDS)
+    float* part_amax = reinterpret_cast<float*>(smem + (size_t)PPB * 2 * kchunk * LDR);
     am = wave_max(am);
     if ((threadIdx.x & 63) == 0) part_amax[threadIdx.x >> 6] = am;
     __syncthreads();
@@ -215,7 +216,7 @@ int launch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int he
   constexpr int LDR = HD + Vec16<T>::N;
   const int n_prob = n_seq * heads;
   const int kchunk = map.n_tok < 256 ? map.n_tok : 256;
-  const size_t lds = (size_t)PPB * 2 * kchunk * LDR * sizeof(T);
+  const size_t lds = (size_t)PPB * 2 * kchunk * LDR * sizeof(T) + 16;   // (+ the four absmax partials)
   if (lds > 160 * 1024) return -2;
   auto kern = attn_rows_kernel<T, HD, TPP, OUTS>;
   static PerDeviceOnce once;                          // (one per template instantiation = per kernel)

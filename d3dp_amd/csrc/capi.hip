@@ -156,6 +156,8 @@ struct d3dp_ctx {
   }
   int pad_override = -1;         // D3DP_SEQ_PAD=0|1: measurement switch (pad without the skewed schedule, or the reverse)
   bool train_x2 = true;          // D3DP_TRAIN_IMPL=f32: the training Linears on the fp32 matrix cores (round-1 path, cross-check)
+  bool train_attn_x2 = true;     // D3DP_TRAIN_ATTN=f32: the temporal attention of the training step on the fp32 matrix cores
+                                 // (round-4 kernels, cross-check) instead of the split-fp16 kernels of train_attn.hip
   int pingpong = 0;              // D3DP_X2_PP=1: the ping-pong form of the EXACT Linear (gemm_x2.hip; bit-identical results;
                                  // measured 1.5-2 % SLOWER on the whole step, gpurun c8); 2 = D3DP_X2_WIDE=1: the 256 x 256
                                  // tile form (bit-identical; ties with the default, profiles/r04_gemm_probes.md section 4)
@@ -372,6 +374,8 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->fold = !(nf && nf[0] == '1');
   const char* ti = getenv("D3DP_TRAIN_IMPL");
   c->train_x2 = !(ti && !strcmp(ti, "f32"));
+  const char* ta = getenv("D3DP_TRAIN_ATTN");
+  c->train_attn_x2 = !(ta && !strcmp(ta, "f32"));
   {
     // Measurement switches of experiments that were measured and not adopted: the row-class skewed schedule
     // (D3DP_X2_SKEW=1|2|4), the ping-pong (D3DP_X2_PP=1) and wide (D3DP_X2_WIDE=1) forms of the EXACT Linear, norm2 folded into
@@ -954,6 +958,7 @@ struct TrainLayout {
   size_t x_cols, x_block;           // every Linear's activation operand, transposed form [K][2 Tp], kept from the forward pass for wgrad
   size_t w_rows, w_cols, w_block;   // every weight's split operands (row form / transposed form), prepared once per step: w_block floats per block
   size_t Tp_max;                    // columns (tokens, padded) of a transposed operand row
+  size_t stats_x2, stats_x2_stride; // per block: (log-sum-exp, dO . O) of every query of the split-fp16 temporal attention
   size_t red, red_floats;           // partial sums of the backward pass (LayerNorm gammas / betas, biases, embedding side),
                                     // summed in a fixed order by d3dp_train_reduce_many at its end
   size_t total_floats;
@@ -997,6 +1002,8 @@ TrainLayout train_layout(const d3dp_cfg& g, int B) {
     L.w_rows = take(L.w_block * 2 * g.depth);
     L.w_cols = take(L.w_block * 2 * g.depth);
   }
+  L.stats_x2_stride = (d3dp_train_attn_x2_stats_bytes(B * std::max(g.frames, g.joints), std::max(g.frames, g.joints), g.heads) / 4 + 63) / 64 * 64;
+  L.stats_x2 = take(L.stats_x2_stride * 2 * g.depth);
   {
     const size_t lnb = (size_t)D3DP_LN_BWD_BLOCKS * 2 * L.C;         // one LayerNorm call's [dgamma | dbeta] rows
     const size_t fmax = std::max<size_t>(3 * L.C, L.Hd);
@@ -1063,6 +1070,7 @@ struct X2Train {
   // transposed form -- for the backward pass of the same step, whose wgrad / dgrad read the same tensors: 128 of the step's
   // 320 absmax launches are not repeated.  The backward pass allocates its own (the gradients) from kBwdSlot0.
   static constexpr int kBwdSlot0 = 4096;
+  static constexpr int kQkvSlot0 = 2048;               // forward range: slot kQkvSlot0 + block = absmax of that block's qkv OUTPUT
   int next = 0;
   unsigned* amax() const { return reinterpret_cast<unsigned*>(ws + L.slots); }
   float* uns() const { return ws + L.slots + 8192; }
@@ -1112,7 +1120,7 @@ struct X2Train {
   // launch as a split-K product (Z chunks of the contraction: tn Z short work items instead of tn long ones) whose partial
   // sums are added in a fixed order.
   int gemm(const float* A2, const float* W2, const float* bias, const float* ua, const float* uw, float* out, int T, int N,
-           int K) {
+           int K, unsigned* out_amax = nullptr) {
     const int tn = (N + 127) / 128, q = T / 256, rem = T - q * 256;
     const int rounds_all = ((q + (rem ? 1 : 0)) * tn + n_cu - 1) / n_cu, rounds_full = (q * tn + n_cu - 1) / n_cu;
     const int nk = K / 32;
@@ -1122,17 +1130,19 @@ struct X2Train {
     // (measured: a last round of a few tiles runs its k-steps at 0.75 us -- few CUs active, full clock -- against 1.4 us in a
     //  full round, so for 16 k-steps it costs 12 us, what the second launch and the sum cost too: split from 32 k-steps on)
     if (rem == 0 || q == 0 || rounds_all == rounds_full || Z == 1 || nk < 32 || (size_t)Z * rem * N > (size_t)(1024 + 64) * 256 * 128)
-      return d3dp_launch_linear_f16x2_dyn(A2, W2, bias, ua, uw, out, T, N, K, 1, st);
-    int r = d3dp_launch_linear_f16x2_dyn(A2, W2, bias, ua, uw, out, q * 256, N, K, 1, st);
+      return d3dp_launch_linear_f16x2_dyn(A2, W2, bias, ua, uw, out, T, N, K, 1, st, out_amax);
+    int r = d3dp_launch_linear_f16x2_dyn(A2, W2, bias, ua, uw, out, q * 256, N, K, 1, st, out_amax);
     if (r) return r;
     r = d3dp_launch_linear_f16x2_dyn(A2 + (size_t)q * 256 * K, W2, nullptr, ua, uw, ws + L.part, rem, N, K, Z, st);   // (a row = 2 K fp16 = K floats)
     if (r) return r;
-    d3dp_launch_sum_partials_bias(ws + L.part, bias, out + (size_t)q * 256 * N, (size_t)rem * N, N, Z, st);
+    d3dp_launch_sum_partials_bias(ws + L.part, bias, out + (size_t)q * 256 * N, (size_t)rem * N, N, Z, st, out_amax);
     return 0;
   }
   // out[T, N] = A[T, K] W[N, K]^T + bias     (l: the Linear's index, see the slots above)
   // (a_amax_ready: the kernel that produced A already left its absmax in slot 2 l)
-  int forward(int l, const float* A, const float* W, const float* bias, float* out, int T, int N, int K, bool a_amax_ready = false) {
+  // (out_amax: optional slot for the OUTPUT's absmax, left by the product's epilogue)
+  int forward(int l, const float* A, const float* W, const float* bias, float* out, int T, int N, int K, bool a_amax_ready = false,
+              unsigned* out_amax = nullptr) {
     const int sa = 2 * l, sw = 2 * l + 1;
     if (l < 0 || sw >= kBwdSlot0) return -1;
     if (!a_amax_ready) d3dp_launch_absmax(A, (size_t)T * K, amax() + sa, st);
@@ -1151,16 +1161,16 @@ struct X2Train {
       d3dp_launch_absmax(W, (size_t)N * K, amax() + sw, st);
       rows(W, N, K, ws + L.op_w, sw);
     }
-    return gemm(ws + L.op_a, w2, bias, uns() + sa, uns() + sw, out, T, N, K);
+    return gemm(ws + L.op_a, w2, bias, uns() + sa, uns() + sw, out, T, N, K, out_amax);
   }
   // dX[T, K] = dY[T, N] W[N, K]   (sdy: the absmax slot of dY, shared with wgrad; l: the forward Linear whose W this is)
-  int dgrad(int l, const float* dY, int sdy, const float* W, float* dX, int T, int N, int K) {
+  int dgrad(int l, const float* dY, int sdy, const float* W, float* dX, int T, int N, int K, unsigned* out_amax = nullptr) {
     const int sw = 2 * l + 1;
     if (!dy_ready) rows(dY, T, N, ws + L.op_a, sdy);
     const float* wt = ws + L.op_w;
     if (batched) wt = ws + L.w_cols + woff(l);         // (prepared by the forward pass of this step)
     else cols(W, N, K, N, ws + L.op_w, sw);            // W^T: [K][2 N]  (N % 32 == 0: the model's widths)
-    return gemm(ws + L.op_a, wt, nullptr, uns() + sdy, uns() + sw, dX, T, K, N);
+    return gemm(ws + L.op_a, wt, nullptr, uns() + sdy, uns() + sw, dX, T, K, N, out_amax);
   }
   // split count / padded token count of the wgrad product dW[N, K] = dY^T X
   void wgrad_split(int T, int N, int K, int& Z, int& Tp) const {
@@ -1226,9 +1236,12 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     LAUNCH_TRY(x2.begin(true));
     LAUNCH_TRY(x2.prepare_weights(c));
   }
-  auto lin = [&](int l, const float* A, const float* W, const float* bias, float* out, int M, int N, int K, bool a_amax_ready = false) {
-    return use_x2 ? x2.forward(l, A, W, bias, out, M, N, K, a_amax_ready) : lin32(A, W, bias, out, M, N, K, st);
+  auto lin = [&](int l, const float* A, const float* W, const float* bias, float* out, int M, int N, int K, bool a_amax_ready = false,
+                 unsigned* out_amax = nullptr) {
+    return use_x2 ? x2.forward(l, A, W, bias, out, M, N, K, a_amax_ready, out_amax) : lin32(A, W, bias, out, M, N, K, st);
   };
+  // temporal attention on split-fp16 operands (train_attn.hip): needs the split Linears' device-side scales, head dim 64, <= 256 frames
+  const bool attn_x2 = use_x2 && c->train_attn_x2 && C / g.heads == 64 && F <= 256;
   LAUNCH_TRY(d3dp_launch_time_mlp(t, c->freq, c->t1w, c->t1b, c->t3w, c->t3b, ws + L.temb, B, C, st));
   float* slab0 = ws + L.saved0;
   LAUNCH_TRY(d3dp_launch_embed_ln(0, x2d, x3d, ws + L.temb, c->ew, c->eb, c->spos, c->ste[0].n1w, c->ste[0].n1b,
@@ -1242,10 +1255,14 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     const int kind = blk & 1, d = blk >> 1;
     const BlockDev& w = kind ? c->tte[d] : c->ste[d];
     float* S = ws + L.saved0 + (size_t)blk * L.saved_stride;
-    LAUNCH_TRY(lin(4 * blk, xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C, true));
+    unsigned* qkv_amax = (attn_x2 && kind == 1) ? x2.amax() + X2Train::kQkvSlot0 + blk : nullptr;
+    LAUNCH_TRY(lin(4 * blk, xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C, true, qkv_amax));
     bool att_ready = true;
     if (kind == 0)
       LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * F, spatial_map(F, J), C, g.heads, st, slot(4 * blk + 1)));
+    else if (attn_x2)
+      LAUNCH_TRY(d3dp_train_attn_x2_fwd(S + L.o_qkv, S + L.o_att, ws + L.stats_x2 + (size_t)blk * L.stats_x2_stride, B * J,
+                                        temporal_map(F, J), C, g.heads, qkv_amax, slot(4 * blk + 1), st));
     else if (use_x2 && C / g.heads == 64 && F <= 256) {  // temporal axis on the fp32 matrix cores (bitwise an fp32 fmaf chain per
       LAUNCH_TRY(d3dp_launch_attn_temporal_f32(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st));   // product)
       att_ready = false;
@@ -1313,6 +1330,7 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     LAUNCH_TRY(x2.begin(false));
     x2.batched = 8 * g.depth <= D3DP_WPREP_MAX;          // (the forward pass of this step left the weight operands in place)
   }
+  const bool attn_x2 = use_x2 && c->train_attn_x2 && C / g.heads == 64 && F <= 256;   // (as the forward pass of this step)
   Reducer red{ws + L.red, L.red_floats, 0, st};
   const int lnrows = d3dp_train_ln_bwd_blocks(T);        // partial rows one LayerNorm-backward call leaves
   // [dgamma | dbeta] partial rows of a LayerNorm with `calls` backward calls per step (the shared norms: one per depth), and
@@ -1355,8 +1373,8 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     return d3dp_launch_linear_f32_splitk(At, Xt, dW, N, K, Tp, st);       // contraction over tokens: split-K
   };
   // dgrad: dX[T, K] = dY[T, N] W[N, K]   (W transposed to [K, N])
-  auto dgrad = [&](int l, const float* dY, int N, const float* W, int K, float* dX) -> int {
-    if (use_x2) return sdy < 0 ? -1 : x2.dgrad(l, dY, sdy, W, dX, T, N, K);  // (always right behind the wgrad of the same dY)
+  auto dgrad = [&](int l, const float* dY, int N, const float* W, int K, float* dX, unsigned* out_amax = nullptr) -> int {
+    if (use_x2) return sdy < 0 ? -1 : x2.dgrad(l, dY, sdy, W, dX, T, N, K, out_amax);  // (always right behind the wgrad of the same dY)
     int r;
     if ((r = d3dp_train_transpose_pad(W, Wt, N, K, N, st))) return r;
     return lin32(dY, Wt, zb, dX, T, K, N, st);
@@ -1423,12 +1441,23 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
       dy = mk ? dC : dA;
       // ---- attention branch ----
       LAUNCH_TRY(wgrad(4 * blk + 1, dy, C, S + L.o_att, C, G(gw.proj_w), G(gw.proj_b), ps));
-      LAUNCH_TRY(dgrad(4 * blk + 1, dy, C, (const float*)w.proj_w, C, dB));                                             // d att
     }
-    if (kind == 0) LAUNCH_TRY(d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * F, spatial_map(F, J), C, g.heads, st));
-    else LAUNCH_TRY(d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * J, temporal_map(F, J), C, g.heads, st));
+    int ps_dqkv = -1;
+    if (attn_x2 && kind == 1) {
+      // temporal axis on split-fp16 operands: the proj dgrad leaves d att's absmax, the attention backward that of dqkv
+      D3DP_FRESH(pdo, pado)
+      D3DP_FRESH(pq, paq)
+      LAUNCH_TRY(dgrad(4 * blk + 1, dy, C, (const float*)w.proj_w, C, dB, pado));                                       // d att
+      LAUNCH_TRY(d3dp_train_attn_x2_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats_x2 + (size_t)blk * L.stats_x2_stride, B * J,
+                                        temporal_map(F, J), C, g.heads, x2.amax() + X2Train::kQkvSlot0 + blk, pado, paq, st));
+      ps_dqkv = pq;
+    } else {
+      LAUNCH_TRY(dgrad(4 * blk + 1, dy, C, (const float*)w.proj_w, C, dB));                                             // d att
+      if (kind == 0) LAUNCH_TRY(d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * F, spatial_map(F, J), C, g.heads, st));
+      else LAUNCH_TRY(d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * J, temporal_map(F, J), C, g.heads, st));
+    }
     if (!use_x2) LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xin, w.n1w, w.n1b, g.eps_block, nullptr, F, J, xn, T, C, st));    // xn1
-    LAUNCH_TRY(wgrad(4 * blk, dqkv, 3 * C, xn, C, G(gw.qkv_w), G(gw.qkv_b)));
+    LAUNCH_TRY(wgrad(4 * blk, dqkv, 3 * C, xn, C, G(gw.qkv_w), G(gw.qkv_b), ps_dqkv));
     LAUNCH_TRY(dgrad(4 * blk, dqkv, 3 * C, (const float*)w.qkv_w, C, dC));                                          // d xn1
     float* pn1 = ln_part(gw.norm1_w, gw.norm1_b, 1);
     if (!pn1) return fail(D3DP_ESTATE, "d3dp_train_backward: partial-sum region too small");

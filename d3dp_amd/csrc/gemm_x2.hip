@@ -1422,11 +1422,13 @@ __global__ __launch_bounds__(768) void gemm_f16x2_skew_kernel(const f16* __restr
 //     the fp32-MFMA path this replaces).
 // Structure: the lock-step kernel above without the lagged MFMAs and with the plain fp32 epilogue (8 + 4 waves, 256 x 128 x 32
 // tiles, 3-stage LDS-DMA ring, one barrier per k-step).
+//   * amax_out (optional; Z = 1 launches): the output's absmax, one atomicMax per workgroup -- the operand scale of whatever
+//     split-fp16 kernel consumes the output next (the training attention kernels: q / k / v and dO), without an absmax pass.
 __global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restrict__ A2, const f16* __restrict__ W2,
                                                              const float* __restrict__ bias, const float* __restrict__ dynA,
                                                              const float* __restrict__ dynW, float* __restrict__ out, int M,
                                                              int N, int Kfull, int NKz, int tiles_n, int tiles_per_z,
-                                                             int total_items) {
+                                                             int total_items, unsigned* __restrict__ amax_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int G = gridDim.x;
   const int L = xcd_remap(blockIdx.x, G);
@@ -1478,6 +1480,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restri
       X2_BARRIER();
       if (g + 2 < gtot) issue();
     }
+    if (amax_out) X2_BARRIER();                        // (the compute waves' absmax hand-over below)
     return;
   }
 
@@ -1487,6 +1490,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restri
   const int offW = XA_BYTES + (wc * 64 + fi) * 128 + swz128(fi, fg) * 16, offWl = offW ^ 64;
   const float unscale = dynA[0] * dynW[0];             // 1 / (scale of A x scale of W): powers of two, exact
   __builtin_amdgcn_s_setprio(1);
+  float am = 0.f;
   int slot = 0;
 #pragma unroll 1
   for (int ti = 0; ti < n_my; ++ti) {
@@ -1532,11 +1536,26 @@ __global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = pm0 + mi * 16 + r;
-          if (m < M)
-            *reinterpret_cast<f32x4*>(o + (size_t)m * N) =
-                (f32x4){fmaf(acc[mi][0][r], unscale, bz.x), fmaf(acc[mi][1][r], unscale, bz.y),
-                        fmaf(acc[mi][2][r], unscale, bz.z), fmaf(acc[mi][3][r], unscale, bz.w)};
+          if (m < M) {
+            const f32x4 v = {fmaf(acc[mi][0][r], unscale, bz.x), fmaf(acc[mi][1][r], unscale, bz.y),
+                             fmaf(acc[mi][2][r], unscale, bz.z), fmaf(acc[mi][3][r], unscale, bz.w)};
+            *reinterpret_cast<f32x4*>(o + (size_t)m * N) = v;
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+          }
         }
+    }
+  }
+  if (amax_out) {                                      // (uniform: a kernel argument)
+    float* part = reinterpret_cast<float*>(smem + XNSTAGE * XSTAGE);   // behind the ring, which slower waves may still be reading
+    am = wave_max(am);
+    if (lane == 0) part[wave] = am;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    X2_BARRIER();
+    if (wave == 0 && lane == 0) {
+      float m = part[0];
+#pragma unroll
+      for (int w = 1; w < XNCW; ++w) m = fmaxf(m, part[w]);
+      atomicMax(amax_out, __float_as_uint(m));
     }
   }
 }
@@ -1605,63 +1624,77 @@ __global__ __launch_bounds__(256) void split2h_t_dyn_kernel(const float* __restr
 // One pass over an fp32 matrix src [R][C] for everything the training step needs from it as a split-fp16 operand: the row
 // form [R][2 C] (a forward Linear's / dgrad's operand), the transposed form [C][2 Rpad] (wgrad's operand; rows R .. Rpad - 1
 // zero) and, for a gradient dY, its column sums (the bias gradient) -- as three kernels (split2h_dyn, split2h_t_dyn, colsum)
-// the same tensor was read three times.  blockIdx.y = a strip of 32 columns; a workgroup strides over tiles of 128 rows x 32
-// columns: FOUR 16-byte loads per thread in flight (round 4: one, on 512 workgroups -- two per CU -- which left the kernel
-// latency-bound at 3.4 TB/s), the row form leaves as 8-byte stores, the transposed form through LDS as 16-byte stores (8
-// source rows of one destination row and plane per store).  Column sums: this workgroup's rows into row blockIdx.x of
-// `colpart` (gridDim.x rows of C floats, summed in a fixed order by d3dp_train_reduce_many: no float atomics).
-// C % 32 == 0, Rpad % 32 == 0.
+// the same tensor was read three times.  blockIdx.y = a strip of 32 columns; a workgroup takes tiles of DY_ROWS rows x 32
+// columns (one tile per workgroup at the configs[4] size: every workgroup resident at once): SIX 16-byte loads per thread in
+// flight (round 4: one load per thread on 512 workgroups -- two per CU -- which left the kernel latency-bound at 2.7 TB/s),
+// and every store instruction writes WHOLE 128-byte lines of both outputs: the row form as one 16-byte store per lane
+// (neighbouring lanes swap their hi / lo halves by DPP: even lane -> 8 columns of hi, odd lane -> lo), the transposed form
+// through LDS with lanes 0-3 of an 8-lane group writing the hi half and lanes 4-7 the lo half of ONE line (8 source rows of
+// one destination row and plane per lane).  Column sums: this workgroup's rows into row blockIdx.x of `colpart` (gridDim.x
+// rows of C floats, summed in a fixed order by d3dp_train_reduce_many: no float atomics).  C % 32 == 0, Rpad % 32 == 0.
+constexpr int DY_SUB = 6, DY_ROWS = 32 * DY_SUB;      // 192 rows per tile
 __global__ __launch_bounds__(256) void dyprep_kernel(const float* __restrict__ s, f16* __restrict__ drow, f16* __restrict__ dcol,
                                                      float* __restrict__ colpart, int R, int C, int Rpad,
                                                      const unsigned* __restrict__ amax, float* __restrict__ unscale) {
-  __shared__ float tile[128][33];
+  __shared__ float tile[DY_ROWS][33];
   const float sc = dyn_scale(amax[0]);
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) unscale[0] = 1.0f / sc;
   const int c0 = blockIdx.y * 32;
   const int tr = threadIdx.x >> 3, tj = threadIdx.x & 7, tq = tj * 4;   // phase 1: source row u 32 + tr, columns tq .. tq + 3
   const int nblk = Rpad / 32;                           // 32-row blocks of the transposed form
+  const bool odd = tj & 1;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int rt = blockIdx.x; rt * 4 < nblk; rt += gridDim.x) {
-    float4 v[4];
+  for (int rt = blockIdx.x; rt * DY_SUB < nblk; rt += gridDim.x) {
+    float4 v[DY_SUB];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int r = rt * 128 + u * 32 + tr;
+    for (int u = 0; u < DY_SUB; ++u) {
+      const int r = rt * DY_ROWS + u * 32 + tr;
       v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r < R) v[u] = *reinterpret_cast<const float4*>(s + (size_t)r * C + c0 + tq);
     }
     __syncthreads();                                    // (the previous tile's transposed reads are done)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int r = rt * 128 + u * 32 + tr;
+    for (int u = 0; u < DY_SUB; ++u) {
+      const int r = rt * DY_ROWS + u * 32 + tr;
       acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
       const float vs[4] = {v[u].x * sc, v[u].y * sc, v[u].z * sc, v[u].w * sc};
       float* trow = &tile[u * 32 + tr][tq];
       trow[0] = vs[0]; trow[1] = vs[1]; trow[2] = vs[2]; trow[3] = vs[3];
-      if (r < R) {                                       // row form: the 128-byte h2i block of row r, columns c0 .. c0 + 31
-        f16x4 hi, lo;
+      // row form: the 128-byte h2i block of row r, columns c0 .. c0 + 31 -- lanes 2 j / 2 j + 1 hold columns 8 j .. 8 j + 7:
+      // the even lane stores both hi halves, the odd lane both lo halves (quad_perm [1,0,3,2]: the value of lane ^ 1)
+      f16x4 hi, lo;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { f16 h, l; split2h_scaled(vs[e], h, l); hi[e] = h; lo[e] = l; }
-        f16* blk = drow + (size_t)r * 2 * C + (size_t)blockIdx.y * 64 + tq;
-        *reinterpret_cast<f16x4*>(blk) = hi;
-        *reinterpret_cast<f16x4*>(blk + 32) = lo;
+      for (int e = 0; e < 4; ++e) { f16 h, l; split2h_scaled(vs[e], h, l); hi[e] = h; lo[e] = l; }
+      const uint2 hh = __builtin_bit_cast(uint2, hi), ll = __builtin_bit_cast(uint2, lo);
+      const uint2 send = odd ? hh : ll;
+      uint2 recv;
+      recv.x = __builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xF, 0xF, false);
+      recv.y = __builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xF, 0xF, false);
+      using u32x4 = unsigned __attribute__((ext_vector_type(4)));
+      const u32x4 o16 = odd ? (u32x4){recv.x, recv.y, ll.x, ll.y} : (u32x4){hh.x, hh.y, recv.x, recv.y};
+      if (r < R) {
+        f16* blk = drow + (size_t)r * 2 * C + (size_t)blockIdx.y * 64 + (tq & ~7) + (odd ? 32 : 0);
+        *reinterpret_cast<u32x4*>(blk) = o16;
       }
     }
     __syncthreads();
-    // transposed form: destination row c0 + tr; this thread's two (block, 8-row group) pairs of the tile's 4 x 4
+    // transposed form: destination row c0 + tr; lanes tj 0-3 write the hi half, tj 4-7 the lo half of the line of block u
+    {
+      const int g8 = tj & 3;
+      const bool lo_half = tj >= 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int u = (tj >> 2) + 2 * i, g8 = tj & 3;
-      if (rt * 4 + u < nblk) {
-        f16x8 hi, lo;
+      for (int u = 0; u < DY_SUB; ++u) {
+        if (rt * DY_SUB + u < nblk) {
+          f16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          f16 h, l;
-          split2h_scaled(tile[u * 32 + g8 * 8 + e][tr], h, l);
-          hi[e] = h; lo[e] = l;
+          for (int e = 0; e < 8; ++e) {
+            const float x = tile[u * 32 + g8 * 8 + e][tr];
+            const f16 h = (f16)x;
+            o[e] = lo_half ? (f16)(x - (float)h) : h;
+          }
+          f16* blk = dcol + (size_t)(c0 + tr) * 2 * Rpad + (size_t)(rt * DY_SUB + u) * 64 + (lo_half ? 32 : 0) + g8 * 8;
+          *reinterpret_cast<f16x8*>(blk) = o;
         }
-        f16* blk = dcol + (size_t)(c0 + tr) * 2 * Rpad + (size_t)(rt * 4 + u) * 64 + g8 * 8;
-        *reinterpret_cast<f16x8*>(blk) = hi;
-        *reinterpret_cast<f16x8*>(blk + 32) = lo;
       }
     }
   }
@@ -1753,12 +1786,24 @@ __global__ void sum_partials_kernel(const float* __restrict__ part, float* __res
 }
 
 // out[r][c] = sum_z part[z][r][c] + bias[c]   (the split-K remainder rows of a training Linear; bias may be null)
-__global__ void sum_partials_bias_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
-                                         size_t n, int N, int Z) {
+// (amax: optional absmax slot of these rows, as gemm_f16x2_dyn_kernel's)
+__global__ __launch_bounds__(256) void sum_partials_bias_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                                float* __restrict__ out, size_t n, int N, int Z,
+                                                                unsigned* __restrict__ amax) {
+  __shared__ float pm[4];
+  float m = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float a = part[i];
     for (int z = 1; z < Z; ++z) a += part[(size_t)z * n + i];
-    out[i] = bias ? a + bias[i % N] : a;
+    a = bias ? a + bias[i % N] : a;
+    out[i] = a;
+    m = fmaxf(m, fabsf(a));
+  }
+  if (amax) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) pm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(fmaxf(fmaxf(pm[0], pm[1]), fmaxf(pm[2], pm[3]))));
   }
 }
 
@@ -2023,18 +2068,18 @@ void d3dp_launch_fold_ln(const float* W, const float* gamma, const float* beta, 
 // ---- training-step launchers (gemm_f16x2_dyn_kernel and its operand kernels) ---------------------------------------
 // out_z[M, N] = A2 (chunk z) . W2 (chunk z)^T x dynA x dynW (+ bias): Kfull = Z NKz 32 columns per operand row
 int d3dp_launch_linear_f16x2_dyn(const void* A2, const void* W2, const float* bias, const float* dynA, const float* dynW,
-                                 float* out, int M, int N, int Kfull, int Z, hipStream_t st) {
-  if (M <= 0 || N % 4 != 0 || Z < 1 || Kfull % (XBK * Z) != 0) return -1;
+                                 float* out, int M, int N, int Kfull, int Z, hipStream_t st, unsigned* amax_out) {
+  if (M <= 0 || N % 4 != 0 || Z < 1 || Kfull % (XBK * Z) != 0 || (amax_out && Z != 1)) return -1;
   const int NKz = Kfull / XBK / Z;
   const int tm = (M + XBM - 1) / XBM, tn = (N + XBN - 1) / XBN;
   static PerDeviceOnce once;
   const int cus = once.get([&](int dev) {
-    return d3dp_lds_opt_in(reinterpret_cast<const void*>(gemm_f16x2_dyn_kernel), XNSTAGE * XSTAGE) < 0 ? -3 : d3dp_cu_count(dev);
+    return d3dp_lds_opt_in(reinterpret_cast<const void*>(gemm_f16x2_dyn_kernel), XNSTAGE * XSTAGE + 64) < 0 ? -3 : d3dp_cu_count(dev);
   });
   if (cus < 0) return -3;
   const int items = tm * tn * Z, grid = items < cus ? items : cus;
-  hipLaunchKernelGGL(gemm_f16x2_dyn_kernel, dim3(grid), dim3((XNCW + 4) * 64), XNSTAGE * XSTAGE, st, (const f16*)A2,
-                     (const f16*)W2, bias, dynA, dynW, out, M, N, Kfull, NKz, tn, tm * tn, items);
+  hipLaunchKernelGGL(gemm_f16x2_dyn_kernel, dim3(grid), dim3((XNCW + 4) * 64), XNSTAGE * XSTAGE + 64, st, (const f16*)A2,
+                     (const f16*)W2, bias, dynA, dynW, out, M, N, Kfull, NKz, tn, tm * tn, items, amax_out);
   return 0;
 }
 
@@ -2054,7 +2099,8 @@ void d3dp_launch_split2_t_dyn(const float* src, void* dst, int R, int C, int Rpa
 int d3dp_launch_dyprep(const float* src, void* drow, void* dcol, float* colpart, int R, int C, int Rpad, const unsigned* amax,
                        float* unscale, hipStream_t st) {
   if (C % 32 != 0 || Rpad % 32 != 0 || Rpad < R) return -1;
-  // D3DP_DYPREP_ROWS x C / 32 workgroups (768 at C = 512: three per CU), each with 16 KiB of loads in flight
+  // one 192-row tile per workgroup where that needs at most D3DP_DYPREP_ROWS of them (configs[4]: 87 x C / 32 workgroups, all
+  // resident at once); `colpart` always receives D3DP_DYPREP_ROWS rows (workgroup rows without a tile write zeros)
   hipLaunchKernelGGL(dyprep_kernel, dim3(D3DP_DYPREP_ROWS, C / 32), dim3(256), 0, st, src, (f16*)drow, (f16*)dcol, colpart, R, C, Rpad, amax, unscale);
   return 0;
 }
@@ -2069,9 +2115,10 @@ int d3dp_launch_wprep(const D3dpWPrepTable& tb, void* rows_base, void* cols_base
   return 0;
 }
 
-void d3dp_launch_sum_partials_bias(const float* part, const float* bias, float* out, size_t n, int N, int Z, hipStream_t st) {
-  const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-  hipLaunchKernelGGL(sum_partials_bias_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, part, bias, out, n, N, Z);
+void d3dp_launch_sum_partials_bias(const float* part, const float* bias, float* out, size_t n, int N, int Z, hipStream_t st,
+                                   unsigned* amax) {
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+  hipLaunchKernelGGL(sum_partials_bias_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, part, bias, out, n, N, Z, amax);
 }
 void d3dp_launch_sum_partials(const float* part, float* out, size_t n, int Z, hipStream_t st) {
   const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);

@@ -78,8 +78,9 @@ void d3dp_launch_split2(const float* src, void* dst, size_t n, float scale, hipS
 // ---- the training step's split-fp16 Linear (gemm_x2.hip, gemm_f16x2_dyn_kernel): operand scales live on the device ----
 // out_z[M, N] (z = 0 .. Z-1, M N floats apart) = A2[M][2 Kfull] . W2[N][2 Kfull]^T over k-chunk z, x dynA[0] x dynW[0], + bias
 // (bias may be null).  Kfull % (32 Z) == 0, N % 4 == 0.
+// amax_out (optional, Z == 1): absmax slot of the output (bit pattern of a non-negative float, pre-zeroed; one atomicMax per workgroup)
 int d3dp_launch_linear_f16x2_dyn(const void* A2, const void* W2, const float* bias, const float* dynA, const float* dynW,
-                                 float* out, int M, int N, int Kfull, int Z, hipStream_t st);
+                                 float* out, int M, int N, int Kfull, int Z, hipStream_t st, unsigned* amax_out = nullptr);
 // src [R][C] fp32 -> h2i [R][2 Cpad] (zero columns behind C) at the power of two the tensor's absmax (amax[0], bits of a
 // float >= 0, d3dp_launch_absmax) asks for; unscale[0] = 1 / that scale
 void d3dp_launch_split2_dyn(const float* src, void* dst, int R, int C, int Cpad, const unsigned* amax, float* unscale,
@@ -90,7 +91,7 @@ void d3dp_launch_split2_t_dyn(const float* src, void* dst, int R, int C, int Rpa
 // out[i] = sum over z of part[z n + i], z ascending
 // src [R][C] -> row form [R][2 C], transposed form [C][2 Rpad] and (colpart != null) its column sums as D3DP_DYPREP_ROWS
 // partial rows of C floats (every row written; summed by d3dp_train_reduce_many) in one pass (gemm_x2.hip)
-constexpr int D3DP_DYPREP_ROWS = 48;
+constexpr int D3DP_DYPREP_ROWS = 96;
 int d3dp_launch_dyprep(const float* src, void* drow, void* dcol, float* colpart, int R, int C, int Rpad, const unsigned* amax,
                        float* unscale, hipStream_t st);
 // the training step's weight operands in three launches (gemm_x2.hip): absmax -> slot, rows form [N][2 K] at rows_base + 2 off
@@ -100,7 +101,8 @@ struct D3dpWPrepItem { const float* w; int N, K, slot, pad; size_t off; };
 struct D3dpWPrepTable { D3dpWPrepItem it[D3DP_WPREP_MAX]; int n; };
 int d3dp_launch_wprep(const D3dpWPrepTable& tb, void* rows_base, void* cols_base, unsigned* amax, float* unscale, hipStream_t st);
 void d3dp_launch_sum_partials(const float* part, float* out, size_t n, int Z, hipStream_t st);
-void d3dp_launch_sum_partials_bias(const float* part, const float* bias, float* out, size_t n, int N, int Z, hipStream_t st);
+void d3dp_launch_sum_partials_bias(const float* part, const float* bias, float* out, size_t n, int N, int Z, hipStream_t st,
+                                   unsigned* amax = nullptr);
 void d3dp_launch_absmax(const float* src, size_t n, unsigned* out, hipStream_t st);
 // flag[0] |= 1 if any of x[0..n) is inf / nan
 void d3dp_launch_nonfinite_flag(const float* x, size_t n, unsigned* flag, hipStream_t st);
@@ -215,6 +217,16 @@ size_t d3dp_train_attn_stats_bytes(int n_seq, int n_tok, int heads);
 int d3dp_train_attn_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, void* stats, int n_seq,
                         SeqMap map, int C, int heads, hipStream_t st);
 constexpr int D3DP_EMBED_BWD_ROWS = 64;
+// ---- train_attn.hip: the training step's attention on split-fp16 operands (head dim 64, <= 256 tokens per sequence) ----
+// stats: d3dp_train_attn_x2_stats_bytes per attention (the forward leaves the log-sum-exp of every query for the backward pass);
+// amax_qkv / amax_do: absmax slots of the whole qkv tensor / of dout (left by the Linears that produced them); amax_out
+// (optional): absmax slot of the result.
+size_t d3dp_train_attn_x2_stats_bytes(int n_seq, int n_tok, int heads);
+int d3dp_train_attn_x2_fwd(const float* qkv, float* out, void* stats, int n_seq, SeqMap map, int C, int heads,
+                           const unsigned* amax_qkv, unsigned* amax_out, hipStream_t st);
+int d3dp_train_attn_x2_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, void* stats, int n_seq, SeqMap map,
+                           int C, int heads, const unsigned* amax_qkv, const unsigned* amax_do, unsigned* amax_out,
+                           hipStream_t st);
 int d3dp_train_embed_bwd(const float* dx, const float* x2d, const float* x3d, float* part, int T, int C, hipStream_t st);
 int d3dp_train_head_linear(const float* z, const float* w, const float* b, float* out, int T, int C, hipStream_t st);
 int d3dp_train_head_bwd(const float* g, const float* z, const float* w, float* dz, float* part, int* rows, int T, int C,

@@ -1,0 +1,526 @@
+// Attention of the TRAINING step on the fp16 matrix cores (reference common/mixste.py:63-82 inside
+// main.py:387-401's forward / backward), head dim 64, sequences of up to 256 tokens (the temporal axis: 243 frames).
+//
+// Round 4 ran the temporal forward and both backward passes on the FP32 matrix cores (v_mfma_f32_16x16x4_f32: 1/16 of the fp16
+// rate; 5.9 ms of the 27 ms configs[4] step).  Here every product runs on split-fp16 operands like the step's Linears
+// (gemm_x2.hip): x 2^s = hi + lo, three v_mfma_f32_16x16x32_f16 passes lo.hi + hi.lo + hi.hi into one fp32 accumulator --
+// fp32-class results at 5.3 x fewer matrix-pipe cycles.  Operand scales are DEVICE values, like the Linears': q, k, v share
+// the power of two the qkv Linear's output absmax asks for, dO the one of the proj dgrad's output (both left by the GEMM
+// epilogues, gemm_f16x2_dyn_kernel), probabilities use 2^10 (P <= 1), and dS -- whose magnitude no bound predicts within
+// eight bits -- a RUNNING power of two per query (pass Q) / per key (pass KV): when a new key pair raises the row's
+// largest |dS| the accumulators are rescaled by the (exact) ratio, as an online softmax rescales its output.
+//
+// Three kernels, one (sequence, head) problem x one group of eight 16-row tiles per workgroup, one tile per wave:
+//   forward : K, V as split images in LDS; S^T = K Q^T per key pair, online softmax, O^T += V^T P^T.  Leaves
+//             L_i = log2 sum_j exp(s_ij) per query (the softmax's log-sum-exp in base 2) for the backward pass.
+//   pass Q  : K, V images; per key pair S^T = K Q^T, dP^T = V dO^T, P = exp2(s - L), dS^T = P^T (dP^T - D) / 8,
+//             dQ^T += K^T dS^T.  Writes D_i = dO_i . O_i beside L_i.
+//   pass KV : Q, dO images and (L, D); per query pair S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS.
+// LDS image of a [n][64] matrix: two planes (hi | lo) of 128-byte rows, 16-byte slot s of row r at s ^ (((r >> 1) & 3) << 1)
+// -- the V image of attention.hip: conflict-free for the transposed fragment reads (ds_read_b64_tr_b16: 4 rows x 32 B per 16
+// lanes) AND for the row fragment reads (ds_read_b128, whose lane groups pair rows {0-3, 12-15} of one slot with rows {4-11}
+// of the neighbouring one) -- so ONE image serves both uses of K (S^T and dQ^T) and of Q / dO in pass KV.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int TA_NW = 8;                               // waves (= 16-row tiles) per workgroup
+constexpr float kLog2e = 1.44269504088896340736f;
+typedef __bf16 v4bf16_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int ta_seq_base(const SeqMap& m, int s) {
+  return (s / m.inner) * m.outer_stride + (s % m.inner) * m.inner_stride;
+}
+__device__ __forceinline__ int ta_sw(int row) { return ((row >> 1) & 3) << 1; }
+
+// scale of a split operand from its absmax slot (as gemm_x2.hip dyn_scale): the largest magnitude lands in [2^13, 2^14)
+__device__ __forceinline__ float ta_scale(const unsigned* amax) {
+  const float m = __uint_as_float(amax[0]);
+  if (!(m > 0.f) || !(m < INFINITY)) return 1.0f;
+  int e;
+  frexpf(m, &e);
+  return ldexpf(1.0f, 14 - e);
+}
+__device__ __forceinline__ float ta_opaque(float x) { asm volatile("" : "+v"(x)); return x; }
+
+__device__ __forceinline__ void ta_split8(const float4 a, const float4 b, f16x8& hi, f16x8& lo, float sc) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { f16 h, l; split2h_scaled(v[e] * sc, h, l); hi[e] = h; lo[e] = l; }
+}
+
+// rows [0, n) x 64 channels of an fp32 matrix (row stride `rs` floats) -> the hi / lo images (values x sc); rows [n, NK)
+// zero.  Four 16-byte slots per thread and pass, all loads of a pass in flight before the first conversion.
+template <int NK, int NT>
+__device__ __forceinline__ void ta_stage(const float* __restrict__ src, size_t rs, int n, float sc, char* img, int tid) {
+  constexpr int PLANE = NK * 128;
+  constexpr int ITEMS = NK * 8;                        // 16-byte slots of one plane
+  for (int i0 = 0; i0 < ITEMS; i0 += 4 * NT) {
+    float4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = i0 + u * NT + tid, row = idx >> 3, slot = idx & 7;
+      a[u] = make_float4(0.f, 0.f, 0.f, 0.f); b[u] = a[u];
+      if (idx < ITEMS && row < n) {
+        const float* p = src + (size_t)row * rs + slot * 8;
+        a[u] = *reinterpret_cast<const float4*>(p);
+        b[u] = *reinterpret_cast<const float4*>(p + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = i0 + u * NT + tid, row = idx >> 3, slot = idx & 7;
+      if (idx < ITEMS) {
+        f16x8 hi, lo;
+        ta_split8(a[u], b[u], hi, lo, sc);
+        const int off = row * 128 + ((slot ^ ta_sw(row)) << 4);
+        *reinterpret_cast<f16x8*>(img + off) = hi;
+        *reinterpret_cast<f16x8*>(img + PLANE + off) = lo;
+      }
+    }
+  }
+}
+
+// per-lane fragment addresses inside an image (hi plane; the lo plane is PLANE bytes further)
+//   r0 / r1 : ROW fragment -- image row (16 t + lane & 15), channels 8 fg .. + 7 (r0) and 32 + 8 fg .. + 7 (r1); tile t at + t 2048
+//   t[dn]   : TRANSPOSED fragment -- channel dn 16 + (lane & 15), image rows 32 c + 4 fg + {0..3} (first read) and + 16 (second,
+//             2048 bytes further); chunk c at + c 4096.  (attention.hip make_frag_bases, V image)
+struct TAFrag { const char* r0; const char* r1; const char* t[4]; };
+__device__ __forceinline__ TAFrag ta_frag(const char* img, int lane) {
+  TAFrag f;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int sw = ta_sw(fi);                            // (independent of the tile: rows advance in multiples of 16)
+  f.r0 = img + fi * 128 + ((fg ^ sw) << 4);
+  f.r1 = img + fi * 128 + (((4 + fg) ^ sw) << 4);
+  const int j = fi >> 2, qd = fi & 3, row = 4 * fg + j;
+  const int vs = (row >> 1) & 3;
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) f.t[dn] = img + row * 128 + ((dn ^ vs) << 5) + qd * 8;
+  return f;
+}
+__device__ __forceinline__ f16x8 ta_tr(const char* p) {
+  const v4bf16_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) v4bf16_t*)(p));
+  const v4bf16_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) v4bf16_t*)(p + 2048));
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  return __builtin_bit_cast(f16x8, (bf16x8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
+}
+#define TA_MFMA(A, B, ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16((A), (B), (ACC), 0, 0, 0)
+
+// the two 16-row tiles t, t + 1 of  (image rows) x (a register operand): acc_a / acc_b [row 16 t' + 4 fg + r][column lane & 15]
+//   = sum_d img[row][d] x[column][d]  -- lo.hi + hi.lo + hi.hi over the two 32-deep halves of d.
+template <int PLANE>
+__device__ __forceinline__ void ta_rows_pair(const TAFrag& f, int t, const f16x8 (&xh)[2], const f16x8 (&xl)[2], f32x4& a, f32x4& b) {
+  const char* p0 = f.r0 + t * 2048;
+  const char* p1 = f.r1 + t * 2048;
+  const f16x8 al0 = *reinterpret_cast<const f16x8*>(p0 + PLANE), al1 = *reinterpret_cast<const f16x8*>(p1 + PLANE);
+  const f16x8 bl0 = *reinterpret_cast<const f16x8*>(p0 + 2048 + PLANE), bl1 = *reinterpret_cast<const f16x8*>(p1 + 2048 + PLANE);
+  const f16x8 ah0 = *reinterpret_cast<const f16x8*>(p0), ah1 = *reinterpret_cast<const f16x8*>(p1);
+  const f16x8 bh0 = *reinterpret_cast<const f16x8*>(p0 + 2048), bh1 = *reinterpret_cast<const f16x8*>(p1 + 2048);
+  a = (f32x4){0.f, 0.f, 0.f, 0.f}; b = a;
+  TA_MFMA(al0, xh[0], a); TA_MFMA(bl0, xh[0], b);
+  TA_MFMA(al1, xh[1], a); TA_MFMA(bl1, xh[1], b);
+  TA_MFMA(ah0, xl[0], a); TA_MFMA(bh0, xl[0], b);
+  TA_MFMA(ah1, xl[1], a); TA_MFMA(bh1, xl[1], b);
+  TA_MFMA(ah0, xh[0], a); TA_MFMA(bh0, xh[0], b);
+  TA_MFMA(ah1, xh[1], a); TA_MFMA(bh1, xh[1], b);
+}
+// acc[dn][channel dn 16 + 4 fg + i][column] += sum over the 32 image rows of chunk c of img[row][channel] y[row][column]
+// (y as a split register operand in the k order of the transposed fragments: rows 4 fg + r of tile 2 c, then of tile 2 c + 1)
+template <int PLANE>
+__device__ __forceinline__ void ta_tr_chunk(const TAFrag& f, int c, const f16x8& yh, const f16x8& yl, f32x4 (&acc)[4]) {
+  f16x8 th[4], tl[4];
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) { th[dn] = ta_tr(f.t[dn] + c * 4096); tl[dn] = ta_tr(f.t[dn] + c * 4096 + PLANE); }
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) TA_MFMA(tl[dn], yh, acc[dn]);
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) TA_MFMA(th[dn], yl, acc[dn]);
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) TA_MFMA(th[dn], yh, acc[dn]);
+}
+
+// this lane's 16 values of a [.][64] fp32 row as a split register operand (column operand of ta_rows_pair): channels
+// 8 fg .. + 7 and 32 + 8 fg .. + 7
+__device__ __forceinline__ void ta_load_row_op(const float* row, int fg, float sc, f16x8 (&h)[2], f16x8 (&l)[2]) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const float* p = row + half * 32 + fg * 8;
+    ta_split8(*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4), h[half], l[half], sc);
+  }
+}
+
+// eight values (two tiles x four rows) -> one split register operand at the power of two 2^(140 - eb) (eb: biased exponent
+// the caller keeps >= that of the largest magnitude: |y| 2^(140 - eb) < 2^14)
+__device__ __forceinline__ void ta_split_run(const float (&y)[8], int eb, f16x8& h, f16x8& l) {
+  const float sc = __uint_as_float((unsigned)(267 - eb) << 23);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = ta_opaque(y[e] * sc);              // (opaque: both halves must round the SAME number)
+    const f16 hh = (f16)v;
+    h[e] = hh;
+    l[e] = (f16)(v - (float)hh);
+  }
+}
+// biased exponent of max |y[e]| over the lane's eight values and the four lanes that share its column
+__device__ __forceinline__ int ta_exp_of_max(const float (&y)[8]) {
+  float m = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(y[e]));
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  return (int)(__float_as_uint(m) >> 23);
+}
+
+struct TAStat { float L, D; };                         // L = log2 sum_j exp(s_ij) (s = q.k / 8), D = dO_i . O_i
+
+__device__ __forceinline__ void ta_block_amax(float am, unsigned* amax, float* part) {
+  am = wave_max(am);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = am;
+  __syncthreads();
+  if (threadIdx.x == 0 && amax) {
+    float m = part[0];
+#pragma unroll
+    for (int w = 1; w < TA_NW; ++w) m = fmaxf(m, part[w]);
+    atomicMax(amax, __float_as_uint(m));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// forward
+template <int NKT>
+__global__ __launch_bounds__(TA_NW * 64) void tattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                              TAStat* __restrict__ stats, SeqMap map, int C, int heads, int groups,
+                                                              const unsigned* __restrict__ amax_qkv, unsigned* __restrict__ amax_out) {
+  constexpr int NK = 16 * NKT, PLANE = NK * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* kimg = smem;
+  char* vimg = smem + 2 * PLANE;
+  float* part = reinterpret_cast<float*>(smem + 4 * PLANE);
+  const int n = map.n_tok;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int prob = blockIdx.x / groups, group = blockIdx.x % groups;
+  const int seq = prob / heads, head = prob % heads;
+  const int base = ta_seq_base(map, seq);
+  const size_t ld = (size_t)3 * C, rs = (size_t)map.tok_stride * ld;
+  const float sq = ta_scale(amax_qkv);
+  const float* p0 = qkv + (size_t)base * ld + (size_t)head * 64;
+  ta_stage<NK, TA_NW * 64>(p0 + C, rs, n, sq, kimg, tid);
+  ta_stage<NK, TA_NW * 64>(p0 + 2 * C, rs, n, sq, vimg, tid);
+  __syncthreads();
+  const int qt = group * TA_NW + wave;
+  float am = 0.f;
+  if (qt * 16 < n) {
+    const int fi = lane & 15, fg = lane >> 4;
+    const int q = qt * 16 + fi;
+    const size_t tok = (size_t)(base + min(q, n - 1) * map.tok_stride);
+    f16x8 qh[2], ql[2];
+    ta_load_row_op(qkv + tok * ld + head * 64, fg, sq, qh, ql);
+    const TAFrag fk = ta_frag(kimg, lane), fv = ta_frag(vimg, lane);
+    const float cexp = 0.125f * kLog2e / (sq * sq);   // raw accumulator -> logit in base-2 units
+    float mrun = -INFINITY, lrun = 0.f;                // running row maximum (base-2 logit units) and denominator
+    f32x4 o[4];
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NKT; t += 2) {
+      f32x4 a, b;
+      ta_rows_pair<PLANE>(fk, t, qh, ql, a, b);
+      float s[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[r] = (16 * t + 4 * fg + r < n) ? a[r] * cexp : -INFINITY;
+        s[4 + r] = (16 * (t + 1) + 4 * fg + r < n) ? b[r] * cexp : -INFINITY;
+      }
+      float mx = s[0];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) mx = fmaxf(mx, s[e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun, mx);              // (finite from the first pair on: key 0 exists)
+      const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+      mrun = mnew;
+      float psum = 0.f;
+      f16x8 ph, pl;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float y = __builtin_amdgcn_exp2f(s[e] - mnew + 10.0f);   // p x 1024
+        psum += y;
+        const f16 hh = (f16)y;
+        ph[e] = hh;
+        pl[e] = (f16)fmaf(y, 1.0f, -(float)hh);
+      }
+      psum += __shfl_xor(psum, 16, 64);
+      psum += __shfl_xor(psum, 32, 64);
+      lrun = fmaf(lrun, alpha, psum);
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) o[dn] *= alpha;
+      ta_tr_chunk<PLANE>(fv, t >> 1, ph, pl, o);
+    }
+    // o = (v scale) x 1024 x sum_j p_j v_j against the running maximum; lrun = 1024 x sum_j p_j
+    const float inv = 1.0f / (sq * lrun);
+    if (q < n) {
+      float* dst = out + tok * C + head * 64 + fg * 4;     // O^T[d = dn 16 + 4 fg + i][query fi]
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) {
+        const float4 r4 = make_float4(o[dn][0] * inv, o[dn][1] * inv, o[dn][2] * inv, o[dn][3] * inv);
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(r4.x), fabsf(r4.y)), fmaxf(fabsf(r4.z), fabsf(r4.w))));
+        *reinterpret_cast<float4*>(dst + dn * 16) = r4;
+      }
+      if (fg == 0) stats[(size_t)prob * n + q].L = mrun + __builtin_amdgcn_logf(lrun) - 10.0f;   // log2(sum exp2(s))
+    }
+  }
+  if (amax_out) ta_block_amax(am, amax_out, part);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// backward, pass Q: dQ (and D_i into the statistics)
+template <int NKT>
+__global__ __launch_bounds__(TA_NW * 64) void tattn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                                const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                                TAStat* __restrict__ stats, SeqMap map, int C, int heads, int groups,
+                                                                const unsigned* __restrict__ amax_qkv,
+                                                                const unsigned* __restrict__ amax_do, unsigned* __restrict__ amax_out) {
+  constexpr int NK = 16 * NKT, PLANE = NK * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* kimg = smem;
+  char* vimg = smem + 2 * PLANE;
+  float* part = reinterpret_cast<float*>(smem + 4 * PLANE);
+  const int n = map.n_tok;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int prob = blockIdx.x / groups, group = blockIdx.x % groups;
+  const int seq = prob / heads, head = prob % heads;
+  const int base = ta_seq_base(map, seq);
+  const size_t ld = (size_t)3 * C, rs = (size_t)map.tok_stride * ld;
+  const float sq = ta_scale(amax_qkv), sg = ta_scale(amax_do);
+  const float* p0 = qkv + (size_t)base * ld + (size_t)head * 64;
+  ta_stage<NK, TA_NW * 64>(p0 + C, rs, n, sq, kimg, tid);
+  ta_stage<NK, TA_NW * 64>(p0 + 2 * C, rs, n, sq, vimg, tid);
+  __syncthreads();
+  const int qt = group * TA_NW + wave;
+  float am = 0.f;
+  if (qt * 16 < n) {
+    const int fi = lane & 15, fg = lane >> 4;
+    const int q = qt * 16 + fi;
+    const size_t tok = (size_t)(base + min(q, n - 1) * map.tok_stride);
+    f16x8 qh[2], ql[2], gh[2], gl[2];
+    ta_load_row_op(qkv + tok * ld + head * 64, fg, sq, qh, ql);
+    ta_load_row_op(dout + tok * C + head * 64, fg, sg, gh, gl);
+    float D = 0.f;
+    {
+      const float* gs = dout + tok * C + head * 64;
+      const float* os = o + tok * C + head * 64;
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int c4 = 0; c4 < 2; ++c4) {
+          const float4 g = *reinterpret_cast<const float4*>(gs + half * 32 + fg * 8 + c4 * 4);
+          const float4 ov = *reinterpret_cast<const float4*>(os + half * 32 + fg * 8 + c4 * 4);
+          D = fmaf(g.x, ov.x, D); D = fmaf(g.y, ov.y, D); D = fmaf(g.z, ov.z, D); D = fmaf(g.w, ov.w, D);
+        }
+      D += __shfl_xor(D, 16, 64);
+      D += __shfl_xor(D, 32, 64);
+    }
+    const float L = stats[(size_t)prob * n + min(q, n - 1)].L;
+    const TAFrag fk = ta_frag(kimg, lane), fv = ta_frag(vimg, lane);
+    const float cexp = 0.125f * kLog2e / (sq * sq);
+    const float cdp = 1.0f / (sq * sg);                // raw dP accumulator -> true scale
+    int eb = 20;                                       // running biased exponent of the row's largest |dS| (floor 2^-107)
+    f32x4 dq[4];
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) dq[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NKT; t += 2) {
+      f32x4 a, b, c, d;
+      ta_rows_pair<PLANE>(fk, t, qh, ql, a, b);        // S^T  [key][query]
+      ta_rows_pair<PLANE>(fv, t, gh, gl, c, d);        // dP^T [key][query]
+      float ds[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pa = __builtin_amdgcn_exp2f(fmaf(a[r], cexp, -L)), pb = __builtin_amdgcn_exp2f(fmaf(b[r], cexp, -L));
+        ds[r] = (16 * t + 4 * fg + r < n) ? pa * (fmaf(c[r], cdp, -D)) * 0.125f : 0.f;
+        ds[4 + r] = (16 * (t + 1) + 4 * fg + r < n) ? pb * (fmaf(d[r], cdp, -D)) * 0.125f : 0.f;
+      }
+      const int en = max(eb, ta_exp_of_max(ds));
+      if (en != eb) {                                  // (uniform over the four lanes of a column; exact rescale)
+#pragma unroll
+        for (int dn = 0; dn < 4; ++dn)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dq[dn][i] = ldexpf(dq[dn][i], eb - en);
+        eb = en;
+      }
+      f16x8 sh, sl;
+      ta_split_run(ds, eb, sh, sl);
+      ta_tr_chunk<PLANE>(fk, t >> 1, sh, sl, dq);      // dQ^T[d][query] += K^T dS^T
+    }
+    if (q < n) {
+      const float un = 1.0f / sq;
+      float* dst = dqkv + tok * ld + head * 64 + fg * 4;
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) {
+        const float4 r4 = make_float4(ldexpf(dq[dn][0], eb - 140) * un, ldexpf(dq[dn][1], eb - 140) * un,
+                                      ldexpf(dq[dn][2], eb - 140) * un, ldexpf(dq[dn][3], eb - 140) * un);
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(r4.x), fabsf(r4.y)), fmaxf(fabsf(r4.z), fabsf(r4.w))));
+        *reinterpret_cast<float4*>(dst + dn * 16) = r4;
+      }
+      if (fg == 0) stats[(size_t)prob * n + q].D = D;
+    }
+  }
+  if (amax_out) ta_block_amax(am, amax_out, part);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// backward, pass KV: dK, dV
+template <int NKT>
+__global__ __launch_bounds__(TA_NW * 64) void tattn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                 float* __restrict__ dqkv, const TAStat* __restrict__ stats,
+                                                                 SeqMap map, int C, int heads, int groups,
+                                                                 const unsigned* __restrict__ amax_qkv,
+                                                                 const unsigned* __restrict__ amax_do, unsigned* __restrict__ amax_out) {
+  constexpr int NK = 16 * NKT, PLANE = NK * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* qimg = smem;
+  char* gimg = smem + 2 * PLANE;
+  float2* st = reinterpret_cast<float2*>(smem + 4 * PLANE);          // [NK] (L, D)
+  float* part = reinterpret_cast<float*>(smem + 4 * PLANE + NK * 8);
+  const int n = map.n_tok;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int prob = blockIdx.x / groups, group = blockIdx.x % groups;
+  const int seq = prob / heads, head = prob % heads;
+  const int base = ta_seq_base(map, seq);
+  const size_t ld = (size_t)3 * C, rs = (size_t)map.tok_stride * ld;
+  const float sq = ta_scale(amax_qkv), sg = ta_scale(amax_do);
+  ta_stage<NK, TA_NW * 64>(qkv + (size_t)base * ld + (size_t)head * 64, rs, n, sq, qimg, tid);
+  ta_stage<NK, TA_NW * 64>(dout + (size_t)base * C + (size_t)head * 64, (size_t)map.tok_stride * C, n, sg, gimg, tid);
+  for (int i = tid; i < NK; i += TA_NW * 64) {
+    // rows >= n: their Q and dO image rows are zero, so any FINITE p and dS contribute nothing: L = +large keeps p = 0
+    float2 v = make_float2(1.0e30f, 0.f);
+    if (i < n) { const TAStat s = stats[(size_t)prob * n + i]; v = make_float2(s.L, s.D); }
+    st[i] = v;
+  }
+  __syncthreads();
+  const int kt = group * TA_NW + wave;
+  float am = 0.f;
+  if (kt * 16 < n) {
+    const int fi = lane & 15, fg = lane >> 4;
+    const int key = kt * 16 + fi;
+    const bool live = key < n;
+    const size_t tok = (size_t)(base + min(key, n - 1) * map.tok_stride);
+    f16x8 kh[2], kl[2], vh[2], vl[2];
+    ta_load_row_op(qkv + tok * ld + C + head * 64, fg, sq, kh, kl);
+    ta_load_row_op(qkv + tok * ld + 2 * C + head * 64, fg, sq, vh, vl);
+    const TAFrag fq = ta_frag(qimg, lane), fgr = ta_frag(gimg, lane);
+    const float cexp = 0.125f * kLog2e / (sq * sq);
+    const float cdp = 1.0f / (sq * sg);
+    int eb = 20;
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) { dk[dn] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dn] = dk[dn]; }
+#pragma unroll
+    for (int t = 0; t < NKT; t += 2) {
+      f32x4 a, b, c, d;
+      ta_rows_pair<PLANE>(fq, t, kh, kl, a, b);        // S  [query][key]
+      ta_rows_pair<PLANE>(fgr, t, vh, vl, c, d);       // dP [query][key]
+      float ds[8];
+      f16x8 ph, pl;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float2 sa = st[16 * t + 4 * fg + r], sb = st[16 * (t + 1) + 4 * fg + r];
+        float pa = __builtin_amdgcn_exp2f(fmaf(a[r], cexp, -sa.x)), pb = __builtin_amdgcn_exp2f(fmaf(b[r], cexp, -sb.x));
+        if (!live) { pa = 0.f; pb = 0.f; }
+        ds[r] = pa * (fmaf(c[r], cdp, -sa.y)) * 0.125f;
+        ds[4 + r] = pb * (fmaf(d[r], cdp, -sb.y)) * 0.125f;
+        const float ya = ta_opaque(pa * 1024.0f), yb = ta_opaque(pb * 1024.0f);
+        const f16 ha = (f16)ya, hb = (f16)yb;
+        ph[r] = ha; pl[r] = (f16)(ya - (float)ha);
+        ph[4 + r] = hb; pl[4 + r] = (f16)(yb - (float)hb);
+      }
+      ta_tr_chunk<PLANE>(fgr, t >> 1, ph, pl, dv);     // dV^T[d][key] += dO^T P
+      const int en = max(eb, ta_exp_of_max(ds));
+      if (en != eb) {
+#pragma unroll
+        for (int dn = 0; dn < 4; ++dn)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dk[dn][i] = ldexpf(dk[dn][i], eb - en);
+        eb = en;
+      }
+      f16x8 sh, sl;
+      ta_split_run(ds, eb, sh, sl);
+      ta_tr_chunk<PLANE>(fq, t >> 1, sh, sl, dk);      // dK^T[d][key] += Q^T dS
+    }
+    if (live) {
+      const float uk = 1.0f / sq, uv = 1.0f / (sg * 1024.0f);
+      float* dst = dqkv + tok * ld + C + head * 64 + fg * 4;
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) {
+        const float4 k4 = make_float4(ldexpf(dk[dn][0], eb - 140) * uk, ldexpf(dk[dn][1], eb - 140) * uk,
+                                      ldexpf(dk[dn][2], eb - 140) * uk, ldexpf(dk[dn][3], eb - 140) * uk);
+        const float4 v4 = make_float4(dv[dn][0] * uv, dv[dn][1] * uv, dv[dn][2] * uv, dv[dn][3] * uv);
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(k4.x), fabsf(k4.y)), fmaxf(fabsf(k4.z), fabsf(k4.w))));
+        am = fmaxf(am, fmaxf(fmaxf(fabsf(v4.x), fabsf(v4.y)), fmaxf(fabsf(v4.z), fabsf(v4.w))));
+        *reinterpret_cast<float4*>(dst + dn * 16) = k4;
+        *reinterpret_cast<float4*>(dst + C + dn * 16) = v4;
+      }
+    }
+  }
+  if (amax_out) ta_block_amax(am, amax_out, part);
+}
+
+template <int NKT>
+int ta_launch(int which, const float* qkv, const float* o, const float* dout, float* out, float* dqkv, void* stats, int n_seq,
+              SeqMap map, int C, int heads, const unsigned* amax_qkv, const unsigned* amax_do, unsigned* amax_out,
+              hipStream_t st) {
+  constexpr int NK = 16 * NKT;
+  const size_t lds = (size_t)4 * NK * 128 + NK * 8 + 64;
+  static PerDeviceOnce once;
+  if (once.get([&](int) {
+        return d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_fwd_kernel<NKT>), 160 * 1024) < 0 ? -3
+               : d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_bwd_q_kernel<NKT>), 160 * 1024) < 0 ? -3
+               : d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_bwd_kv_kernel<NKT>), 160 * 1024);
+      }) < 0) return -3;
+  const int tiles = (map.n_tok + 15) / 16, groups = (tiles + TA_NW - 1) / TA_NW;
+  const dim3 grid(n_seq * heads * groups), blk(TA_NW * 64);
+  TAStat* s = reinterpret_cast<TAStat*>(stats);
+  if (which == 0)
+    hipLaunchKernelGGL((tattn_fwd_kernel<NKT>), grid, blk, lds, st, qkv, out, s, map, C, heads, groups, amax_qkv, amax_out);
+  else {
+    hipLaunchKernelGGL((tattn_bwd_q_kernel<NKT>), grid, blk, lds, st, qkv, o, dout, dqkv, s, map, C, heads, groups, amax_qkv, amax_do,
+                       amax_out);
+    hipLaunchKernelGGL((tattn_bwd_kv_kernel<NKT>), grid, blk, lds, st, qkv, dout, dqkv, (const TAStat*)s, map, C, heads, groups,
+                       amax_qkv, amax_do, amax_out);
+  }
+  return 0;
+}
+
+int ta_dispatch(int which, const float* qkv, const float* o, const float* dout, float* out, float* dqkv, void* stats, int n_seq,
+                SeqMap map, int C, int heads, const unsigned* amax_qkv, const unsigned* amax_do, unsigned* amax_out,
+                hipStream_t st) {
+  const int n = map.n_tok;
+  if (C / heads != 64 || C % 4 != 0 || n < 1 || n > 256 || !amax_qkv || !stats) return -2;
+#define TA_CASE(NKT_) return ta_launch<NKT_>(which, qkv, o, dout, out, dqkv, stats, n_seq, map, C, heads, amax_qkv, amax_do, amax_out, st);
+  if (n <= 32) { TA_CASE(2) }
+  if (n <= 64) { TA_CASE(4) }
+  if (n <= 128) { TA_CASE(8) }
+  TA_CASE(16)
+#undef TA_CASE
+}
+
+}  // namespace
+
+size_t d3dp_train_attn_x2_stats_bytes(int n_seq, int n_tok, int heads) { return (size_t)n_seq * heads * n_tok * sizeof(TAStat); }
+
+// out [T, C] = softmax(q k^T / 8) v per (sequence, head); stats: n_seq x heads x n_tok (L, D) pairs for the backward pass;
+// amax_qkv: absmax slot of the whole qkv tensor (the qkv Linear's epilogue); amax_out (optional): absmax slot of `out`
+int d3dp_train_attn_x2_fwd(const float* qkv, float* out, void* stats, int n_seq, SeqMap map, int C, int heads,
+                           const unsigned* amax_qkv, unsigned* amax_out, hipStream_t st) {
+  if (!qkv || !out) return -1;
+  return ta_dispatch(0, qkv, nullptr, nullptr, out, nullptr, stats, n_seq, map, C, heads, amax_qkv, nullptr, amax_out, st);
+}
+// dqkv [T, 3C] = the gradient of (q | k | v) given dout [T, C]; o: the forward output; amax_do: absmax slot of dout;
+// amax_out (optional): absmax slot of dqkv (both passes add to it)
+int d3dp_train_attn_x2_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, void* stats, int n_seq, SeqMap map,
+                           int C, int heads, const unsigned* amax_qkv, const unsigned* amax_do, unsigned* amax_out,
+                           hipStream_t st) {
+  if (!qkv || !o || !dout || !dqkv || !amax_do) return -1;
+  return ta_dispatch(1, qkv, o, dout, nullptr, dqkv, stats, n_seq, map, C, heads, amax_qkv, amax_do, amax_out, st);
+}

@@ -137,10 +137,18 @@ def jpma_allgather(preds_local: torch.Tensor, traj: torch.Tensor, cam: torch.Ten
                                               agg.data_ptr(), sel.data_ptr(), 0, 0, R, B, K, Hl, Fr, J, int(zero_root),
                                               _lib.current_stream()), "d3dp_jpma_gathered")
         return agg, sel
-    # host tensors (the gloo tests): the torch statement of the same selection on the flat layout
+    # host tensors (the gloo tests and `bench.py --dist-dry-run`): the torch statement of the same selection on the flat
+    # layout, one clip at a time (at the BASELINE configs[3] shape the flat tensor is 1.27 GB and the projection's temporaries
+    # several times that: eight ranks of it do not fit one host)
     from .jpma import jpma_combine, jpma_winners
-    flat = gathered_view(g).reshape(B, K, R * Hl, Fr, J, 3)
-    return jpma_combine(jpma_winners(flat, traj, cam, gt_2d, h_offset=0, zero_root=zero_root)[None])
+    view = gathered_view(g)
+    aggs, sels = [], []
+    for b in range(B):
+        flat = view[b:b + 1].reshape(1, K, R * Hl, Fr, J, 3)
+        a, s_ = jpma_combine(jpma_winners(flat, traj[b:b + 1], cam, gt_2d[b:b + 1], h_offset=0, zero_root=zero_root)[None])
+        aggs.append(a)
+        sels.append(s_)
+    return torch.cat(aggs), torch.cat(sels)
 
 
 def rank_generator(seed: int, rank: int, device) -> torch.Generator:

@@ -484,11 +484,14 @@ class MixSTE2(nn.Module):
 
     def train_arithmetic(self) -> str:
         """What the training step's Linears run on (bench.py reports it next to the step time)."""
-        attn = "fp32 attention (fp32 MFMA: temporal forward, backward of both axes; spatial forward on the VALU)"
+        x2a = os.environ.get("D3DP_TRAIN_ATTN") != "f32" and self.embed_dim // self.num_heads == 64 and self.num_frame <= 256
+        attn = ("temporal attention forward and backward on split-fp16 operands (fp16 MFMA, running power-of-two scale for dS); "
+                "spatial attention forward on the VALU, backward on the fp32 matrix cores") if x2a else \
+               "fp32 attention (fp32 MFMA: temporal forward, backward of both axes; spatial forward on the VALU)"
         if os.environ.get("D3DP_TRAIN_ATTN_BWD", "")[:1] == "v":
-            attn = "fp32 attention (temporal forward on fp32 MFMA, backward on the VALU: D3DP_TRAIN_ATTN_BWD=valu)"
+            attn += "; D3DP_TRAIN_ATTN_BWD=valu: every fp32 attention backward on the VALU kernels instead"
         if os.environ.get("D3DP_TRAIN_IMPL") == "f32":
-            return "fp32 MFMA Linears (D3DP_TRAIN_IMPL=f32), " + attn
+            return "fp32 MFMA Linears (D3DP_TRAIN_IMPL=f32), fp32 attention"
         return ("split-fp16 Linears (forward, dgrad, split-K wgrad: three fp16-MFMA passes, fp32 accumulate, device-side operand "
                 "scales), " + attn)
 

@@ -1092,37 +1092,52 @@ def test_training_step_config5_vs_oracle_autograd():
 
 @pytest.mark.parametrize("Fr", [9, 40, 81, 243])
 def test_attention_backward_on_matrix_cores_matches_the_valu_kernels(monkeypatch, Fr):
-    """Head-dim-64 attention takes the fp32-MFMA backward (train.hip attn_bwd_{q,kv}_mfma_kernel: 2, 4, 8 or 16 key tiles --
-    the spatial axis' 17 joints and F = 9 frames use 2); D3DP_TRAIN_ATTN_BWD=valu keeps the two-threads-per-row VALU kernels.  Both are fp32 arithmetic in a
-    different summation order: every parameter gradient of a training step agrees to fp32 noise."""
+    """Head-dim-64 attention of the training step, three implementations of the same arithmetic:
+      x2   (default)             -- temporal axis forward AND backward on split-fp16 operands (train_attn.hip: three fp16-MFMA
+                                    passes per product, device-side operand scales, running power-of-two scale for dS); spatial
+                                    axis backward on the fp32 matrix cores;
+      mfma (D3DP_TRAIN_ATTN=f32) -- the round-4 kernels: fp32-MFMA temporal forward and backward (train.hip attn_bwd_{q,kv}_mfma_kernel:
+                                    2, 4, 8 or 16 key tiles -- the spatial axis' 17 joints and F = 9 frames use 2);
+      valu (+ D3DP_TRAIN_ATTN_BWD=valu) -- the two-threads-per-row VALU backward kernels.
+    All fp32-class in a different summation order: every parameter gradient of a training step agrees to fp32 noise."""
     B, cs, dep = 2, 512, 2
     args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
     sd = make_state_dict(11, cs, dep, Fr)
-    m = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=True)
-    m.load_state_dict(sd, strict=False)
-    m = m.cuda().train()
     x2d = torch.from_numpy(synthetic_inputs_2d(911, B, Fr)).cuda()
     gt = torch.from_numpy(synthetic_noise(912, (B, Fr, 17, 3))) * 0.3
     gt[:, :, 0] = 0
     gt = gt.cuda()
     t = torch.tensor([[30], [700]], dtype=torch.long)
     noise = torch.from_numpy(synthetic_noise(913, (B, Fr, 17, 3)))
-    grads = []
-    for impl in ("valu", "mfma"):
-        monkeypatch.setenv("D3DP_TRAIN_ATTN_BWD", impl)
-        m.zero_grad(set_to_none=True)
+    grads, preds = {}, {}
+    for impl in ("valu", "mfma", "x2"):
+        if impl == "x2":
+            monkeypatch.delenv("D3DP_TRAIN_ATTN", raising=False)
+            monkeypatch.delenv("D3DP_TRAIN_ATTN_BWD", raising=False)
+        else:
+            monkeypatch.setenv("D3DP_TRAIN_ATTN", "f32")               # (read when the context is created: one model each)
+            monkeypatch.setenv("D3DP_TRAIN_ATTN_BWD", impl)
+        m = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=True)
+        m.load_state_dict(sd, strict=False)
+        m = m.cuda().train()
         pred = m(x2d, gt, t=t, noise=noise, droppath={})
         loss = torch.mean(torch.norm(pred - gt, dim=-1))
         loss.backward(loss.clone().detach())
         torch.cuda.synchronize()
-        grads.append({k: p.grad.double().cpu() for k, p in m.pose_estimator.named_parameters()})
-    worst = 0.0
-    for k in grads[0]:
-        err = (grads[0][k] - grads[1][k]).norm().item() / max(grads[0][k].norm().item(), 1e-30)
-        worst = max(worst, err)
-        assert err < 2e-5, (k, err)
-    assert any(not torch.equal(grads[0][k], grads[1][k]) for k in grads[0])   # (the switch did select another kernel)
-    print(f"attention backward, F={Fr}: MFMA vs VALU kernels, worst relative gradient difference {worst:.2e}")
+        preds[impl] = pred.detach().double().cpu()
+        grads[impl] = {k: p.grad.double().cpu() for k, p in m.pose_estimator.named_parameters()}
+        assert all(torch.isfinite(g).all() for g in grads[impl].values()), impl
+    for impl in ("mfma", "x2"):
+        worst = 0.0
+        for k in grads["valu"]:
+            err = (grads["valu"][k] - grads[impl][k]).norm().item() / max(grads["valu"][k].norm().item(), 1e-30)
+            worst = max(worst, err)
+            assert err < 2e-5, (impl, k, err)
+        assert any(not torch.equal(grads["valu"][k], grads[impl][k]) for k in grads["valu"])   # (the switch did select another kernel)
+        dp = (preds[impl] - preds["valu"]).abs().max().item()
+        assert dp < 2e-5, (impl, dp)
+        print(f"attention of the training step, F={Fr}: {impl} vs VALU kernels, worst relative gradient difference {worst:.2e}, "
+              f"prediction max |diff| {dp:.2e}")
 
 
 def test_training_step_fp32_linears_cross_check(monkeypatch):

@@ -9,7 +9,7 @@ mkdir -p ../lib/variants/obj
 O=../lib/variants/obj/${NAME}_${FILE%.hip}.o
 EXTRA=""; case $FILE in gemm*.hip) EXTRA=-fno-slp-vectorize;; jpma.hip) EXTRA=-ffp-contract=off;; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $EXTRA $FLAGS -c $FILE -o $O
-OBJS=""; for f in gemm gemm_x2 attention pointwise sampler jpma caller train capi; do
+OBJS=""; for f in gemm gemm_x2 attention pointwise sampler jpma caller train train_attn capi; do
   if [ "$f.hip" = "$FILE" ]; then OBJS="$OBJS $O"; else OBJS="$OBJS ../lib/obj/$f.o"; fi; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libd3dp_$NAME.so $OBJS
 echo built d3dp_amd/lib/variants/libd3dp_$NAME.so
