@@ -1002,7 +1002,7 @@ TrainLayout train_layout(const d3dp_cfg& g, int B) {
     L.w_rows = take(L.w_block * 2 * g.depth);
     L.w_cols = take(L.w_block * 2 * g.depth);
   }
-  L.stats_x2_stride = (d3dp_train_attn_x2_stats_bytes(B * std::max(g.frames, g.joints), std::max(g.frames, g.joints), g.heads) / 4 + 63) / 64 * 64;
+  L.stats_x2_stride = (d3dp_train_attn_x2_stats_bytes(B * g.joints, g.frames, g.heads) / 4 + 63) / 64 * 64;   // (temporal axis: B J sequences of F tokens)
   L.stats_x2 = take(L.stats_x2_stride * 2 * g.depth);
   {
     const size_t lnb = (size_t)D3DP_LN_BWD_BLOCKS * 2 * L.C;         // one LayerNorm call's [dgamma | dbeta] rows
