@@ -955,7 +955,8 @@ struct TrainLayout {
   size_t xn, y, hid, dA, dB, dC, dqkv, dh, z, At, Xt, Wt, dtemb, stats;
   // split-fp16 operands of the training Linears (X2Train below): row form [rows][2 K] and transposed form [features][2 Tp]
   size_t op_a, op_w, op_at, op_xt, part, slots;
-  size_t x_cols, x_block;           // every Linear's activation operand, transposed form [K][2 Tp], kept from the forward pass for wgrad
+  size_t x_cols, x_block;           // every Linear's activation operand kept from the forward pass for its wgrad: the ROW form [Tp][2 K]
+                                    // where the TN kernel applies (it is then also the forward product's operand), else the transposed [K][2 Tp]
   size_t w_rows, w_cols, w_block;   // every weight's split operands (row form / transposed form), prepared once per step: w_block floats per block
   size_t Tp_max;                    // columns (tokens, padded) of a transposed operand row
   size_t stats_x2, stats_x2_stride; // per block: (log-sum-exp, dO . O) of every query of the split-fp16 temporal attention
@@ -990,7 +991,7 @@ TrainLayout train_layout(const d3dp_cfg& g, int B) {
   {
     const size_t fmax = std::max<size_t>(3 * L.C, L.Hd), kmax = std::max<size_t>(L.C, L.Hd);
     L.Tp_max = ((L.T + 31) / 32 + 64) * 32;          // (room for rounding the k-steps up to a multiple of the split count)
-    L.op_a = take(L.T * fmax);                       // [T][2 fmax] fp16 = T fmax floats
+    L.op_a = take(L.Tp_max * fmax);                  // [Tp][2 fmax] fp16 = Tp fmax floats (rows T .. Tp - 1: the TN wgrad's zero rows)
     L.op_w = take(fmax * kmax);                      // [N][2 K] or [K][2 N] fp16
     L.op_at = take(fmax * L.Tp_max);                 // dY^T: [N][2 Tp] fp16
     L.op_xt = take(kmax * L.Tp_max);                 // X^T:  [K][2 Tp] fp16
@@ -1008,7 +1009,7 @@ TrainLayout train_layout(const d3dp_cfg& g, int B) {
     const size_t lnb = (size_t)D3DP_LN_BWD_BLOCKS * 2 * L.C;         // one LayerNorm call's [dgamma | dbeta] rows
     const size_t fmax = std::max<size_t>(3 * L.C, L.Hd);
     L.red_floats = (size_t)(6 * g.depth + 2) * lnb                   // 3 LayerNorm backward calls per block + the head's
-                   + (size_t)8 * g.depth * D3DP_DYPREP_ROWS * fmax   // bias gradients: the column sums of every dY
+                   + (size_t)2 * g.depth * std::max(D3DP_DYPREP_ROWS, D3DP_ROWPREP_ROWS) * (5 * L.C + L.Hd + 256)   // bias gradients: the column sums of every dY
                    + (size_t)512 * (3 * L.C + 4) + (size_t)D3DP_EMBED_BWD_ROWS * 5 * L.C + (size_t)512 * L.C   // head, embedding
                    + (size_t)kGroupSlices * (g.joints + (size_t)B) * L.C + 4096;                                // spos, time embedding
     L.red = take(L.red_floats);
@@ -1146,13 +1147,19 @@ struct X2Train {
     const int sa = 2 * l, sw = 2 * l + 1;
     if (l < 0 || sw >= kBwdSlot0) return -1;
     if (!a_amax_ready) d3dp_launch_absmax(A, (size_t)T * K, amax() + sa, st);
+    const float* a2 = ws + L.op_a;
     {
-      // row form for this product and, in the same pass, the transposed form the wgrad of this Linear will want: the
-      // backward pass then neither recomputes this activation (LayerNorm / GELU outputs) nor reads it again
+      // the operand of this product and, in the same pass, what the wgrad of this Linear will want of it: the backward pass
+      // then neither recomputes this activation (LayerNorm / GELU outputs) nor reads it again.  Where the TN wgrad kernel applies
+      // that is the SAME row form (kept, zero rows behind T), else a second, transposed form.
       int Z, Tp;
       wgrad_split(T, N, K, Z, Tp);
       if ((size_t)Tp > L.Tp_max) return -1;
-      const int r = d3dp_launch_dyprep(A, ws + L.op_a, ws + L.x_cols + xoff(l), nullptr, T, K, Tp, amax() + sa, uns() + sa, st);
+      int r;
+      if (d3dp_tn_applies(N, K)) {
+        a2 = ws + L.x_cols + xoff(l);
+        r = d3dp_launch_rowprep(A, ws + L.x_cols + xoff(l), nullptr, nullptr, T, Tp, K, amax() + sa, uns() + sa, st);
+      } else r = d3dp_launch_dyprep(A, ws + L.op_a, ws + L.x_cols + xoff(l), nullptr, T, K, Tp, amax() + sa, uns() + sa, st);
       if (r) return r;
     }
     const float* w2 = ws + L.op_w;
@@ -1161,7 +1168,7 @@ struct X2Train {
       d3dp_launch_absmax(W, (size_t)N * K, amax() + sw, st);
       rows(W, N, K, ws + L.op_w, sw);
     }
-    return gemm(ws + L.op_a, w2, bias, uns() + sa, uns() + sw, out, T, N, K, out_amax);
+    return gemm(a2, w2, bias, uns() + sa, uns() + sw, out, T, N, K, out_amax);
   }
   // dX[T, K] = dY[T, N] W[N, K]   (sdy: the absmax slot of dY, shared with wgrad; l: the forward Linear whose W this is)
   int dgrad(int l, const float* dY, int sdy, const float* W, float* dX, int T, int N, int K, unsigned* out_amax = nullptr) {
@@ -1184,11 +1191,15 @@ struct X2Train {
   // -> op_at (wgrad), the bias gradient's partial column sums -> bias_part (D3DP_DYPREP_ROWS rows of N floats).  `dy_ready`
   // then tells dgrad / wgrad not to build them again.
   bool dy_ready = false;
-  int prep_dy(const float* dY, int sdy, float* bias_part, int T, int N, int K) {
+  static constexpr int kBiasRows = D3DP_DYPREP_ROWS > D3DP_ROWPREP_ROWS ? D3DP_DYPREP_ROWS : D3DP_ROWPREP_ROWS;   // capacity of bias_part
+  int prep_dy(const float* dY, int sdy, float* bias_part, int* bias_rows, int T, int N, int K) {
     int Z, Tp;
     wgrad_split(T, N, K, Z, Tp);
     if ((size_t)Tp > L.Tp_max) return -1;
     dy_ready = true;
+    if (d3dp_tn_applies(N, K))       // the row form alone (zero rows behind T): dgrad's operand AND the TN wgrad's
+      return d3dp_launch_rowprep(dY, ws + L.op_a, bias_part, bias_rows, T, Tp, N, amax() + sdy, uns() + sdy, st);
+    *bias_rows = D3DP_DYPREP_ROWS;
     return d3dp_launch_dyprep(dY, ws + L.op_a, ws + L.op_at, bias_part, T, N, Tp, amax() + sdy, uns() + sdy, st);
   }
   // dW[N, K] = dY[T, N]^T X[T, K]   (X: the activation operand of forward Linear l)
@@ -1197,10 +1208,16 @@ struct X2Train {
     int Z, Tp;
     wgrad_split(T, N, K, Z, Tp);
     if ((size_t)Tp > L.Tp_max || (size_t)Z * N * K > (size_t)(1024 + 64) * 256 * 128) return -1;
-    if (!dy_ready) cols(dY, T, N, Tp, ws + L.op_at, sdy);   // dY^T: [N][2 Tp]
-    (void)X;                                           // X^T [K][2 Tp]: left by the forward pass of this step
-    const int r = d3dp_launch_linear_f16x2_dyn(ws + L.op_at, ws + L.x_cols + xoff(l), nullptr, uns() + sdy, uns() + sx,
-                                               ws + L.part, N, K, Tp, Z, st);
+    (void)X;                                           // X's operand form: left by the forward pass of this step
+    int r;
+    if (d3dp_tn_applies(N, K)) {                        // both operands in their row forms [Tp][2 .]: nothing was transposed
+      if (!dy_ready) return -1;
+      r = d3dp_launch_linear_f16x2_tn(ws + L.op_a, ws + L.x_cols + xoff(l), uns() + sdy, uns() + sx, ws + L.part, N, K, Tp, Z, st);
+    } else {
+      if (!dy_ready) cols(dY, T, N, Tp, ws + L.op_at, sdy);   // dY^T: [N][2 Tp]
+      r = d3dp_launch_linear_f16x2_dyn(ws + L.op_at, ws + L.x_cols + xoff(l), nullptr, uns() + sdy, uns() + sx, ws + L.part, N, K,
+                                       Tp, Z, st);
+    }
     if (r) return r;
     d3dp_launch_sum_partials(ws + L.part, dW, (size_t)N * K, Z, st);
     return 0;
@@ -1356,10 +1373,11 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     if (use_x2) {
       sdy = pre_slot >= 0 ? pre_slot : x2.slot_for(dY, (size_t)T * N);
       if (sdy < 0) return -1;
-      float* bp = red.take((size_t)D3DP_DYPREP_ROWS * N);
+      float* bp = red.take((size_t)X2Train::kBiasRows * N);
+      int brows = 0;
       if (!bp) return -1;
-      red.add(bp, dbias, N, D3DP_DYPREP_ROWS, N);
-      if ((r = x2.prep_dy(dY, sdy, bp, T, N, K))) return r;
+      if ((r = x2.prep_dy(dY, sdy, bp, &brows, T, N, K))) return r;
+      red.add(bp, dbias, N, brows, N);
       return x2.wgrad(l, dY, sdy, X, dW, T, N, K);
     }
     float* bp = red.take((size_t)D3DP_DYPREP_ROWS * N);

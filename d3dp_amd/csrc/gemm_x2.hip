@@ -1560,6 +1560,150 @@ __global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The training step's weight gradient  dW[N, K] = dY[T, N]^T X[T, K]  straight from the ROW forms of its two operands (the "TN"
+// form): out_z[n][k] = sum over the tokens t of chunk z of A2[t][n] W2[t][k], x dynA[0] x dynW[0].
+// Round 4 fed wgrad the TRANSPOSED forms [features][2 Tp] through the kernel above, which every forward Linear's input and
+// every dY had to be written out in a second time by a tile transpose (dyprep_kernel: 9.8 GB and 3.5 ms of the configs[4] step,
+// its scattered 128-byte writes at 2.8 TB/s).  Here the contraction runs over ROWS of the operands: a k-step is 32 token rows,
+// the A slab 32 rows x 256 features (1 KiB per row = 8 h2i blocks, ONE LDS-DMA wave-instruction), the W slab 32 rows x 128
+// features (512 B per row, two rows per instruction) -- the same 48 KiB per stage, 12 pieces per loader wave and k-step as the
+// kernel above, and the same 8 + 4 waves, 3-stage ring and barrier structure.  The fragments an MFMA wants -- 8 consecutive
+// TOKENS of one feature -- are columns of the slab: ds_read_b64_tr_b16 (the transposed fragment read of attention.hip's V
+// image: 4 token rows x 16 features per 16 lanes) delivers them; lane group g holds the tokens {4 g + j} and {16 + 4 g + j} of
+// the k-step for BOTH operands, so the k order of the two fragments agrees.  LDS swizzle: 16-byte slot s of token row r sits at
+// s ^ ((r & 7) << 1): the eight rows a transposed read touches per cycle land in eight different 32-byte bank groups (the rows
+// are 1 KiB / 512 B apart: unswizzled they would all hit the same one).
+// Rows T .. Tp - 1 of both operands must exist and be ZERO (dyprep_kernel writes them).  Output: a lane holds
+// out[n = .. + 4 g + r][k = .. + 16 ni + i] -- 4-byte stores, 64 contiguous bytes per 16 lanes; the partial tiles are small (N K
+// floats per chunk) and summed by sum_partials_kernel.
+__global__ __launch_bounds__(768) void gemm_f16x2_tn_kernel(const f16* __restrict__ A2, const f16* __restrict__ W2,
+                                                            const float* __restrict__ dynA, const float* __restrict__ dynW,
+                                                            float* __restrict__ out, int N, int K, int NKz, int tiles_k,
+                                                            int tiles_per_z, int total_items) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int G = gridDim.x;
+  const int L = xcd_remap(blockIdx.x, G);
+  const int n_my = (total_items - L + G - 1) / G;      // work items L, L+G, ...: item = z tiles_per_z + tile
+  const int gtot = n_my * NKz;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (gtot <= 0) return;
+
+  if (wave >= XNCW) {
+    // ---------------------------------------------------------------- loader waves: 8 A pieces + 4 W pieces per k-step each
+    const int lw = wave - XNCW;
+    int ti = 0, ks = 0, slot = 0;
+    const f16* pa;                                     // this lane's source of A piece 0 of the current item (k-step 0)
+    const f16* pw;
+    size_t a_row = 0, w_row = 0;                       // fp16 elements per operand row
+    auto issue = [&]() {
+      if (ks == 0) {
+        const int item = L + ti * G;
+        const int z = item / tiles_per_z, t = item - z * tiles_per_z;
+        const int n0 = (t / tiles_k) * XBM, k0 = (t % tiles_k) * XBN;
+        const size_t t0 = (size_t)z * NKz * XBK;       // first token row of the chunk
+        a_row = (size_t)2 * N; w_row = (size_t)2 * K;
+        // A piece i = token row lw 8 + i of the k-step (1 KiB: features n0 .. n0 + 255); lane l fetches logical slot l ^ swz
+        // (N % 256 == 0 and K % 128 == 0: the launcher sends other shapes to the kernel above)
+        pa = A2 + (t0 + lw * 8) * a_row + (size_t)n0 * 2;
+        pw = W2 + (t0 + lw * 8) * w_row + (size_t)k0 * 2;
+      }
+      char* base = smem + slot * XSTAGE;
+      const size_t ro = (size_t)ks * XBK;              // token rows into the chunk
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = lw * 8 + i;                      // token row of the k-step; r & 7 == i
+        __builtin_amdgcn_global_load_lds(GPTR(pa + (ro + i) * a_row + ((lane ^ (i << 1)) << 3)), LPTR(base + r * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = lw * 8 + 2 * i + (lane >> 5);    // two token rows per piece: lanes 0-31 / 32-63
+        const int l32 = lane & 31;
+        __builtin_amdgcn_global_load_lds(GPTR(pw + (ro + 2 * i + (lane >> 5)) * w_row + ((l32 ^ ((r & 7) << 1)) << 3)),
+                                         LPTR(base + XA_BYTES + (lw * 8 + 2 * i) * 512), 16, 0, 0);
+      }
+      if (++ks == NKz) { ks = 0; ++ti; }
+      slot = (slot == XNSTAGE - 1) ? 0 : slot + 1;
+    };
+    issue();
+    if (gtot > 1) issue();
+    for (int g = 0; g < gtot; ++g) {
+      if (g + 1 < gtot) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      X2_BARRIER();
+      if (g + 2 < gtot) issue();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute waves: 64 (n) x 64 (k) of the 256 x 128 tile
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int j = fi >> 2, qd = fi & 3, row = 4 * fg + j;        // transposed read: lanes 4 j .. 4 j + 3 point at token row 4 fg + j
+  // slot of the 16 features (mi / ni) x plane inside a token row: block b = wr 2 + (mi >> 1) (A) / wc 2 + (ni >> 1) (W),
+  // slot = b 8 + plane 4 + (mi & 1) 2 + (qd >> 1); the swizzle of rows `row` and `row + 16` is the same (r & 7)
+  auto a_off = [&](int mi, int pl) { return row * 1024 + (((((wr * 2 + (mi >> 1)) << 3) | (pl << 2) | ((mi & 1) << 1) | (qd >> 1)) ^ ((row & 7) << 1)) << 4) + ((qd & 1) << 3); };
+  auto w_off = [&](int ni, int pl) { return XA_BYTES + row * 512 + (((((wc * 2 + (ni >> 1)) << 3) | (pl << 2) | ((ni & 1) << 1) | (qd >> 1)) ^ ((row & 7) << 1)) << 4) + ((qd & 1) << 3); };
+  typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+  typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+  auto tr8 = [&](const char* p, int second) {         // 8 tokens of one feature: rows 4 fg + {0..3} and 16 + 4 fg + {0..3}
+    const v4bf a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) v4bf*)(p));
+    const v4bf b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) v4bf*)(p + second));
+    return __builtin_bit_cast(f16x8, (v8bf){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
+  };
+  int offA[4][2], offW[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) { offA[m][pl] = a_off(m, pl); offW[m][pl] = w_off(m, pl); }
+  const float unscale = dynA[0] * dynW[0];
+  __builtin_amdgcn_s_setprio(1);
+  int slot = 0;
+#pragma unroll 1
+  for (int ti = 0; ti < n_my; ++ti) {
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ks = 0; ks < NKz; ++ks) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      X2_BARRIER();
+      const char* sb = smem + slot * XSTAGE;
+      slot = (slot == XNSTAGE - 1) ? 0 : slot + 1;
+      f16x8 wf[4][2];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wf[ni][pl] = tr8(sb + offW[ni][pl], 16 * 512);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const f16x8 ah = tr8(sb + offA[mi][0], 16 * 1024);
+        const f16x8 al = tr8(sb + offA[mi][1], 16 * 1024);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wf[ni][1], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wf[ni][0], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wf[ni][0], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    // epilogue: lane holds out[nn = n0 + wr 64 + mi 16 + 4 fg + r][kk = k0 + wc 64 + ni 16 + fi]
+    const int item = L + ti * G;
+    const int z = item / tiles_per_z, t = item - z * tiles_per_z;
+    const int n0 = (t / tiles_k) * XBM, k0 = (t % tiles_k) * XBN;
+    float* o = out + (size_t)z * N * K + (size_t)(n0 + wr * 64 + 4 * fg) * K + k0 + wc * 64 + fi;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) o[(size_t)(mi * 16 + r) * K + ni * 16] = acc[mi][ni][r] * unscale;
+  }
+}
+
 // scale of a split operand from its absmax (bit pattern of a non-negative float, absmax_kernel): the power of two that
 // puts the largest magnitude in [2^13, 2^14) (as capi.hip does for the inference weights); 1 for an all-zero tensor
 __device__ __forceinline__ float dyn_scale(unsigned amax_bits) {
@@ -1709,6 +1853,67 @@ __global__ __launch_bounds__(256) void dyprep_kernel(const float* __restrict__ s
       for (int j = 0; j < 32; ++j) t += cs[j * 33 + threadIdx.x];
       colpart[(size_t)blockIdx.x * C + c0 + threadIdx.x] = t;
     }
+  }
+}
+
+// The ROW form alone, as a streaming pass over whole rows (the TN weight-gradient kernel above reads both of its operands in
+// this form, so nothing is transposed): src [R][C] fp32 -> drow [Rpad][2 C] h2i (rows R .. Rpad - 1 ZERO: the TN kernel
+// contracts over them) and, for a gradient, its column sums as gridDim.x partial rows of C floats (fixed-order reduction by
+// d3dp_train_reduce_many).  A thread owns 8 consecutive columns (two 16-byte loads, one 16-byte store per plane) of the rows
+// r = 4 blockIdx.x + (tid >> 6), + 4 gridDim.x, ...: reads and writes are contiguous in memory -- unlike the tile transpose of
+// dyprep_kernel, whose 128-byte pieces land 66 KB apart.  C % 512 == 0 or C <= 512 with C % 8 == 0 (P = ceil(C / 512) passes).
+template <int P>
+__global__ __launch_bounds__(256) void rowprep_kernel(const float* __restrict__ s, f16* __restrict__ drow, float* __restrict__ colpart,
+                                                      int R, int Rpad, int C, const unsigned* __restrict__ amax,
+                                                      float* __restrict__ unscale) {
+  __shared__ float cs[4][P * 512];
+  const float sc = dyn_scale(amax[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) unscale[0] = 1.0f / sc;
+  const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  float acc[P][8];
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[p][e] = 0.f;
+  constexpr int U = P == 1 ? 4 : 2;                    // rows per wave and iteration: 8 loads of 16 bytes in flight per thread
+  const int rstep = gridDim.x * 4;
+  for (int r0 = blockIdx.x * 4 + rl; r0 < Rpad; r0 += rstep * U) {
+    float4 a[U][P], b[U][P];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int r = r0 + u * rstep, c = p * 512 + l * 8;
+        a[u][p] = make_float4(0.f, 0.f, 0.f, 0.f); b[u][p] = a[u][p];
+        if (r < R && c < C) {
+          a[u][p] = *reinterpret_cast<const float4*>(s + (size_t)r * C + c);
+          b[u][p] = *reinterpret_cast<const float4*>(s + (size_t)r * C + c + 4);
+        }
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int r = r0 + u * rstep, c = p * 512 + l * 8;
+        if (r < Rpad && c < C) {
+          const float v[8] = {a[u][p].x, a[u][p].y, a[u][p].z, a[u][p].w, b[u][p].x, b[u][p].y, b[u][p].z, b[u][p].w};
+          f16x8 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { acc[p][e] += v[e]; f16 h, lw; split2h_scaled(v[e] * sc, h, lw); hi[e] = h; lo[e] = lw; }
+          f16* row = drow + (size_t)r * 2 * C + h2i_col(c);
+          *reinterpret_cast<f16x8*>(row) = hi;
+          *reinterpret_cast<f16x8*>(row + kH2iLo) = lo;
+        }
+      }
+  }
+  if (colpart) {
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[rl][p * 512 + l * 8 + e] = acc[p][e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+      colpart[(size_t)blockIdx.x * C + c] = ((cs[0][c] + cs[1][c]) + cs[2][c]) + cs[3][c];
   }
 }
 
@@ -2105,6 +2310,41 @@ int d3dp_launch_dyprep(const float* src, void* drow, void* dcol, float* colpart,
   return 0;
 }
 
+// the row form alone (+ column sums): see rowprep_kernel.  *rows = partial rows written to colpart (<= D3DP_ROWPREP_ROWS)
+int d3dp_launch_rowprep(const float* src, void* drow, float* colpart, int* rows, int R, int Rpad, int C, const unsigned* amax,
+                        float* unscale, hipStream_t st) {
+  if (C % 8 != 0 || Rpad < R || C > 1536 || (C > 512 && C % 512 != 0)) return -1;
+  int g = (Rpad + 3) / 4;
+  const int cap = colpart ? D3DP_ROWPREP_ROWS : 1024;   // (every workgroup leaves one partial row of column sums)
+  if (g > cap) g = cap;
+  if (rows) *rows = g;
+  const int P = (C + 511) / 512;
+  f16* d = (f16*)drow;
+  if (P == 1) hipLaunchKernelGGL((rowprep_kernel<1>), dim3(g), dim3(256), 0, st, src, d, colpart, R, Rpad, C, amax, unscale);
+  else if (P == 2) hipLaunchKernelGGL((rowprep_kernel<2>), dim3(g), dim3(256), 0, st, src, d, colpart, R, Rpad, C, amax, unscale);
+  else hipLaunchKernelGGL((rowprep_kernel<3>), dim3(g), dim3(256), 0, st, src, d, colpart, R, Rpad, C, amax, unscale);
+  return 0;
+}
+
+// out_z[N, K] = sum over the token rows of chunk z of A2[t][n] W2[t][k], x dynA x dynW: Tp = Z NKz 32 rows per operand (rows
+// beyond the real ones zero), N % 256 == 0, K % 128 == 0 (d3dp_tn_applies)
+bool d3dp_tn_applies(int N, int K) { return N % XBM == 0 && K % XBN == 0; }
+int d3dp_launch_linear_f16x2_tn(const void* A2, const void* W2, const float* dynA, const float* dynW, float* out, int N, int K,
+                                int Tp, int Z, hipStream_t st) {
+  if (!d3dp_tn_applies(N, K) || Z < 1 || Tp % (XBK * Z) != 0) return -1;
+  const int NKz = Tp / XBK / Z;
+  const int tn = N / XBM, tk = K / XBN;
+  static PerDeviceOnce once;
+  const int cus = once.get([&](int dev) {
+    return d3dp_lds_opt_in(reinterpret_cast<const void*>(gemm_f16x2_tn_kernel), XNSTAGE * XSTAGE) < 0 ? -3 : d3dp_cu_count(dev);
+  });
+  if (cus < 0) return -3;
+  const int items = tn * tk * Z, grid = items < cus ? items : cus;
+  hipLaunchKernelGGL(gemm_f16x2_tn_kernel, dim3(grid), dim3((XNCW + 4) * 64), XNSTAGE * XSTAGE, st, (const f16*)A2, (const f16*)W2,
+                     dynA, dynW, out, N, K, NKz, tk, tn * tk, items);
+  return 0;
+}
+
 int d3dp_launch_wprep(const D3dpWPrepTable& tb, void* rows_base, void* cols_base, unsigned* amax, float* unscale, hipStream_t st) {
   if (tb.n < 1 || tb.n > D3DP_WPREP_MAX) return -1;
   for (int i = 0; i < tb.n; ++i)
@@ -2117,7 +2357,8 @@ int d3dp_launch_wprep(const D3dpWPrepTable& tb, void* rows_base, void* cols_base
 
 void d3dp_launch_sum_partials_bias(const float* part, const float* bias, float* out, size_t n, int N, int Z, hipStream_t st,
                                    unsigned* amax) {
-  const unsigned blocks = (unsigned)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+  const unsigned cap = amax ? 256 : 2048;              // (with an absmax: one atomic per workgroup)
+  const unsigned blocks = (unsigned)((n + 255) / 256 < cap ? (n + 255) / 256 : cap);
   hipLaunchKernelGGL(sum_partials_bias_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, part, bias, out, n, N, Z, amax);
 }
 void d3dp_launch_sum_partials(const float* part, float* out, size_t n, int Z, hipStream_t st) {

@@ -94,6 +94,16 @@ void d3dp_launch_split2_t_dyn(const float* src, void* dst, int R, int C, int Rpa
 constexpr int D3DP_DYPREP_ROWS = 96;
 int d3dp_launch_dyprep(const float* src, void* drow, void* dcol, float* colpart, int R, int C, int Rpad, const unsigned* amax,
                        float* unscale, hipStream_t st);
+// the row form alone as a streaming pass: src [R][C] -> drow [Rpad][2 C] (rows R .. Rpad - 1 zero) + optional column sums as *rows
+// (<= D3DP_ROWPREP_ROWS) partial rows of C floats; C <= 1536
+constexpr int D3DP_ROWPREP_ROWS = 512;
+int d3dp_launch_rowprep(const float* src, void* drow, float* colpart, int* rows, int R, int Rpad, int C, const unsigned* amax,
+                        float* unscale, hipStream_t st);
+// wgrad straight from the ROW forms (gemm_f16x2_tn_kernel): out_z[N, K] = sum_{t in chunk z} A2[t][n] W2[t][k] x dynA x dynW,
+// Tp = Z NKz 32 rows per operand (rows beyond the real ones zero).  d3dp_tn_applies: N % 256 == 0 and K % 128 == 0.
+bool d3dp_tn_applies(int N, int K);
+int d3dp_launch_linear_f16x2_tn(const void* A2, const void* W2, const float* dynA, const float* dynW, float* out, int N, int K,
+                                int Tp, int Z, hipStream_t st);
 // the training step's weight operands in three launches (gemm_x2.hip): absmax -> slot, rows form [N][2 K] at rows_base + 2 off
 // halves, transposed form [K][2 N] at cols_base + 2 off halves, unscale[slot] = 1 / scale
 constexpr int D3DP_WPREP_MAX = 64;
