@@ -156,8 +156,9 @@ struct d3dp_ctx {
   }
   int pad_override = -1;         // D3DP_SEQ_PAD=0|1: measurement switch (pad without the skewed schedule, or the reverse)
   bool train_x2 = true;          // D3DP_TRAIN_IMPL=f32: the training Linears on the fp32 matrix cores (round-1 path, cross-check)
-  bool train_attn_x2 = true;     // D3DP_TRAIN_ATTN=f32: the temporal attention of the training step on the fp32 matrix cores
-                                 // (round-4 kernels, cross-check) instead of the split-fp16 kernels of train_attn.hip
+  int train_attn_x2 = 2;         // the training step's attention on the split-fp16 kernels of train_attn.hip: 2 = both axes (default),
+                                 // 1 = D3DP_TRAIN_ATTN=x2t: the temporal axis only, 0 = D3DP_TRAIN_ATTN=f32: neither (the round-4
+                                 // fp32 kernels -- fp32-MFMA temporal forward and backward, VALU spatial forward: the cross-check)
   int pingpong = 0;              // D3DP_X2_PP=1: the ping-pong form of the EXACT Linear (gemm_x2.hip; bit-identical results;
                                  // measured 1.5-2 % SLOWER on the whole step, gpurun c8); 2 = D3DP_X2_WIDE=1: the 256 x 256
                                  // tile form (bit-identical; ties with the default, profiles/r04_gemm_probes.md section 4)
@@ -375,7 +376,7 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   const char* ti = getenv("D3DP_TRAIN_IMPL");
   c->train_x2 = !(ti && !strcmp(ti, "f32"));
   const char* ta = getenv("D3DP_TRAIN_ATTN");
-  c->train_attn_x2 = !(ta && !strcmp(ta, "f32"));
+  c->train_attn_x2 = (ta && !strcmp(ta, "f32")) ? 0 : (ta && !strcmp(ta, "x2t")) ? 1 : 2;
   {
     // Measurement switches of experiments that were measured and not adopted: the row-class skewed schedule
     // (D3DP_X2_SKEW=1|2|4), the ping-pong (D3DP_X2_PP=1) and wide (D3DP_X2_WIDE=1) forms of the EXACT Linear, norm2 folded into
@@ -1257,8 +1258,9 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
                  unsigned* out_amax = nullptr) {
     return use_x2 ? x2.forward(l, A, W, bias, out, M, N, K, a_amax_ready, out_amax) : lin32(A, W, bias, out, M, N, K, st);
   };
-  // temporal attention on split-fp16 operands (train_attn.hip): needs the split Linears' device-side scales, head dim 64, <= 256 frames
-  const bool attn_x2 = use_x2 && c->train_attn_x2 && C / g.heads == 64 && F <= 256;
+  // attention on split-fp16 operands (train_attn.hip): needs the split Linears' device-side scales, head dim 64, <= 256 frames
+  const bool attn_x2 = use_x2 && c->train_attn_x2 > 0 && C / g.heads == 64 && F <= 256;
+  const bool attn_x2_s = attn_x2 && c->train_attn_x2 > 1;      // the spatial axis too
   LAUNCH_TRY(d3dp_launch_time_mlp(t, c->freq, c->t1w, c->t1b, c->t3w, c->t3b, ws + L.temb, B, C, st));
   float* slab0 = ws + L.saved0;
   LAUNCH_TRY(d3dp_launch_embed_ln(0, x2d, x3d, ws + L.temb, c->ew, c->eb, c->spos, c->ste[0].n1w, c->ste[0].n1b,
@@ -1272,12 +1274,16 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     const int kind = blk & 1, d = blk >> 1;
     const BlockDev& w = kind ? c->tte[d] : c->ste[d];
     float* S = ws + L.saved0 + (size_t)blk * L.saved_stride;
-    unsigned* qkv_amax = (attn_x2 && kind == 1) ? x2.amax() + X2Train::kQkvSlot0 + blk : nullptr;
+    const bool ax2 = kind == 1 ? attn_x2 : attn_x2_s;
+    unsigned* qkv_amax = ax2 ? x2.amax() + X2Train::kQkvSlot0 + blk : nullptr;
     LAUNCH_TRY(lin(4 * blk, xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C, true, qkv_amax));
     bool att_ready = true;
-    if (kind == 0)
+    if (kind == 0 && ax2)
+      LAUNCH_TRY(d3dp_train_attn_x2_fwd(S + L.o_qkv, S + L.o_att, ws + L.stats_x2 + (size_t)blk * L.stats_x2_stride, B * F,
+                                        spatial_map(F, J), C, g.heads, qkv_amax, slot(4 * blk + 1), st));
+    else if (kind == 0)
       LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * F, spatial_map(F, J), C, g.heads, st, slot(4 * blk + 1)));
-    else if (attn_x2)
+    else if (ax2)
       LAUNCH_TRY(d3dp_train_attn_x2_fwd(S + L.o_qkv, S + L.o_att, ws + L.stats_x2 + (size_t)blk * L.stats_x2_stride, B * J,
                                         temporal_map(F, J), C, g.heads, qkv_amax, slot(4 * blk + 1), st));
     else if (use_x2 && C / g.heads == 64 && F <= 256) {  // temporal axis on the fp32 matrix cores (bitwise an fp32 fmaf chain per
@@ -1347,7 +1353,8 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     LAUNCH_TRY(x2.begin(false));
     x2.batched = 8 * g.depth <= D3DP_WPREP_MAX;          // (the forward pass of this step left the weight operands in place)
   }
-  const bool attn_x2 = use_x2 && c->train_attn_x2 && C / g.heads == 64 && F <= 256;   // (as the forward pass of this step)
+  const bool attn_x2 = use_x2 && c->train_attn_x2 > 0 && C / g.heads == 64 && F <= 256;   // (as the forward pass of this step)
+  const bool attn_x2_s = attn_x2 && c->train_attn_x2 > 1;
   Reducer red{ws + L.red, L.red_floats, 0, st};
   const int lnrows = d3dp_train_ln_bwd_blocks(T);        // partial rows one LayerNorm-backward call leaves
   // [dgamma | dbeta] partial rows of a LayerNorm with `calls` backward calls per step (the shared norms: one per depth), and
@@ -1461,13 +1468,14 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
       LAUNCH_TRY(wgrad(4 * blk + 1, dy, C, S + L.o_att, C, G(gw.proj_w), G(gw.proj_b), ps));
     }
     int ps_dqkv = -1;
-    if (attn_x2 && kind == 1) {
-      // temporal axis on split-fp16 operands: the proj dgrad leaves d att's absmax, the attention backward that of dqkv
+    if (kind == 1 ? attn_x2 : attn_x2_s) {
+      // split-fp16 operands: the proj dgrad leaves d att's absmax, the attention backward that of dqkv
       D3DP_FRESH(pdo, pado)
       D3DP_FRESH(pq, paq)
       LAUNCH_TRY(dgrad(4 * blk + 1, dy, C, (const float*)w.proj_w, C, dB, pado));                                       // d att
-      LAUNCH_TRY(d3dp_train_attn_x2_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats_x2 + (size_t)blk * L.stats_x2_stride, B * J,
-                                        temporal_map(F, J), C, g.heads, x2.amax() + X2Train::kQkvSlot0 + blk, pado, paq, st));
+      LAUNCH_TRY(d3dp_train_attn_x2_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats_x2 + (size_t)blk * L.stats_x2_stride,
+                                        kind ? B * J : B * F, kind ? temporal_map(F, J) : spatial_map(F, J), C, g.heads,
+                                        x2.amax() + X2Train::kQkvSlot0 + blk, pado, paq, st));
       ps_dqkv = pq;
     } else {
       LAUNCH_TRY(dgrad(4 * blk + 1, dy, C, (const float*)w.proj_w, C, dB));                                             // d att

@@ -10,7 +10,9 @@
 // eight bits -- a RUNNING power of two per query (pass Q) / per key (pass KV): when a new key pair raises the row's
 // largest |dS| the accumulators are rescaled by the (exact) ratio, as an online softmax rescales its output.
 //
-// Three kernels, one (sequence, head) problem x one group of eight 16-row tiles per workgroup, one tile per wave:
+// Three kernels; a work unit = one (sequence, head) problem x one group of NW 16-row tiles, one tile per wave (NW = 8 for the
+// long sequences: two groups per 243-frame problem; NW = 2 for the spatial axis' 17 joints: 128-thread workgroups, ten of them
+// per CU); workgroups walk the units grid-stride, so a launch ends with at most a few thousand absmax atomics:
 //   forward : K, V as split images in LDS; S^T = K Q^T per key pair, online softmax, O^T += V^T P^T.  Leaves
 //             L_i = log2 sum_j exp(s_ij) per query (the softmax's log-sum-exp in base 2) for the backward pass.
 //   pass Q  : K, V images; per key pair S^T = K Q^T, dP^T = V dO^T, P = exp2(s - L), dS^T = P^T (dP^T - D) / 8,
@@ -25,7 +27,6 @@
 
 namespace {
 
-constexpr int TA_NW = 8;                               // waves (= 16-row tiles) per workgroup
 constexpr float kLog2e = 1.44269504088896340736f;
 typedef __bf16 v4bf16_t __attribute__((ext_vector_type(4)));
 
@@ -174,6 +175,7 @@ __device__ __forceinline__ int ta_exp_of_max(const float (&y)[8]) {
 
 struct TAStat { float L, D; };                         // L = log2 sum_j exp(s_ij) (s = q.k / 8), D = dO_i . O_i
 
+template <int NW>
 __device__ __forceinline__ void ta_block_amax(float am, unsigned* amax, float* part) {
   am = wave_max(am);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = am;
@@ -181,17 +183,18 @@ __device__ __forceinline__ void ta_block_amax(float am, unsigned* amax, float* p
   if (threadIdx.x == 0 && amax) {
     float m = part[0];
 #pragma unroll
-    for (int w = 1; w < TA_NW; ++w) m = fmaxf(m, part[w]);
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, part[w]);
     atomicMax(amax, __float_as_uint(m));
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
 // forward
-template <int NKT>
-__global__ __launch_bounds__(TA_NW * 64) void tattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                              TAStat* __restrict__ stats, SeqMap map, int C, int heads, int groups,
-                                                              const unsigned* __restrict__ amax_qkv, unsigned* __restrict__ amax_out) {
+template <int NKT, int NW>
+__global__ __launch_bounds__(NW * 64) void tattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                           TAStat* __restrict__ stats, SeqMap map, int C, int heads, int groups,
+                                                           int n_work, const unsigned* __restrict__ amax_qkv,
+                                                           unsigned* __restrict__ amax_out) {
   constexpr int NK = 16 * NKT, PLANE = NK * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
@@ -199,17 +202,19 @@ __global__ __launch_bounds__(TA_NW * 64) void tattn_fwd_kernel(const float* __re
   float* part = reinterpret_cast<float*>(smem + 4 * PLANE);
   const int n = map.n_tok;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int prob = blockIdx.x / groups, group = blockIdx.x % groups;
-  const int seq = prob / heads, head = prob % heads;
-  const int base = ta_seq_base(map, seq);
   const size_t ld = (size_t)3 * C, rs = (size_t)map.tok_stride * ld;
   const float sq = ta_scale(amax_qkv);
-  const float* p0 = qkv + (size_t)base * ld + (size_t)head * 64;
-  ta_stage<NK, TA_NW * 64>(p0 + C, rs, n, sq, kimg, tid);
-  ta_stage<NK, TA_NW * 64>(p0 + 2 * C, rs, n, sq, vimg, tid);
-  __syncthreads();
-  const int qt = group * TA_NW + wave;
   float am = 0.f;
+  for (int unit = blockIdx.x; unit < n_work; unit += gridDim.x) {
+  const int prob = unit / groups, group = unit % groups;
+  const int seq = prob / heads, head = prob % heads;
+  const int base = ta_seq_base(map, seq);
+  const float* p0 = qkv + (size_t)base * ld + (size_t)head * 64;
+  if (unit != (int)blockIdx.x) __syncthreads();        // every wave is done with the previous unit's images
+  ta_stage<NK, NW * 64>(p0 + C, rs, n, sq, kimg, tid);
+  ta_stage<NK, NW * 64>(p0 + 2 * C, rs, n, sq, vimg, tid);
+  __syncthreads();
+  const int qt = group * NW + wave;
   if (qt * 16 < n) {
     const int fi = lane & 15, fg = lane >> 4;
     const int q = qt * 16 + fi;
@@ -270,17 +275,18 @@ __global__ __launch_bounds__(TA_NW * 64) void tattn_fwd_kernel(const float* __re
       if (fg == 0) stats[(size_t)prob * n + q].L = mrun + __builtin_amdgcn_logf(lrun) - 10.0f;   // log2(sum exp2(s))
     }
   }
-  if (amax_out) ta_block_amax(am, amax_out, part);
+  }
+  if (amax_out) ta_block_amax<NW>(am, amax_out, part);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
 // backward, pass Q: dQ (and D_i into the statistics)
-template <int NKT>
-__global__ __launch_bounds__(TA_NW * 64) void tattn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
-                                                                const float* __restrict__ dout, float* __restrict__ dqkv,
-                                                                TAStat* __restrict__ stats, SeqMap map, int C, int heads, int groups,
-                                                                const unsigned* __restrict__ amax_qkv,
-                                                                const unsigned* __restrict__ amax_do, unsigned* __restrict__ amax_out) {
+template <int NKT, int NW>
+__global__ __launch_bounds__(NW * 64) void tattn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                             const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                             TAStat* __restrict__ stats, SeqMap map, int C, int heads, int groups,
+                                                             int n_work, const unsigned* __restrict__ amax_qkv,
+                                                             const unsigned* __restrict__ amax_do, unsigned* __restrict__ amax_out) {
   constexpr int NK = 16 * NKT, PLANE = NK * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
@@ -288,17 +294,19 @@ __global__ __launch_bounds__(TA_NW * 64) void tattn_bwd_q_kernel(const float* __
   float* part = reinterpret_cast<float*>(smem + 4 * PLANE);
   const int n = map.n_tok;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int prob = blockIdx.x / groups, group = blockIdx.x % groups;
-  const int seq = prob / heads, head = prob % heads;
-  const int base = ta_seq_base(map, seq);
   const size_t ld = (size_t)3 * C, rs = (size_t)map.tok_stride * ld;
   const float sq = ta_scale(amax_qkv), sg = ta_scale(amax_do);
-  const float* p0 = qkv + (size_t)base * ld + (size_t)head * 64;
-  ta_stage<NK, TA_NW * 64>(p0 + C, rs, n, sq, kimg, tid);
-  ta_stage<NK, TA_NW * 64>(p0 + 2 * C, rs, n, sq, vimg, tid);
-  __syncthreads();
-  const int qt = group * TA_NW + wave;
   float am = 0.f;
+  for (int unit = blockIdx.x; unit < n_work; unit += gridDim.x) {
+  const int prob = unit / groups, group = unit % groups;
+  const int seq = prob / heads, head = prob % heads;
+  const int base = ta_seq_base(map, seq);
+  const float* p0 = qkv + (size_t)base * ld + (size_t)head * 64;
+  if (unit != (int)blockIdx.x) __syncthreads();
+  ta_stage<NK, NW * 64>(p0 + C, rs, n, sq, kimg, tid);
+  ta_stage<NK, NW * 64>(p0 + 2 * C, rs, n, sq, vimg, tid);
+  __syncthreads();
+  const int qt = group * NW + wave;
   if (qt * 16 < n) {
     const int fi = lane & 15, fg = lane >> 4;
     const int q = qt * 16 + fi;
@@ -366,17 +374,18 @@ __global__ __launch_bounds__(TA_NW * 64) void tattn_bwd_q_kernel(const float* __
       if (fg == 0) stats[(size_t)prob * n + q].D = D;
     }
   }
-  if (amax_out) ta_block_amax(am, amax_out, part);
+  }
+  if (amax_out) ta_block_amax<NW>(am, amax_out, part);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
 // backward, pass KV: dK, dV
-template <int NKT>
-__global__ __launch_bounds__(TA_NW * 64) void tattn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                                 float* __restrict__ dqkv, const TAStat* __restrict__ stats,
-                                                                 SeqMap map, int C, int heads, int groups,
-                                                                 const unsigned* __restrict__ amax_qkv,
-                                                                 const unsigned* __restrict__ amax_do, unsigned* __restrict__ amax_out) {
+template <int NKT, int NW>
+__global__ __launch_bounds__(NW * 64) void tattn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                              float* __restrict__ dqkv, const TAStat* __restrict__ stats,
+                                                              SeqMap map, int C, int heads, int groups, int n_work,
+                                                              const unsigned* __restrict__ amax_qkv,
+                                                              const unsigned* __restrict__ amax_do, unsigned* __restrict__ amax_out) {
   constexpr int NK = 16 * NKT, PLANE = NK * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* qimg = smem;
@@ -385,22 +394,24 @@ __global__ __launch_bounds__(TA_NW * 64) void tattn_bwd_kv_kernel(const float* _
   float* part = reinterpret_cast<float*>(smem + 4 * PLANE + NK * 8);
   const int n = map.n_tok;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int prob = blockIdx.x / groups, group = blockIdx.x % groups;
-  const int seq = prob / heads, head = prob % heads;
-  const int base = ta_seq_base(map, seq);
   const size_t ld = (size_t)3 * C, rs = (size_t)map.tok_stride * ld;
   const float sq = ta_scale(amax_qkv), sg = ta_scale(amax_do);
-  ta_stage<NK, TA_NW * 64>(qkv + (size_t)base * ld + (size_t)head * 64, rs, n, sq, qimg, tid);
-  ta_stage<NK, TA_NW * 64>(dout + (size_t)base * C + (size_t)head * 64, (size_t)map.tok_stride * C, n, sg, gimg, tid);
-  for (int i = tid; i < NK; i += TA_NW * 64) {
+  float am = 0.f;
+  for (int unit = blockIdx.x; unit < n_work; unit += gridDim.x) {
+  const int prob = unit / groups, group = unit % groups;
+  const int seq = prob / heads, head = prob % heads;
+  const int base = ta_seq_base(map, seq);
+  if (unit != (int)blockIdx.x) __syncthreads();
+  ta_stage<NK, NW * 64>(qkv + (size_t)base * ld + (size_t)head * 64, rs, n, sq, qimg, tid);
+  ta_stage<NK, NW * 64>(dout + (size_t)base * C + (size_t)head * 64, (size_t)map.tok_stride * C, n, sg, gimg, tid);
+  for (int i = tid; i < NK; i += NW * 64) {
     // rows >= n: their Q and dO image rows are zero, so any FINITE p and dS contribute nothing: L = +large keeps p = 0
     float2 v = make_float2(1.0e30f, 0.f);
     if (i < n) { const TAStat s = stats[(size_t)prob * n + i]; v = make_float2(s.L, s.D); }
     st[i] = v;
   }
   __syncthreads();
-  const int kt = group * TA_NW + wave;
-  float am = 0.f;
+  const int kt = group * NW + wave;
   if (kt * 16 < n) {
     const int fi = lane & 15, fg = lane >> 4;
     const int key = kt * 16 + fi;
@@ -463,31 +474,33 @@ __global__ __launch_bounds__(TA_NW * 64) void tattn_bwd_kv_kernel(const float* _
       }
     }
   }
-  if (amax_out) ta_block_amax(am, amax_out, part);
+  }
+  if (amax_out) ta_block_amax<NW>(am, amax_out, part);
 }
 
 template <int NKT>
 int ta_launch(int which, const float* qkv, const float* o, const float* dout, float* out, float* dqkv, void* stats, int n_seq,
               SeqMap map, int C, int heads, const unsigned* amax_qkv, const unsigned* amax_do, unsigned* amax_out,
               hipStream_t st) {
-  constexpr int NK = 16 * NKT;
+  constexpr int NK = 16 * NKT, NW = NKT <= 2 ? 2 : (NKT <= 4 ? 4 : 8);
   const size_t lds = (size_t)4 * NK * 128 + NK * 8 + 64;
   static PerDeviceOnce once;
   if (once.get([&](int) {
-        return d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_fwd_kernel<NKT>), 160 * 1024) < 0 ? -3
-               : d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_bwd_q_kernel<NKT>), 160 * 1024) < 0 ? -3
-               : d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_bwd_kv_kernel<NKT>), 160 * 1024);
+        return d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_fwd_kernel<NKT, NW>), 160 * 1024) < 0 ? -3
+               : d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_bwd_q_kernel<NKT, NW>), 160 * 1024) < 0 ? -3
+               : d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_bwd_kv_kernel<NKT, NW>), 160 * 1024);
       }) < 0) return -3;
-  const int tiles = (map.n_tok + 15) / 16, groups = (tiles + TA_NW - 1) / TA_NW;
-  const dim3 grid(n_seq * heads * groups), blk(TA_NW * 64);
+  const int tiles = (map.n_tok + 15) / 16, groups = (tiles + NW - 1) / NW;
+  const int n_work = n_seq * heads * groups;
+  const dim3 grid(n_work < 2048 ? n_work : 2048), blk(NW * 64);   // (<= 2048 absmax atomics per launch)
   TAStat* s = reinterpret_cast<TAStat*>(stats);
   if (which == 0)
-    hipLaunchKernelGGL((tattn_fwd_kernel<NKT>), grid, blk, lds, st, qkv, out, s, map, C, heads, groups, amax_qkv, amax_out);
+    hipLaunchKernelGGL((tattn_fwd_kernel<NKT, NW>), grid, blk, lds, st, qkv, out, s, map, C, heads, groups, n_work, amax_qkv, amax_out);
   else {
-    hipLaunchKernelGGL((tattn_bwd_q_kernel<NKT>), grid, blk, lds, st, qkv, o, dout, dqkv, s, map, C, heads, groups, amax_qkv, amax_do,
-                       amax_out);
-    hipLaunchKernelGGL((tattn_bwd_kv_kernel<NKT>), grid, blk, lds, st, qkv, dout, dqkv, (const TAStat*)s, map, C, heads, groups,
+    hipLaunchKernelGGL((tattn_bwd_q_kernel<NKT, NW>), grid, blk, lds, st, qkv, o, dout, dqkv, s, map, C, heads, groups, n_work,
                        amax_qkv, amax_do, amax_out);
+    hipLaunchKernelGGL((tattn_bwd_kv_kernel<NKT, NW>), grid, blk, lds, st, qkv, dout, dqkv, (const TAStat*)s, map, C, heads, groups,
+                       n_work, amax_qkv, amax_do, amax_out);
   }
   return 0;
 }

@@ -1093,9 +1093,9 @@ def test_training_step_config5_vs_oracle_autograd():
 @pytest.mark.parametrize("Fr", [9, 40, 81, 243])
 def test_attention_backward_on_matrix_cores_matches_the_valu_kernels(monkeypatch, Fr):
     """Head-dim-64 attention of the training step, three implementations of the same arithmetic:
-      x2   (default)             -- temporal axis forward AND backward on split-fp16 operands (train_attn.hip: three fp16-MFMA
-                                    passes per product, device-side operand scales, running power-of-two scale for dS); spatial
-                                    axis backward on the fp32 matrix cores;
+      x2   (default)             -- BOTH axes forward and backward on split-fp16 operands (train_attn.hip: three fp16-MFMA passes
+                                    per product, device-side operand scales, running power-of-two scale for dS);
+      x2t  (D3DP_TRAIN_ATTN=x2t) -- the temporal axis on those kernels, the spatial axis as below;
       mfma (D3DP_TRAIN_ATTN=f32) -- the round-4 kernels: fp32-MFMA temporal forward and backward (train.hip attn_bwd_{q,kv}_mfma_kernel:
                                     2, 4, 8 or 16 key tiles -- the spatial axis' 17 joints and F = 9 frames use 2);
       valu (+ D3DP_TRAIN_ATTN_BWD=valu) -- the two-threads-per-row VALU backward kernels.
@@ -1110,9 +1110,12 @@ def test_attention_backward_on_matrix_cores_matches_the_valu_kernels(monkeypatch
     t = torch.tensor([[30], [700]], dtype=torch.long)
     noise = torch.from_numpy(synthetic_noise(913, (B, Fr, 17, 3)))
     grads, preds = {}, {}
-    for impl in ("valu", "mfma", "x2"):
-        if impl == "x2":
+    for impl in ("valu", "mfma", "x2t", "x2"):
+        if impl == "x2":                                                # both axes on the split-fp16 kernels (the default)
             monkeypatch.delenv("D3DP_TRAIN_ATTN", raising=False)
+            monkeypatch.delenv("D3DP_TRAIN_ATTN_BWD", raising=False)
+        elif impl == "x2t":                                             # the temporal axis only
+            monkeypatch.setenv("D3DP_TRAIN_ATTN", "x2t")
             monkeypatch.delenv("D3DP_TRAIN_ATTN_BWD", raising=False)
         else:
             monkeypatch.setenv("D3DP_TRAIN_ATTN", "f32")               # (read when the context is created: one model each)
@@ -1127,7 +1130,7 @@ def test_attention_backward_on_matrix_cores_matches_the_valu_kernels(monkeypatch
         preds[impl] = pred.detach().double().cpu()
         grads[impl] = {k: p.grad.double().cpu() for k, p in m.pose_estimator.named_parameters()}
         assert all(torch.isfinite(g).all() for g in grads[impl].values()), impl
-    for impl in ("mfma", "x2"):
+    for impl in ("mfma", "x2t", "x2"):
         worst = 0.0
         for k in grads["valu"]:
             err = (grads["valu"][k] - grads[impl][k]).norm().item() / max(grads["valu"][k].norm().item(), 1e-30)
