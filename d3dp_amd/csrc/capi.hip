@@ -156,6 +156,13 @@ struct d3dp_ctx {
   }
   int pad_override = -1;         // D3DP_SEQ_PAD=0|1: measurement switch (pad without the skewed schedule, or the reverse)
   bool train_x2 = true;          // D3DP_TRAIN_IMPL=f32: the training Linears on the fp32 matrix cores (round-1 path, cross-check)
+  // The backward pass runs every weight-gradient product (the TN / split-K kernel and the sum of its partial tiles) on a second
+  // stream beside the dgrad product of the same dY and the row kernels that follow it: each of these persistent Linears keeps one
+  // workgroup per CU, so a tail round of a few tiles or a launch ramp leaves CUs idle that the other product's workgroups fill.
+  // Forked and joined with events on the caller's stream (nothing synchronises the host); D3DP_TRAIN_OVERLAP=0 keeps one stream.
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool train_overlap = true;
   int train_attn_x2 = 2;         // the training step's attention on the split-fp16 kernels of train_attn.hip: 2 = both axes (default),
                                  // 1 = D3DP_TRAIN_ATTN=x2t: the temporal axis only, 0 = D3DP_TRAIN_ATTN=f32: neither (the round-4
                                  // fp32 kernels -- fp32-MFMA temporal forward and backward, VALU spatial forward: the cross-check)
@@ -375,6 +382,8 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->fold = !(nf && nf[0] == '1');
   const char* ti = getenv("D3DP_TRAIN_IMPL");
   c->train_x2 = !(ti && !strcmp(ti, "f32"));
+  const char* ov = getenv("D3DP_TRAIN_OVERLAP");
+  c->train_overlap = !(ov && ov[0] == '0');
   const char* ta = getenv("D3DP_TRAIN_ATTN");
   c->train_attn_x2 = (ta && !strcmp(ta, "f32")) ? 0 : (ta && !strcmp(ta, "x2t")) ? 1 : 2;
   {
@@ -419,6 +428,9 @@ int d3dp_destroy(d3dp_ctx* c) {
   for (auto& e : c->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->arena) (void)hipFree(c->arena);
   if (c->d_flag) (void)hipFree(c->d_flag);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->aux) (void)hipStreamDestroy(c->aux);
   delete c;
   return D3DP_OK;
 }
@@ -955,7 +967,7 @@ struct TrainLayout {
   // temporaries
   size_t xn, y, hid, dA, dB, dC, dqkv, dh, z, At, Xt, Wt, dtemb, stats;
   // split-fp16 operands of the training Linears (X2Train below): row form [rows][2 K] and transposed form [features][2 Tp]
-  size_t op_a, op_w, op_at, op_xt, part, slots;
+  size_t op_a, op_w, op_at, op_xt, part, part_rem, slots;
   size_t x_cols, x_block;           // every Linear's activation operand kept from the forward pass for its wgrad: the ROW form [Tp][2 K]
                                     // where the TN kernel applies (it is then also the forward product's operand), else the transposed [K][2 Tp]
   size_t w_rows, w_cols, w_block;   // every weight's split operands (row form / transposed form), prepared once per step: w_block floats per block
@@ -987,7 +999,7 @@ TrainLayout train_layout(const d3dp_cfg& g, int B) {
   L.dqkv = take(3 * L.unit); L.dh = take(L.T * L.Hd); L.z = take(L.unit);
   const size_t wide = std::max<size_t>(3 * L.C, L.Hd);
   L.At = take(wide * L.Tpad); L.Xt = take(wide * L.Tpad); L.Wt = take(wide * wide);
-  L.dtemb = take((size_t)B * L.C);
+  L.dtemb = take((size_t)B * 2 * L.C);              // (the training forward's time-MLP hidden layer borrows it: B x 2 C)
   L.stats = take(d3dp_train_attn_stats_bytes(B * std::max(g.frames, g.joints), std::max(g.frames, g.joints), g.heads) / 4 + 64);
   {
     const size_t fmax = std::max<size_t>(3 * L.C, L.Hd), kmax = std::max<size_t>(L.C, L.Hd);
@@ -997,6 +1009,8 @@ TrainLayout train_layout(const d3dp_cfg& g, int B) {
     L.op_at = take(fmax * L.Tp_max);                 // dY^T: [N][2 Tp] fp16
     L.op_xt = take(kmax * L.Tp_max);                 // X^T:  [K][2 Tp] fp16
     L.part = take((size_t)(1024 + 64) * 256 * 128);  // split-K partial products: at most ~ (CUs + tiles) output tiles
+    L.part_rem = take((size_t)16 * 256 * fmax);      // ... of a forward / dgrad product's remainder rows (its own region: the
+                                                     // weight-gradient product of the same dY runs concurrently on the second stream)
     L.slots = take(2 * 8192);                        // absmax words | 1 / scale per operand
     L.w_block = 4 * L.C * L.C + 2 * L.Hd * L.C;      // qkv | proj | fc1 | fc2 of one block ([N][2 K] fp16 = N K floats each)
     L.x_block = (3 * L.C + L.Hd) * L.Tp_max;         // qkv | proj | fc1 | fc2 inputs of one block
@@ -1067,6 +1081,7 @@ struct X2Train {
   float* ws;
   const TrainLayout& L;
   int n_cu;
+  hipStream_t st_w = nullptr;                          // the weight-gradient products' stream (null: `st`)
   // absmax / unscale slots: the forward pass owns slots 2 l (activation operand) and 2 l + 1 (weight) of its Linear l = 4 block
   // + {qkv, proj, fc1, fc2} and leaves them -- with the operands themselves: the weights' two forms and every activation's
   // transposed form -- for the backward pass of the same step, whose wgrad / dgrad read the same tensors: 128 of the step's
@@ -1122,7 +1137,7 @@ struct X2Train {
   // launch as a split-K product (Z chunks of the contraction: tn Z short work items instead of tn long ones) whose partial
   // sums are added in a fixed order.
   int gemm(const float* A2, const float* W2, const float* bias, const float* ua, const float* uw, float* out, int T, int N,
-           int K, unsigned* out_amax = nullptr) {
+           int K, unsigned* out_amax = nullptr, int amax_pos = 0) {
     const int tn = (N + 127) / 128, q = T / 256, rem = T - q * 256;
     const int rounds_all = ((q + (rem ? 1 : 0)) * tn + n_cu - 1) / n_cu, rounds_full = (q * tn + n_cu - 1) / n_cu;
     const int nk = K / 32;
@@ -1131,25 +1146,28 @@ struct X2Train {
       if (nk % z == 0) Z = z;
     // (measured: a last round of a few tiles runs its k-steps at 0.75 us -- few CUs active, full clock -- against 1.4 us in a
     //  full round, so for 16 k-steps it costs 12 us, what the second launch and the sum cost too: split from 32 k-steps on)
-    if (rem == 0 || q == 0 || rounds_all == rounds_full || Z == 1 || nk < 32 || (size_t)Z * rem * N > (size_t)(1024 + 64) * 256 * 128)
-      return d3dp_launch_linear_f16x2_dyn(A2, W2, bias, ua, uw, out, T, N, K, 1, st, out_amax);
-    int r = d3dp_launch_linear_f16x2_dyn(A2, W2, bias, ua, uw, out, q * 256, N, K, 1, st, out_amax);
+    if (rem == 0 || q == 0 || rounds_all == rounds_full || Z == 1 || nk < 32 || (size_t)Z * rem * N > (size_t)16 * 256 * std::max<size_t>(3 * L.C, L.Hd))
+      return d3dp_launch_linear_f16x2_dyn(A2, W2, bias, ua, uw, out, T, N, K, 1, st, out_amax, amax_pos);
+    int r = d3dp_launch_linear_f16x2_dyn(A2, W2, bias, ua, uw, out, q * 256, N, K, 1, st, out_amax, amax_pos);
     if (r) return r;
-    r = d3dp_launch_linear_f16x2_dyn(A2 + (size_t)q * 256 * K, W2, nullptr, ua, uw, ws + L.part, rem, N, K, Z, st);   // (a row = 2 K fp16 = K floats)
+    r = d3dp_launch_linear_f16x2_dyn(A2 + (size_t)q * 256 * K, W2, nullptr, ua, uw, ws + L.part_rem, rem, N, K, Z, st);   // (a row = 2 K fp16 = K floats)
     if (r) return r;
-    d3dp_launch_sum_partials_bias(ws + L.part, bias, out + (size_t)q * 256 * N, (size_t)rem * N, N, Z, st, out_amax);
+    d3dp_launch_sum_partials_bias(ws + L.part_rem, bias, out + (size_t)q * 256 * N, (size_t)rem * N, N, Z, st, out_amax, amax_pos);
     return 0;
   }
   // out[T, N] = A[T, K] W[N, K]^T + bias     (l: the Linear's index, see the slots above)
   // (a_amax_ready: the kernel that produced A already left its absmax in slot 2 l)
   // (out_amax: optional slot for the OUTPUT's absmax, left by the product's epilogue)
+  // (a_prepared: the activation operand of Linear l -- planes at x_cols + xoff(l), zero rows behind T, unscale slot 2 l -- was
+  //  written by its producer: gelu_operand below)
   int forward(int l, const float* A, const float* W, const float* bias, float* out, int T, int N, int K, bool a_amax_ready = false,
-              unsigned* out_amax = nullptr) {
+              unsigned* out_amax = nullptr, int amax_pos = 0, bool a_prepared = false) {
     const int sa = 2 * l, sw = 2 * l + 1;
     if (l < 0 || sw >= kBwdSlot0) return -1;
-    if (!a_amax_ready) d3dp_launch_absmax(A, (size_t)T * K, amax() + sa, st);
+    if (!a_amax_ready && !a_prepared) d3dp_launch_absmax(A, (size_t)T * K, amax() + sa, st);
     const float* a2 = ws + L.op_a;
-    {
+    if (a_prepared) a2 = ws + L.x_cols + xoff(l);
+    else {
       // the operand of this product and, in the same pass, what the wgrad of this Linear will want of it: the backward pass
       // then neither recomputes this activation (LayerNorm / GELU outputs) nor reads it again.  Where the TN wgrad kernel applies
       // that is the SAME row form (kept, zero rows behind T), else a second, transposed form.
@@ -1169,7 +1187,17 @@ struct X2Train {
       d3dp_launch_absmax(W, (size_t)N * K, amax() + sw, st);
       rows(W, N, K, ws + L.op_w, sw);
     }
-    return gemm(a2, w2, bias, uns() + sa, uns() + sw, out, T, N, K, out_amax);
+    return gemm(a2, w2, bias, uns() + sa, uns() + sw, out, T, N, K, out_amax, amax_pos);
+  }
+  // whether Linear l (N out features, K in) takes its GELU'd input straight from its producer's output: TN shapes only (the
+  // row form is then also the wgrad operand)
+  bool gelu_operand_applies(int N, int K) const { return d3dp_tn_applies(N, K); }
+  static constexpr int kPmaxSlot0 = 3072;              // forward range: slot kPmaxSlot0 + block = largest positive fc1 output
+  int gelu_operand(int l, const float* hpre, int blk, int T, int N, int K) {
+    int Z, Tp;
+    wgrad_split(T, N, K, Z, Tp);
+    if ((size_t)Tp > L.Tp_max) return -1;
+    return d3dp_launch_gelu_rowprep(hpre, ws + L.x_cols + xoff(l), T, Tp, K, amax() + kPmaxSlot0 + blk, amax() + 2 * l, uns() + 2 * l, st);
   }
   // dX[T, K] = dY[T, N] W[N, K]   (sdy: the absmax slot of dY, shared with wgrad; l: the forward Linear whose W this is)
   int dgrad(int l, const float* dY, int sdy, const float* W, float* dX, int T, int N, int K, unsigned* out_amax = nullptr) {
@@ -1211,16 +1239,17 @@ struct X2Train {
     if ((size_t)Tp > L.Tp_max || (size_t)Z * N * K > (size_t)(1024 + 64) * 256 * 128) return -1;
     (void)X;                                           // X's operand form: left by the forward pass of this step
     int r;
+    hipStream_t sw = st_w ? st_w : st;
     if (d3dp_tn_applies(N, K)) {                        // both operands in their row forms [Tp][2 .]: nothing was transposed
       if (!dy_ready) return -1;
-      r = d3dp_launch_linear_f16x2_tn(ws + L.op_a, ws + L.x_cols + xoff(l), uns() + sdy, uns() + sx, ws + L.part, N, K, Tp, Z, st);
+      r = d3dp_launch_linear_f16x2_tn(ws + L.op_a, ws + L.x_cols + xoff(l), uns() + sdy, uns() + sx, ws + L.part, N, K, Tp, Z, sw);
     } else {
-      if (!dy_ready) cols(dY, T, N, Tp, ws + L.op_at, sdy);   // dY^T: [N][2 Tp]
+      if (!dy_ready) return -1;                         // (the transposed form: left by prep_dy)
       r = d3dp_launch_linear_f16x2_dyn(ws + L.op_at, ws + L.x_cols + xoff(l), nullptr, uns() + sdy, uns() + sx, ws + L.part, N, K,
-                                       Tp, Z, st);
+                                       Tp, Z, sw);
     }
     if (r) return r;
-    d3dp_launch_sum_partials(ws + L.part, dW, (size_t)N * K, Z, st);
+    d3dp_launch_sum_partials(ws + L.part, dW, (size_t)N * K, Z, sw);
     return 0;
   }
 };
@@ -1255,13 +1284,14 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     LAUNCH_TRY(x2.prepare_weights(c));
   }
   auto lin = [&](int l, const float* A, const float* W, const float* bias, float* out, int M, int N, int K, bool a_amax_ready = false,
-                 unsigned* out_amax = nullptr) {
-    return use_x2 ? x2.forward(l, A, W, bias, out, M, N, K, a_amax_ready, out_amax) : lin32(A, W, bias, out, M, N, K, st);
+                 unsigned* out_amax = nullptr, int amax_pos = 0, bool a_prepared = false) {
+    return use_x2 ? x2.forward(l, A, W, bias, out, M, N, K, a_amax_ready, out_amax, amax_pos, a_prepared)
+                  : lin32(A, W, bias, out, M, N, K, st);
   };
   // attention on split-fp16 operands (train_attn.hip): needs the split Linears' device-side scales, head dim 64, <= 256 frames
   const bool attn_x2 = use_x2 && c->train_attn_x2 > 0 && C / g.heads == 64 && F <= 256;
   const bool attn_x2_s = attn_x2 && c->train_attn_x2 > 1;      // the spatial axis too
-  LAUNCH_TRY(d3dp_launch_time_mlp(t, c->freq, c->t1w, c->t1b, c->t3w, c->t3b, ws + L.temb, B, C, st));
+  LAUNCH_TRY(d3dp_train_time_mlp(t, c->freq, c->t1w, c->t1b, c->t3w, c->t3b, ws + L.dtemb, ws + L.temb, B, C, st));   // (dtemb: free until the backward pass; needs B x 2 C)
   float* slab0 = ws + L.saved0;
   LAUNCH_TRY(d3dp_launch_embed_ln(0, x2d, x3d, ws + L.temb, c->ew, c->eb, c->spos, c->ste[0].n1w, c->ste[0].n1b,
                                   g.eps_block, slab0 + L.o_xin, xn, 0, B, 1, F, J, C, st));
@@ -1293,9 +1323,18 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     LAUNCH_TRY(lin(4 * blk + 1, S + L.o_att, (const float*)w.proj_w, w.proj_b, y, T, C, C, att_ready));
     LAUNCH_TRY(d3dp_train_add_mask_ln(S + L.o_xin, y, mask_ptr(masks, g, B, blk, 0), kind, F, J, w.n2w, w.n2b, g.eps_block,
                                       S + L.o_xmid, xn, slot(4 * blk + 2), T, C, st));
-    LAUNCH_TRY(lin(4 * blk + 2, xn, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, true));
-    LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, slot(4 * blk + 3), st));
-    LAUNCH_TRY(lin(4 * blk + 3, hid, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd, true));
+    if (use_x2 && x2.gelu_operand_applies(C, Hd)) {
+      // the fc2 operand = split(GELU(fc1 output)) in one pass, its scale from the largest positive fc1 output (the fc1
+      // epilogue leaves it): no fp32 hidden tensor, no separate operand pass
+      LAUNCH_TRY(lin(4 * blk + 2, xn, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, true,
+                     x2.amax() + X2Train::kPmaxSlot0 + blk, 1));
+      LAUNCH_TRY(x2.gelu_operand(4 * blk + 3, S + L.o_hpre, blk, T, C, Hd));
+      LAUNCH_TRY(lin(4 * blk + 3, nullptr, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd, true, nullptr, 0, true));
+    } else {
+      LAUNCH_TRY(lin(4 * blk + 2, xn, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, true));
+      LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, slot(4 * blk + 3), st));
+      LAUNCH_TRY(lin(4 * blk + 3, hid, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd, true));
+    }
     // the block's end in one pass: residual add, the shared norm (+ Temporal_pos_embed after the first spatial block,
     // mixste.py:250) -> the next block's input, that block's norm1 -> its qkv operand (after the last block: the head's
     // LayerNorm -> z)
@@ -1353,6 +1392,20 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     LAUNCH_TRY(x2.begin(false));
     x2.batched = 8 * g.depth <= D3DP_WPREP_MAX;          // (the forward pass of this step left the weight operands in place)
   }
+  // second stream for the weight-gradient products (see d3dp_ctx::aux)
+  const bool overlap = use_x2 && c->train_overlap;
+  if (overlap && !c->aux) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  }
+  bool forked = false;                                   // a weight-gradient product may still be running on c->aux
+  auto join = [&]() -> int {                             // the caller's stream waits for it (before op_a / the partial tiles are reused)
+    if (!forked) return 0;
+    forked = false;
+    if (hipEventRecord(c->ev_join, c->aux) != hipSuccess || hipStreamWaitEvent(st, c->ev_join, 0) != hipSuccess) return -3;
+    return 0;
+  };
   const bool attn_x2 = use_x2 && c->train_attn_x2 > 0 && C / g.heads == 64 && F <= 256;   // (as the forward pass of this step)
   const bool attn_x2_s = attn_x2 && c->train_attn_x2 > 1;
   Reducer red{ws + L.red, L.red_floats, 0, st};
@@ -1383,8 +1436,14 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
       float* bp = red.take((size_t)X2Train::kBiasRows * N);
       int brows = 0;
       if (!bp) return -1;
+      if ((r = join())) return r;                        // the previous weight-gradient product is done with op_a and the partial tiles
       if ((r = x2.prep_dy(dY, sdy, bp, &brows, T, N, K))) return r;
       red.add(bp, dbias, N, brows, N);
+      if (overlap) {
+        if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->aux, c->ev_fork, 0) != hipSuccess) return -3;
+        x2.st_w = c->aux;
+        forked = true;
+      }
       return x2.wgrad(l, dY, sdy, X, dW, T, N, K);
     }
     float* bp = red.take((size_t)D3DP_DYPREP_ROWS * N);
@@ -1507,6 +1566,7 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     }
   }
 #undef D3DP_FRESH
+  LAUNCH_TRY(join());                                    // every weight gradient is on the caller's stream's timeline again
   // ---- embedding, position and time embeddings (dB = d of the embedded tokens) ------------------------------------
   {
     float* ep = red.take((size_t)D3DP_EMBED_BWD_ROWS * 5 * C);

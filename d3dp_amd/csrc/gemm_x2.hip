@@ -1422,13 +1422,14 @@ __global__ __launch_bounds__(768) void gemm_f16x2_skew_kernel(const f16* __restr
 //     the fp32-MFMA path this replaces).
 // Structure: the lock-step kernel above without the lagged MFMAs and with the plain fp32 epilogue (8 + 4 waves, 256 x 128 x 32
 // tiles, 3-stage LDS-DMA ring, one barrier per k-step).
-//   * amax_out (optional; Z = 1 launches): the output's absmax, one atomicMax per workgroup -- the operand scale of whatever
-//     split-fp16 kernel consumes the output next (the training attention kernels: q / k / v and dO), without an absmax pass.
+//   * amax_out (optional; Z = 1 launches): the output's absmax (amax_pos: its largest positive value), one atomicMax per
+//     workgroup -- the operand scale of whatever split-fp16 kernel consumes the output next (the training attention kernels:
+//     q / k / v and dO; the fc2 operand GELU(fc1 output): gelu_rowprep_kernel), without an absmax pass.
 __global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restrict__ A2, const f16* __restrict__ W2,
                                                              const float* __restrict__ bias, const float* __restrict__ dynA,
                                                              const float* __restrict__ dynW, float* __restrict__ out, int M,
                                                              int N, int Kfull, int NKz, int tiles_n, int tiles_per_z,
-                                                             int total_items, unsigned* __restrict__ amax_out) {
+                                                             int total_items, unsigned* __restrict__ amax_out, int amax_pos) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int G = gridDim.x;
   const int L = xcd_remap(blockIdx.x, G);
@@ -1540,7 +1541,9 @@ __global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restri
             const f32x4 v = {fmaf(acc[mi][0][r], unscale, bz.x), fmaf(acc[mi][1][r], unscale, bz.y),
                              fmaf(acc[mi][2][r], unscale, bz.z), fmaf(acc[mi][3][r], unscale, bz.w)};
             *reinterpret_cast<f32x4*>(o + (size_t)m * N) = v;
-            am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            // (amax_pos: the largest POSITIVE value instead of the largest magnitude -- what bounds GELU of this output)
+            am = amax_pos ? fmaxf(am, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])))
+                          : fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
           }
         }
     }
@@ -1917,6 +1920,57 @@ __global__ __launch_bounds__(256) void rowprep_kernel(const float* __restrict__ 
   }
 }
 
+// The fc2 operand of the training step straight from the fc1 output:  drow [Rpad][2 C] (h2i, rows R .. Rpad - 1 zero) =
+// split(GELU(src)) -- without the fp32 hidden tensor in between (round 4: gelu_fwd wrote it, the operand pass read it again).
+// The operand scale needs max |GELU(x)| BEFORE the first element is written; it follows from the largest positive x alone,
+// which the fc1 Linear's epilogue leaves in `pmax` (gemm_f16x2_dyn_kernel, amax_pos): GELU is increasing on x > -0.75 and
+// |GELU(x)| <= 0.17 for x < 0, so max |GELU| = max(GELU(pmax), at most 0.17) -- exact whenever GELU(pmax) >= 0.17, and the
+// same power of two otherwise unless every activation is tiny.  Writes amax_out[0] (the bits of that bound) and unscale[0].
+__global__ __launch_bounds__(256) void gelu_rowprep_kernel(const float* __restrict__ s, f16* __restrict__ drow, int R, int Rpad,
+                                                           int C, const unsigned* __restrict__ pmax, unsigned* __restrict__ amax_out,
+                                                           float* __restrict__ unscale) {
+  const float pm = __uint_as_float(pmax[0]);
+  const float bound = fmaxf(gelu_erf_rational(pm), 0.17004f);
+  const float sc = dyn_scale(__float_as_uint(bound));
+  if (blockIdx.x == 0 && threadIdx.x == 0) { unscale[0] = 1.0f / sc; amax_out[0] = __float_as_uint(bound); }
+  const int G8 = C / 8;
+  const size_t n = (size_t)Rpad * G8, stride = (size_t)gridDim.x * 256;
+  for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 2 * stride) {
+    float4 a[2], b[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t i = i0 + u * stride;
+      const size_t r = i / G8;
+      const int c = (int)(i - r * G8) * 8;
+      a[u] = make_float4(0.f, 0.f, 0.f, 0.f); b[u] = a[u];
+      if (i < n && r < (size_t)R) {
+        a[u] = *reinterpret_cast<const float4*>(s + r * C + c);
+        b[u] = *reinterpret_cast<const float4*>(s + r * C + c + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t i = i0 + u * stride;
+      if (i < n) {
+        const size_t r = i / G8;
+        const int c = (int)(i - r * G8) * 8;
+        const float v[8] = {a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y, b[u].z, b[u].w};
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float g = r < (size_t)R ? gelu_erf_rational(v[e]) : 0.f;
+          f16 h, l;
+          split2h_scaled(g * sc, h, l);
+          hi[e] = h; lo[e] = l;
+        }
+        f16* row = drow + r * 2 * (size_t)C + h2i_col(c);
+        *reinterpret_cast<f16x8*>(row) = hi;
+        *reinterpret_cast<f16x8*>(row + kH2iLo) = lo;
+      }
+    }
+  }
+}
+
 // ---- the training step's weight operands, all Linears of the model in three launches ------------------------------------
 // (per-weight launches of absmax / split2h_dyn / split2h_t_dyn: 192 launches of 5 - 6 us for 100 MB of weights per step)
 // blockIdx.y = the weight; a workgroup row strides over that weight only.
@@ -1994,7 +2048,7 @@ __global__ void sum_partials_kernel(const float* __restrict__ part, float* __res
 // (amax: optional absmax slot of these rows, as gemm_f16x2_dyn_kernel's)
 __global__ __launch_bounds__(256) void sum_partials_bias_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                                 float* __restrict__ out, size_t n, int N, int Z,
-                                                                unsigned* __restrict__ amax) {
+                                                                unsigned* __restrict__ amax, int amax_pos) {
   __shared__ float pm[4];
   float m = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -2002,7 +2056,7 @@ __global__ __launch_bounds__(256) void sum_partials_bias_kernel(const float* __r
     for (int z = 1; z < Z; ++z) a += part[(size_t)z * n + i];
     a = bias ? a + bias[i % N] : a;
     out[i] = a;
-    m = fmaxf(m, fabsf(a));
+    m = fmaxf(m, amax_pos ? a : fabsf(a));
   }
   if (amax) {
     m = wave_max(m);
@@ -2273,7 +2327,7 @@ void d3dp_launch_fold_ln(const float* W, const float* gamma, const float* beta, 
 // ---- training-step launchers (gemm_f16x2_dyn_kernel and its operand kernels) ---------------------------------------
 // out_z[M, N] = A2 (chunk z) . W2 (chunk z)^T x dynA x dynW (+ bias): Kfull = Z NKz 32 columns per operand row
 int d3dp_launch_linear_f16x2_dyn(const void* A2, const void* W2, const float* bias, const float* dynA, const float* dynW,
-                                 float* out, int M, int N, int Kfull, int Z, hipStream_t st, unsigned* amax_out) {
+                                 float* out, int M, int N, int Kfull, int Z, hipStream_t st, unsigned* amax_out, int amax_pos) {
   if (M <= 0 || N % 4 != 0 || Z < 1 || Kfull % (XBK * Z) != 0 || (amax_out && Z != 1)) return -1;
   const int NKz = Kfull / XBK / Z;
   const int tm = (M + XBM - 1) / XBM, tn = (N + XBN - 1) / XBN;
@@ -2284,7 +2338,7 @@ int d3dp_launch_linear_f16x2_dyn(const void* A2, const void* W2, const float* bi
   if (cus < 0) return -3;
   const int items = tm * tn * Z, grid = items < cus ? items : cus;
   hipLaunchKernelGGL(gemm_f16x2_dyn_kernel, dim3(grid), dim3((XNCW + 4) * 64), XNSTAGE * XSTAGE + 64, st, (const f16*)A2,
-                     (const f16*)W2, bias, dynA, dynW, out, M, N, Kfull, NKz, tn, tm * tn, items, amax_out);
+                     (const f16*)W2, bias, dynA, dynW, out, M, N, Kfull, NKz, tn, tm * tn, items, amax_out, amax_pos);
   return 0;
 }
 
@@ -2326,6 +2380,15 @@ int d3dp_launch_rowprep(const float* src, void* drow, float* colpart, int* rows,
   return 0;
 }
 
+int d3dp_launch_gelu_rowprep(const float* src, void* drow, int R, int Rpad, int C, const unsigned* pmax, unsigned* amax_out,
+                             float* unscale, hipStream_t st) {
+  if (C % 32 != 0 || Rpad < R) return -1;
+  const size_t n = (size_t)Rpad * (C / 8);
+  const unsigned blocks = (unsigned)((n + 511) / 512 < 2048 ? (n + 511) / 512 : 2048);
+  hipLaunchKernelGGL(gelu_rowprep_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, src, (f16*)drow, R, Rpad, C, pmax, amax_out, unscale);
+  return 0;
+}
+
 // out_z[N, K] = sum over the token rows of chunk z of A2[t][n] W2[t][k], x dynA x dynW: Tp = Z NKz 32 rows per operand (rows
 // beyond the real ones zero), N % 256 == 0, K % 128 == 0 (d3dp_tn_applies)
 bool d3dp_tn_applies(int N, int K) { return N % XBM == 0 && K % XBN == 0; }
@@ -2356,10 +2419,10 @@ int d3dp_launch_wprep(const D3dpWPrepTable& tb, void* rows_base, void* cols_base
 }
 
 void d3dp_launch_sum_partials_bias(const float* part, const float* bias, float* out, size_t n, int N, int Z, hipStream_t st,
-                                   unsigned* amax) {
+                                   unsigned* amax, int amax_pos) {
   const unsigned cap = amax ? 256 : 2048;              // (with an absmax: one atomic per workgroup)
   const unsigned blocks = (unsigned)((n + 255) / 256 < cap ? (n + 255) / 256 : cap);
-  hipLaunchKernelGGL(sum_partials_bias_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, part, bias, out, n, N, Z, amax);
+  hipLaunchKernelGGL(sum_partials_bias_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, part, bias, out, n, N, Z, amax, amax_pos);
 }
 void d3dp_launch_sum_partials(const float* part, float* out, size_t n, int Z, hipStream_t st) {
   const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);

@@ -80,7 +80,12 @@ void d3dp_launch_split2(const float* src, void* dst, size_t n, float scale, hipS
 // (bias may be null).  Kfull % (32 Z) == 0, N % 4 == 0.
 // amax_out (optional, Z == 1): absmax slot of the output (bit pattern of a non-negative float, pre-zeroed; one atomicMax per workgroup)
 int d3dp_launch_linear_f16x2_dyn(const void* A2, const void* W2, const float* bias, const float* dynA, const float* dynW,
-                                 float* out, int M, int N, int Kfull, int Z, hipStream_t st, unsigned* amax_out = nullptr);
+                                 float* out, int M, int N, int Kfull, int Z, hipStream_t st, unsigned* amax_out = nullptr,
+                                 int amax_pos = 0);   // (amax_pos: the largest POSITIVE output value instead of the largest magnitude)
+// drow [Rpad][2 C] = split(GELU(src [R][C])) (rows R .. Rpad - 1 zero) at the scale max(GELU(pmax), 0.17) asks for (pmax: the
+// largest positive value of src, left by the Linear that produced it); writes that bound to amax_out[0] and 1 / scale to unscale[0]
+int d3dp_launch_gelu_rowprep(const float* src, void* drow, int R, int Rpad, int C, const unsigned* pmax, unsigned* amax_out,
+                             float* unscale, hipStream_t st);
 // src [R][C] fp32 -> h2i [R][2 Cpad] (zero columns behind C) at the power of two the tensor's absmax (amax[0], bits of a
 // float >= 0, d3dp_launch_absmax) asks for; unscale[0] = 1 / that scale
 void d3dp_launch_split2_dyn(const float* src, void* dst, int R, int C, int Cpad, const unsigned* amax, float* unscale,
@@ -112,7 +117,7 @@ struct D3dpWPrepTable { D3dpWPrepItem it[D3DP_WPREP_MAX]; int n; };
 int d3dp_launch_wprep(const D3dpWPrepTable& tb, void* rows_base, void* cols_base, unsigned* amax, float* unscale, hipStream_t st);
 void d3dp_launch_sum_partials(const float* part, float* out, size_t n, int Z, hipStream_t st);
 void d3dp_launch_sum_partials_bias(const float* part, const float* bias, float* out, size_t n, int N, int Z, hipStream_t st,
-                                   unsigned* amax = nullptr);
+                                   unsigned* amax = nullptr, int amax_pos = 0);
 void d3dp_launch_absmax(const float* src, size_t n, unsigned* out, hipStream_t st);
 // flag[0] |= 1 if any of x[0..n) is inf / nan
 void d3dp_launch_nonfinite_flag(const float* x, size_t n, unsigned* flag, hipStream_t st);
@@ -241,6 +246,9 @@ int d3dp_train_embed_bwd(const float* dx, const float* x2d, const float* x3d, fl
 int d3dp_train_head_linear(const float* z, const float* w, const float* b, float* out, int T, int C, hipStream_t st);
 int d3dp_train_head_bwd(const float* g, const float* z, const float* w, float* dz, float* part, int* rows, int T, int C,
                         hipStream_t st);
+// the time-embedding MLP of the training step (one wave per output unit, two launches); hidden: scratch of B x 2 C floats
+int d3dp_train_time_mlp(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2, const float* b2,
+                        float* hidden, float* temb, int B, int C, hipStream_t st);
 int d3dp_train_time_mlp_bwd(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2,
                             const float* dtemb, float* dw1, float* db1, float* dw2, float* db2, int B, int C,
                             hipStream_t st);

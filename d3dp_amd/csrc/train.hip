@@ -696,6 +696,42 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   if (c == 0) { row[3 * C] = sb[0]; row[3 * C + 1] = sb[1]; row[3 * C + 2] = sb[2]; }
 }
 
+// ---- time MLP forward for the training step: one WAVE per output unit, coalesced weight rows ----------------------------
+// (mixste.py:127-139, 179-184.  The inference kernel -- one workgroup per batch element, one serial dot product per thread with
+//  strided weight reads -- is invisible beside a 6-second sampler call but was 175 us = 0.8 % of the configs[4] step.)
+// layer 1: h[b][o] = GELU(sum_k e_b[k] w1[o][k] + b1[o]),  e_b = [sin(t_b freq) | cos(t_b freq)],  o < 2 C
+__global__ __launch_bounds__(256) void time_mlp1_kernel(const int64_t* __restrict__ t, const float* __restrict__ freq,
+                                                        const float* __restrict__ w1, const float* __restrict__ b1,
+                                                        float* __restrict__ h, int B, int C) {
+  const int lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= B * 2 * C) return;
+  const int b = unit / (2 * C), o = unit - b * 2 * C, half = C / 2;
+  const float tv = (float)t[b];
+  const float* wr = w1 + (size_t)o * C;
+  float a = 0.f;
+  for (int k = lane; k < C; k += 64) {
+    const float e = k < half ? sinf(tv * freq[k]) : cosf(tv * freq[k - half]);
+    a = fmaf(e, wr[k], a);
+  }
+  a = wave_sum(a);
+  if (lane == 0) h[unit] = gelu_erf(a + b1[o]);
+}
+// layer 2: temb[b][o] = sum_k h[b][k] w2[o][k] + b2[o],  o < C
+__global__ __launch_bounds__(256) void time_mlp2_kernel(const float* __restrict__ h, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, float* __restrict__ temb, int B, int C) {
+  const int lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= B * C) return;
+  const int b = unit / C, o = unit - b * C;
+  const float* wr = w2 + (size_t)o * 2 * C;
+  const float* hb = h + (size_t)b * 2 * C;
+  float a = 0.f;
+  for (int k = lane; k < 2 * C; k += 64) a = fmaf(hb[k], wr[k], a);
+  a = wave_sum(a);
+  if (lane == 0) temb[unit] = a + b2[o];
+}
+
 // ---- time MLP backward: one WAVE per hidden unit k of the 2C ---------------------------------------------------------
 // (mixste.py:127-139: sinusoid -> Linear(C, 2C) -> GELU -> Linear(2C, C)).  The wave keeps row k of w1 and column k of w2
 // in registers, walks the batch in order (deterministic sums, no atomics) and owns row k of dw1, column k of dw2 and
@@ -1160,6 +1196,14 @@ int d3dp_train_head_bwd(const float* g, const float* z, const float* w, float* d
   if (!rows) return -1;
   *rows = T < 512 ? T : 512;
   hipLaunchKernelGGL(head_bwd_kernel, dim3((C + 255) / 256, *rows), dim3(256), 0, st, g, z, w, dz, part, T, C);
+  return 0;
+}
+// hidden: scratch of B x 2 C floats
+int d3dp_train_time_mlp(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2, const float* b2,
+                        float* hidden, float* temb, int B, int C, hipStream_t st) {
+  if (B < 1 || C % 2 != 0) return -1;
+  hipLaunchKernelGGL(time_mlp1_kernel, dim3((B * 2 * C + 3) / 4), dim3(256), 0, st, t, freq, w1, b1, hidden, B, C);
+  hipLaunchKernelGGL(time_mlp2_kernel, dim3((B * C + 3) / 4), dim3(256), 0, st, hidden, w2, b2, temb, B, C);
   return 0;
 }
 int d3dp_train_time_mlp_bwd(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2,
