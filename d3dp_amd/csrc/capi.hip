@@ -1160,8 +1160,12 @@ struct X2Train {
   // (out_amax: optional slot for the OUTPUT's absmax, left by the product's epilogue)
   // (a_prepared: the activation operand of Linear l -- planes at x_cols + xoff(l), zero rows behind T, unscale slot 2 l -- was
   //  written by its producer: gelu_operand below)
+  // (ln_w / ln_b / ln_eps: A is the INPUT of the LayerNorm whose output is this Linear's operand, slot 2 l holds that output's
+  //  absmax: the operand pass normalises on the fly, d3dp_launch_rowprep_ln -- TN shapes with K <= 512 only, see ln_operand_applies)
+  bool ln_operand_applies(int N, int K) const { return d3dp_tn_applies(N, K) && K <= 512; }
   int forward(int l, const float* A, const float* W, const float* bias, float* out, int T, int N, int K, bool a_amax_ready = false,
-              unsigned* out_amax = nullptr, int amax_pos = 0, bool a_prepared = false) {
+              unsigned* out_amax = nullptr, int amax_pos = 0, bool a_prepared = false, const float* ln_w = nullptr,
+              const float* ln_b = nullptr, float ln_eps = 0.f) {
     const int sa = 2 * l, sw = 2 * l + 1;
     if (l < 0 || sw >= kBwdSlot0) return -1;
     if (!a_amax_ready && !a_prepared) d3dp_launch_absmax(A, (size_t)T * K, amax() + sa, st);
@@ -1175,7 +1179,11 @@ struct X2Train {
       wgrad_split(T, N, K, Z, Tp);
       if ((size_t)Tp > L.Tp_max) return -1;
       int r;
-      if (d3dp_tn_applies(N, K)) {
+      if (ln_w) {
+        if (!ln_operand_applies(N, K) || !a_amax_ready) return -1;
+        a2 = ws + L.x_cols + xoff(l);
+        r = d3dp_launch_rowprep_ln(A, ln_w, ln_b, ln_eps, ws + L.x_cols + xoff(l), T, Tp, K, amax() + sa, uns() + sa, st);
+      } else if (d3dp_tn_applies(N, K)) {
         a2 = ws + L.x_cols + xoff(l);
         r = d3dp_launch_rowprep(A, ws + L.x_cols + xoff(l), nullptr, nullptr, T, Tp, K, amax() + sa, uns() + sa, st);
       } else r = d3dp_launch_dyprep(A, ws + L.op_a, ws + L.x_cols + xoff(l), nullptr, T, K, Tp, amax() + sa, uns() + sa, st);
@@ -1221,13 +1229,17 @@ struct X2Train {
   // then tells dgrad / wgrad not to build them again.
   bool dy_ready = false;
   static constexpr int kBiasRows = D3DP_DYPREP_ROWS > D3DP_ROWPREP_ROWS ? D3DP_DYPREP_ROWS : D3DP_ROWPREP_ROWS;   // capacity of bias_part
-  int prep_dy(const float* dY, int sdy, float* bias_part, int* bias_rows, int T, int N, int K) {
+  // (mask: the DropPath scales still to be applied to dY's rows -- TN shapes only, see mask_in_prep_applies)
+  bool mask_in_prep_applies(int N, int K) const { return d3dp_tn_applies(N, K); }
+  int prep_dy(const float* dY, int sdy, float* bias_part, int* bias_rows, int T, int N, int K, const float* mask = nullptr,
+              int axis = 0, int F = 1, int J = 1) {
     int Z, Tp;
     wgrad_split(T, N, K, Z, Tp);
     if ((size_t)Tp > L.Tp_max) return -1;
     dy_ready = true;
     if (d3dp_tn_applies(N, K))       // the row form alone (zero rows behind T): dgrad's operand AND the TN wgrad's
-      return d3dp_launch_rowprep(dY, ws + L.op_a, bias_part, bias_rows, T, Tp, N, amax() + sdy, uns() + sdy, st);
+      return d3dp_launch_rowprep(dY, ws + L.op_a, bias_part, bias_rows, T, Tp, N, amax() + sdy, uns() + sdy, st, mask, axis, F, J);
+    if (mask) return -1;
     *bias_rows = D3DP_DYPREP_ROWS;
     return d3dp_launch_dyprep(dY, ws + L.op_a, ws + L.op_at, bias_part, T, N, Tp, amax() + sdy, uns() + sdy, st);
   }
@@ -1284,10 +1296,13 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     LAUNCH_TRY(x2.prepare_weights(c));
   }
   auto lin = [&](int l, const float* A, const float* W, const float* bias, float* out, int M, int N, int K, bool a_amax_ready = false,
-                 unsigned* out_amax = nullptr, int amax_pos = 0, bool a_prepared = false) {
-    return use_x2 ? x2.forward(l, A, W, bias, out, M, N, K, a_amax_ready, out_amax, amax_pos, a_prepared)
+                 unsigned* out_amax = nullptr, int amax_pos = 0, bool a_prepared = false, const float* ln_w = nullptr,
+                 const float* ln_b = nullptr, float ln_eps = 0.f) {
+    return use_x2 ? x2.forward(l, A, W, bias, out, M, N, K, a_amax_ready, out_amax, amax_pos, a_prepared, ln_w, ln_b, ln_eps)
                   : lin32(A, W, bias, out, M, N, K, st);
   };
+  // the qkv / fc1 operands straight from the INPUT of the LayerNorm in front of them (no fp32 normalised activation is written)
+  const bool ln_fused = use_x2 && x2.ln_operand_applies(3 * C, C) && x2.ln_operand_applies(Hd, C);
   // attention on split-fp16 operands (train_attn.hip): needs the split Linears' device-side scales, head dim 64, <= 256 frames
   const bool attn_x2 = use_x2 && c->train_attn_x2 > 0 && C / g.heads == 64 && F <= 256;
   const bool attn_x2_s = attn_x2 && c->train_attn_x2 > 1;      // the spatial axis too
@@ -1306,7 +1321,9 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     float* S = ws + L.saved0 + (size_t)blk * L.saved_stride;
     const bool ax2 = kind == 1 ? attn_x2 : attn_x2_s;
     unsigned* qkv_amax = ax2 ? x2.amax() + X2Train::kQkvSlot0 + blk : nullptr;
-    LAUNCH_TRY(lin(4 * blk, xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C, true, qkv_amax));
+    if (ln_fused) LAUNCH_TRY(lin(4 * blk, S + L.o_xin, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C, true, qkv_amax, 0, false,
+                                 w.n1w, w.n1b, g.eps_block));
+    else LAUNCH_TRY(lin(4 * blk, xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C, true, qkv_amax));
     bool att_ready = true;
     if (kind == 0 && ax2)
       LAUNCH_TRY(d3dp_train_attn_x2_fwd(S + L.o_qkv, S + L.o_att, ws + L.stats_x2 + (size_t)blk * L.stats_x2_stride, B * F,
@@ -1322,16 +1339,19 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     } else LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st, slot(4 * blk + 1)));
     LAUNCH_TRY(lin(4 * blk + 1, S + L.o_att, (const float*)w.proj_w, w.proj_b, y, T, C, C, att_ready));
     LAUNCH_TRY(d3dp_train_add_mask_ln(S + L.o_xin, y, mask_ptr(masks, g, B, blk, 0), kind, F, J, w.n2w, w.n2b, g.eps_block,
-                                      S + L.o_xmid, xn, slot(4 * blk + 2), T, C, st));
+                                      S + L.o_xmid, ln_fused ? nullptr : xn, slot(4 * blk + 2), T, C, st));
+    const float* fc1_in = ln_fused ? S + L.o_xmid : xn;
+    const float *f1w = ln_fused ? w.n2w : nullptr, *f1b = ln_fused ? w.n2b : nullptr;
     if (use_x2 && x2.gelu_operand_applies(C, Hd)) {
       // the fc2 operand = split(GELU(fc1 output)) in one pass, its scale from the largest positive fc1 output (the fc1
       // epilogue leaves it): no fp32 hidden tensor, no separate operand pass
-      LAUNCH_TRY(lin(4 * blk + 2, xn, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, true,
-                     x2.amax() + X2Train::kPmaxSlot0 + blk, 1));
+      LAUNCH_TRY(lin(4 * blk + 2, fc1_in, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, true,
+                     x2.amax() + X2Train::kPmaxSlot0 + blk, 1, false, f1w, f1b, g.eps_block));
       LAUNCH_TRY(x2.gelu_operand(4 * blk + 3, S + L.o_hpre, blk, T, C, Hd));
       LAUNCH_TRY(lin(4 * blk + 3, nullptr, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd, true, nullptr, 0, true));
     } else {
-      LAUNCH_TRY(lin(4 * blk + 2, xn, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, true));
+      LAUNCH_TRY(lin(4 * blk + 2, fc1_in, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, true, nullptr, 0, false, f1w, f1b,
+                     g.eps_block));
       LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, slot(4 * blk + 3), st));
       LAUNCH_TRY(lin(4 * blk + 3, hid, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd, true));
     }
@@ -1344,8 +1364,8 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     if (!last) { const BlockDev& wn = kind ? c->ste[d + 1] : c->tte[d]; nw = wn.n1w; nb = wn.n1b; }
     LAUNCH_TRY(d3dp_train_add_mask_ln2(S + L.o_xmid, y, mask_ptr(masks, g, B, blk, 1), kind, F, J, kind ? c->tnw : c->snw,
                                        kind ? c->tnb : c->snb, g.eps_block, (kind == 0 && d == 0) ? c->tpos : nullptr, nw, nb,
-                                       last ? g.eps_head : g.eps_block, S + L.o_xout, x_next, last ? ws + L.z : xn,
-                                       last ? nullptr : slot(4 * (blk + 1)), T, C, st));
+                                       last ? g.eps_head : g.eps_block, S + L.o_xout, x_next,
+                                       last ? ws + L.z : (ln_fused ? nullptr : xn), last ? nullptr : slot(4 * (blk + 1)), T, C, st));
   }
   LAUNCH_TRY(d3dp_train_head_linear(ws + L.z, c->hw, c->hb, out, T, C, st));
   HIP_TRY(hipGetLastError());
@@ -1428,7 +1448,9 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
   // wgrad: dW[N, K] = dY[T, N]^T X[T, K]  (fp32 path: both operands transposed to [*, Tpad], zero padded)
   // (dbias: the Linear's bias gradient = column sums of dY, left as partial rows and summed at the end)
   // (pre_slot >= 0: the kernel that produced dY left its absmax there)
-  auto wgrad = [&](int l, const float* dY, int N, const float* X, int K, float* dW, float* dbias, int pre_slot = -1) -> int {
+  // (mk / mk_axis: DropPath scales the operand pass still has to apply to dY's rows -- then dY is the UNSCALED gradient)
+  auto wgrad = [&](int l, const float* dY, int N, const float* X, int K, float* dW, float* dbias, int pre_slot = -1,
+                   const float* mk = nullptr, int mk_axis = 0) -> int {
     int r;
     if (use_x2) {
       sdy = pre_slot >= 0 ? pre_slot : x2.slot_for(dY, (size_t)T * N);
@@ -1437,7 +1459,7 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
       int brows = 0;
       if (!bp) return -1;
       if ((r = join())) return r;                        // the previous weight-gradient product is done with op_a and the partial tiles
-      if ((r = x2.prep_dy(dY, sdy, bp, &brows, T, N, K))) return r;
+      if ((r = x2.prep_dy(dY, sdy, bp, &brows, T, N, K, mk, mk_axis, F, J))) return r;
       red.add(bp, dbias, N, brows, N);
       if (overlap) {
         if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->aux, c->ev_fork, 0) != hipSuccess) return -3;
@@ -1448,7 +1470,7 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     }
     float* bp = red.take((size_t)D3DP_DYPREP_ROWS * N);
     int rows = 0;
-    if (!bp) return -1;
+    if (!bp || mk) return -1;
     if ((r = d3dp_train_colsum(dY, bp, &rows, D3DP_DYPREP_ROWS, T, N, st))) return r;
     red.add(bp, dbias, N, rows, N);
     if ((r = d3dp_train_transpose_pad(dY, At, T, N, Tp, st))) return r;
@@ -1485,16 +1507,20 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
   }
   // dB = d x_out of the last block; its DropPath-scaled form (the fc2 dY) in dC with its absmax in slot ps
   const float* dy = nullptr;                             // the dY of the branch about to be differentiated
+  const float* dy_mask = nullptr;                        // ... and the DropPath scales its operand pass still has to apply
   int ps_next = -1;
+  // (the DropPath-scaled gradient is not stored where the operand pass can apply the scales itself: only its absmax is)
+  const bool mip2 = use_x2 && x2.mask_in_prep_applies(C, Hd), mip1 = use_x2 && x2.mask_in_prep_applies(C, C);
   {
     const int lb = nblk - 1, lk = lb & 1;
     const float* S = ws + L.saved0 + (size_t)lb * L.saved_stride;
     const float* mk = mask_ptr(masks, g, B, lb, 1);
     D3DP_FRESH(ps, pa)
     LAUNCH_TRY(d3dp_train_ln_bwd(dC, ws + L.x_final, c->hnw, g.eps_head, nullptr, nullptr, S + L.o_xout, lk ? c->tnw : c->snw,
-                                 g.eps_block, dB, mk, lk, F, J, mk ? dC : nullptr, pa, part_hn,
+                                 g.eps_block, dB, mk, lk, F, J, (mk && !mip2) ? dC : nullptr, pa, part_hn,
                                  (lk ? part_tn : part_sn) + (size_t)(lb >> 1) * lnrows * 2 * C, T, C, st));
-    dy = mk ? dC : dB;
+    dy = (mk && !mip2) ? dC : dB;
+    dy_mask = mip2 ? mk : nullptr;
     ps_next = ps;
   }
   for (int blk = nblk - 1; blk >= 0; --blk) {
@@ -1505,7 +1531,7 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     // here: dB = d x_out(blk), dy = its DropPath-scaled form, absmax in slot ps_next
     // ---- MLP branch ----
     if (!use_x2) LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, nullptr, st));   // (x2: wgrad reads the forward pass' operand)
-    LAUNCH_TRY(wgrad(4 * blk + 3, dy, C, hid, Hd, G(gw.fc2_w), G(gw.fc2_b), ps_next));
+    LAUNCH_TRY(wgrad(4 * blk + 3, dy, C, hid, Hd, G(gw.fc2_w), G(gw.fc2_b), ps_next, dy_mask, kind));
     LAUNCH_TRY(dgrad(4 * blk + 3, dy, C, (const float*)w.fc2_w, Hd, dh));                                               // d hidden
     {
       D3DP_FRESH(ps, pa)
@@ -1521,10 +1547,10 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
       D3DP_FRESH(ps, pa)
       if (!pn) return fail(D3DP_ESTATE, "d3dp_train_backward: partial-sum region too small");
       LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xmid, w.n2w, g.eps_block, dB, nullptr, nullptr, nullptr, 0.f, dA, mk, kind, F, J,
-                                   mk ? dC : nullptr, pa, pn, nullptr, T, C, st));
-      dy = mk ? dC : dA;
+                                   (mk && !mip1) ? dC : nullptr, pa, pn, nullptr, T, C, st));
+      dy = (mk && !mip1) ? dC : dA;
       // ---- attention branch ----
-      LAUNCH_TRY(wgrad(4 * blk + 1, dy, C, S + L.o_att, C, G(gw.proj_w), G(gw.proj_b), ps));
+      LAUNCH_TRY(wgrad(4 * blk + 1, dy, C, S + L.o_att, C, G(gw.proj_w), G(gw.proj_b), ps, mip1 ? mk : nullptr, kind));
     }
     int ps_dqkv = -1;
     if (kind == 1 ? attn_x2 : attn_x2_s) {
@@ -1555,10 +1581,11 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
       float* g_out = pb == 0 ? ws + L.z : nullptr;       // d of Temporal_pos_embed's sum (added behind block 0's shared norm)
       D3DP_FRESH(ps, pa)
       LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xin, w.n1w, g.eps_block, dA, g_out, Sp + L.o_xout, pk ? c->tnw : c->snw, g.eps_block,
-                                   dB, mk, pk, F, J, mk ? dC : nullptr, pa, pn1,
+                                   dB, mk, pk, F, J, (mk && !mip2) ? dC : nullptr, pa, pn1,
                                    (pk ? part_tn : part_sn) + (size_t)(pb >> 1) * lnrows * 2 * C, T, C, st));
       if (g_out) LAUNCH_TRY(d3dp_train_groupsum(g_out, G(grads->temporal_pos), T, C, 1, F, J, 1, st));
-      dy = mk ? dC : dB;
+      dy = (mk && !mip2) ? dC : dB;
+      dy_mask = mip2 ? mk : nullptr;
       ps_next = ps;
     } else {
       LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xin, w.n1w, g.eps_block, dA, nullptr, nullptr, nullptr, 0.f, dB, nullptr, 0, F, J,

@@ -1865,10 +1865,13 @@ __global__ __launch_bounds__(256) void dyprep_kernel(const float* __restrict__ s
 // d3dp_train_reduce_many).  A thread owns 8 consecutive columns (two 16-byte loads, one 16-byte store per plane) of the rows
 // r = 4 blockIdx.x + (tid >> 6), + 4 gridDim.x, ...: reads and writes are contiguous in memory -- unlike the tile transpose of
 // dyprep_kernel, whose 128-byte pieces land 66 KB apart.  C % 512 == 0 or C <= 512 with C % 8 == 0 (P = ceil(C / 512) passes).
+// mask (optional): per-sample DropPath scales -- row r is multiplied by mask[sample(r)] first (sample = r / J on the spatial
+// axis, (r / (F J)) J + r % J on the temporal one): the backward pass then never stores the scaled gradient, only its absmax.
 template <int P>
 __global__ __launch_bounds__(256) void rowprep_kernel(const float* __restrict__ s, f16* __restrict__ drow, float* __restrict__ colpart,
                                                       int R, int Rpad, int C, const unsigned* __restrict__ amax,
-                                                      float* __restrict__ unscale) {
+                                                      float* __restrict__ unscale, const float* __restrict__ mask, int axis, int F,
+                                                      int J) {
   __shared__ float cs[4][P * 512];
   const float sc = dyn_scale(amax[0]);
   if (blockIdx.x == 0 && threadIdx.x == 0) unscale[0] = 1.0f / sc;
@@ -1899,7 +1902,10 @@ __global__ __launch_bounds__(256) void rowprep_kernel(const float* __restrict__ 
       for (int p = 0; p < P; ++p) {
         const int r = r0 + u * rstep, c = p * 512 + l * 8;
         if (r < Rpad && c < C) {
-          const float v[8] = {a[u][p].x, a[u][p].y, a[u][p].z, a[u][p].w, b[u][p].x, b[u][p].y, b[u][p].z, b[u][p].w};
+          float mk = 1.0f;
+          if (mask && r < R) mk = mask[axis == 0 ? r / J : (r / (F * J)) * J + r % J];
+          const float v[8] = {a[u][p].x * mk, a[u][p].y * mk, a[u][p].z * mk, a[u][p].w * mk,
+                              b[u][p].x * mk, b[u][p].y * mk, b[u][p].z * mk, b[u][p].w * mk};
           f16x8 hi, lo;
 #pragma unroll
           for (int e = 0; e < 8; ++e) { acc[p][e] += v[e]; f16 h, lw; split2h_scaled(v[e] * sc, h, lw); hi[e] = h; lo[e] = lw; }
@@ -1917,6 +1923,65 @@ __global__ __launch_bounds__(256) void rowprep_kernel(const float* __restrict__ 
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256)
       colpart[(size_t)blockIdx.x * C + c] = ((cs[0][c] + cs[1][c]) + cs[2][c]) + cs[3][c];
+  }
+}
+
+// The row form of a LayerNorm's OUTPUT from its INPUT: drow [Rpad][2 C] = split(LN(src [R][C]; w, b, eps)) (rows R .. Rpad - 1
+// zero), the scale from `amax` -- which the kernel that produced src left there as the absmax of this very LayerNorm output,
+// computed on the fly and not stored.  The forward pass of the training step then never writes the fp32 normalised activation
+// (its only reader was this operand pass).  One wave per row, a lane owns 8 consecutive columns (C <= 512, C % 8 == 0).
+__global__ __launch_bounds__(256) void rowprep_ln_kernel(const float* __restrict__ s, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float eps, f16* __restrict__ drow, int R,
+                                                         int Rpad, int C, const unsigned* __restrict__ amax,
+                                                         float* __restrict__ unscale) {
+  const float sc = dyn_scale(amax[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) unscale[0] = 1.0f / sc;
+  const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = l * 8;
+  const bool on = c < C;
+  float wl[8], bl[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { wl[e] = on ? w[c + e] : 0.f; bl[e] = on ? b[c + e] : 0.f; }
+  const int rstep = gridDim.x * 4;
+  const float invC = 1.0f / (float)C;
+  for (int r0 = blockIdx.x * 4 + rl; r0 < Rpad; r0 += 2 * rstep) {
+    float4 a[2], bb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = r0 + u * rstep;
+      a[u] = make_float4(0.f, 0.f, 0.f, 0.f); bb[u] = a[u];
+      if (r < R && on) {
+        a[u] = *reinterpret_cast<const float4*>(s + (size_t)r * C + c);
+        bb[u] = *reinterpret_cast<const float4*>(s + (size_t)r * C + c + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = r0 + u * rstep;
+      if (r >= Rpad) continue;                           // (wave-uniform)
+      float v[8] = {a[u].x, a[u].y, a[u].z, a[u].w, bb[u].x, bb[u].y, bb[u].z, bb[u].w};
+      float sm = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sm += v[e];
+      const float mean = wave_sum(sm) * invC;
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = on ? v[e] - mean : 0.f; q = fmaf(d, d, q); }
+      const float rstd = 1.0f / sqrtf(wave_sum(q) * invC + eps);
+      if (on) {
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float y = r < R ? fmaf((v[e] - mean) * rstd, wl[e], bl[e]) : 0.f;
+          f16 h, lw;
+          split2h_scaled(y * sc, h, lw);
+          hi[e] = h; lo[e] = lw;
+        }
+        f16* row = drow + (size_t)r * 2 * C + h2i_col(c);
+        *reinterpret_cast<f16x8*>(row) = hi;
+        *reinterpret_cast<f16x8*>(row + kH2iLo) = lo;
+      }
+    }
   }
 }
 
@@ -2365,8 +2430,17 @@ int d3dp_launch_dyprep(const float* src, void* drow, void* dcol, float* colpart,
 }
 
 // the row form alone (+ column sums): see rowprep_kernel.  *rows = partial rows written to colpart (<= D3DP_ROWPREP_ROWS)
+int d3dp_launch_rowprep_ln(const float* src, const float* w, const float* b, float eps, void* drow, int R, int Rpad, int C,
+                           const unsigned* amax, float* unscale, hipStream_t st) {
+  if (C % 32 != 0 || C > 512 || Rpad < R || !w || !b) return -1;
+  int g = (Rpad + 3) / 4;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(rowprep_ln_kernel, dim3(g), dim3(256), 0, st, src, w, b, eps, (f16*)drow, R, Rpad, C, amax, unscale);
+  return 0;
+}
+
 int d3dp_launch_rowprep(const float* src, void* drow, float* colpart, int* rows, int R, int Rpad, int C, const unsigned* amax,
-                        float* unscale, hipStream_t st) {
+                        float* unscale, hipStream_t st, const float* mask, int axis, int F, int J) {
   if (C % 8 != 0 || Rpad < R || C > 1536 || (C > 512 && C % 512 != 0)) return -1;
   int g = (Rpad + 3) / 4;
   const int cap = colpart ? D3DP_ROWPREP_ROWS : 1024;   // (every workgroup leaves one partial row of column sums)
@@ -2374,9 +2448,10 @@ int d3dp_launch_rowprep(const float* src, void* drow, float* colpart, int* rows,
   if (rows) *rows = g;
   const int P = (C + 511) / 512;
   f16* d = (f16*)drow;
-  if (P == 1) hipLaunchKernelGGL((rowprep_kernel<1>), dim3(g), dim3(256), 0, st, src, d, colpart, R, Rpad, C, amax, unscale);
-  else if (P == 2) hipLaunchKernelGGL((rowprep_kernel<2>), dim3(g), dim3(256), 0, st, src, d, colpart, R, Rpad, C, amax, unscale);
-  else hipLaunchKernelGGL((rowprep_kernel<3>), dim3(g), dim3(256), 0, st, src, d, colpart, R, Rpad, C, amax, unscale);
+  if (mask && (J < 1 || F < 1)) return -1;
+  if (P == 1) hipLaunchKernelGGL((rowprep_kernel<1>), dim3(g), dim3(256), 0, st, src, d, colpart, R, Rpad, C, amax, unscale, mask, axis, F, J);
+  else if (P == 2) hipLaunchKernelGGL((rowprep_kernel<2>), dim3(g), dim3(256), 0, st, src, d, colpart, R, Rpad, C, amax, unscale, mask, axis, F, J);
+  else hipLaunchKernelGGL((rowprep_kernel<3>), dim3(g), dim3(256), 0, st, src, d, colpart, R, Rpad, C, amax, unscale, mask, axis, F, J);
   return 0;
 }
 

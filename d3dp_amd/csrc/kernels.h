@@ -102,8 +102,13 @@ int d3dp_launch_dyprep(const float* src, void* drow, void* dcol, float* colpart,
 // the row form alone as a streaming pass: src [R][C] -> drow [Rpad][2 C] (rows R .. Rpad - 1 zero) + optional column sums as *rows
 // (<= D3DP_ROWPREP_ROWS) partial rows of C floats; C <= 1536
 constexpr int D3DP_ROWPREP_ROWS = 512;
+// (mask: optional per-sample scales applied to the rows first -- sample = r / J (axis 0) or (r / (F J)) J + r % J (axis 1))
 int d3dp_launch_rowprep(const float* src, void* drow, float* colpart, int* rows, int R, int Rpad, int C, const unsigned* amax,
-                        float* unscale, hipStream_t st);
+                        float* unscale, hipStream_t st, const float* mask = nullptr, int axis = 0, int F = 1, int J = 1);
+// drow = split(LayerNorm(src; w, b, eps)): the operand of a Linear fed by a LayerNorm, from the LayerNorm's INPUT (amax: the
+// absmax of the LayerNorm's output, left by the kernel that produced src); C <= 512
+int d3dp_launch_rowprep_ln(const float* src, const float* w, const float* b, float eps, void* drow, int R, int Rpad, int C,
+                           const unsigned* amax, float* unscale, hipStream_t st);
 // wgrad straight from the ROW forms (gemm_f16x2_tn_kernel): out_z[N, K] = sum_{t in chunk z} A2[t][n] W2[t][k] x dynA x dynW,
 // Tp = Z NKz 32 rows per operand (rows beyond the real ones zero).  d3dp_tn_applies: N % 256 == 0 and K % 128 == 0.
 bool d3dp_tn_applies(int N, int K);
@@ -192,10 +197,11 @@ extern "C" int d3dp_clip_count(int32_t n, int32_t F);
 // ---- train.hip (training step, fp32) -------------------------------------------------------------------------
 // (amax: optional absmax slot of a kernel's result -- bit pattern of a non-negative float, pre-zeroed, one atomicMax per
 //  workgroup -- so that the split-fp16 Linear that consumes the result needs no absmax pass of its own)
-// x_out = x_in + mask[sample] y ; xn = LN(x_out)
+// x_out = x_in + mask[sample] y ; xn = LN(x_out)  (xn may be null: only amax, the absmax of LN(x_out), is produced)
 int d3dp_train_add_mask_ln(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* w,
                            const float* b, float eps, float* x_out, float* xn, unsigned* amax, int T, int C, hipStream_t st);
-// x_out = x_in + mask[sample] y ; x_next = LN_a(x_out) (+ pos[f]) ; xn = LN_b(x_next) (xn may be null: no second norm)
+// x_out = x_in + mask[sample] y ; x_next = LN_a(x_out) (+ pos[f]) ; xn = LN_b(x_next)  (wb null: no second norm; xn null with
+// wb given: LN_b's output is not stored, only its absmax)
 int d3dp_train_add_mask_ln2(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* wa,
                             const float* ba, float eps_a, const float* pos, const float* wb, const float* bb, float eps_b,
                             float* x_out, float* x_next, float* xn, unsigned* amax, int T, int C, hipStream_t st);

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void add_mask_ln_kernel(const float* __restric
     R::stats(v, eps, mean, rstd);
 #pragma unroll
     for (int i = 0; i < NV; ++i) { v[i] = fmaf((v[i] - mean) * rstd, wl[i], bl[i]); am = fmaxf(am, fabsf(v[i])); }
-    R::store(xn + (size_t)tok * C, lane, v);
+    if (xn) R::store(xn + (size_t)tok * C, lane, v);     // (null: only its absmax is wanted -- the operand pass recomputes it)
   }
   block_amax_commit(am, amax);
 }
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void add_mask_ln_kernel(const float* __restric
 // ---- the end of a block in ONE pass over its rows (mixste.py:113-115 second line, then :243/:250 or :257/:273):
 //   x_out = x_in + m[sample] * y ;  x_next = LN_a(x_out) (+ pos[f]) ;  xn = LN_b(x_next)  (+ absmax of xn)
 // LN_a = the shared Spatial / Temporal norm, LN_b = the next block's norm1 (the head's LayerNorm after the last block;
-// xn == nullptr: no second norm).  As three kernels (add_mask_ln, ln_pos, ln_pos) the row was written and read back twice.
+// wb == nullptr: no second norm; xn == nullptr: LN_b's output is not stored, only its absmax).  As three kernels (add_mask_ln, ln_pos, ln_pos) the row was written and read back twice.
 template <int C>
 __global__ __launch_bounds__(256) void add_mask_ln2_kernel(const float* __restrict__ x_in, const float* __restrict__ y,
                                                            const float* __restrict__ mask, int axis, int F, int J,
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void add_mask_ln2_kernel(const float* __restri
   for (int i = 0; i < NV; ++i) {
     const int c = R::col(i, lane);
     wal[i] = wa[c]; bal[i] = ba[c];
-    wbl[i] = xn ? wb[c] : 0.f; bbl[i] = xn ? bb[c] : 0.f;
+    wbl[i] = wb ? wb[c] : 0.f; bbl[i] = wb ? bb[c] : 0.f;
   }
   float am = 0.f;
   for (int tok = blockIdx.x * 4 + (threadIdx.x >> 6); tok < T; tok += gridDim.x * 4) {
@@ -153,11 +153,11 @@ __global__ __launch_bounds__(256) void add_mask_ln2_kernel(const float* __restri
       for (int i = 0; i < NV; ++i) v[i] = fmaf((v[i] - mean) * rstd, wal[i], bal[i]);
     }
     R::store(x_next + (size_t)tok * C, lane, v);
-    if (xn) {
+    if (wb) {                                            // (xn null: only the absmax of LN_b's output is wanted)
       R::stats(v, eps_b, mean, rstd);
 #pragma unroll
       for (int i = 0; i < NV; ++i) { v[i] = fmaf((v[i] - mean) * rstd, wbl[i], bbl[i]); am = fmaxf(am, fabsf(v[i])); }
-      R::store(xn + (size_t)tok * C, lane, v);
+      if (xn) R::store(xn + (size_t)tok * C, lane, v);
     }
   }
   block_amax_commit(am, amax);
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const int64_t* __rest
 static int row_blocks(int T) { return (T + 3) / 4 < kRowBlocks ? (T + 3) / 4 : kRowBlocks; }
 int d3dp_train_add_mask_ln(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* w,
                            const float* b, float eps, float* x_out, float* xn, unsigned* amax, int T, int C, hipStream_t st) {
-  if (!w || !b || !xn) return -1;
+  if (!w || !b || (!xn && !amax)) return -1;
   TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((add_mask_ln_kernel<CC>), dim3(row_blocks(T)), dim3(256), 0, st, x_in, y, mask, axis,
                                          F, J, w, b, eps, x_out, xn, amax, T))
   return 0;
@@ -820,7 +820,7 @@ int d3dp_train_add_mask_ln(const float* x_in, const float* y, const float* mask,
 int d3dp_train_add_mask_ln2(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* wa,
                             const float* ba, float eps_a, const float* pos, const float* wb, const float* bb, float eps_b,
                             float* x_out, float* x_next, float* xn, unsigned* amax, int T, int C, hipStream_t st) {
-  if (!wa || !ba || !x_out || !x_next || (xn && (!wb || !bb))) return -1;
+  if (!wa || !ba || !x_out || !x_next || (xn && !wb) || (wb && !bb)) return -1;
   TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((add_mask_ln2_kernel<CC>), dim3(row_blocks(T)), dim3(256), 0, st, x_in, y, mask, axis,
                                          F, J, wa, ba, eps_a, pos, wb, bb, eps_b, x_out, x_next, xn, amax, T))
   return 0;
