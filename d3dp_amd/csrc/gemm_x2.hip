@@ -1944,35 +1944,52 @@ __global__ __launch_bounds__(256) void rowprep_ln_kernel(const float* __restrict
   for (int e = 0; e < 8; ++e) { wl[e] = on ? w[c + e] : 0.f; bl[e] = on ? b[c + e] : 0.f; }
   const int rstep = gridDim.x * 4;
   const float invC = 1.0f / (float)C;
-  for (int r0 = blockIdx.x * 4 + rl; r0 < Rpad; r0 += 2 * rstep) {
-    float4 a[2], bb[2];
+  constexpr int U = 4;                                   // rows per wave and iteration: their loads and reductions interleave
+  for (int r0 = blockIdx.x * 4 + rl; r0 < Rpad; r0 += U * rstep) {
+    float v[U][8];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int r = r0 + u * rstep;
-      a[u] = make_float4(0.f, 0.f, 0.f, 0.f); bb[u] = a[u];
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bb = a;
       if (r < R && on) {
-        a[u] = *reinterpret_cast<const float4*>(s + (size_t)r * C + c);
-        bb[u] = *reinterpret_cast<const float4*>(s + (size_t)r * C + c + 4);
+        a = *reinterpret_cast<const float4*>(s + (size_t)r * C + c);
+        bb = *reinterpret_cast<const float4*>(s + (size_t)r * C + c + 4);
       }
+      v[u][0] = a.x; v[u][1] = a.y; v[u][2] = a.z; v[u][3] = a.w; v[u][4] = bb.x; v[u][5] = bb.y; v[u][6] = bb.z; v[u][7] = bb.w;
     }
+    float mean[U], rstd[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int r = r0 + u * rstep;
-      if (r >= Rpad) continue;                           // (wave-uniform)
-      float v[8] = {a[u].x, a[u].y, a[u].z, a[u].w, bb[u].x, bb[u].y, bb[u].z, bb[u].w};
+    for (int u = 0; u < U; ++u) {
       float sm = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) sm += v[e];
-      const float mean = wave_sum(sm) * invC;
+      for (int e = 0; e < 8; ++e) sm += v[u][e];
+      mean[u] = sm;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int u = 0; u < U; ++u) mean[u] += __shfl_xor(mean[u], o, 64);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      mean[u] *= invC;
       float q = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = on ? v[e] - mean : 0.f; q = fmaf(d, d, q); }
-      const float rstd = 1.0f / sqrtf(wave_sum(q) * invC + eps);
-      if (on) {
+      for (int e = 0; e < 8; ++e) { const float d = on ? v[u][e] - mean[u] : 0.f; q = fmaf(d, d, q); }
+      rstd[u] = q;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int u = 0; u < U; ++u) rstd[u] += __shfl_xor(rstd[u], o, 64);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + u * rstep;
+      if (r < Rpad && on) {
+        const float rs = 1.0f / sqrtf(rstd[u] * invC + eps);
         f16x8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float y = r < R ? fmaf((v[e] - mean) * rstd, wl[e], bl[e]) : 0.f;
+          const float y = r < R ? fmaf((v[u][e] - mean[u]) * rs, wl[e], bl[e]) : 0.f;
           f16 h, lw;
           split2h_scaled(y * sc, h, lw);
           hi[e] = h; lo[e] = lw;

@@ -416,16 +416,14 @@ class MixSTE2(nn.Module):
             return m.to(device).contiguous()
         if not self.training or not self.drop_path_rate:
             return None
-        rates = [x.item() for x in torch.linspace(0, self.drop_path_rate, dep)]
-        m = torch.ones((2 * dep, 2, smax), dtype=torch.float32, device=device)
-        for i, r in enumerate(rates):
-            if r == 0.0:
-                continue
-            keep = 1.0 - r
-            for kind, S in ((0, B * Fr), (1, B * J)):
-                for br in (0, 1):
-                    m[2 * i + kind, br, :S] = torch.empty(S, device=device).bernoulli_(keep) / keep
-        return m
+        # every block's masks in three launches (one uniform draw over the whole table, a compare and a divide) instead of a
+        # bernoulli + divide + copy per (block, branch): ~100 tiny launches per training step
+        keep = getattr(self, "_droppath_keep", None)
+        if keep is None or keep.device != device:
+            rates = torch.linspace(0, self.drop_path_rate, dep)
+            keep = (1.0 - rates).repeat_interleave(2).reshape(2 * dep, 1, 1).to(device=device, dtype=torch.float32)
+            self._droppath_keep = keep                    # (rate 0 -> keep 1: rand() < 1 always, scale 1 -- an Identity, mixste.py:100)
+        return ((torch.rand((2 * dep, 2, smax), device=device) < keep).to(torch.float32) / keep).contiguous()
 
     def _train_io(self, x_2d, x_3d, t):
         B, Fr, J, _ = x_3d.shape
