@@ -53,41 +53,32 @@ __device__ __forceinline__ void ta_split8(const float4 a, const float4 b, f16x8&
 
 // rows [0, n) x 64 channels of an fp32 matrix (row stride `rs` floats) -> the hi / lo images (values x sc); rows [n, NK)
 // zero.  Four 16-byte slots per thread and pass, all loads of a pass in flight before the first conversion.
-// IPT 16-byte slots per thread cover one plane's NK x 8 slots (NT threads): loaded as raw fp32 (ta_stage_load) and converted
-// into the images later (ta_stage_store) -- the kernels below request the NEXT unit's rows before they compute the current
-// one, so a unit's staging latency hides behind the previous unit's arithmetic.
-template <int NK, int NT> struct TAStageRegs {
-  static constexpr int IPT = (NK * 8 + NT - 1) / NT;
-  float4 a[IPT], b[IPT];
-};
 template <int NK, int NT>
-__device__ __forceinline__ void ta_stage_load(const float* __restrict__ src, size_t rs, int n, int tid, TAStageRegs<NK, NT>& g) {
-  constexpr int ITEMS = NK * 8;                        // 16-byte slots of one plane
-#pragma unroll
-  for (int u = 0; u < TAStageRegs<NK, NT>::IPT; ++u) {
-    const int idx = u * NT + tid, row = idx >> 3, slot = idx & 7;
-    g.a[u] = make_float4(0.f, 0.f, 0.f, 0.f); g.b[u] = g.a[u];
-    if (idx < ITEMS && row < n) {
-      const float* p = src + (size_t)row * rs + slot * 8;
-      g.a[u] = *reinterpret_cast<const float4*>(p);
-      g.b[u] = *reinterpret_cast<const float4*>(p + 4);
-    }
-  }
-}
-// rows [0, n) x 64 channels (values x sc) -> the hi / lo images; rows [n, NK) zero
-template <int NK, int NT>
-__device__ __forceinline__ void ta_stage_store(const TAStageRegs<NK, NT>& g, float sc, char* img, int tid) {
+__device__ __forceinline__ void ta_stage(const float* __restrict__ src, size_t rs, int n, float sc, char* img, int tid) {
   constexpr int PLANE = NK * 128;
-  constexpr int ITEMS = NK * 8;
+  constexpr int ITEMS = NK * 8;                        // 16-byte slots of one plane
+  for (int i0 = 0; i0 < ITEMS; i0 += 4 * NT) {
+    float4 a[4], b[4];
 #pragma unroll
-  for (int u = 0; u < TAStageRegs<NK, NT>::IPT; ++u) {
-    const int idx = u * NT + tid, row = idx >> 3, slot = idx & 7;
-    if (idx < ITEMS) {
-      f16x8 hi, lo;
-      ta_split8(g.a[u], g.b[u], hi, lo, sc);
-      const int off = row * 128 + ((slot ^ ta_sw(row)) << 4);
-      *reinterpret_cast<f16x8*>(img + off) = hi;
-      *reinterpret_cast<f16x8*>(img + PLANE + off) = lo;
+    for (int u = 0; u < 4; ++u) {
+      const int idx = i0 + u * NT + tid, row = idx >> 3, slot = idx & 7;
+      a[u] = make_float4(0.f, 0.f, 0.f, 0.f); b[u] = a[u];
+      if (idx < ITEMS && row < n) {
+        const float* p = src + (size_t)row * rs + slot * 8;
+        a[u] = *reinterpret_cast<const float4*>(p);
+        b[u] = *reinterpret_cast<const float4*>(p + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = i0 + u * NT + tid, row = idx >> 3, slot = idx & 7;
+      if (idx < ITEMS) {
+        f16x8 hi, lo;
+        ta_split8(a[u], b[u], hi, lo, sc);
+        const int off = row * 128 + ((slot ^ ta_sw(row)) << 4);
+        *reinterpret_cast<f16x8*>(img + off) = hi;
+        *reinterpret_cast<f16x8*>(img + PLANE + off) = lo;
+      }
     }
   }
 }
@@ -214,23 +205,15 @@ __global__ __launch_bounds__(NW * 64) void tattn_fwd_kernel(const float* __restr
   const size_t ld = (size_t)3 * C, rs = (size_t)map.tok_stride * ld;
   const float sq = ta_scale(amax_qkv);
   float am = 0.f;
-  TAStageRegs<NK, NW * 64> gk, gv;
-  auto request = [&](int unit) {                       // the K / V rows of `unit`, raw, into registers
-    const int prob = unit / groups;
-    const float* p0 = qkv + (size_t)ta_seq_base(map, prob / heads) * ld + (size_t)(prob % heads) * 64;
-    ta_stage_load<NK, NW * 64>(p0 + C, rs, n, tid, gk);
-    ta_stage_load<NK, NW * 64>(p0 + 2 * C, rs, n, tid, gv);
-  };
-  if ((int)blockIdx.x < n_work) request(blockIdx.x);
   for (int unit = blockIdx.x; unit < n_work; unit += gridDim.x) {
   const int prob = unit / groups, group = unit % groups;
   const int seq = prob / heads, head = prob % heads;
   const int base = ta_seq_base(map, seq);
+  const float* p0 = qkv + (size_t)base * ld + (size_t)head * 64;
   if (unit != (int)blockIdx.x) __syncthreads();        // every wave is done with the previous unit's images
-  ta_stage_store<NK, NW * 64>(gk, sq, kimg, tid);
-  ta_stage_store<NK, NW * 64>(gv, sq, vimg, tid);
+  ta_stage<NK, NW * 64>(p0 + C, rs, n, sq, kimg, tid);
+  ta_stage<NK, NW * 64>(p0 + 2 * C, rs, n, sq, vimg, tid);
   __syncthreads();
-  if (unit + (int)gridDim.x < n_work) request(unit + gridDim.x);   // lands while this unit computes
   const int qt = group * NW + wave;
   if (qt * 16 < n) {
     const int fi = lane & 15, fg = lane >> 4;
@@ -314,23 +297,15 @@ __global__ __launch_bounds__(NW * 64) void tattn_bwd_q_kernel(const float* __res
   const size_t ld = (size_t)3 * C, rs = (size_t)map.tok_stride * ld;
   const float sq = ta_scale(amax_qkv), sg = ta_scale(amax_do);
   float am = 0.f;
-  TAStageRegs<NK, NW * 64> gk, gv;
-  auto request = [&](int unit) {
-    const int prob = unit / groups;
-    const float* p0 = qkv + (size_t)ta_seq_base(map, prob / heads) * ld + (size_t)(prob % heads) * 64;
-    ta_stage_load<NK, NW * 64>(p0 + C, rs, n, tid, gk);
-    ta_stage_load<NK, NW * 64>(p0 + 2 * C, rs, n, tid, gv);
-  };
-  if ((int)blockIdx.x < n_work) request(blockIdx.x);
   for (int unit = blockIdx.x; unit < n_work; unit += gridDim.x) {
   const int prob = unit / groups, group = unit % groups;
   const int seq = prob / heads, head = prob % heads;
   const int base = ta_seq_base(map, seq);
+  const float* p0 = qkv + (size_t)base * ld + (size_t)head * 64;
   if (unit != (int)blockIdx.x) __syncthreads();
-  ta_stage_store<NK, NW * 64>(gk, sq, kimg, tid);
-  ta_stage_store<NK, NW * 64>(gv, sq, vimg, tid);
+  ta_stage<NK, NW * 64>(p0 + C, rs, n, sq, kimg, tid);
+  ta_stage<NK, NW * 64>(p0 + 2 * C, rs, n, sq, vimg, tid);
   __syncthreads();
-  if (unit + (int)gridDim.x < n_work) request(unit + gridDim.x);
   const int qt = group * NW + wave;
   if (qt * 16 < n) {
     const int fi = lane & 15, fg = lane >> 4;
@@ -422,21 +397,13 @@ __global__ __launch_bounds__(NW * 64) void tattn_bwd_kv_kernel(const float* __re
   const size_t ld = (size_t)3 * C, rs = (size_t)map.tok_stride * ld;
   const float sq = ta_scale(amax_qkv), sg = ta_scale(amax_do);
   float am = 0.f;
-  TAStageRegs<NK, NW * 64> gq, gg;
-  auto request = [&](int unit) {
-    const int prob = unit / groups;
-    const int b0 = ta_seq_base(map, prob / heads), hd = prob % heads;
-    ta_stage_load<NK, NW * 64>(qkv + (size_t)b0 * ld + (size_t)hd * 64, rs, n, tid, gq);
-    ta_stage_load<NK, NW * 64>(dout + (size_t)b0 * C + (size_t)hd * 64, (size_t)map.tok_stride * C, n, tid, gg);
-  };
-  if ((int)blockIdx.x < n_work) request(blockIdx.x);
   for (int unit = blockIdx.x; unit < n_work; unit += gridDim.x) {
   const int prob = unit / groups, group = unit % groups;
   const int seq = prob / heads, head = prob % heads;
   const int base = ta_seq_base(map, seq);
   if (unit != (int)blockIdx.x) __syncthreads();
-  ta_stage_store<NK, NW * 64>(gq, sq, qimg, tid);
-  ta_stage_store<NK, NW * 64>(gg, sg, gimg, tid);
+  ta_stage<NK, NW * 64>(qkv + (size_t)base * ld + (size_t)head * 64, rs, n, sq, qimg, tid);
+  ta_stage<NK, NW * 64>(dout + (size_t)base * C + (size_t)head * 64, (size_t)map.tok_stride * C, n, sg, gimg, tid);
   for (int i = tid; i < NK; i += NW * 64) {
     // rows >= n: their Q and dO image rows are zero, so any FINITE p and dS contribute nothing: L = +large keeps p = 0
     float2 v = make_float2(1.0e30f, 0.f);
@@ -444,7 +411,6 @@ __global__ __launch_bounds__(NW * 64) void tattn_bwd_kv_kernel(const float* __re
     st[i] = v;
   }
   __syncthreads();
-  if (unit + (int)gridDim.x < n_work) request(unit + gridDim.x);
   const int kt = group * NW + wave;
   if (kt * 16 < n) {
     const int fi = lane & 15, fg = lane >> 4;
