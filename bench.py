@@ -399,7 +399,7 @@ def attach_traffic(roof, numerics, chunk_seqs, batch=None):
     They are printed only when this run uses that very build AND launches the kernel over the same number of rows (within
     5 %): counters of another build or another pass size are not this run's traffic."""
     sha, tj, seen = lib_sha256(), None, []
-    for name in ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json"):   # newest first; keyed by the library's hash
+    for name in ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json"):   # newest first; keyed by the library's hash
         tpath = os.path.join(REPO, "profiles", name)
         if os.path.exists(tpath):
             cand = json.load(open(tpath)).get(numerics, {}).get(roof["kernel"])
@@ -424,15 +424,18 @@ def attach_traffic(roof, numerics, chunk_seqs, batch=None):
                             f"bytes/launch {tj['algorithmic_bytes_per_launch']} (read amplification "
                             f"{tj.get('read_amplification', float('nan')):.2f}x: the weight matrix is re-fetched by every XCD "
                             f"every tile round); hardware MFMA busy {tj.get('mfma_util_hw', float('nan')):.3f} of kernel cycles")
-    spath = os.path.join(REPO, "profiles", "r04_step_pmc.json")
-    if os.path.exists(spath):
+    for sname in ("r05_step_pmc.json", "r04_step_pmc.json"):
+        spath = os.path.join(REPO, "profiles", sname)
+        if not os.path.exists(spath):
+            continue
         st = json.load(open(spath)).get(numerics)
         if st and st.get("lib_sha256") == sha and (batch is None or st.get("batch") == batch):
             roof["hbm_tb_per_step"] = st["hbm_tb_per_step"]
             roof["mfma_busy_hw"] = st["mfma_busy_hw"]
             roof["step_counters_note"] = ("whole step, every kernel: HBM bytes (FETCH_SIZE x2 + WRITE_SIZE) and sum of "
                                           "SQ_VALU_MFMA_BUSY_CYCLES / 1024 over sum of GRBM_GUI_ACTIVE / 8, one rocprofv3 --pmc "
-                                          f"pass per counter set of this build at --batch {st.get('batch')} (profiles/r04_step_pmc_{numerics}.md)")
+                                          f"pass per counter set of this build at --batch {st.get('batch')} (profiles/{sname[:3]}_step_pmc_{numerics}.md)")
+            break
 
 
 def profile_step(model, x2d, x2f, gen):

@@ -11,7 +11,7 @@ import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1]
-RN = sys.argv[2] if len(sys.argv) > 2 else "r04"
+RN = sys.argv[2] if len(sys.argv) > 2 else "r05"
 F = os.path.join(R, "gpurun_out", TAG)
 P = os.path.join(R, "profiles")
 F_, J_, C_ = 243, 17, 512
@@ -102,4 +102,19 @@ if os.path.exists(os.path.join(F, "kernel_stats.md")):
            f"{d['roofline']['avg_launch_ms'] * 1e3:.1f} us"
            + (f", in this profiled run: {prof['roofline']['avg_launch_ms'] * 1e3:.1f} us." if prof.get("roofline") else "."), ""]
     open(os.path.join(P, RN + "_bench_c3_kernel_stats.md"), "w").write("\n".join(hdr) + open(os.path.join(F, "kernel_stats.md")).read())
+# ---- round 5: the training step's kernel table, the parity printout, the variants' test log
+tk = os.path.join(F, "train_kernel_stats.md")
+if os.path.exists(tk):
+    tl = [l.strip() for l in open(os.path.join(F, "train_prof.log")) if l.startswith("train step")] if os.path.exists(os.path.join(F, "train_prof.log")) else []
+    c5 = d.get("configs", {}).get("c5_train_step", {})
+    hdr = ["# rocprofv3 --kernel-trace --stats -- python tools/train_bench.py 5   (7 steps of BASELINE configs[4]: B=4, F=243, cs=512, dep=8, incl. AdamW;",
+           "# tools/gpu_round.sh trainstats).  Per-kernel durations are measured with the weight-gradient products running on a second",
+           "# stream beside the dgrad products (d3dp_ctx::aux): the two GEMM kernels' and sum_partials' times below are CONCURRENT",
+           "# durations and do not add up to the step (D3DP_TRAIN_OVERLAP=0 serialises them).",
+           f"# step time in the profiled run: {tl[-1] if tl else 'n/a'}; in bench.py's configs block (no optimizer step): "
+           f"{c5.get('ms_per_step', float('nan')):.2f} ms.", ""]
+    open(os.path.join(P, RN + "_train_step_kernel_stats.md"), "w").write("\n".join(hdr) + open(tk).read())
+for src, dst in (("parity.log", "_parity.log"), ("variants.log", "_variants_tests.log"), ("tests_full.log", "_gpu_tests_full.log")):
+    if os.path.exists(os.path.join(F, src)):
+        shutil.copy(os.path.join(F, src), os.path.join(P, RN + dst))
 print("value", d["value"], "sha", sha[:12])
