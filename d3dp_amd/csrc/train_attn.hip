@@ -110,47 +110,36 @@ __device__ __forceinline__ f16x8 ta_tr(const char* p) {
 
 // the two 16-row tiles t, t + 1 of  (image rows) x (a register operand): acc_a / acc_b [row 16 t' + 4 fg + r][column lane & 15]
 //   = sum_d img[row][d] x[column][d]  -- lo.hi + hi.lo + hi.hi over the two 32-deep halves of d.
-// Fragment reads and products are separate calls: the kernels request the fragments of the NEXT step (and the transposed
-// fragments of this one) right behind a step's matrix instructions, so they land under the vector work that follows
-// (counters, profiles/r05_train_attn_pmc.md: with reads placed at their use the waves sat parked 47 % of their cycles).
-struct TARows { f16x8 al0, al1, bl0, bl1, ah0, ah1, bh0, bh1; };
 template <int PLANE>
-__device__ __forceinline__ void ta_rows_load(const TAFrag& f, int t, TARows& x) {
+__device__ __forceinline__ void ta_rows_pair(const TAFrag& f, int t, const f16x8 (&xh)[2], const f16x8 (&xl)[2], f32x4& a, f32x4& b) {
   const char* p0 = f.r0 + t * 2048;
   const char* p1 = f.r1 + t * 2048;
-  x.al0 = *reinterpret_cast<const f16x8*>(p0 + PLANE); x.al1 = *reinterpret_cast<const f16x8*>(p1 + PLANE);
-  x.bl0 = *reinterpret_cast<const f16x8*>(p0 + 2048 + PLANE); x.bl1 = *reinterpret_cast<const f16x8*>(p1 + 2048 + PLANE);
-  x.ah0 = *reinterpret_cast<const f16x8*>(p0); x.ah1 = *reinterpret_cast<const f16x8*>(p1);
-  x.bh0 = *reinterpret_cast<const f16x8*>(p0 + 2048); x.bh1 = *reinterpret_cast<const f16x8*>(p1 + 2048);
-}
-__device__ __forceinline__ void ta_rows_mfma(const TARows& x, const f16x8 (&xh)[2], const f16x8 (&xl)[2], f32x4& a, f32x4& b) {
+  const f16x8 al0 = *reinterpret_cast<const f16x8*>(p0 + PLANE), al1 = *reinterpret_cast<const f16x8*>(p1 + PLANE);
+  const f16x8 bl0 = *reinterpret_cast<const f16x8*>(p0 + 2048 + PLANE), bl1 = *reinterpret_cast<const f16x8*>(p1 + 2048 + PLANE);
+  const f16x8 ah0 = *reinterpret_cast<const f16x8*>(p0), ah1 = *reinterpret_cast<const f16x8*>(p1);
+  const f16x8 bh0 = *reinterpret_cast<const f16x8*>(p0 + 2048), bh1 = *reinterpret_cast<const f16x8*>(p1 + 2048);
   a = (f32x4){0.f, 0.f, 0.f, 0.f}; b = a;
-  TA_MFMA(x.al0, xh[0], a); TA_MFMA(x.bl0, xh[0], b);
-  TA_MFMA(x.al1, xh[1], a); TA_MFMA(x.bl1, xh[1], b);
-  TA_MFMA(x.ah0, xl[0], a); TA_MFMA(x.bh0, xl[0], b);
-  TA_MFMA(x.ah1, xl[1], a); TA_MFMA(x.bh1, xl[1], b);
-  TA_MFMA(x.ah0, xh[0], a); TA_MFMA(x.bh0, xh[0], b);
-  TA_MFMA(x.ah1, xh[1], a); TA_MFMA(x.bh1, xh[1], b);
+  TA_MFMA(al0, xh[0], a); TA_MFMA(bl0, xh[0], b);
+  TA_MFMA(al1, xh[1], a); TA_MFMA(bl1, xh[1], b);
+  TA_MFMA(ah0, xl[0], a); TA_MFMA(bh0, xl[0], b);
+  TA_MFMA(ah1, xl[1], a); TA_MFMA(bh1, xl[1], b);
+  TA_MFMA(ah0, xh[0], a); TA_MFMA(bh0, xh[0], b);
+  TA_MFMA(ah1, xh[1], a); TA_MFMA(bh1, xh[1], b);
 }
 // acc[dn][channel dn 16 + 4 fg + i][column] += sum over the 32 image rows of chunk c of img[row][channel] y[row][column]
 // (y as a split register operand in the k order of the transposed fragments: rows 4 fg + r of tile 2 c, then of tile 2 c + 1)
-struct TATr { f16x8 th[4], tl[4]; };
 template <int PLANE>
-__device__ __forceinline__ void ta_tr_load(const TAFrag& f, int c, TATr& x) {
+__device__ __forceinline__ void ta_tr_chunk(const TAFrag& f, int c, const f16x8& yh, const f16x8& yl, f32x4 (&acc)[4]) {
+  f16x8 th[4], tl[4];
 #pragma unroll
-  for (int dn = 0; dn < 4; ++dn) { x.th[dn] = ta_tr(f.t[dn] + c * 4096); x.tl[dn] = ta_tr(f.t[dn] + c * 4096 + PLANE); }
+  for (int dn = 0; dn < 4; ++dn) { th[dn] = ta_tr(f.t[dn] + c * 4096); tl[dn] = ta_tr(f.t[dn] + c * 4096 + PLANE); }
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) TA_MFMA(tl[dn], yh, acc[dn]);
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) TA_MFMA(th[dn], yl, acc[dn]);
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) TA_MFMA(th[dn], yh, acc[dn]);
 }
-__device__ __forceinline__ void ta_tr_mfma(const TATr& x, const f16x8& yh, const f16x8& yl, f32x4 (&acc)[4]) {
-#pragma unroll
-  for (int dn = 0; dn < 4; ++dn) TA_MFMA(x.tl[dn], yh, acc[dn]);
-#pragma unroll
-  for (int dn = 0; dn < 4; ++dn) TA_MFMA(x.th[dn], yl, acc[dn]);
-#pragma unroll
-  for (int dn = 0; dn < 4; ++dn) TA_MFMA(x.th[dn], yh, acc[dn]);
-}
-// (the fixed placement pays on the long sequences -- one 133-KiB workgroup per CU, two waves per SIMD at up to 256 registers;
-//  the short ones live on occupancy: there the compiler keeps its own, leaner order)
-#define TA_FENCE() do { if constexpr (NKT >= 8) __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // this lane's 16 values of a [.][64] fp32 row as a split register operand (column operand of ta_rows_pair): channels
 // 8 fg .. + 7 and 32 + 8 fg .. + 7
@@ -202,7 +191,7 @@ __device__ __forceinline__ void ta_block_amax(float am, unsigned* amax, float* p
 // ------------------------------------------------------------------------------------------------------------------------
 // forward
 template <int NKT, int NW>
-__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void tattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+__global__ __launch_bounds__(NW * 64) void tattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                            TAStat* __restrict__ stats, SeqMap map, int C, int heads, int groups,
                                                            int n_work, const unsigned* __restrict__ amax_qkv,
                                                            unsigned* __restrict__ amax_out) {
@@ -238,17 +227,10 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void tattn_fwd_kernel(con
     f32x4 o[4];
 #pragma unroll
     for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    TARows rk;
-    ta_rows_load<PLANE>(fk, 0, rk);
 #pragma unroll
     for (int t = 0; t < NKT; t += 2) {
       f32x4 a, b;
-      TA_FENCE();
-      ta_rows_mfma(rk, qh, ql, a, b);
-      TATr tv;
-      ta_tr_load<PLANE>(fv, t >> 1, tv);                // V^T of this pair and K of the next: under the softmax below
-      if (t + 2 < NKT) ta_rows_load<PLANE>(fk, t + 2, rk);
-      TA_FENCE();
+      ta_rows_pair<PLANE>(fk, t, qh, ql, a, b);
       float s[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -278,8 +260,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void tattn_fwd_kernel(con
       lrun = fmaf(lrun, alpha, psum);
 #pragma unroll
       for (int dn = 0; dn < 4; ++dn) o[dn] *= alpha;
-      TA_FENCE();
-      ta_tr_mfma(tv, ph, pl, o);
+      ta_tr_chunk<PLANE>(fv, t >> 1, ph, pl, o);
     }
     // o = (v scale) x 1024 x sum_j p_j v_j against the running maximum; lrun = 1024 x sum_j p_j
     const float inv = 1.0f / (sq * lrun);
@@ -301,7 +282,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void tattn_fwd_kernel(con
 // ------------------------------------------------------------------------------------------------------------------------
 // backward, pass Q: dQ (and D_i into the statistics)
 template <int NKT, int NW>
-__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void tattn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+__global__ __launch_bounds__(NW * 64) void tattn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                              const float* __restrict__ dout, float* __restrict__ dqkv,
                                                              TAStat* __restrict__ stats, SeqMap map, int C, int heads, int groups,
                                                              int n_work, const unsigned* __restrict__ amax_qkv,
@@ -356,19 +337,11 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void tattn_bwd_q_kernel(c
     f32x4 dq[4];
 #pragma unroll
     for (int dn = 0; dn < 4; ++dn) dq[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    TARows rk, rv;
-    ta_rows_load<PLANE>(fk, 0, rk);
-    ta_rows_load<PLANE>(fv, 0, rv);
 #pragma unroll
     for (int t = 0; t < NKT; t += 2) {
       f32x4 a, b, c, d;
-      TA_FENCE();
-      ta_rows_mfma(rk, qh, ql, a, b);                  // S^T  [key][query]
-      ta_rows_mfma(rv, gh, gl, c, d);                  // dP^T [key][query]
-      TATr tk;
-      ta_tr_load<PLANE>(fk, t >> 1, tk);                // K^T of this pair, K / V rows of the next: under the vector work below
-      if (t + 2 < NKT) { ta_rows_load<PLANE>(fk, t + 2, rk); ta_rows_load<PLANE>(fv, t + 2, rv); }
-      TA_FENCE();
+      ta_rows_pair<PLANE>(fk, t, qh, ql, a, b);        // S^T  [key][query]
+      ta_rows_pair<PLANE>(fv, t, gh, gl, c, d);        // dP^T [key][query]
       float ds[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -386,8 +359,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void tattn_bwd_q_kernel(c
       }
       f16x8 sh, sl;
       ta_split_run(ds, eb, sh, sl);
-      TA_FENCE();
-      ta_tr_mfma(tk, sh, sl, dq);                      // dQ^T[d][query] += K^T dS^T
+      ta_tr_chunk<PLANE>(fk, t >> 1, sh, sl, dq);      // dQ^T[d][query] += K^T dS^T
     }
     if (q < n) {
       const float un = 1.0f / sq;
@@ -409,7 +381,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void tattn_bwd_q_kernel(c
 // ------------------------------------------------------------------------------------------------------------------------
 // backward, pass KV: dK, dV
 template <int NKT, int NW>
-__global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void tattn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ __launch_bounds__(NW * 64) void tattn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                               float* __restrict__ dqkv, const TAStat* __restrict__ stats,
                                                               SeqMap map, int C, int heads, int groups, int n_work,
                                                               const unsigned* __restrict__ amax_qkv,
@@ -455,18 +427,11 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void tattn_bwd_kv_kernel(
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dn = 0; dn < 4; ++dn) { dk[dn] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dn] = dk[dn]; }
-    TARows rq, rg;
-    ta_rows_load<PLANE>(fq, 0, rq);
-    ta_rows_load<PLANE>(fgr, 0, rg);
 #pragma unroll
     for (int t = 0; t < NKT; t += 2) {
       f32x4 a, b, c, d;
-      TA_FENCE();
-      ta_rows_mfma(rq, kh, kl, a, b);                  // S  [query][key]
-      ta_rows_mfma(rg, vh, vl, c, d);                  // dP [query][key]
-      TATr tx;
-      ta_tr_load<PLANE>(fgr, t >> 1, tx);               // dO^T of this pair: lands under the probabilities' vector work
-      TA_FENCE();
+      ta_rows_pair<PLANE>(fq, t, kh, kl, a, b);        // S  [query][key]
+      ta_rows_pair<PLANE>(fgr, t, vh, vl, c, d);       // dP [query][key]
       float ds[8];
       f16x8 ph, pl;
 #pragma unroll
@@ -481,11 +446,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void tattn_bwd_kv_kernel(
         ph[r] = ha; pl[r] = (f16)(ya - (float)ha);
         ph[4 + r] = hb; pl[4 + r] = (f16)(yb - (float)hb);
       }
-      TA_FENCE();
-      ta_tr_mfma(tx, ph, pl, dv);                      // dV^T[d][key] += dO^T P
-      ta_tr_load<PLANE>(fq, t >> 1, tx);                // Q^T of this pair and the rows of the next: under the dS work below
-      if (t + 2 < NKT) { ta_rows_load<PLANE>(fq, t + 2, rq); ta_rows_load<PLANE>(fgr, t + 2, rg); }
-      TA_FENCE();
+      ta_tr_chunk<PLANE>(fgr, t >> 1, ph, pl, dv);     // dV^T[d][key] += dO^T P
       const int en = max(eb, ta_exp_of_max(ds));
       if (en != eb) {
 #pragma unroll
@@ -496,8 +457,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 2 : 1) void tattn_bwd_kv_kernel(
       }
       f16x8 sh, sl;
       ta_split_run(ds, eb, sh, sl);
-      TA_FENCE();
-      ta_tr_mfma(tx, sh, sl, dk);                      // dK^T[d][key] += Q^T dS
+      ta_tr_chunk<PLANE>(fq, t >> 1, sh, sl, dk);      // dK^T[d][key] += Q^T dS
     }
     if (live) {
       const float uk = 1.0f / sq, uv = 1.0f / (sg * 1024.0f);
