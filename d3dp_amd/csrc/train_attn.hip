@@ -233,9 +233,13 @@ __global__ __launch_bounds__(NW * 64) void tattn_fwd_kernel(const float* __restr
       ta_rows_pair<PLANE>(fk, t, qh, ql, a, b);
       float s[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[r] = (16 * t + 4 * fg + r < n) ? a[r] * cexp : -INFINITY;
-        s[4 + r] = (16 * (t + 1) + 4 * fg + r < n) ? b[r] * cexp : -INFINITY;
+      for (int r = 0; r < 4; ++r) { s[r] = a[r] * cexp; s[4 + r] = b[r] * cexp; }
+      if (16 * (t + 2) > n) {                          // (uniform: only the last pair(s) hold keys >= n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (16 * t + 4 * fg + r >= n) s[r] = -INFINITY;
+          if (16 * (t + 1) + 4 * fg + r >= n) s[4 + r] = -INFINITY;
+        }
       }
       float mx = s[0];
 #pragma unroll
@@ -346,8 +350,15 @@ __global__ __launch_bounds__(NW * 64) void tattn_bwd_q_kernel(const float* __res
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float pa = __builtin_amdgcn_exp2f(fmaf(a[r], cexp, -L)), pb = __builtin_amdgcn_exp2f(fmaf(b[r], cexp, -L));
-        ds[r] = (16 * t + 4 * fg + r < n) ? pa * (fmaf(c[r], cdp, -D)) * 0.125f : 0.f;
-        ds[4 + r] = (16 * (t + 1) + 4 * fg + r < n) ? pb * (fmaf(d[r], cdp, -D)) * 0.125f : 0.f;
+        ds[r] = pa * (fmaf(c[r], cdp, -D)) * 0.125f;
+        ds[4 + r] = pb * (fmaf(d[r], cdp, -D)) * 0.125f;
+      }
+      if (16 * (t + 2) > n) {                          // (uniform: only the last pair(s) hold keys >= n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (16 * t + 4 * fg + r >= n) ds[r] = 0.f;
+          if (16 * (t + 1) + 4 * fg + r >= n) ds[4 + r] = 0.f;
+        }
       }
       const int en = max(eb, ta_exp_of_max(ds));
       if (en != eb) {                                  // (uniform over the four lanes of a column; exact rescale)
