@@ -893,10 +893,10 @@ def test_deferred_backward_recomputes_its_own_forward(golden_dir):
         return [p.grad.clone() for p in m.parameters()]
 
     a, b = grads(False), grads(True)
-    # (not bit-equal: the split-K weight-gradient GEMM accumulates with fp32 atomics in a run-dependent order; gradients
-    #  taken through the WRONG forward's activations differ by O(1), not by 1e-5)
+    # (gradients taken through the WRONG forward's activations would differ by O(1); the re-run forward reproduces the first
+    #  one's activations exactly and no gradient is summed with float atomics any more: bit-equal)
     for x, y in zip(a, b):
-        assert (x - y).double().norm().item() <= 1e-5 * x.double().norm().item() + 1e-12
+        assert torch.equal(x, y)
 
 
 def test_backward_after_optimizer_step_raises(golden_dir):
