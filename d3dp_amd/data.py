@@ -141,20 +141,19 @@ class ChunkedBatcher(ChunkLineage):
     def next_epoch(self) -> Iterator[Tuple[Optional[np.ndarray], Optional[torch.Tensor], torch.Tensor]]:
         """Yields (cameras or None, batch_3d or None, batch_2d) like the reference generator; the pose batches are
         fp32 GPU tensors."""
-        enabled = True
-        while enabled:
-            start_idx, pairs = self.next_pairs()
-            table = self._tables(pairs)
-            for b_i in range(start_idx, self.num_batches):
-                lo, hi = b_i * self.batch_size, (b_i + 1) * self.batch_size
-                b3, b2 = self.gather(table[lo:hi])
+        bs = self.batch_size
+        while True:
+            first, pairs = self.next_pairs()
+            table = self._tables(pairs)                    # the whole epoch's index table: one upload
+            for k in range(first, self.num_batches):
+                rows = slice(k * bs, (k + 1) * bs)
+                b3, b2 = self.gather(table[rows])
                 if self.endless:
-                    self.state = (b_i + 1, pairs)
-                yield self._cams(pairs[lo:hi]), b3, b2
-            if self.endless:
-                self.state = None
-            else:
-                enabled = False
+                    self.state = (k + 1, pairs)            # where an endless generator resumes
+                yield self._cams(pairs[rows]), b3, b2
+            if not self.endless:
+                return
+            self.state = None
 
 
 class UnchunkedSequences:
@@ -182,24 +181,24 @@ class UnchunkedSequences:
     def set_augment(self, augment):
         self.augment = augment
 
+    def _mirrored(self, x, left, right):
+        """x with its first coordinate negated and the left / right joints swapped (the flip augmentation)."""
+        y = x.clone()
+        y[..., 0] *= -1
+        return y[:, :, flip_perm(left, right, y.shape[2])]
+
     def next_epoch(self):
-        from itertools import zip_longest
-        for cam, s3, s2 in zip_longest(self.cameras, self.poses_3d, self.poses_2d):
-            b_cam = None if cam is None else np.expand_dims(cam, axis=0)
-            b3 = None if s3 is None else s3[None]
-            b2 = s2[None]
-            if self.augment:
-                if b_cam is not None:
-                    b_cam = np.concatenate((b_cam, b_cam), axis=0)
-                    b_cam[1, 2] *= -1
-                    b_cam[1, 7] *= -1
+        n = len(self.poses_2d)
+        for i in range(n):
+            cam = self.cameras[i] if i < len(self.cameras) else None
+            b3 = self.poses_3d[i][None] if i < len(self.poses_3d) else None
+            b2 = self.poses_2d[i][None]
+            b_cam = None if cam is None else np.asarray(cam)[None]
+            if self.augment:                               # second batch element: the mirrored copy (camera: cx and the
+                if b_cam is not None:                      # tangential term change sign)
+                    b_cam = np.repeat(b_cam, 2, axis=0)
+                    b_cam[1, [2, 7]] *= -1
                 if b3 is not None:
-                    f3 = b3.clone()
-                    f3[..., 0] *= -1
-                    f3 = f3[:, :, flip_perm(self.joints_left, self.joints_right, f3.shape[2])]
-                    b3 = torch.cat((b3, f3), dim=0)
-                f2 = b2.clone()
-                f2[..., 0] *= -1
-                f2 = f2[:, :, flip_perm(self.kps_left, self.kps_right, f2.shape[2])]
-                b2 = torch.cat((b2, f2), dim=0)
+                    b3 = torch.cat((b3, self._mirrored(b3, self.joints_left, self.joints_right)), dim=0)
+                b2 = torch.cat((b2, self._mirrored(b2, self.kps_left, self.kps_right)), dim=0)
             yield b_cam, b3, b2

@@ -501,3 +501,30 @@ def test_step_counter_summary_counts_a_kernel_once(tmp_path):
     rows = {l.split("|")[1].strip().strip("`"): [c.strip() for c in l.split("|")[2:-1]] for l in out.read_text().splitlines()[2:]}
     assert rows["ln_kernel<512>"] == ["2", "22", "0"]
     assert rows["embed_ln_kernel<512>"] == ["1", "5", "7"]
+
+
+def test_whole_sequence_generator_appends_the_mirrored_copy():
+    """UnchunkedSequences (generators.py:174-250): one sequence per batch; with augment on, element 1 is the mirrored
+    sequence (x negated, left/right swapped) and its camera has cx and the tangential term negated."""
+    from d3dp_amd.data import UnchunkedSequences
+    rng = np.random.default_rng(5)
+    p2 = [rng.standard_normal((n, 17, 2)).astype(np.float32) for n in (5, 8)]
+    p3 = [rng.standard_normal((n, 17, 3)).astype(np.float32) for n in (5, 8)]
+    cams = [rng.standard_normal(9) for _ in range(2)]
+    gen = UnchunkedSequences(cams, p3, p2, augment=True, kps_left=KL, kps_right=KR, joints_left=KL, joints_right=KR,
+                             device="cpu")
+    assert gen.augment_enabled() is False and gen.num_frames() == 13      # the constructor's augment is ignored (:197)
+    for i, (cam, b3, b2) in enumerate(gen.next_epoch()):
+        assert cam.shape == (1, 9) and b3.shape == (1,) + p3[i].shape and np.array_equal(b2[0].numpy(), p2[i])
+    gen.set_augment(True)
+    for i, (cam, b3, b2) in enumerate(gen.next_epoch()):
+        for got, src in ((b2, p2[i]), (b3, p3[i])):
+            want = src.copy()
+            want[..., 0] *= -1
+            want[:, KL + KR] = want[:, KR + KL]
+            assert np.array_equal(got[0].numpy(), src) and np.array_equal(got[1].numpy(), want)
+        want_cam = np.array(cams[i])
+        want_cam[[2, 7]] *= -1
+        assert np.array_equal(cam[0], cams[i]) and np.array_equal(cam[1], want_cam)
+    for cam, b3, b2 in UnchunkedSequences(None, None, p2, device="cpu").next_epoch():
+        assert cam is None and b3 is None and b2.shape[0] == 1
