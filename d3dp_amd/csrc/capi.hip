@@ -161,8 +161,13 @@ struct d3dp_ctx {
   // workgroup per CU, so a tail round of a few tiles or a launch ramp leaves CUs idle that the other product's workgroups fill.
   // Forked and joined with events on the caller's stream (nothing synchronises the host); D3DP_TRAIN_OVERLAP=0 keeps one stream.
   hipStream_t aux = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_done[2] = {nullptr, nullptr};
   bool train_overlap = true;
+  int train_overlap_sets = 2;    // D3DP_TRAIN_OVERLAP=1: one operand set (every operand pass waits for the product before it)
+  bool train_gelu_in_prep = true;// D3DP_TRAIN_GELU=pass: d h_pre by a pass of its own (gelu_bwd_kernel) instead of inside the fc1 gradients' operand pass
+  bool train_wgrad_merged = true;// D3DP_TRAIN_WGRAD=each: a launch (and 32 MB of partial tiles) per weight gradient instead of one per block
+  bool train_tail_blocks = true; // D3DP_TRAIN_TAIL=split: the round-4 handling of a batch's last T mod 256 rows (an extra round of tiles,
+                                 // or a split-K launch of their own) instead of the 16 x 64 blocks at the end of the product's kernel
   int train_attn_x2 = 2;         // the training step's attention on the split-fp16 kernels of train_attn.hip: 2 = both axes (default),
                                  // 1 = D3DP_TRAIN_ATTN=x2t: the temporal axis only, 0 = D3DP_TRAIN_ATTN=f32: neither (the round-4
                                  // fp32 kernels -- fp32-MFMA temporal forward and backward, VALU spatial forward: the cross-check)
@@ -351,6 +356,33 @@ extern "C" {
 int d3dp_abi_version(void) { return D3DP_ABI_VERSION; }
 // test hook (not part of the ABI in include/d3dp_hip.h): 1 if this library carries the experiment kernels of gemm_x2.hip
 int d3dp_debug_x2_variants(void) { return d3dp_x2_variants_built() ? 1 : 0; }
+// test hook (not part of the ABI): the training step's split-fp16 Linear alone, out[M, N] = A[M, K] W[N, K]^T + bias on fp32
+// device operands -- absmax, operand passes and gemm_f16x2_dyn_kernel as the step launches them.  tail: 0 = the rows behind the
+// last whole 256-row tile as one more row of tiles, 1 = as 16 x 64 blocks at the end of the kernel.  amax_out: optional
+// pre-zeroed device slot (amax_pos: see kernels.h).  Allocates its operand buffers and synchronises the stream.
+int d3dp_debug_train_linear(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
+                            int32_t tail, unsigned* amax_out, int32_t amax_pos, void* stream) {
+  if (!A || !W || !out || M < 1 || N < 4 || N % 4 || K < 32 || K % 32) return fail(D3DP_EINVAL, "d3dp_debug_train_linear: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  char* buf = nullptr;
+  const size_t a_bytes = (size_t)M * K * 4, w_bytes = (size_t)N * K * 4;
+  HIP_TRY(hipMalloc((void**)&buf, a_bytes + w_bytes + 64));
+  unsigned* amax = reinterpret_cast<unsigned*>(buf + a_bytes + w_bytes);
+  float* uns = reinterpret_cast<float*>(amax + 8);
+  int rc = hipMemsetAsync(amax, 0, 64, st) == hipSuccess ? 0 : -3;
+  if (!rc) {
+    d3dp_launch_absmax(A, (size_t)M * K, amax, st);
+    d3dp_launch_absmax(W, (size_t)N * K, amax + 1, st);
+    d3dp_launch_split2_dyn(A, buf, M, K, K, amax, uns, st);
+    d3dp_launch_split2_dyn(W, buf + a_bytes, N, K, K, amax + 1, uns + 1, st);
+    rc = d3dp_launch_linear_f16x2_dyn(buf, buf + a_bytes, bias, uns, uns + 1, out, M, N, K, 1, st, amax_out, amax_pos, tail);
+  }
+  const hipError_t e = hipStreamSynchronize(st);
+  (void)hipFree(buf);
+  if (rc) return fail(rc == -3 ? D3DP_EHIP : D3DP_EINVAL, "d3dp_debug_train_linear: launch refused (%d)", rc);
+  if (e != hipSuccess) return fail(D3DP_EHIP, "d3dp_debug_train_linear: %s", hipGetErrorString(e));
+  return 0;
+}
 const char* d3dp_last_error(void) { return g_err.c_str(); }
 const char* d3dp_profile_class_name(int32_t cls) {
   return (cls >= 0 && cls < D3DP_PROFILE_CLASSES) ? kClassNames[cls] : "";
@@ -384,6 +416,13 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->train_x2 = !(ti && !strcmp(ti, "f32"));
   const char* ov = getenv("D3DP_TRAIN_OVERLAP");
   c->train_overlap = !(ov && ov[0] == '0');
+  c->train_overlap_sets = (ov && ov[0] == '1') ? 1 : 2;
+  const char* tg = getenv("D3DP_TRAIN_GELU");
+  c->train_gelu_in_prep = !(tg && !strcmp(tg, "pass"));
+  const char* tw = getenv("D3DP_TRAIN_WGRAD");
+  c->train_wgrad_merged = !(tw && !strcmp(tw, "each"));
+  const char* tt = getenv("D3DP_TRAIN_TAIL");
+  c->train_tail_blocks = !(tt && !strcmp(tt, "split"));
   const char* ta = getenv("D3DP_TRAIN_ATTN");
   c->train_attn_x2 = (ta && !strcmp(ta, "f32")) ? 0 : (ta && !strcmp(ta, "x2t")) ? 1 : 2;
   {
@@ -429,7 +468,8 @@ int d3dp_destroy(d3dp_ctx* c) {
   if (c->arena) (void)hipFree(c->arena);
   if (c->d_flag) (void)hipFree(c->d_flag);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  for (hipEvent_t e : c->ev_done)
+    if (e) (void)hipEventDestroy(e);
   if (c->aux) (void)hipStreamDestroy(c->aux);
   delete c;
   return D3DP_OK;
@@ -968,6 +1008,7 @@ struct TrainLayout {
   size_t xn, y, hid, dA, dB, dC, dqkv, dh, z, At, Xt, Wt, dtemb, stats;
   // split-fp16 operands of the training Linears (X2Train below): row form [rows][2 K] and transposed form [features][2 Tp]
   size_t op_a, op_w, op_at, op_xt, part, part_rem, slots;
+  size_t op_a2, op_at2, part2;      // a second set of the dY operand and partial-tile regions: two weight-gradient products in flight
   size_t x_cols, x_block;           // every Linear's activation operand kept from the forward pass for its wgrad: the ROW form [Tp][2 K]
                                     // where the TN kernel applies (it is then also the forward product's operand), else the transposed [K][2 Tp]
   size_t w_rows, w_cols, w_block;   // every weight's split operands (row form / transposed form), prepared once per step: w_block floats per block
@@ -1004,11 +1045,13 @@ TrainLayout train_layout(const d3dp_cfg& g, int B) {
   {
     const size_t fmax = std::max<size_t>(3 * L.C, L.Hd), kmax = std::max<size_t>(L.C, L.Hd);
     L.Tp_max = ((L.T + 31) / 32 + 64) * 32;          // (room for rounding the k-steps up to a multiple of the split count)
-    L.op_a = take(L.Tp_max * fmax);                  // [Tp][2 fmax] fp16 = Tp fmax floats (rows T .. Tp - 1: the TN wgrad's zero rows)
+    const size_t dy_all = 5 * L.C + L.Hd;            // the four dY of a block side by side (their weight gradients go out as ONE launch)
+    L.op_a = take(L.Tp_max * dy_all);                // [Tp][2 N] fp16 = Tp N floats per dY (rows T .. Tp - 1: the TN wgrad's zero rows)
     L.op_w = take(fmax * kmax);                      // [N][2 K] or [K][2 N] fp16
     L.op_at = take(fmax * L.Tp_max);                 // dY^T: [N][2 Tp] fp16
     L.op_xt = take(kmax * L.Tp_max);                 // X^T:  [K][2 Tp] fp16
     L.part = take((size_t)(1024 + 64) * 256 * 128);  // split-K partial products: at most ~ (CUs + tiles) output tiles
+    L.op_a2 = take(L.Tp_max * dy_all); L.op_at2 = take(fmax * L.Tp_max); L.part2 = take((size_t)(1024 + 64) * 256 * 128);
     L.part_rem = take((size_t)16 * 256 * fmax);      // ... of a forward / dgrad product's remainder rows (its own region: the
                                                      // weight-gradient product of the same dY runs concurrently on the second stream)
     L.slots = take(2 * 8192);                        // absmax words | 1 / scale per operand
@@ -1082,6 +1125,51 @@ struct X2Train {
   const TrainLayout& L;
   int n_cu;
   hipStream_t st_w = nullptr;                          // the weight-gradient products' stream (null: `st`)
+  bool tail_blocks = true;                             // d3dp_ctx::train_tail_blocks
+  // the dY operand (row form / transposed form) and the weight-gradient product's partial tiles live in one of two sets of
+  // regions: the backward pass alternates, so that the operand pass of the next dY need not wait for the product of this one
+  size_t o_a = 0, o_at = 0, o_part = 0, set_base = 0, set_used = 0;
+  void use_set(int s) {
+    set_base = o_a = s ? L.op_a2 : L.op_a; set_used = 0; n_def = 0;
+    o_at = s ? L.op_at2 : L.op_at; o_part = s ? L.part2 : L.part;
+  }
+  // The four weight gradients of a block as ONE launch (gemm_f16x2_tn_kernel's product table): each dY's operand pass takes the
+  // next region of the set, wgrad() only records its product, flush_wgrads() launches them and the sum of their partial tiles.
+  // On where every Linear of the block has a TN shape (merged_setup); mZ / mTp: split count and padded token count of the merged list.
+  bool merged = false;
+  int mZ = 1, mTp = 0, n_def = 0;
+  D3dpTnProduct def[D3DP_TN_MAX];
+  float* def_dw[D3DP_TN_MAX];
+  void merged_setup(int T, bool on) {
+    const int C = (int)L.C, Hd = (int)L.Hd;
+    const int shapes[4][2] = {{C, Hd}, {Hd, C}, {C, C}, {3 * C, C}};     // fc2, fc1, proj, qkv: [N, K] of dW
+    int tiles = 0;
+    bool ok = on;
+    size_t nk_sum = 0;
+    for (auto& sh : shapes) { ok = ok && d3dp_tn_applies(sh[0], sh[1]); tiles += ((sh[0] + 255) / 256) * ((sh[1] + 127) / 128); nk_sum += (size_t)sh[0] * sh[1]; }
+    const int nk = (T + 31) / 32;
+    mZ = std::max(1, std::min(std::min(n_cu / std::max(tiles, 1), 64), nk / 4));
+    mTp = mZ * ((nk + mZ - 1) / mZ) * 32;
+    merged = ok && (size_t)mTp <= L.Tp_max && (size_t)mZ * nk_sum <= (size_t)(1024 + 64) * 256 * 128;
+  }
+  // rows the operands of the weight gradient dW[N, K] must have (zero behind T)
+  int pad_rows(int T, int N, int K) const {
+    int Z, Tp;
+    wgrad_split(T, N, K, Z, Tp);
+    return merged ? std::max(Tp, mTp) : Tp;
+  }
+  int flush_wgrads() {
+    if (!n_def) return 0;
+    hipStream_t sw = st_w ? st_w : st;
+    int r = d3dp_launch_linear_f16x2_tn_many(def, n_def, mTp, mZ, sw);
+    if (r) return r;
+    D3dpSumTable tb{};
+    tb.n = n_def; tb.Z = mZ;
+    for (int i = 0; i < n_def; ++i) { tb.part[i] = def[i].out; tb.out[i] = def_dw[i]; tb.n4[i] = (size_t)def[i].N * def[i].K / 4; }
+    d3dp_launch_sum_partials_many(tb, sw);
+    n_def = 0;
+    return 0;
+  }
   // absmax / unscale slots: the forward pass owns slots 2 l (activation operand) and 2 l + 1 (weight) of its Linear l = 4 block
   // + {qkv, proj, fc1, fc2} and leaves them -- with the operands themselves: the weights' two forms and every activation's
   // transposed form -- for the backward pass of the same step, whose wgrad / dgrad read the same tensors: 128 of the step's
@@ -1146,6 +1234,9 @@ struct X2Train {
       if (nk % z == 0) Z = z;
     // (measured: a last round of a few tiles runs its k-steps at 0.75 us -- few CUs active, full clock -- against 1.4 us in a
     //  full round, so for 16 k-steps it costs 12 us, what the second launch and the sum cost too: split from 32 k-steps on)
+    // the remainder rows as 16 x 64 blocks at the end of the same launch (gemm_f16x2_dyn_kernel): wherever they would cost a round
+    if (tail_blocks && rem && q && rounds_all > rounds_full && nk % 16 == 0)
+      return d3dp_launch_linear_f16x2_dyn(A2, W2, bias, ua, uw, out, T, N, K, 1, st, out_amax, amax_pos, 1);
     if (rem == 0 || q == 0 || rounds_all == rounds_full || Z == 1 || nk < 32 || (size_t)Z * rem * N > (size_t)16 * 256 * std::max<size_t>(3 * L.C, L.Hd))
       return d3dp_launch_linear_f16x2_dyn(A2, W2, bias, ua, uw, out, T, N, K, 1, st, out_amax, amax_pos);
     int r = d3dp_launch_linear_f16x2_dyn(A2, W2, bias, ua, uw, out, q * 256, N, K, 1, st, out_amax, amax_pos);
@@ -1169,14 +1260,13 @@ struct X2Train {
     const int sa = 2 * l, sw = 2 * l + 1;
     if (l < 0 || sw >= kBwdSlot0) return -1;
     if (!a_amax_ready && !a_prepared) d3dp_launch_absmax(A, (size_t)T * K, amax() + sa, st);
-    const float* a2 = ws + L.op_a;
+    const float* a2 = ws + o_a;
     if (a_prepared) a2 = ws + L.x_cols + xoff(l);
     else {
       // the operand of this product and, in the same pass, what the wgrad of this Linear will want of it: the backward pass
       // then neither recomputes this activation (LayerNorm / GELU outputs) nor reads it again.  Where the TN wgrad kernel applies
       // that is the SAME row form (kept, zero rows behind T), else a second, transposed form.
-      int Z, Tp;
-      wgrad_split(T, N, K, Z, Tp);
+      const int Tp = pad_rows(T, N, K);
       if ((size_t)Tp > L.Tp_max) return -1;
       int r;
       if (ln_w) {
@@ -1186,7 +1276,7 @@ struct X2Train {
       } else if (d3dp_tn_applies(N, K)) {
         a2 = ws + L.x_cols + xoff(l);
         r = d3dp_launch_rowprep(A, ws + L.x_cols + xoff(l), nullptr, nullptr, T, Tp, K, amax() + sa, uns() + sa, st);
-      } else r = d3dp_launch_dyprep(A, ws + L.op_a, ws + L.x_cols + xoff(l), nullptr, T, K, Tp, amax() + sa, uns() + sa, st);
+      } else r = d3dp_launch_dyprep(A, ws + o_a, ws + L.x_cols + xoff(l), nullptr, T, K, Tp, amax() + sa, uns() + sa, st);
       if (r) return r;
     }
     const float* w2 = ws + L.op_w;
@@ -1202,19 +1292,18 @@ struct X2Train {
   bool gelu_operand_applies(int N, int K) const { return d3dp_tn_applies(N, K); }
   static constexpr int kPmaxSlot0 = 3072;              // forward range: slot kPmaxSlot0 + block = largest positive fc1 output
   int gelu_operand(int l, const float* hpre, int blk, int T, int N, int K) {
-    int Z, Tp;
-    wgrad_split(T, N, K, Z, Tp);
+    const int Tp = pad_rows(T, N, K);
     if ((size_t)Tp > L.Tp_max) return -1;
     return d3dp_launch_gelu_rowprep(hpre, ws + L.x_cols + xoff(l), T, Tp, K, amax() + kPmaxSlot0 + blk, amax() + 2 * l, uns() + 2 * l, st);
   }
   // dX[T, K] = dY[T, N] W[N, K]   (sdy: the absmax slot of dY, shared with wgrad; l: the forward Linear whose W this is)
   int dgrad(int l, const float* dY, int sdy, const float* W, float* dX, int T, int N, int K, unsigned* out_amax = nullptr) {
     const int sw = 2 * l + 1;
-    if (!dy_ready) rows(dY, T, N, ws + L.op_a, sdy);
+    if (!dy_ready) rows(dY, T, N, ws + o_a, sdy);
     const float* wt = ws + L.op_w;
     if (batched) wt = ws + L.w_cols + woff(l);         // (prepared by the forward pass of this step)
     else cols(W, N, K, N, ws + L.op_w, sw);            // W^T: [K][2 N]  (N % 32 == 0: the model's widths)
-    return gemm(ws + L.op_a, wt, nullptr, uns() + sdy, uns() + sw, dX, T, K, N, out_amax);
+    return gemm(ws + o_a, wt, nullptr, uns() + sdy, uns() + sw, dX, T, K, N, out_amax);
   }
   // split count / padded token count of the wgrad product dW[N, K] = dY^T X
   void wgrad_split(int T, int N, int K, int& Z, int& Tp) const {
@@ -1230,18 +1319,26 @@ struct X2Train {
   bool dy_ready = false;
   static constexpr int kBiasRows = D3DP_DYPREP_ROWS > D3DP_ROWPREP_ROWS ? D3DP_DYPREP_ROWS : D3DP_ROWPREP_ROWS;   // capacity of bias_part
   // (mask: the DropPath scales still to be applied to dY's rows -- TN shapes only, see mask_in_prep_applies)
+  // (gelu_pre: dY is d hidden and the Linear's dY is dY x gelu'(gelu_pre), formed by the operand pass; slot sdy then holds the
+  //  absmax of d hidden -- TN shapes the row pass takes only, see gelu_in_prep_applies)
   bool mask_in_prep_applies(int N, int K) const { return d3dp_tn_applies(N, K); }
+  bool gelu_in_prep_applies(int N, int K) const { return d3dp_tn_applies(N, K) && N <= 1536; }
   int prep_dy(const float* dY, int sdy, float* bias_part, int* bias_rows, int T, int N, int K, const float* mask = nullptr,
-              int axis = 0, int F = 1, int J = 1) {
-    int Z, Tp;
-    wgrad_split(T, N, K, Z, Tp);
+              int axis = 0, int F = 1, int J = 1, const float* gelu_pre = nullptr) {
+    const int Tp = pad_rows(T, N, K);
     if ((size_t)Tp > L.Tp_max) return -1;
+    if (merged) {                    // the next region of the set: the block's four dY stay until flush_wgrads()
+      if (set_used + L.Tp_max * (size_t)N > L.Tp_max * (5 * L.C + L.Hd)) return -1;
+      o_a = set_base + set_used;
+      set_used += L.Tp_max * (size_t)N;
+    }
     dy_ready = true;
     if (d3dp_tn_applies(N, K))       // the row form alone (zero rows behind T): dgrad's operand AND the TN wgrad's
-      return d3dp_launch_rowprep(dY, ws + L.op_a, bias_part, bias_rows, T, Tp, N, amax() + sdy, uns() + sdy, st, mask, axis, F, J);
-    if (mask) return -1;
+      return d3dp_launch_rowprep(dY, ws + o_a, bias_part, bias_rows, T, Tp, N, amax() + sdy, uns() + sdy, st, mask, axis, F, J,
+                                 gelu_pre);
+    if (mask || gelu_pre) return -1;
     *bias_rows = D3DP_DYPREP_ROWS;
-    return d3dp_launch_dyprep(dY, ws + L.op_a, ws + L.op_at, bias_part, T, N, Tp, amax() + sdy, uns() + sdy, st);
+    return d3dp_launch_dyprep(dY, ws + o_a, ws + o_at, bias_part, T, N, Tp, amax() + sdy, uns() + sdy, st);
   }
   // dW[N, K] = dY[T, N]^T X[T, K]   (X: the activation operand of forward Linear l)
   int wgrad(int l, const float* dY, int sdy, const float* X, float* dW, int T, int N, int K) {
@@ -1250,18 +1347,26 @@ struct X2Train {
     wgrad_split(T, N, K, Z, Tp);
     if ((size_t)Tp > L.Tp_max || (size_t)Z * N * K > (size_t)(1024 + 64) * 256 * 128) return -1;
     (void)X;                                           // X's operand form: left by the forward pass of this step
+    if (merged) {                                      // recorded; launched with the block's other three by flush_wgrads()
+      if (!dy_ready || n_def >= D3DP_TN_MAX || !d3dp_tn_applies(N, K)) return -1;
+      size_t po = 0;
+      for (int i = 0; i < n_def; ++i) po += (size_t)mZ * def[i].N * def[i].K;
+      def[n_def] = D3dpTnProduct{ws + o_a, ws + L.x_cols + xoff(l), uns() + sdy, uns() + sx, ws + o_part + po, N, K, 0, 0};
+      def_dw[n_def++] = dW;
+      return 0;
+    }
     int r;
     hipStream_t sw = st_w ? st_w : st;
     if (d3dp_tn_applies(N, K)) {                        // both operands in their row forms [Tp][2 .]: nothing was transposed
       if (!dy_ready) return -1;
-      r = d3dp_launch_linear_f16x2_tn(ws + L.op_a, ws + L.x_cols + xoff(l), uns() + sdy, uns() + sx, ws + L.part, N, K, Tp, Z, sw);
+      r = d3dp_launch_linear_f16x2_tn(ws + o_a, ws + L.x_cols + xoff(l), uns() + sdy, uns() + sx, ws + o_part, N, K, Tp, Z, sw);
     } else {
       if (!dy_ready) return -1;                         // (the transposed form: left by prep_dy)
-      r = d3dp_launch_linear_f16x2_dyn(ws + L.op_at, ws + L.x_cols + xoff(l), nullptr, uns() + sdy, uns() + sx, ws + L.part, N, K,
+      r = d3dp_launch_linear_f16x2_dyn(ws + o_at, ws + L.x_cols + xoff(l), nullptr, uns() + sdy, uns() + sx, ws + o_part, N, K,
                                        Tp, Z, sw);
     }
     if (r) return r;
-    d3dp_launch_sum_partials(ws + L.part, dW, (size_t)N * K, Z, sw);
+    d3dp_launch_sum_partials(ws + o_part, dW, (size_t)N * K, Z, sw);
     return 0;
   }
 };
@@ -1290,6 +1395,9 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
   const int T = (int)L.T, C = g.channels, F = g.frames, J = g.joints, Hd = g.hidden;
   float *xn = ws + L.xn, *y = ws + L.y, *hid = ws + L.hid;
   X2Train x2{st, ws, L, c->n_cu};
+  x2.use_set(0);
+  x2.tail_blocks = c->train_tail_blocks;
+  x2.merged_setup(T, c->train_wgrad_merged);
   const bool use_x2 = c->train_x2 && C % 32 == 0 && Hd % 32 == 0;
   if (use_x2) {
     LAUNCH_TRY(x2.begin(true));
@@ -1407,6 +1515,9 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
         *dh = ws + L.dh, *At = ws + L.At, *Xt = ws + L.Xt, *Wt = ws + L.Wt;
 
   X2Train x2{st, ws, L, c->n_cu};
+  x2.use_set(0);
+  x2.tail_blocks = c->train_tail_blocks;
+  x2.merged_setup(T, c->train_wgrad_merged);
   const bool use_x2 = c->train_x2 && C % 32 == 0 && Hd % 32 == 0;
   if (use_x2) {
     LAUNCH_TRY(x2.begin(false));
@@ -1417,15 +1528,21 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
   if (overlap && !c->aux) {
     HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    for (hipEvent_t& e : c->ev_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
-  bool forked = false;                                   // a weight-gradient product may still be running on c->aux
-  auto join = [&]() -> int {                             // the caller's stream waits for it (before op_a / the partial tiles are reused)
-    if (!forked) return 0;
-    forked = false;
-    if (hipEventRecord(c->ev_join, c->aux) != hipSuccess || hipStreamWaitEvent(st, c->ev_join, 0) != hipSuccess) return -3;
-    return 0;
+  // Up to two weight-gradient products are in flight on c->aux, each with its own operand / partial-tile set (X2Train::use_set):
+  // product k takes set k & 1 and the caller's stream waits for product k - 2 before the operand pass overwrites that set -- not
+  // for product k - 1, which goes on beside the dgrad product and the row kernels of this dY.  D3DP_TRAIN_OVERLAP=1: one set,
+  // every operand pass waits for the product before it (the first form of this overlap).
+  bool pending[2] = {false, false};
+  int n_wgrad = 0, cur_set = 0;
+  const int n_sets = c->train_overlap_sets;
+  auto wait_set = [&](int s) -> int {                    // the caller's stream waits for the product that last used set s
+    if (!pending[s]) return 0;
+    pending[s] = false;
+    return hipStreamWaitEvent(st, c->ev_done[s], 0) == hipSuccess ? 0 : -3;
   };
+  auto join = [&]() -> int { int r = wait_set(0); return r ? r : wait_set(1); };
   const bool attn_x2 = use_x2 && c->train_attn_x2 > 0 && C / g.heads == 64 && F <= 256;   // (as the forward pass of this step)
   const bool attn_x2_s = attn_x2 && c->train_attn_x2 > 1;
   Reducer red{ws + L.red, L.red_floats, 0, st};
@@ -1449,8 +1566,9 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
   // (dbias: the Linear's bias gradient = column sums of dY, left as partial rows and summed at the end)
   // (pre_slot >= 0: the kernel that produced dY left its absmax there)
   // (mk / mk_axis: DropPath scales the operand pass still has to apply to dY's rows -- then dY is the UNSCALED gradient)
+  // (gelu_pre: dY is d hidden, the Linear's dY is dY x gelu'(gelu_pre) and pre_slot holds the absmax of d hidden: split-fp16 path)
   auto wgrad = [&](int l, const float* dY, int N, const float* X, int K, float* dW, float* dbias, int pre_slot = -1,
-                   const float* mk = nullptr, int mk_axis = 0) -> int {
+                   const float* mk = nullptr, int mk_axis = 0, const float* gelu_pre = nullptr) -> int {
     int r;
     if (use_x2) {
       sdy = pre_slot >= 0 ? pre_slot : x2.slot_for(dY, (size_t)T * N);
@@ -1458,19 +1576,44 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
       float* bp = red.take((size_t)X2Train::kBiasRows * N);
       int brows = 0;
       if (!bp) return -1;
-      if ((r = join())) return r;                        // the previous weight-gradient product is done with op_a and the partial tiles
-      if ((r = x2.prep_dy(dY, sdy, bp, &brows, T, N, K, mk, mk_axis, F, J))) return r;
-      red.add(bp, dbias, N, brows, N);
-      if (overlap) {
-        if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->aux, c->ev_fork, 0) != hipSuccess) return -3;
-        x2.st_w = c->aux;
-        forked = true;
+      if (x2.merged) {
+        // one launch per block: l = 4 block + {3, 2, 1, 0} arrive in this order; the set changes with the block
+        if ((l & 3) == 3) {
+          cur_set = overlap ? (n_wgrad++ % n_sets) : 0;
+          if ((r = wait_set(cur_set))) return r;         // the block that last used this set is done with its operands and partial tiles
+          x2.use_set(cur_set);
+        }
+        if ((r = x2.prep_dy(dY, sdy, bp, &brows, T, N, K, mk, mk_axis, F, J, gelu_pre))) return r;
+        red.add(bp, dbias, N, brows, N);
+        if ((r = x2.wgrad(l, dY, sdy, X, dW, T, N, K))) return r;      // (recorded)
+        if ((l & 3) != 0) return 0;
+        if (overlap) {
+          if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->aux, c->ev_fork, 0) != hipSuccess) return -3;
+          x2.st_w = c->aux;
+        }
+        if ((r = x2.flush_wgrads())) return r;
+        if (overlap) {
+          if (hipEventRecord(c->ev_done[cur_set], c->aux) != hipSuccess) return -3;
+          pending[cur_set] = true;
+        }
+        return 0;
       }
-      return x2.wgrad(l, dY, sdy, X, dW, T, N, K);
+      const int set = overlap ? (n_wgrad++ % n_sets) : 0;
+      if ((r = wait_set(set))) return r;                 // the product that last used this set is done with its operand and partial tiles
+      x2.use_set(set);
+      if ((r = x2.prep_dy(dY, sdy, bp, &brows, T, N, K, mk, mk_axis, F, J, gelu_pre))) return r;
+      red.add(bp, dbias, N, brows, N);
+      if (!overlap) return x2.wgrad(l, dY, sdy, X, dW, T, N, K);
+      if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->aux, c->ev_fork, 0) != hipSuccess) return -3;
+      x2.st_w = c->aux;
+      if ((r = x2.wgrad(l, dY, sdy, X, dW, T, N, K))) return r;
+      if (hipEventRecord(c->ev_done[set], c->aux) != hipSuccess) return -3;
+      pending[set] = true;
+      return 0;
     }
     float* bp = red.take((size_t)D3DP_DYPREP_ROWS * N);
     int rows = 0;
-    if (!bp || mk) return -1;
+    if (!bp || mk || gelu_pre) return -1;
     if ((r = d3dp_train_colsum(dY, bp, &rows, D3DP_DYPREP_ROWS, T, N, st))) return r;
     red.add(bp, dbias, N, rows, N);
     if ((r = d3dp_train_transpose_pad(dY, At, T, N, Tp, st))) return r;
@@ -1532,12 +1675,15 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     // ---- MLP branch ----
     if (!use_x2) LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, nullptr, st));   // (x2: wgrad reads the forward pass' operand)
     LAUNCH_TRY(wgrad(4 * blk + 3, dy, C, hid, Hd, G(gw.fc2_w), G(gw.fc2_b), ps_next, dy_mask, kind));
-    LAUNCH_TRY(dgrad(4 * blk + 3, dy, C, (const float*)w.fc2_w, Hd, dh));                                               // d hidden
     {
+      // d hidden = dy W_fc2; d h_pre = d hidden x gelu'(h_pre).  Split-fp16 path: the product is formed by the operand pass of
+      // the fc1 gradients (the only reader of d h_pre), from the absmax of d hidden the fc2 dgrad's epilogue leaves
+      const bool gip = use_x2 && c->train_gelu_in_prep && x2.gelu_in_prep_applies(Hd, C);
       D3DP_FRESH(ps, pa)
-      LAUNCH_TRY(d3dp_train_gelu_bwd(dh, S + L.o_hpre, dh, (size_t)T * Hd, pa, st));                       // d h_pre
+      LAUNCH_TRY(dgrad(4 * blk + 3, dy, C, (const float*)w.fc2_w, Hd, dh, gip ? pa : nullptr));                         // d hidden
+      if (!gip) LAUNCH_TRY(d3dp_train_gelu_bwd(dh, S + L.o_hpre, dh, (size_t)T * Hd, pa, st));             // d h_pre
       if (!use_x2) LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xmid, w.n2w, w.n2b, g.eps_block, nullptr, F, J, xn, T, C, st));   // xn2
-      LAUNCH_TRY(wgrad(4 * blk + 2, dh, Hd, xn, C, G(gw.fc1_w), G(gw.fc1_b), ps));
+      LAUNCH_TRY(wgrad(4 * blk + 2, dh, Hd, xn, C, G(gw.fc1_w), G(gw.fc1_b), ps, nullptr, 0, gip ? S + L.o_hpre : nullptr));
       LAUNCH_TRY(dgrad(4 * blk + 2, dh, Hd, (const float*)w.fc1_w, C, dC));                                             // d xn2
     }
     // norm2 backward + the residual: dA = d x_mid; its DropPath-scaled form (the proj dY) over dC

@@ -75,6 +75,14 @@ __device__ __forceinline__ float gelu_erf_rational(float x) {
   return fmaf(hx, e, hx);
 }
 
+// d GELU(v) / dv = Phi(v) + v phi(v) on the same rational erf; |.| <= 1.1290 (at v = sqrt 2)
+__device__ __forceinline__ float gelu_grad_rational(float v) {
+  const float cdf = fmaf(0.5f, erf_rational(v * 0.70710678118654752440f), 0.5f);
+  const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(v * v * -0.72134752044448170368f);   // exp(-v^2 / 2) = 2^(-v^2 log2(e) / 2)
+  return fmaf(v, pdf, cdf);
+}
+constexpr float kGeluGradMax = 1.13f;                  // (bound used for operand scales: dh gelu'(h) from the absmax of dh)
+
 // two elements at a time on the packed fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32): the same arithmetic per
 // element, half the instructions for the polynomials -- for epilogues, where no MFMA is in flight to be disturbed by them
 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -1429,7 +1429,8 @@ __global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restri
                                                              const float* __restrict__ bias, const float* __restrict__ dynA,
                                                              const float* __restrict__ dynW, float* __restrict__ out, int M,
                                                              int N, int Kfull, int NKz, int tiles_n, int tiles_per_z,
-                                                             int total_items, unsigned* __restrict__ amax_out, int amax_pos) {
+                                                             int total_items, unsigned* __restrict__ amax_out, int amax_pos,
+                                                             int rem_m0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int G = gridDim.x;
   const int L = xcd_remap(blockIdx.x, G);
@@ -1438,6 +1439,9 @@ __global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restri
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (gtot <= 0) return;
+  // remainder rows (rem_m0 > 0, Z = 1): blocks of 16 rows x 64 columns, block b to workgroup b mod G -- see the end of the kernel
+  const int rem_cg = (N + 63) >> 6;
+  const int rem_blocks = rem_m0 > 0 ? ((M - rem_m0 + 15) >> 4) * rem_cg : 0;
 
   if (wave >= XNCW) {
     const int lw = wave - XNCW;
@@ -1481,6 +1485,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restri
       X2_BARRIER();
       if (g + 2 < gtot) issue();
     }
+    for (int b = L; b < rem_blocks; b += G) { X2_BARRIER(); X2_BARRIER(); }   // (the compute waves' remainder blocks below)
     if (amax_out) X2_BARRIER();                        // (the compute waves' absmax hand-over below)
     return;
   }
@@ -1548,6 +1553,86 @@ __global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restri
         }
     }
   }
+  // The remainder rows.  The configs[4] batch has M = 16,524 = 64 x 256 + 140 rows: as a 65th row of 256 x 128 tiles the last 140
+  // rows cost every forward / dgrad product a whole extra round of the persistent loop with 4 - 12 of the 256 CUs busy (12 us
+  // of a 35 - 70 us product; round 4 sent them to a second, split-K launch plus a sum kernel where the contraction was long
+  // enough -- no cheaper).  Here the tiles cover the first rem_m0 = 256 q rows only -- a whole number of rounds when q x tiles_n is
+  // a multiple of the CU count, as 64 x {4, 8, 12} is -- and the rows behind them are cut into 16 x 64 blocks, one per workgroup
+  // (140 rows x 512 .. 1536 columns: 72 .. 216 blocks, every CU busy once more for a few microseconds): the eight compute waves
+  // split the contraction (NKz / 8 k-steps each, fragments straight from global memory -- 64 KiB per block, no LDS staging),
+  // exchange their partial accumulators through LDS and wave 0 adds them in wave order (deterministic), applies scale and bias
+  // and stores.  Same MFMA triple per k-step as the tiles, same fp32 accumulation: the only difference to a tile's result is the
+  // grouping of the k-steps into eight partial sums.
+  if (rem_blocks > 0) {
+    const int ksw = NKz / XNCW;                        // k-steps per wave (launcher: NKz % 16 == 0, so an even number)
+    f32x4* xch = reinterpret_cast<f32x4*>(smem);
+#pragma unroll 1
+    for (int b = L; b < rem_blocks; b += G) {
+      const int m0 = rem_m0 + (b / rem_cg) * 16, nb0 = (b % rem_cg) * 64;
+      const size_t kofs = (size_t)wave * ksw * (2 * XBK) + fg * 8;
+      const f16* ap = A2 + (size_t)min(m0 + fi, M - 1) * (2 * Kfull) + kofs;
+      const f16* wp[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) wp[ni] = W2 + (size_t)min(nb0 + 4 * fi + ni, N - 1) * (2 * Kfull) + kofs;
+      f32x4 pacc[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) pacc[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int ks = 0; ks < ksw; ks += 2) {
+        f16x8 ah[2], al[2], wh[2][4], wl[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int o = (ks + u) * (2 * XBK);
+          ah[u] = *reinterpret_cast<const f16x8*>(ap + o);
+          al[u] = *reinterpret_cast<const f16x8*>(ap + o + XBK);
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            wh[u][ni] = *reinterpret_cast<const f16x8*>(wp[ni] + o);
+            wl[u][ni] = *reinterpret_cast<const f16x8*>(wp[ni] + o + XBK);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) pacc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], wl[u][ni], pacc[ni], 0, 0, 0);
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) pacc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], wh[u][ni], pacc[ni], 0, 0, 0);
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) pacc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], wh[u][ni], pacc[ni], 0, 0, 0);
+        }
+      }
+      X2_BARRIER();                                    // nobody reads the ring (or the previous block's partial sums) any more
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) xch[(wave * 4 + ni) * 64 + lane] = pacc[ni];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      X2_BARRIER();
+      if (wave == 0) {
+        f32x4 sum[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          sum[ni] = xch[ni * 64 + lane];
+#pragma unroll
+          for (int w = 1; w < XNCW; ++w) sum[ni] += xch[(w * 4 + ni) * 64 + lane];
+        }
+        const int nb = nb0 + 4 * fi;
+        if (nb < N) {
+          float4 bz = {0.f, 0.f, 0.f, 0.f};
+          if (bias != nullptr) bz = *reinterpret_cast<const float4*>(bias + nb);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * fg + r;
+            if (m < M) {
+              const f32x4 v = {fmaf(sum[0][r], unscale, bz.x), fmaf(sum[1][r], unscale, bz.y), fmaf(sum[2][r], unscale, bz.z),
+                               fmaf(sum[3][r], unscale, bz.w)};
+              *reinterpret_cast<f32x4*>(out + (size_t)m * N + nb) = v;
+              am = amax_pos ? fmaxf(am, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])))
+                            : fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            }
+          }
+        }
+      }
+    }
+  }
   if (amax_out) {                                      // (uniform: a kernel argument)
     float* part = reinterpret_cast<float*>(smem + XNSTAGE * XSTAGE);   // behind the ring, which slower waves may still be reading
     am = wave_max(am);
@@ -1580,14 +1665,24 @@ __global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restri
 // Rows T .. Tp - 1 of both operands must exist and be ZERO (dyprep_kernel writes them).  Output: a lane holds
 // out[n = .. + 4 g + r][k = .. + 16 ni + i] -- 4-byte stores, 64 contiguous bytes per 16 lanes; the partial tiles are small (N K
 // floats per chunk) and summed by sum_partials_kernel.
-__global__ __launch_bounds__(768) void gemm_f16x2_tn_kernel(const f16* __restrict__ A2, const f16* __restrict__ W2,
-                                                            const float* __restrict__ dynA, const float* __restrict__ dynW,
-                                                            float* __restrict__ out, int N, int K, int NKz, int tiles_k,
-                                                            int tiles_per_z, int total_items) {
+// Several products in one launch (D3dpTnTable, kernels.h): the four weight gradients of a block -- fc2, fc1, proj, qkv: 8 + 16 + 16 +
+// 24 = 64 output tiles at configs[4] -- contract over the SAME token rows, so their tiles form one list and the split count is
+// chosen for the list: Z = 4 chunks of 130 k-steps x 64 tiles = 256 equal work items, one per CU.  Launched one by one each
+// product had to be cut into Z = 10 .. 32 chunks to fill the chip by itself: 32 MB of partial tiles written and read again per
+// product (one 128 KiB tile per CU whatever the shape) and a pipeline ramp and a store phase per 17 .. 52 k-steps -- together about
+// as long as the products' matrix work.  Merged, a block writes 32 MB of partial tiles ONCE and ramps once per 130 k-steps.
+__device__ __forceinline__ int tn_find(const D3dpTnTable& tb, int t) {
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < D3DP_TN_MAX; ++j)
+    if (j < tb.n && t >= tb.p[j].tile0) i = j;
+  return i;
+}
+__global__ __launch_bounds__(768) void gemm_f16x2_tn_kernel(D3dpTnTable tb, int NKz, int tiles_per_z, int total_items) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int G = gridDim.x;
   const int L = xcd_remap(blockIdx.x, G);
-  const int n_my = (total_items - L + G - 1) / G;      // work items L, L+G, ...: item = z tiles_per_z + tile
+  const int n_my = (total_items - L + G - 1) / G;      // work items L, L+G, ...: item = z tiles_per_z + tile (of the merged list)
   const int gtot = n_my * NKz;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1603,14 +1698,16 @@ __global__ __launch_bounds__(768) void gemm_f16x2_tn_kernel(const f16* __restric
     auto issue = [&]() {
       if (ks == 0) {
         const int item = L + ti * G;
-        const int z = item / tiles_per_z, t = item - z * tiles_per_z;
-        const int n0 = (t / tiles_k) * XBM, k0 = (t % tiles_k) * XBN;
+        const int z = item / tiles_per_z, tt = item - z * tiles_per_z;
+        const D3dpTnProduct& P = tb.p[tn_find(tb, tt)];
+        const int t = tt - P.tile0;
+        const int n0 = (t / P.tiles_k) * XBM, k0 = (t % P.tiles_k) * XBN;
         const size_t t0 = (size_t)z * NKz * XBK;       // first token row of the chunk
-        a_row = (size_t)2 * N; w_row = (size_t)2 * K;
+        a_row = (size_t)2 * P.N; w_row = (size_t)2 * P.K;
         // A piece i = token row lw 8 + i of the k-step (1 KiB: features n0 .. n0 + 255); lane l fetches logical slot l ^ swz
         // (N % 256 == 0 and K % 128 == 0: the launcher sends other shapes to the kernel above)
-        pa = A2 + (t0 + lw * 8) * a_row + (size_t)n0 * 2;
-        pw = W2 + (t0 + lw * 8) * w_row + (size_t)k0 * 2;
+        pa = (const f16*)P.A2 + (t0 + lw * 8) * a_row + (size_t)n0 * 2;
+        pw = (const f16*)P.W2 + (t0 + lw * 8) * w_row + (size_t)k0 * 2;
       }
       char* base = smem + slot * XSTAGE;
       const size_t ro = (size_t)ks * XBK;              // token rows into the chunk
@@ -1660,7 +1757,6 @@ __global__ __launch_bounds__(768) void gemm_f16x2_tn_kernel(const f16* __restric
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) { offA[m][pl] = a_off(m, pl); offW[m][pl] = w_off(m, pl); }
-  const float unscale = dynA[0] * dynW[0];
   __builtin_amdgcn_s_setprio(1);
   int slot = 0;
 #pragma unroll 1
@@ -1695,9 +1791,12 @@ __global__ __launch_bounds__(768) void gemm_f16x2_tn_kernel(const f16* __restric
     }
     // epilogue: lane holds out[nn = n0 + wr 64 + mi 16 + 4 fg + r][kk = k0 + wc 64 + ni 16 + fi]
     const int item = L + ti * G;
-    const int z = item / tiles_per_z, t = item - z * tiles_per_z;
-    const int n0 = (t / tiles_k) * XBM, k0 = (t % tiles_k) * XBN;
-    float* o = out + (size_t)z * N * K + (size_t)(n0 + wr * 64 + 4 * fg) * K + k0 + wc * 64 + fi;
+    const int z = item / tiles_per_z, tt = item - z * tiles_per_z;
+    const D3dpTnProduct& P = tb.p[tn_find(tb, tt)];
+    const int t = tt - P.tile0, K = P.K;
+    const int n0 = (t / P.tiles_k) * XBM, k0 = (t % P.tiles_k) * XBN;
+    const float unscale = P.dynA[0] * P.dynW[0];
+    float* o = P.out + (size_t)z * P.N * K + (size_t)(n0 + wr * 64 + 4 * fg) * K + k0 + wc * 64 + fi;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -1867,13 +1966,18 @@ __global__ __launch_bounds__(256) void dyprep_kernel(const float* __restrict__ s
 // dyprep_kernel, whose 128-byte pieces land 66 KB apart.  C % 512 == 0 or C <= 512 with C % 8 == 0 (P = ceil(C / 512) passes).
 // mask (optional): per-sample DropPath scales -- row r is multiplied by mask[sample(r)] first (sample = r / J on the spatial
 // axis, (r / (F J)) J + r % J on the temporal one): the backward pass then never stores the scaled gradient, only its absmax.
-template <int P>
+// GELU (gelu_pre [R][C]: the fc1 output of the forward pass): src is d hidden and the operand is d h_pre = src x gelu'(gelu_pre),
+// formed here instead of by a pass of its own (gelu_bwd_kernel: a read of both tensors and a write of the product that only this
+// kernel read again).  `amax` then holds the absmax of SRC (left by the fc2 dgrad's epilogue) and the operand scale follows
+// from the bound |gelu'| <= 1.13: at most one binade below the scale of the true absmax whenever the largest |src| sits where
+// gelu' >= 0.57, and never an overflow -- the two fp16 planes keep 22 bits below whatever power of two is chosen.
+template <int P, bool GELU>
 __global__ __launch_bounds__(256) void rowprep_kernel(const float* __restrict__ s, f16* __restrict__ drow, float* __restrict__ colpart,
                                                       int R, int Rpad, int C, const unsigned* __restrict__ amax,
                                                       float* __restrict__ unscale, const float* __restrict__ mask, int axis, int F,
-                                                      int J) {
+                                                      int J, const float* __restrict__ gelu_pre) {
   __shared__ float cs[4][P * 512];
-  const float sc = dyn_scale(amax[0]);
+  const float sc = GELU ? dyn_scale(__float_as_uint(__uint_as_float(amax[0]) * kGeluGradMax)) : dyn_scale(amax[0]);
   if (blockIdx.x == 0 && threadIdx.x == 0) unscale[0] = 1.0f / sc;
   const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
   float acc[P][8];
@@ -1884,16 +1988,21 @@ __global__ __launch_bounds__(256) void rowprep_kernel(const float* __restrict__ 
   constexpr int U = P == 1 ? 4 : 2;                    // rows per wave and iteration: 8 loads of 16 bytes in flight per thread
   const int rstep = gridDim.x * 4;
   for (int r0 = blockIdx.x * 4 + rl; r0 < Rpad; r0 += rstep * U) {
-    float4 a[U][P], b[U][P];
+    float4 a[U][P], b[U][P], ga[GELU ? U : 1][P], gb[GELU ? U : 1][P];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int p = 0; p < P; ++p) {
         const int r = r0 + u * rstep, c = p * 512 + l * 8;
         a[u][p] = make_float4(0.f, 0.f, 0.f, 0.f); b[u][p] = a[u][p];
+        if constexpr (GELU) { ga[u][p] = a[u][p]; gb[u][p] = a[u][p]; }
         if (r < R && c < C) {
           a[u][p] = *reinterpret_cast<const float4*>(s + (size_t)r * C + c);
           b[u][p] = *reinterpret_cast<const float4*>(s + (size_t)r * C + c + 4);
+          if constexpr (GELU) {
+            ga[u][p] = *reinterpret_cast<const float4*>(gelu_pre + (size_t)r * C + c);
+            gb[u][p] = *reinterpret_cast<const float4*>(gelu_pre + (size_t)r * C + c + 4);
+          }
         }
       }
 #pragma unroll
@@ -1904,8 +2013,13 @@ __global__ __launch_bounds__(256) void rowprep_kernel(const float* __restrict__ 
         if (r < Rpad && c < C) {
           float mk = 1.0f;
           if (mask && r < R) mk = mask[axis == 0 ? r / J : (r / (F * J)) * J + r % J];
-          const float v[8] = {a[u][p].x * mk, a[u][p].y * mk, a[u][p].z * mk, a[u][p].w * mk,
-                              b[u][p].x * mk, b[u][p].y * mk, b[u][p].z * mk, b[u][p].w * mk};
+          float v[8] = {a[u][p].x * mk, a[u][p].y * mk, a[u][p].z * mk, a[u][p].w * mk,
+                        b[u][p].x * mk, b[u][p].y * mk, b[u][p].z * mk, b[u][p].w * mk};
+          if constexpr (GELU) {
+            const float g[8] = {ga[u][p].x, ga[u][p].y, ga[u][p].z, ga[u][p].w, gb[u][p].x, gb[u][p].y, gb[u][p].z, gb[u][p].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_rational(g[e]);
+          }
           f16x8 hi, lo;
 #pragma unroll
           for (int e = 0; e < 8; ++e) { acc[p][e] += v[e]; f16 h, lw; split2h_scaled(v[e] * sc, h, lw); hi[e] = h; lo[e] = lw; }
@@ -2118,10 +2232,49 @@ __global__ __launch_bounds__(256) void wprep_cols_kernel(D3dpWPrepTable tb, f16*
 }
 
 // out[i] = sum_z part[z n + i] in the order z = 0, 1, ... (the deterministic end of a split-K product)
-__global__ void sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int Z) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    float a = part[i];
-    for (int z = 1; z < Z; ++z) a += part[(size_t)z * n + i];
+// A thread owns four consecutive outputs (n % 4 == 0) and keeps eight partials in flight: the partial tiles of a weight gradient
+// are 32 MB (one 256 x 128 tile per CU) whatever its shape, and the one-load-at-a-time form of this kernel read them at 1.9 TB/s.
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float4* __restrict__ part, float4* __restrict__ out, size_t n4, int Z) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4* p = part + i;
+    float4 a = p[0];
+    int z = 1;
+    for (; z + 8 <= Z; z += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(z + u) * n4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
+    for (; z < Z; ++z) {
+      const float4 v = p[(size_t)z * n4];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    out[i] = a;
+  }
+}
+
+// the same for up to D3DP_TN_MAX products at once (blockIdx.y = the product; Z partials each, as d3dp_launch_linear_f16x2_tn_many leaves them)
+__global__ __launch_bounds__(256) void sum_partials_many_kernel(D3dpSumTable tb) {
+  const float4* part = reinterpret_cast<const float4*>(tb.part[blockIdx.y]);
+  float4* out = reinterpret_cast<float4*>(tb.out[blockIdx.y]);
+  const size_t n4 = tb.n4[blockIdx.y];
+  const int Z = tb.Z;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4* p = part + i;
+    float4 a = p[0];
+    int z = 1;
+    for (; z + 4 <= Z; z += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(z + u) * n4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
+    for (; z < Z; ++z) {
+      const float4 v = p[(size_t)z * n4];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
     out[i] = a;
   }
 }
@@ -2409,10 +2562,13 @@ void d3dp_launch_fold_ln(const float* W, const float* gamma, const float* beta, 
 // ---- training-step launchers (gemm_f16x2_dyn_kernel and its operand kernels) ---------------------------------------
 // out_z[M, N] = A2 (chunk z) . W2 (chunk z)^T x dynA x dynW (+ bias): Kfull = Z NKz 32 columns per operand row
 int d3dp_launch_linear_f16x2_dyn(const void* A2, const void* W2, const float* bias, const float* dynA, const float* dynW,
-                                 float* out, int M, int N, int Kfull, int Z, hipStream_t st, unsigned* amax_out, int amax_pos) {
+                                 float* out, int M, int N, int Kfull, int Z, hipStream_t st, unsigned* amax_out, int amax_pos,
+                                 int rem_blocks) {
   if (M <= 0 || N % 4 != 0 || Z < 1 || Kfull % (XBK * Z) != 0 || (amax_out && Z != 1)) return -1;
   const int NKz = Kfull / XBK / Z;
-  const int tm = (M + XBM - 1) / XBM, tn = (N + XBN - 1) / XBN;
+  // rem_blocks: the rows behind the last whole 256-row tile as 16 x 64 blocks at the end of the kernel (see there)
+  const bool rem = rem_blocks && Z == 1 && M > XBM && M % XBM != 0 && NKz % (2 * XNCW) == 0;
+  const int tm = rem ? M / XBM : (M + XBM - 1) / XBM, tn = (N + XBN - 1) / XBN;
   static PerDeviceOnce once;
   const int cus = once.get([&](int dev) {
     return d3dp_lds_opt_in(reinterpret_cast<const void*>(gemm_f16x2_dyn_kernel), XNSTAGE * XSTAGE + 64) < 0 ? -3 : d3dp_cu_count(dev);
@@ -2420,7 +2576,8 @@ int d3dp_launch_linear_f16x2_dyn(const void* A2, const void* W2, const float* bi
   if (cus < 0) return -3;
   const int items = tm * tn * Z, grid = items < cus ? items : cus;
   hipLaunchKernelGGL(gemm_f16x2_dyn_kernel, dim3(grid), dim3((XNCW + 4) * 64), XNSTAGE * XSTAGE + 64, st, (const f16*)A2,
-                     (const f16*)W2, bias, dynA, dynW, out, M, N, Kfull, NKz, tn, tm * tn, items, amax_out, amax_pos);
+                     (const f16*)W2, bias, dynA, dynW, out, M, N, Kfull, NKz, tn, tm * tn, items, amax_out, amax_pos,
+                     rem ? tm * XBM : 0);
   return 0;
 }
 
@@ -2457,7 +2614,7 @@ int d3dp_launch_rowprep_ln(const float* src, const float* w, const float* b, flo
 }
 
 int d3dp_launch_rowprep(const float* src, void* drow, float* colpart, int* rows, int R, int Rpad, int C, const unsigned* amax,
-                        float* unscale, hipStream_t st, const float* mask, int axis, int F, int J) {
+                        float* unscale, hipStream_t st, const float* mask, int axis, int F, int J, const float* gelu_pre) {
   if (C % 8 != 0 || Rpad < R || C > 1536 || (C > 512 && C % 512 != 0)) return -1;
   int g = (Rpad + 3) / 4;
   const int cap = colpart ? D3DP_ROWPREP_ROWS : 1024;   // (every workgroup leaves one partial row of column sums)
@@ -2466,9 +2623,13 @@ int d3dp_launch_rowprep(const float* src, void* drow, float* colpart, int* rows,
   const int P = (C + 511) / 512;
   f16* d = (f16*)drow;
   if (mask && (J < 1 || F < 1)) return -1;
-  if (P == 1) hipLaunchKernelGGL((rowprep_kernel<1>), dim3(g), dim3(256), 0, st, src, d, colpart, R, Rpad, C, amax, unscale, mask, axis, F, J);
-  else if (P == 2) hipLaunchKernelGGL((rowprep_kernel<2>), dim3(g), dim3(256), 0, st, src, d, colpart, R, Rpad, C, amax, unscale, mask, axis, F, J);
-  else hipLaunchKernelGGL((rowprep_kernel<3>), dim3(g), dim3(256), 0, st, src, d, colpart, R, Rpad, C, amax, unscale, mask, axis, F, J);
+#define D3DP_ROWPREP(PP, GG) hipLaunchKernelGGL((rowprep_kernel<PP, GG>), dim3(g), dim3(256), 0, st, src, d, colpart, R, Rpad, C, amax, unscale, mask, axis, F, J, gelu_pre)
+  if (gelu_pre) {
+    if (P == 1) D3DP_ROWPREP(1, true); else if (P == 2) D3DP_ROWPREP(2, true); else D3DP_ROWPREP(3, true);
+  } else {
+    if (P == 1) D3DP_ROWPREP(1, false); else if (P == 2) D3DP_ROWPREP(2, false); else D3DP_ROWPREP(3, false);
+  }
+#undef D3DP_ROWPREP
   return 0;
 }
 
@@ -2484,20 +2645,33 @@ int d3dp_launch_gelu_rowprep(const float* src, void* drow, int R, int Rpad, int 
 // out_z[N, K] = sum over the token rows of chunk z of A2[t][n] W2[t][k], x dynA x dynW: Tp = Z NKz 32 rows per operand (rows
 // beyond the real ones zero), N % 256 == 0, K % 128 == 0 (d3dp_tn_applies)
 bool d3dp_tn_applies(int N, int K) { return N % XBM == 0 && K % XBN == 0; }
-int d3dp_launch_linear_f16x2_tn(const void* A2, const void* W2, const float* dynA, const float* dynW, float* out, int N, int K,
-                                int Tp, int Z, hipStream_t st) {
-  if (!d3dp_tn_applies(N, K) || Z < 1 || Tp % (XBK * Z) != 0) return -1;
+// n products over the same Tp token rows in one launch: out_p,z[N_p, K_p] (z = 0 .. Z - 1, N_p K_p floats apart)
+int d3dp_launch_linear_f16x2_tn_many(const D3dpTnProduct* prods, int n, int Tp, int Z, hipStream_t st) {
+  if (n < 1 || n > D3DP_TN_MAX || Z < 1 || Tp % (XBK * Z) != 0) return -1;
+  D3dpTnTable tb{};
+  tb.n = n;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    tb.p[i] = prods[i];
+    if (!d3dp_tn_applies(tb.p[i].N, tb.p[i].K)) return -1;
+    tb.p[i].tiles_k = tb.p[i].K / XBN;
+    tb.p[i].tile0 = tiles;
+    tiles += (tb.p[i].N / XBM) * tb.p[i].tiles_k;
+  }
   const int NKz = Tp / XBK / Z;
-  const int tn = N / XBM, tk = K / XBN;
   static PerDeviceOnce once;
   const int cus = once.get([&](int dev) {
     return d3dp_lds_opt_in(reinterpret_cast<const void*>(gemm_f16x2_tn_kernel), XNSTAGE * XSTAGE) < 0 ? -3 : d3dp_cu_count(dev);
   });
   if (cus < 0) return -3;
-  const int items = tn * tk * Z, grid = items < cus ? items : cus;
-  hipLaunchKernelGGL(gemm_f16x2_tn_kernel, dim3(grid), dim3((XNCW + 4) * 64), XNSTAGE * XSTAGE, st, (const f16*)A2, (const f16*)W2,
-                     dynA, dynW, out, N, K, NKz, tk, tn * tk, items);
+  const int items = tiles * Z, grid = items < cus ? items : cus;
+  hipLaunchKernelGGL(gemm_f16x2_tn_kernel, dim3(grid), dim3((XNCW + 4) * 64), XNSTAGE * XSTAGE, st, tb, NKz, tiles, items);
   return 0;
+}
+int d3dp_launch_linear_f16x2_tn(const void* A2, const void* W2, const float* dynA, const float* dynW, float* out, int N, int K,
+                                int Tp, int Z, hipStream_t st) {
+  const D3dpTnProduct one{A2, W2, dynA, dynW, out, N, K, 0, 0};
+  return d3dp_launch_linear_f16x2_tn_many(&one, 1, Tp, Z, st);
 }
 
 int d3dp_launch_wprep(const D3dpWPrepTable& tb, void* rows_base, void* cols_base, unsigned* amax, float* unscale, hipStream_t st) {
@@ -2516,7 +2690,15 @@ void d3dp_launch_sum_partials_bias(const float* part, const float* bias, float* 
   const unsigned blocks = (unsigned)((n + 255) / 256 < cap ? (n + 255) / 256 : cap);
   hipLaunchKernelGGL(sum_partials_bias_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, part, bias, out, n, N, Z, amax, amax_pos);
 }
+void d3dp_launch_sum_partials_many(const D3dpSumTable& tb, hipStream_t st) {
+  size_t most = 0;
+  for (int i = 0; i < tb.n; ++i) most = tb.n4[i] > most ? tb.n4[i] : most;
+  const unsigned blocks = (unsigned)((most + 255) / 256 < 1024 ? (most + 255) / 256 : 1024);
+  hipLaunchKernelGGL(sum_partials_many_kernel, dim3(blocks ? blocks : 1, tb.n), dim3(256), 0, st, tb);
+}
 void d3dp_launch_sum_partials(const float* part, float* out, size_t n, int Z, hipStream_t st) {
-  const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, part, out, n, Z);
+  const size_t n4 = n / 4;                               // (n = N K of a Linear: a multiple of 4)
+  const unsigned blocks = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, reinterpret_cast<const float4*>(part),
+                     reinterpret_cast<float4*>(out), n4, Z);
 }

@@ -79,9 +79,12 @@ void d3dp_launch_split2(const float* src, void* dst, size_t n, float scale, hipS
 // out_z[M, N] (z = 0 .. Z-1, M N floats apart) = A2[M][2 Kfull] . W2[N][2 Kfull]^T over k-chunk z, x dynA[0] x dynW[0], + bias
 // (bias may be null).  Kfull % (32 Z) == 0, N % 4 == 0.
 // amax_out (optional, Z == 1): absmax slot of the output (bit pattern of a non-negative float, pre-zeroed; one atomicMax per workgroup)
+// (amax_pos: the largest POSITIVE output value instead of the largest magnitude)
+// (rem_blocks: Z == 1, M > 256, Kfull % 512 == 0 -- the M mod 256 rows behind the last whole tile go to 16 x 64 blocks spread over
+//  all workgroups instead of a last row of mostly empty 256 x 128 tiles; ignored where the conditions do not hold)
 int d3dp_launch_linear_f16x2_dyn(const void* A2, const void* W2, const float* bias, const float* dynA, const float* dynW,
                                  float* out, int M, int N, int Kfull, int Z, hipStream_t st, unsigned* amax_out = nullptr,
-                                 int amax_pos = 0);   // (amax_pos: the largest POSITIVE output value instead of the largest magnitude)
+                                 int amax_pos = 0, int rem_blocks = 0);
 // drow [Rpad][2 C] = split(GELU(src [R][C])) (rows R .. Rpad - 1 zero) at the scale max(GELU(pmax), 0.17) asks for (pmax: the
 // largest positive value of src, left by the Linear that produced it); writes that bound to amax_out[0] and 1 / scale to unscale[0]
 int d3dp_launch_gelu_rowprep(const float* src, void* drow, int R, int Rpad, int C, const unsigned* pmax, unsigned* amax_out,
@@ -103,8 +106,10 @@ int d3dp_launch_dyprep(const float* src, void* drow, void* dcol, float* colpart,
 // (<= D3DP_ROWPREP_ROWS) partial rows of C floats; C <= 1536
 constexpr int D3DP_ROWPREP_ROWS = 512;
 // (mask: optional per-sample scales applied to the rows first -- sample = r / J (axis 0) or (r / (F J)) J + r % J (axis 1))
+// (gelu_pre: optional [R][C]; the operand is src x gelu'(gelu_pre) and amax[0] holds the absmax of SRC, see rowprep_kernel)
 int d3dp_launch_rowprep(const float* src, void* drow, float* colpart, int* rows, int R, int Rpad, int C, const unsigned* amax,
-                        float* unscale, hipStream_t st, const float* mask = nullptr, int axis = 0, int F = 1, int J = 1);
+                        float* unscale, hipStream_t st, const float* mask = nullptr, int axis = 0, int F = 1, int J = 1,
+                        const float* gelu_pre = nullptr);
 // drow = split(LayerNorm(src; w, b, eps)): the operand of a Linear fed by a LayerNorm, from the LayerNorm's INPUT (amax: the
 // absmax of the LayerNorm's output, left by the kernel that produced src); C <= 512
 int d3dp_launch_rowprep_ln(const float* src, const float* w, const float* b, float eps, void* drow, int R, int Rpad, int C,
@@ -114,6 +119,19 @@ int d3dp_launch_rowprep_ln(const float* src, const float* w, const float* b, flo
 bool d3dp_tn_applies(int N, int K);
 int d3dp_launch_linear_f16x2_tn(const void* A2, const void* W2, const float* dynA, const float* dynW, float* out, int N, int K,
                                 int Tp, int Z, hipStream_t st);
+// ... several such products over the same Tp rows in one launch (the weight gradients of a block): one merged tile list, one Z
+constexpr int D3DP_TN_MAX = 4;
+struct D3dpTnProduct {
+  const void* A2; const void* W2;                      // [Tp][2 N] and [Tp][2 K] row forms
+  const float* dynA; const float* dynW;
+  float* out;                                          // Z partial products, N K floats apart
+  int N, K;
+  int tiles_k, tile0;                                  // (filled by the launcher)
+};
+struct D3dpTnTable { D3dpTnProduct p[D3DP_TN_MAX]; int n; };
+int d3dp_launch_linear_f16x2_tn_many(const D3dpTnProduct* prods, int n, int Tp, int Z, hipStream_t st);
+struct D3dpSumTable { const float* part[D3DP_TN_MAX]; float* out[D3DP_TN_MAX]; size_t n4[D3DP_TN_MAX]; int Z; int n; };
+void d3dp_launch_sum_partials_many(const D3dpSumTable& tb, hipStream_t st);   // out_p[i] = sum_z part_p[z n_p + i], z ascending
 // the training step's weight operands in three launches (gemm_x2.hip): absmax -> slot, rows form [N][2 K] at rows_base + 2 off
 // halves, transposed form [K][2 N] at cols_base + 2 off halves, unscale[slot] = 1 / scale
 constexpr int D3DP_WPREP_MAX = 64;

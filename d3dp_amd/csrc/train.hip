@@ -339,11 +339,7 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__
 }
 
 // dpre = dh * (Phi(x) + x phi(x))
-__device__ __forceinline__ float gelu_grad(float v) {
-  const float cdf = fmaf(0.5f, erf_rational(v * kInvSqrt2), 0.5f);
-  const float pdf = kInvSqrt2Pi * __builtin_amdgcn_exp2f(v * v * -0.72134752044448170368f);   // exp(-v^2 / 2) = 2^(-v^2 log2(e) / 2)
-  return fmaf(v, pdf, cdf);
-}
+__device__ __forceinline__ float gelu_grad(float v) { return gelu_grad_rational(v); }
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* dh, const float* __restrict__ x, float* dpre, size_t n4,
                                                        unsigned* __restrict__ amax) {   // dpre may alias dh
   float m = 0.f;

@@ -1344,3 +1344,46 @@ def test_non_finite_weights_load_and_propagate():
         assert not torch.isfinite(want).all(), key             # the reference's output is non-finite ...
         assert net.nonfinite_seen(), key                       # ... and the library says so about its own (d3dp_status)
         assert out.shape == want.shape
+
+
+# ---- the training step's Linear alone: the rows behind the last whole 256-row tile ----------------------------------------------
+def _train_linear(A, W, b, tail, amax_pos=0):
+    import ctypes as C
+    lib = _lib.load()
+    fn = lib.d3dp_debug_train_linear                       # test hook of capi.hip (not in include/d3dp_hip.h)
+    fn.restype, fn.argtypes = C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p]
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.full((M, N), float("nan"), device="cuda")
+    amax = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(fn(A.data_ptr(), W.data_ptr(), _lib.ptr(b), out.data_ptr(), M, N, K, tail, amax.data_ptr(), amax_pos, stream()),
+               "d3dp_debug_train_linear")
+    return out, amax.view(torch.float32).item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(16524, 512, 512), (16524, 1536, 512), (16524, 1024, 512), (16524, 512, 1024),
+                                   (16524, 512, 1536), (257, 64, 512), (300, 132, 512), (256 + 255, 512, 1024),
+                                   (3 * 256 + 16, 2048, 512), (2 * 256 + 1, 36, 2048), (700, 512, 480), (200, 512, 512)])
+def test_training_linear_remainder_rows_as_blocks(M, N, K):
+    """gemm_f16x2_dyn_kernel with the rows behind the last whole tile cut into 16 x 64 blocks (what the training step launches
+    wherever they would cost a round of the persistent loop) against the same kernel with a last row of tiles, and both
+    against fp64: split-fp16 operands carry 22 bits, the products accumulate in fp32."""
+    g = torch.Generator(device="cuda").manual_seed(M * 31 + N * 7 + K)
+    A = torch.randn(M, K, device="cuda", generator=g) * 3.0
+    W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    ref = A.double() @ W.double().t() + b.double()
+    tiles, amax_t = _train_linear(A, W, b, 0)
+    blocks, amax_b = _train_linear(A, W, b, 1)
+    scale = (A.double().abs() @ W.double().abs().t()).max().item()       # what the rounding errors of a product scale with
+    assert torch.isfinite(blocks).all()
+    e_t, e_b = (tiles.double() - ref).abs().max().item() / scale, (blocks.double() - ref).abs().max().item() / scale
+    print(f"training Linear M={M} N={N} K={K}: max error / max sum|a||w| = {e_t:.2e} (tiles) {e_b:.2e} (remainder blocks)")
+    assert e_t < 2e-6 and e_b < 2e-6
+    q = M // 256 * 256
+    assert torch.equal(tiles[:q], blocks[:q])                             # the whole tiles are the same work items
+    assert amax_t == tiles.abs().max().item() and amax_b == blocks.abs().max().item()
+    nobias, pmax = _train_linear(A, W, None, 1, amax_pos=1)
+    assert pmax == max(nobias.max().item(), 0.0)
+    assert torch.allclose(nobias.double() + b.double(), blocks.double(), atol=1e-5 * scale, rtol=0)
