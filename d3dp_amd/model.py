@@ -482,16 +482,25 @@ class MixSTE2(nn.Module):
 
     def train_arithmetic(self) -> str:
         """What the training step's Linears run on (bench.py reports it next to the step time)."""
-        x2a = os.environ.get("D3DP_TRAIN_ATTN") != "f32" and self.embed_dim // self.num_heads == 64 and self.num_frame <= 256
-        attn = ("temporal attention forward and backward on split-fp16 operands (fp16 MFMA, running power-of-two scale for dS); "
-                "spatial attention forward on the VALU, backward on the fp32 matrix cores") if x2a else \
-               "fp32 attention (fp32 MFMA: temporal forward, backward of both axes; spatial forward on the VALU)"
+        ta = os.environ.get("D3DP_TRAIN_ATTN", "")
+        x2_ok = self.embed_dim // self.num_heads == 64 and self.num_frame <= 256
+        if ta == "f32" or not x2_ok:
+            attn = "fp32 attention (fp32 MFMA: temporal forward, backward of both axes; spatial forward on the VALU)"
+        elif ta == "x2t":
+            attn = ("temporal attention forward and backward on split-fp16 operands (fp16 MFMA, running power-of-two scale for dS); "
+                    "spatial attention forward on the VALU, backward on the fp32 matrix cores (D3DP_TRAIN_ATTN=x2t)")
+        else:
+            attn = ("attention of both axes, forward and backward, on split-fp16 operands (fp16 MFMA, base-2 online softmax, running "
+                    "power-of-two scale for dS)")
         if os.environ.get("D3DP_TRAIN_ATTN_BWD", "")[:1] == "v":
             attn += "; D3DP_TRAIN_ATTN_BWD=valu: every fp32 attention backward on the VALU kernels instead"
         if os.environ.get("D3DP_TRAIN_IMPL") == "f32":
             return "fp32 MFMA Linears (D3DP_TRAIN_IMPL=f32), fp32 attention"
-        return ("split-fp16 Linears (forward, dgrad, split-K wgrad: three fp16-MFMA passes, fp32 accumulate, device-side operand "
-                "scales), " + attn)
+        wg = ("a launch per weight gradient (D3DP_TRAIN_WGRAD=each)" if os.environ.get("D3DP_TRAIN_WGRAD") == "each"
+              else "the four weight gradients of a block as one TN launch")
+        return ("split-fp16 Linears (three fp16-MFMA passes, fp32 accumulate, device-side operand scales; forward and dgrad on "
+                "256 x 128 tiles with the batch's last T mod 256 rows as 16 x 64 blocks, " + wg + ", partial tiles summed in a "
+                "fixed order), " + attn)
 
     # -- profiling passthrough --------------------------------------------------------------------
     def profile_enable(self, on: bool = True):

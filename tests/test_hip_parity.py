@@ -1179,6 +1179,58 @@ def test_training_step_fp32_linears_cross_check(monkeypatch):
     print(f"training step, fp32-MFMA Linears vs split-fp16 Linears: worst relative gradient difference {worst:.2e}")
 
 
+@pytest.mark.gpu
+def test_training_step_scheduling_switches_agree(monkeypatch):
+    """Round 5's scheduling changes of the training step against the forms they replaced (switches read when the context is
+    created): one launch for a block's four weight gradients / one each (D3DP_TRAIN_WGRAD=each), a batch's last
+    T mod 256 rows as 16 x 64 blocks / as a round of tiles or a split-K launch (D3DP_TRAIN_TAIL=split), d h_pre inside the
+    operand pass / by a pass of its own (D3DP_TRAIN_GELU=pass), two / one / no operand sets on the second stream
+    (D3DP_TRAIN_OVERLAP=1 | 0).  Same arithmetic up to the grouping of fp32 partial sums and one operand scale: loss and every
+    gradient agree to fp32 noise.  T = 2 x 243 x 17 = 32 x 256 + 70 rows: the fc1 products take the remainder-block path."""
+    Fr, B, cs, dep = 243, 2, 512, 2
+    x2d = torch.from_numpy(synthetic_inputs_2d(931, B, Fr)).cuda()
+    gt = torch.from_numpy(synthetic_noise(932, (B, Fr, 17, 3))) * 0.3
+    gt[:, :, 0] = 0
+    gt = gt.cuda()
+    t = torch.tensor([[30], [700]], dtype=torch.long)
+    noise = torch.from_numpy(synthetic_noise(933, (B, Fr, 17, 3)))
+    g = torch.Generator().manual_seed(934)
+    drop = {}
+    for i in range(dep):                                   # recorded DropPath masks: every run scales the same samples
+        for kind, n in (("STEblocks", B * Fr), ("TTEblocks", B * 17)):
+            drop[f"{kind}.{i}"] = tuple((torch.rand(n, generator=g) < 0.85).float() / 0.85 for _ in range(2))
+    switches = ("D3DP_TRAIN_WGRAD", "D3DP_TRAIN_TAIL", "D3DP_TRAIN_GELU", "D3DP_TRAIN_OVERLAP")
+    res = {}
+    for name, env in (("default", {}), ("wgrad_each", {"D3DP_TRAIN_WGRAD": "each"}), ("tail_split", {"D3DP_TRAIN_TAIL": "split"}),
+                      ("gelu_pass", {"D3DP_TRAIN_GELU": "pass"}), ("one_set", {"D3DP_TRAIN_OVERLAP": "1"}),
+                      ("one_stream", {"D3DP_TRAIN_OVERLAP": "0"}),
+                      ("round4", {"D3DP_TRAIN_WGRAD": "each", "D3DP_TRAIN_TAIL": "split", "D3DP_TRAIN_GELU": "pass", "D3DP_TRAIN_OVERLAP": "1"})):
+        for k in switches:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
+        m = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=True)
+        m.load_state_dict(make_state_dict(17, cs, dep, Fr), strict=False)
+        m = m.cuda().train()
+        pred = m(x2d, gt, t=t, noise=noise, droppath=drop)
+        loss = torch.mean(torch.norm(pred - gt, dim=-1))
+        loss.backward(loss.clone().detach())
+        torch.cuda.synchronize()
+        res[name] = (loss.item(), {k: p.grad.double().cpu() for k, p in m.pose_estimator.named_parameters()})
+    ref = res["default"]
+    for name, (loss, grads) in res.items():
+        if name == "default":
+            continue
+        assert abs(loss - ref[0]) < 2e-6, (name, loss, ref[0])
+        worst = max((grads[k] - ref[1][k]).norm().item() / max(ref[1][k].norm().item(), 1e-30) for k in grads)
+        print(f"training step, {name} vs default: loss difference {abs(loss - ref[0]):.1e}, worst relative gradient difference {worst:.2e}")
+        assert worst < 2e-5, (name, worst)
+    # the stream / operand-set switches change no arithmetic at all
+    for name in ("one_set", "one_stream"):
+        assert all(torch.equal(res[name][1][k], ref[1][k]) for k in ref[1]), name
+
+
 def test_bench_launches_its_own_ranks_when_two_gpus_are_visible():
     """`python bench.py --gpus 2` outside a torchrun job re-executes itself as 2 RCCL ranks, checks that the 2-rank
     run on sliced global noise reproduces the 1-rank H=2*H_local run bit for bit, and reports the world size and the
