@@ -1479,13 +1479,14 @@ __global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restri
     };
     issue();
     if (gtot > 1) issue();
+    // (the compute waves' remainder blocks, two barriers each: FIRST, while these two stages are in flight -- see below)
+    for (int b = L; b < rem_blocks; b += G) { X2_BARRIER(); X2_BARRIER(); }
     for (int g = 0; g < gtot; ++g) {
       if (g + 1 < gtot) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       X2_BARRIER();
       if (g + 2 < gtot) issue();
     }
-    for (int b = L; b < rem_blocks; b += G) { X2_BARRIER(); X2_BARRIER(); }   // (the compute waves' remainder blocks below)
     if (amax_out) X2_BARRIER();                        // (the compute waves' absmax hand-over below)
     return;
   }
@@ -1498,6 +1499,88 @@ __global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restri
   __builtin_amdgcn_s_setprio(1);
   float am = 0.f;
   int slot = 0;
+  // The remainder rows.  The configs[4] batch has M = 16,524 = 64 x 256 + 140 rows: as a 65th row of 256 x 128 tiles the last 140
+  // rows cost every forward / dgrad product a whole extra round of the persistent loop with 4 - 12 of the 256 CUs busy (12 us
+  // of a 35 - 70 us product; round 4 sent them to a second, split-K launch plus a sum kernel where the contraction was long
+  // enough -- no cheaper).  Here the tiles cover the first rem_m0 = 256 q rows only -- a whole number of rounds when q x tiles_n is
+  // a multiple of the CU count, as 64 x {4, 8, 12} is -- and the rows behind them are cut into 16 x 64 blocks, one per workgroup
+  // (140 rows x 512 .. 1536 columns: 72 .. 216 blocks, every CU busy once more for a few microseconds): the eight compute waves
+  // split the contraction (NKz / 8 k-steps each, fragments straight from global memory -- 64 KiB per block, no LDS staging),
+  // exchange their partial accumulators through LDS and wave 0 adds them in wave order (deterministic), applies scale and bias
+  // and stores.  The blocks come FIRST: the loader waves have just requested the first two stages of the first tile and the
+  // compute waves would wait for them anyway -- the exchange uses the third stage of the ring, which the loaders fill only
+  // after the first k-step's barrier.  Same MFMA triple per k-step as the tiles, same fp32 accumulation: the only difference to a
+  // tile's result is the grouping of the k-steps into eight partial sums.
+  if (rem_blocks > 0) {
+    const int ksw = NKz / XNCW;                        // k-steps per wave (launcher: NKz % 16 == 0, so an even number)
+    f32x4* xch = reinterpret_cast<f32x4*>(smem + (XNSTAGE - 1) * XSTAGE);
+#pragma unroll 1
+    for (int b = L; b < rem_blocks; b += G) {
+      const int m0 = rem_m0 + (b / rem_cg) * 16, nb0 = (b % rem_cg) * 64;
+      const size_t kofs = (size_t)wave * ksw * (2 * XBK) + fg * 8;
+      const f16* ap = A2 + (size_t)min(m0 + fi, M - 1) * (2 * Kfull) + kofs;
+      const f16* wp[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) wp[ni] = W2 + (size_t)min(nb0 + 4 * fi + ni, N - 1) * (2 * Kfull) + kofs;
+      f32x4 pacc[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) pacc[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int ks = 0; ks < ksw; ks += 2) {
+        f16x8 ah[2], al[2], wh[2][4], wl[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int o = (ks + u) * (2 * XBK);
+          ah[u] = *reinterpret_cast<const f16x8*>(ap + o);
+          al[u] = *reinterpret_cast<const f16x8*>(ap + o + XBK);
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            wh[u][ni] = *reinterpret_cast<const f16x8*>(wp[ni] + o);
+            wl[u][ni] = *reinterpret_cast<const f16x8*>(wp[ni] + o + XBK);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) pacc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], wl[u][ni], pacc[ni], 0, 0, 0);
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) pacc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], wh[u][ni], pacc[ni], 0, 0, 0);
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) pacc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], wh[u][ni], pacc[ni], 0, 0, 0);
+        }
+      }
+      X2_BARRIER();                                    // nobody reads the previous block's partial sums any more
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) xch[(wave * 4 + ni) * 64 + lane] = pacc[ni];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      X2_BARRIER();
+      if (wave == 0) {
+        f32x4 sum[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          sum[ni] = xch[ni * 64 + lane];
+#pragma unroll
+          for (int w = 1; w < XNCW; ++w) sum[ni] += xch[(w * 4 + ni) * 64 + lane];
+        }
+        const int nb = nb0 + 4 * fi;
+        if (nb < N) {
+          float4 bz = {0.f, 0.f, 0.f, 0.f};
+          if (bias != nullptr) bz = *reinterpret_cast<const float4*>(bias + nb);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * fg + r;
+            if (m < M) {
+              const f32x4 v = {fmaf(sum[0][r], unscale, bz.x), fmaf(sum[1][r], unscale, bz.y), fmaf(sum[2][r], unscale, bz.z),
+                               fmaf(sum[3][r], unscale, bz.w)};
+              *reinterpret_cast<f32x4*>(out + (size_t)m * N + nb) = v;
+              am = amax_pos ? fmaxf(am, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])))
+                            : fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            }
+          }
+        }
+      }
+    }
+  }
 #pragma unroll 1
   for (int ti = 0; ti < n_my; ++ti) {
     f32x4 acc[4][4];
@@ -1551,86 +1634,6 @@ __global__ __launch_bounds__(768) void gemm_f16x2_dyn_kernel(const f16* __restri
                           : fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
           }
         }
-    }
-  }
-  // The remainder rows.  The configs[4] batch has M = 16,524 = 64 x 256 + 140 rows: as a 65th row of 256 x 128 tiles the last 140
-  // rows cost every forward / dgrad product a whole extra round of the persistent loop with 4 - 12 of the 256 CUs busy (12 us
-  // of a 35 - 70 us product; round 4 sent them to a second, split-K launch plus a sum kernel where the contraction was long
-  // enough -- no cheaper).  Here the tiles cover the first rem_m0 = 256 q rows only -- a whole number of rounds when q x tiles_n is
-  // a multiple of the CU count, as 64 x {4, 8, 12} is -- and the rows behind them are cut into 16 x 64 blocks, one per workgroup
-  // (140 rows x 512 .. 1536 columns: 72 .. 216 blocks, every CU busy once more for a few microseconds): the eight compute waves
-  // split the contraction (NKz / 8 k-steps each, fragments straight from global memory -- 64 KiB per block, no LDS staging),
-  // exchange their partial accumulators through LDS and wave 0 adds them in wave order (deterministic), applies scale and bias
-  // and stores.  Same MFMA triple per k-step as the tiles, same fp32 accumulation: the only difference to a tile's result is the
-  // grouping of the k-steps into eight partial sums.
-  if (rem_blocks > 0) {
-    const int ksw = NKz / XNCW;                        // k-steps per wave (launcher: NKz % 16 == 0, so an even number)
-    f32x4* xch = reinterpret_cast<f32x4*>(smem);
-#pragma unroll 1
-    for (int b = L; b < rem_blocks; b += G) {
-      const int m0 = rem_m0 + (b / rem_cg) * 16, nb0 = (b % rem_cg) * 64;
-      const size_t kofs = (size_t)wave * ksw * (2 * XBK) + fg * 8;
-      const f16* ap = A2 + (size_t)min(m0 + fi, M - 1) * (2 * Kfull) + kofs;
-      const f16* wp[4];
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) wp[ni] = W2 + (size_t)min(nb0 + 4 * fi + ni, N - 1) * (2 * Kfull) + kofs;
-      f32x4 pacc[4];
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) pacc[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-      for (int ks = 0; ks < ksw; ks += 2) {
-        f16x8 ah[2], al[2], wh[2][4], wl[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int o = (ks + u) * (2 * XBK);
-          ah[u] = *reinterpret_cast<const f16x8*>(ap + o);
-          al[u] = *reinterpret_cast<const f16x8*>(ap + o + XBK);
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) {
-            wh[u][ni] = *reinterpret_cast<const f16x8*>(wp[ni] + o);
-            wl[u][ni] = *reinterpret_cast<const f16x8*>(wp[ni] + o + XBK);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) pacc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], wl[u][ni], pacc[ni], 0, 0, 0);
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) pacc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], wh[u][ni], pacc[ni], 0, 0, 0);
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) pacc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], wh[u][ni], pacc[ni], 0, 0, 0);
-        }
-      }
-      X2_BARRIER();                                    // nobody reads the ring (or the previous block's partial sums) any more
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) xch[(wave * 4 + ni) * 64 + lane] = pacc[ni];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      X2_BARRIER();
-      if (wave == 0) {
-        f32x4 sum[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          sum[ni] = xch[ni * 64 + lane];
-#pragma unroll
-          for (int w = 1; w < XNCW; ++w) sum[ni] += xch[(w * 4 + ni) * 64 + lane];
-        }
-        const int nb = nb0 + 4 * fi;
-        if (nb < N) {
-          float4 bz = {0.f, 0.f, 0.f, 0.f};
-          if (bias != nullptr) bz = *reinterpret_cast<const float4*>(bias + nb);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = m0 + 4 * fg + r;
-            if (m < M) {
-              const f32x4 v = {fmaf(sum[0][r], unscale, bz.x), fmaf(sum[1][r], unscale, bz.y), fmaf(sum[2][r], unscale, bz.z),
-                               fmaf(sum[3][r], unscale, bz.w)};
-              *reinterpret_cast<f32x4*>(out + (size_t)m * N + nb) = v;
-              am = amax_pos ? fmaxf(am, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])))
-                            : fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-            }
-          }
-        }
-      }
     }
   }
   if (amax_out) {                                      // (uniform: a kernel argument)
@@ -1963,7 +1966,7 @@ __global__ __launch_bounds__(256) void dyprep_kernel(const float* __restrict__ s
 // contracts over them) and, for a gradient, its column sums as gridDim.x partial rows of C floats (fixed-order reduction by
 // d3dp_train_reduce_many).  A thread owns 8 consecutive columns (two 16-byte loads, one 16-byte store per plane) of the rows
 // r = 4 blockIdx.x + (tid >> 6), + 4 gridDim.x, ...: reads and writes are contiguous in memory -- unlike the tile transpose of
-// dyprep_kernel, whose 128-byte pieces land 66 KB apart.  C % 512 == 0 or C <= 512 with C % 8 == 0 (P = ceil(C / 512) passes).
+// dyprep_kernel, whose 128-byte pieces land 66 KB apart.  C % 32 == 0, C <= 1536 (P = ceil(C / 512) column passes per row).
 // mask (optional): per-sample DropPath scales -- row r is multiplied by mask[sample(r)] first (sample = r / J on the spatial
 // axis, (r / (F J)) J + r % J on the temporal one): the backward pass then never stores the scaled gradient, only its absmax.
 // GELU (gelu_pre [R][C]: the fc1 output of the forward pass): src is d hidden and the operand is d h_pre = src x gelu'(gelu_pre),
@@ -2615,7 +2618,7 @@ int d3dp_launch_rowprep_ln(const float* src, const float* w, const float* b, flo
 
 int d3dp_launch_rowprep(const float* src, void* drow, float* colpart, int* rows, int R, int Rpad, int C, const unsigned* amax,
                         float* unscale, hipStream_t st, const float* mask, int axis, int F, int J, const float* gelu_pre) {
-  if (C % 8 != 0 || Rpad < R || C > 1536 || (C > 512 && C % 512 != 0)) return -1;
+  if (C % 32 != 0 || Rpad < R || C > 1536) return -1;      // (P = ceil(C / 512) column passes; a lane whose 8 columns lie behind C idles)
   int g = (Rpad + 3) / 4;
   const int cap = colpart ? D3DP_ROWPREP_ROWS : 1024;   // (every workgroup leaves one partial row of column sums)
   if (g > cap) g = cap;

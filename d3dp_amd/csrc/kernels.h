@@ -103,7 +103,7 @@ constexpr int D3DP_DYPREP_ROWS = 96;
 int d3dp_launch_dyprep(const float* src, void* drow, void* dcol, float* colpart, int R, int C, int Rpad, const unsigned* amax,
                        float* unscale, hipStream_t st);
 // the row form alone as a streaming pass: src [R][C] -> drow [Rpad][2 C] (rows R .. Rpad - 1 zero) + optional column sums as *rows
-// (<= D3DP_ROWPREP_ROWS) partial rows of C floats; C <= 1536
+// (<= D3DP_ROWPREP_ROWS) partial rows of C floats; C % 32 == 0, C <= 1536
 constexpr int D3DP_ROWPREP_ROWS = 512;
 // (mask: optional per-sample scales applied to the rows first -- sample = r / J (axis 0) or (r / (F J)) J + r % J (axis 1))
 // (gelu_pre: optional [R][C]; the operand is src x gelu'(gelu_pre) and amax[0] holds the absmax of SRC, see rowprep_kernel)

@@ -632,6 +632,25 @@ def test_sampler_on_a_clip_longer_than_256_frames(numerics):
         assert m.pose_estimator.exact_scales()[2] == "f16x2"      # the Linears stay on the split-fp16 kernels
 
 
+@pytest.mark.parametrize("numerics", ["exact", "fast"])
+def test_sampler_at_the_reference_small_width(numerics):
+    """cs = 256 (the reference's smaller `-cs`; 8 heads of 32 channels, hidden 512): the sampler against the oracle at the
+    same tolerances as cs = 512.  The 64-wide-head attention kernels do not apply at this width -- the library must route around
+    them, not fail."""
+    frames, cs, dep, B, H, K = 27, 256, 2, 2, 2, 2
+    sd = make_state_dict(29, cs, dep, frames)
+    x2d = synthetic_inputs_2d(291, B, frames)
+    noises = [torch.from_numpy(synthetic_noise(292 + k, (B, H, frames, 17, 3))) for k in range(K)]
+    want = orc.ddim_sample_flip(orc.strip_prefix(sd), orc.cosine_schedule(1000), torch.from_numpy(x2d),
+                                torch.from_numpy(flip_2d(x2d)), H, K, dep, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, noises)
+    m = make_model(frames, cs, dep, H, K, numerics, 29)
+    out = m(torch.from_numpy(x2d).cuda(), None, input_2d_flip=torch.from_numpy(flip_2d(x2d)).cuda(), noise=noises)
+    assert out.shape == (B, K, H, frames, 17, 3) and torch.isfinite(out).all()
+    err = orc.mpjpe_mm(out.cpu(), want)
+    print(f"cs=256 {numerics}: MPJPE vs the fp32 oracle {err:.3e} mm")
+    assert err <= (EXACT_TOL_MM if numerics == "exact" else FAST_TOL_MM)
+
+
 def test_sampler_fast_mode_reported(golden_dir):
     g = load_g(golden_dir, "g4_sampler_H3K5")
     cs, dep, Fr, B, H, K = (int(g[k]) for k in ("cs", "dep", "frames", "B", "H", "K"))
@@ -1143,11 +1162,13 @@ def test_attention_backward_on_matrix_cores_matches_the_valu_kernels(monkeypatch
               f"prediction max |diff| {dp:.2e}")
 
 
-def test_training_step_fp32_linears_cross_check(monkeypatch):
+@pytest.mark.parametrize("cs", [512, 256])
+def test_training_step_fp32_linears_cross_check(monkeypatch, cs):
     """D3DP_TRAIN_IMPL=f32 (read when the context is created) keeps the training Linears on the fp32 matrix cores -- the round-1
     path, left in as the cross-check of the split-fp16 one with its fused operand preparation: loss and every parameter
-    gradient of one step agree between the two to fp32 noise."""
-    Fr, B, cs, dep = 27, 2, 512, 2
+    gradient of one step agree between the two to fp32 noise.  cs = 256 (the reference's smaller model: 32-wide heads, so the
+    attention stays on the fp32 kernels) has other tile counts in the merged weight-gradient launch: 16 tiles x 16 chunks."""
+    Fr, B, dep = 27, 2, 2
     x2d = torch.from_numpy(synthetic_inputs_2d(921, B, Fr)).cuda()
     gt = torch.from_numpy(synthetic_noise(922, (B, Fr, 17, 3))) * 0.3
     gt[:, :, 0] = 0

@@ -7,7 +7,9 @@ import torch
 
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from d3dp_amd import D3DP  # noqa: E402
+from d3dp_amd import D3DP, _lib  # noqa: E402
+if os.environ.get("D3DP_LIB"):          # A/B of differently compiled libraries
+    _lib.LIB_PATH = os.environ["D3DP_LIB"]
 from d3dp_amd.optim import HipAdamW  # noqa: E402
 from d3dp_amd.weights import H36M_JOINTS_LEFT as KL, H36M_JOINTS_RIGHT as KR, make_state_dict  # noqa: E402
 
