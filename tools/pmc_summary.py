@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Average rocprofv3 --pmc counter values per dispatch for kernels whose name contains a substring.
-usage: pmc_summary.py <counter_collection.csv> <substring> [out.md]"""
+"""Average rocprofv3 --pmc counter values per dispatch for kernels whose name matches a regular expression.
+usage: pmc_summary.py <counter_collection.csv> <regex> [out.md]"""
 import collections
 import csv
+import re
 import sys
 
 
@@ -13,7 +14,7 @@ def main(path, sub, out=None):
     dur = collections.defaultdict(list)
     for r in rows:
         k = r["Kernel_Name"]
-        if sub not in k:
+        if not re.search(sub, k):
             continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[(k, r["Counter_Name"])] += 1
