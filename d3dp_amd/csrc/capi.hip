@@ -156,10 +156,11 @@ struct d3dp_ctx {
   }
   int pad_override = -1;         // D3DP_SEQ_PAD=0|1: measurement switch (pad without the skewed schedule, or the reverse)
   bool train_x2 = true;          // D3DP_TRAIN_IMPL=f32: the training Linears on the fp32 matrix cores (round-1 path, cross-check)
-  // The backward pass runs every weight-gradient product (the TN / split-K kernel and the sum of its partial tiles) on a second
-  // stream beside the dgrad product of the same dY and the row kernels that follow it: each of these persistent Linears keeps one
-  // workgroup per CU, so a tail round of a few tiles or a launch ramp leaves CUs idle that the other product's workgroups fill.
-  // Forked and joined with events on the caller's stream (nothing synchronises the host); D3DP_TRAIN_OVERLAP=0 keeps one stream.
+  // The backward pass runs the weight-gradient products (one merged TN launch per block, or one launch per Linear, and the sum of
+  // their partial tiles) on a second stream beside the rest of the backward pass: a block's launch goes on while the next block's
+  // dgrad products, attention and row kernels run (two operand / partial-tile sets, X2Train::use_set).  Forked and joined with events
+  // on the caller's stream (nothing synchronises the host); D3DP_TRAIN_OVERLAP=0 keeps one stream.  Worth 0.2 ms of a 21 ms step
+  // since the weight gradients are one launch per block: kept because it costs nothing.
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_done[2] = {nullptr, nullptr};
   bool train_overlap = true;
@@ -1221,9 +1222,11 @@ struct X2Train {
   }
   // out[T, N] = A2 . W2^T (+ bias) with T = 256 q + rem rows.  The persistent kernel works in rounds of n_cu tiles of 256 x 128;
   // the configs[4] batch has T = 16,524 = 64 x 256 + 140, so every forward / dgrad product had ONE row of tiles too many for
-  // a whole number of rounds (fc2: 260 tiles on 256 CUs = two rounds for 1.02 rounds of work).  When the remainder rows cost a round of their own they go to a second
-  // launch as a split-K product (Z chunks of the contraction: tn Z short work items instead of tn long ones) whose partial
-  // sums are added in a fixed order.
+  // a whole number of rounds (fc2: 260 tiles on 256 CUs = two rounds for 1.02 rounds of work).  Where the remainder rows would cost
+  // a round of their own the kernel takes them as 16 x 64 blocks spread over all workgroups (round 5; gemm_f16x2_dyn_kernel).
+  // D3DP_TRAIN_TAIL=split, and contractions that are not a multiple of 16 k-steps, keep round 4's form: from 32 k-steps on a
+  // second launch as a split-K product (Z chunks of the contraction: tn Z short work items instead of tn long ones) whose
+  // partial sums are added in a fixed order, else the extra round.
   int gemm(const float* A2, const float* W2, const float* bias, const float* ua, const float* uw, float* out, int T, int N,
            int K, unsigned* out_amax = nullptr, int amax_pos = 0) {
     const int tn = (N + 127) / 128, q = T / 256, rem = T - q * 256;

@@ -1417,9 +1417,10 @@ __global__ __launch_bounds__(768) void gemm_f16x2_skew_kernel(const f16* __restr
 //     of two its own absmax asks for (split2h_dyn_kernel / split2h_t_dyn_kernel below write 1 / scale next to the planes) and
 //     this kernel reads the two factors -- no host synchronisation anywhere in the step;
 //   * Z chunks of the contraction (k-steps z NKz .. (z + 1) NKz - 1 of rows of 2 Kfull fp16) go to Z x tiles work items:
-//     wgrad contracts over the 16,524 tokens of a batch into at most 24 output tiles, far too few for 256 CUs unsplit; the
-//     partial results are summed in a fixed order by sum_partials_kernel (deterministic, unlike the fp32-atomic split-K of
-//     the fp32-MFMA path this replaces).
+//     a weight gradient in its transposed-operand form (shapes the TN kernel below does not take) contracts over the 16,524
+//     tokens of a batch into at most 24 output tiles, far too few for 256 CUs unsplit; the partial results are summed in a
+//     fixed order by sum_partials_kernel (deterministic, unlike the fp32-atomic split-K of the fp32-MFMA path this replaces);
+//   * rem_m0 (optional; Z = 1 launches): the rows behind the last whole 256-row tile as 16 x 64 blocks -- see the compute waves.
 // Structure: the lock-step kernel above without the lagged MFMAs and with the plain fp32 epilogue (8 + 4 waves, 256 x 128 x 32
 // tiles, 3-stage LDS-DMA ring, one barrier per k-step).
 //   * amax_out (optional; Z = 1 launches): the output's absmax (amax_pos: its largest positive value), one atomicMax per
