@@ -212,7 +212,10 @@ int d3dp_jpma_ex(const float* pred, const float* traj, const float* cam, const f
  * masks: NULL, or DropPath scales (timm semantics, values 0 or 1/keep) laid out [2*depth blocks (STE0,TTE0,STE1,..)]
  * [2 branches (attention, MLP)][B*max(F,J)] floats; entry s of a spatial block is sample b*F+f, of a temporal block b*J+n.
  * d3dp_train_forward keeps every activation the backward needs in `workspace`; d3dp_train_backward must follow with the
- * same inputs/masks/workspace.  grads: device fp32 buffers shaped like the weights (zeroed, then filled, here). */
+ * same inputs/masks/workspace.  grads: device fp32 buffers shaped like the weights (zeroed, then filled, here).
+ * d3dp_train_backward launches a block's weight-gradient product on a second, library-owned stream, forked from and joined
+ * back to `stream` with events before it returns (the host is never synchronised; env D3DP_TRAIN_OVERLAP=0: one stream).
+ * No gradient is accumulated with float atomics: the same inputs give the same bits. */
 int d3dp_train_workspace_bytes(const d3dp_ctx* ctx, int32_t B, size_t* bytes);
 int d3dp_train_forward(d3dp_ctx* ctx, const float* x2d, const float* x3d, const int64_t* t, const float* masks, float* out,
                        int32_t B, void* workspace, size_t workspace_bytes, void* stream);
