@@ -632,12 +632,13 @@ def test_sampler_on_a_clip_longer_than_256_frames(numerics):
         assert m.pose_estimator.exact_scales()[2] == "f16x2"      # the Linears stay on the split-fp16 kernels
 
 
+@pytest.mark.parametrize("cs", [256, 128])
 @pytest.mark.parametrize("numerics", ["exact", "fast"])
-def test_sampler_at_the_reference_small_width(numerics):
-    """cs = 256 (the reference's smaller `-cs`; 8 heads of 32 channels, hidden 512): the sampler against the oracle at the
-    same tolerances as cs = 512.  The 64-wide-head attention kernels do not apply at this width -- the library must route around
-    them, not fail."""
-    frames, cs, dep, B, H, K = 27, 256, 2, 2, 2, 2
+def test_sampler_at_the_reference_small_width(numerics, cs):
+    """cs = 256 (the reference's smaller `-cs`; 8 heads of 32 channels, hidden 512) and cs = 128: the sampler against the oracle
+    at the same tolerances as cs = 512.  The 64-wide-head attention kernels do not apply at these widths -- the library must
+    route around them, not fail."""
+    frames, dep, B, H, K = 27, 2, 2, 2, 2
     sd = make_state_dict(29, cs, dep, frames)
     x2d = synthetic_inputs_2d(291, B, frames)
     noises = [torch.from_numpy(synthetic_noise(292 + k, (B, H, frames, 17, 3))) for k in range(K)]
@@ -647,7 +648,7 @@ def test_sampler_at_the_reference_small_width(numerics):
     out = m(torch.from_numpy(x2d).cuda(), None, input_2d_flip=torch.from_numpy(flip_2d(x2d)).cuda(), noise=noises)
     assert out.shape == (B, K, H, frames, 17, 3) and torch.isfinite(out).all()
     err = orc.mpjpe_mm(out.cpu(), want)
-    print(f"cs=256 {numerics}: MPJPE vs the fp32 oracle {err:.3e} mm")
+    print(f"cs={cs} {numerics}: MPJPE vs the fp32 oracle {err:.3e} mm")
     assert err <= (EXACT_TOL_MM if numerics == "exact" else FAST_TOL_MM)
 
 
@@ -1162,12 +1163,13 @@ def test_attention_backward_on_matrix_cores_matches_the_valu_kernels(monkeypatch
               f"prediction max |diff| {dp:.2e}")
 
 
-@pytest.mark.parametrize("cs", [512, 256])
+@pytest.mark.parametrize("cs", [512, 256, 128])
 def test_training_step_fp32_linears_cross_check(monkeypatch, cs):
     """D3DP_TRAIN_IMPL=f32 (read when the context is created) keeps the training Linears on the fp32 matrix cores -- the round-1
     path, left in as the cross-check of the split-fp16 one with its fused operand preparation: loss and every parameter
     gradient of one step agree between the two to fp32 noise.  cs = 256 (the reference's smaller model: 32-wide heads, so the
-    attention stays on the fp32 kernels) has other tile counts in the merged weight-gradient launch: 16 tiles x 16 chunks."""
+    attention stays on the fp32 kernels) has other tile counts in the merged weight-gradient launch: 16 tiles x 16 chunks; at
+    cs = 128 no Linear has a TN shape and the weight gradients take the transposed-operand path, one launch each."""
     Fr, B, dep = 27, 2, 2
     x2d = torch.from_numpy(synthetic_inputs_2d(921, B, Fr)).cuda()
     gt = torch.from_numpy(synthetic_noise(922, (B, Fr, 17, 3))) * 0.3
