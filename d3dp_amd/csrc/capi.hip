@@ -1084,13 +1084,16 @@ const float* mask_ptr(const float* masks, const d3dp_cfg& g, int B, int blk, int
 }
 
 // The backward pass' deferred, fixed-order sums: kernels leave partial rows in the workspace's `red` region (bump-allocated
-// here), `add` records where they go, `flush` launches d3dp_train_reduce_many over what was recorded (<= D3DP_REDUCE_MAX
-// destinations per launch).  Nothing in the backward pass adds floats atomically: its gradients are bit-reproducible.
+// here), `add` only RECORDS where they go -- an item may be recorded long before its partial rows exist (the shared norms' rows are
+// written by one LayerNorm-backward call per block) -- and `flush`, called once every producer has been launched, walks the list
+// in launches of <= D3DP_REDUCE_MAX destinations (d3dp_train_reduce_many).  (Round 5 flushed from inside `add` when the table
+// was full: at depth >= 6 that reduced the shared norms' rows before the remaining blocks had written theirs -- ADVICE r5.)
+// Nothing in the backward pass adds floats atomically: its gradients are bit-reproducible.
 struct Reducer {
   float* base;
   size_t cap, used = 0;
   hipStream_t st;
-  D3dpReduceTable tb{};
+  std::vector<D3dpReduceItem> items{};
   int rc = 0;
   float* take(size_t n) {
     n = (n + 63) / 64 * 64;
@@ -1101,12 +1104,16 @@ struct Reducer {
   }
   void add(const float* part, float* dst, size_t n, size_t count, size_t stride, bool accumulate = false) {
     if (!part || !dst || rc) { rc = rc ? rc : -1; return; }
-    if (tb.count == D3DP_REDUCE_MAX) flush();
-    tb.it[tb.count++] = D3dpReduceItem{part, dst, (unsigned)n, (unsigned)count, (unsigned)stride, accumulate ? 1u : 0u};
+    items.push_back(D3dpReduceItem{part, dst, (unsigned)n, (unsigned)count, (unsigned)stride, accumulate ? 1u : 0u});
   }
   void flush() {
-    if (tb.count > 0 && rc == 0) rc = d3dp_train_reduce_many(tb, st);
-    tb.count = 0;
+    for (size_t i = 0; i < items.size() && rc == 0; i += D3DP_REDUCE_MAX) {
+      D3dpReduceTable tb{};
+      tb.count = (int)std::min<size_t>(D3DP_REDUCE_MAX, items.size() - i);
+      for (int j = 0; j < tb.count; ++j) tb.it[j] = items[i + j];
+      rc = d3dp_train_reduce_many(tb, st);
+    }
+    items.clear();
   }
 };
 
@@ -1549,6 +1556,7 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
   const bool attn_x2 = use_x2 && c->train_attn_x2 > 0 && C / g.heads == 64 && F <= 256;   // (as the forward pass of this step)
   const bool attn_x2_s = attn_x2 && c->train_attn_x2 > 1;
   Reducer red{ws + L.red, L.red_floats, 0, st};
+  red.items.reserve(24 * (size_t)g.depth + 32);
   const int lnrows = d3dp_train_ln_bwd_blocks(T);        // partial rows one LayerNorm-backward call leaves
   // [dgamma | dbeta] partial rows of a LayerNorm with `calls` backward calls per step (the shared norms: one per depth), and
   // their two destinations; call i writes rows [i lnrows, (i + 1) lnrows)
@@ -1727,7 +1735,8 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
       const int pb = blk - 1, pk = pb & 1;
       const float* Sp = ws + L.saved0 + (size_t)pb * L.saved_stride;
       const float* mk = mask_ptr(masks, g, B, pb, 1);
-      float* g_out = pb == 0 ? ws + L.z : nullptr;       // d of Temporal_pos_embed's sum (added behind block 0's shared norm)
+      float* g_out = pb == 0 ? ws + L.y : nullptr;       // d of Temporal_pos_embed's sum (added behind block 0's shared norm); y: a forward
+                                                         // temporary -- NOT z, which a second backward over the same forward reads again
       D3DP_FRESH(ps, pa)
       LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xin, w.n1w, g.eps_block, dA, g_out, Sp + L.o_xout, pk ? c->tnw : c->snw, g.eps_block,
                                    dB, mk, pk, F, J, (mk && !mip2) ? dC : nullptr, pa, pn1,

@@ -46,8 +46,12 @@ def init_from_env(backend: Optional[str] = None, timeout_s: float = 180.0) -> tu
         try:
             if backend == "nccl":
                 if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
-                    raise RuntimeError("HSA_ENABLE_IPC_MODE_LEGACY=%r: this host driver only supports dmabuf IPC (needs 0, "
-                                       "set before the process's first HIP call)" % os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
+                    # a deliberate choice on a stack whose legacy IPC works is the user's to make: warn, and let
+                    # the probe collective below decide; its failure message names the variable
+                    import warnings
+                    warnings.warn("d3dp_amd.dist: HSA_ENABLE_IPC_MODE_LEGACY=%r; hosts whose driver only supports dmabuf IPC "
+                                  "need 0 (set before the process's first HIP call) or RCCL fails in hipIpcGetMemHandle"
+                                  % os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
                 if torch.cuda.device_count() <= local:
                     raise RuntimeError(f"LOCAL_RANK={local} but only {torch.cuda.device_count()} device(s) visible")
                 torch.cuda.set_device(local)

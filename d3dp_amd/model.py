@@ -207,6 +207,10 @@ class MixSTE2(nn.Module):
     def __setstate__(self, d):
         super().__setstate__(d)
         self._states_lock = threading.Lock()
+        if "_param_names" not in self.__dict__:       # pickles of whole modules saved before round 5
+            self._param_names = tuple(n for n, _ in self.named_parameters())
+        self.__dict__.setdefault("_src_sig", None)
+        self.__dict__.pop("_droppath_keep", None)      # (a cached device tensor; rebuilt on the next training step)
 
     def _drop_ctx(self):
         """Destroy every device's context (owner only; a replica just forgets nothing -- the states are not its own)."""
@@ -418,12 +422,17 @@ class MixSTE2(nn.Module):
             return None
         # every block's masks in three launches (one uniform draw over the whole table, a compare and a divide) instead of a
         # bernoulli + divide + copy per (block, branch): ~100 tiny launches per training step
-        keep = getattr(self, "_droppath_keep", None)
-        if keep is None or keep.device != device:
+        key = (device, float(self.drop_path_rate), dep)
+        cached = self.__dict__.get("_droppath_keep")
+        if cached is None or cached[0] != key:        # (keyed on the rate too: changing drop_path_rate takes effect)
             rates = torch.linspace(0, self.drop_path_rate, dep)
             keep = (1.0 - rates).repeat_interleave(2).reshape(2 * dep, 1, 1).to(device=device, dtype=torch.float32)
-            self._droppath_keep = keep                    # (rate 0 -> keep 1: rand() < 1 always, scale 1 -- an Identity, mixste.py:100)
-        return ((torch.rand((2 * dep, 2, smax), device=device) < keep).to(torch.float32) / keep).contiguous()
+            # (rate 0 -> keep 1: rand() < 1 always, scale 1 -- an Identity, mixste.py:100; rate 1 -> keep 0: everything dropped and,
+            #  like timm's `if keep_prob > 0` guard, no division by the zero keep rate)
+            cached = (key, keep, torch.where(keep > 0, keep, torch.ones_like(keep)))
+            self.__dict__["_droppath_keep"] = cached
+        _, keep, div = cached
+        return ((torch.rand((2 * dep, 2, smax), device=device) < keep).to(torch.float32) / div).contiguous()
 
     def _train_io(self, x_2d, x_3d, t):
         B, Fr, J, _ = x_3d.shape

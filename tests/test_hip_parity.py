@@ -1394,6 +1394,82 @@ def test_training_step_is_bit_reproducible():
     assert all(torch.isfinite(g).all() for g in g0) and any(g.abs().max() > 0 for g in g0)
 
 
+def _small_deep_training_model(Fr=27, B=2, cs=128, dep=8, seed=17):
+    args = SimpleNamespace(number_of_frames=Fr, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
+    sd = make_state_dict(seed, cs, dep, Fr)
+    m = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=True)
+    m.load_state_dict(sd, strict=False)
+    return m.cuda().train(), sd
+
+
+def test_training_first_step_at_depth_8_on_a_poisoned_workspace():
+    """at the reference's default depth (dep = 8: 140 reduction items against 80 per launch) the fixed-order
+    reduction of round 5 ran its first launch from INSIDE the block loop, over the shared Spatial_norm / Temporal_norm partial rows
+    of blocks not yet differentiated -- stale rows of the previous step, or whatever torch.empty left on the first.  Here: one
+    step on OTHER inputs, the whole workspace overwritten with NaN bit patterns, then the step under test -- every gradient
+    against torch autograd through the CPU oracle."""
+    Fr, B, cs, dep = 27, 2, 128, 8
+    m, sd = _small_deep_training_model(Fr, B, cs, dep)
+    gen = torch.Generator().manual_seed(9)
+    dpd = {}
+    rates = [x.item() for x in torch.linspace(0, 0.1, dep)]
+    for i in range(1, dep):
+        mk = lambda S: (torch.rand(S, 1, 1, generator=gen) < 1 - rates[i]).float() / (1 - rates[i])
+        dpd[f"STEblocks.{i}"] = (mk(B * Fr), mk(B * Fr))
+        dpd[f"TTEblocks.{i}"] = (mk(B * 17), mk(B * 17))
+
+    def step(seed, tvals):
+        x2d = torch.from_numpy(synthetic_inputs_2d(seed, B, Fr))
+        gt = torch.from_numpy(synthetic_noise(seed + 1, (B, Fr, 17, 3))) * 0.3
+        noise = torch.from_numpy(synthetic_noise(seed + 2, (B, Fr, 17, 3)))
+        t = torch.tensor(tvals, dtype=torch.long).reshape(-1, 1)
+        m.zero_grad(set_to_none=True)
+        pred = m(x2d.cuda(), gt.cuda(), t=t, noise=noise, droppath=dpd)
+        loss = torch.mean(torch.norm(pred - gt.cuda(), dim=-1))
+        loss.backward(loss.clone().detach())
+        torch.cuda.synchronize()
+        return x2d, gt, noise, t
+
+    step(700, [17, 803])                                   # allocates the workspace, leaves ITS partial rows behind
+    st = m.pose_estimator._state()
+    st.train_ws.fill_(0xFF)                                # every float of the workspace: a NaN
+    x2d, gt, noise, t = step(800, [250, 999])
+    po = {k: v.clone().requires_grad_(True) for k, v in orc.strip_prefix(sd).items()}
+    xp = orc.prepare_targets(orc.cosine_schedule(1000), gt, t[:, 0], noise)
+    pred_o = orc.mixste_forward(po, x2d, xp, t[:, 0], dep, droppath=dpd)
+    loss_o = torch.mean(torch.norm(pred_o - gt, dim=-1))
+    loss_o.backward(loss_o.clone().detach())
+    worst = ("", 0.0)
+    for name, p in m.pose_estimator.named_parameters():
+        assert torch.isfinite(p.grad).all(), name
+        ref = po[name].grad.double()
+        err = (p.grad.cpu().double() - ref).norm().item() / max(ref.norm().item(), 1e-12)
+        worst = max(worst, (name, err), key=lambda v: v[1])
+        assert err < 2e-3, (name, err)
+    print(f"dep = 8, first step on a poisoned workspace: worst relative gradient error {worst[1]:.2e} ({worst[0]})")
+
+
+def test_second_backward_over_the_same_forward_gives_the_same_gradients():
+    """the backward pass reads the head LayerNorm's output `z` as the forward pass left it; round 5 then
+    overwrote it (scratch for the Temporal_pos_embed gradient), so a second backward over the same forward (retain_graph=True:
+    no forward re-run, the generation counter is unchanged) took head.1.weight's gradient from garbage.  Two backward passes
+    over one forward must agree bit for bit."""
+    m, _ = _small_deep_training_model(27, 2, 128, 2, seed=5)
+    x2d = torch.from_numpy(synthetic_inputs_2d(31, 2, 27)).cuda()
+    gt = (torch.from_numpy(synthetic_noise(32, (2, 27, 17, 3))) * 0.3).cuda()
+    pred = m(x2d, gt, t=torch.tensor([[40], [900]]), noise=torch.from_numpy(synthetic_noise(33, (2, 27, 17, 3))))
+    loss = torch.mean(torch.norm(pred - gt, dim=-1))
+    loss.backward(loss.clone().detach(), retain_graph=True)
+    torch.cuda.synchronize()
+    first = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    loss.backward(loss.clone().detach())
+    torch.cuda.synchronize()
+    for n, p in m.named_parameters():
+        assert torch.equal(first[n], p.grad), n
+    assert first["pose_estimator.head.1.weight"].abs().max() > 0
+
+
 def test_non_finite_weights_load_and_propagate():
     """a diverged checkpoint (inf / nan in ANY weight tensor) loads like it does in the reference and produces
     non-finite outputs there too, whichever tensor holds the value -- never a load-time error in one case and a silent

@@ -397,6 +397,31 @@ def test_deepcopy_and_pickle_of_a_model_do_not_share_library_handles(fake_lib):
     assert fake_lib.destroyed == [h2, h] and m.pose_estimator._ctx is None
 
 
+def test_droppath_masks_follow_the_rate_and_never_divide_by_zero():
+    """the cached keep-rates are keyed on (device, drop_path_rate, depth) -- a changed rate takes effect on the next
+    step --, a rate of 1.0 drops every sample without 0/0 (timm guards `keep_prob > 0`), and a module pickled before
+    `_param_names` existed still resolves its weights."""
+    import pickle
+    m = D3DP(tiny_args(), KL, KR, is_train=True)
+    net = m.pose_estimator.train()
+    dev = torch.device("cpu")
+    net.drop_path_rate = 0.0
+    assert net._droppath_masks(2, dev) is None
+    net.drop_path_rate = 0.5
+    a = net._droppath_masks(64, dev)
+    last = a[-2:]                                          # the last block: rate 0.5 -> scales 0 or 2
+    assert set(last.unique().tolist()) <= {0.0, 2.0} and (last == 0).any() and torch.all(a[:2] == 1.0)
+    net.drop_path_rate = 1.0                               # picked up without touching the cache by hand
+    b = net._droppath_masks(64, dev)
+    assert torch.isfinite(b).all() and torch.all(b[-2:] == 0.0)
+    d = net.__getstate__()
+    d.pop("_param_names")
+    old = object.__new__(type(net))
+    old.__setstate__(d)
+    assert old._param_names == net._param_names and len(old._weight_tensors()) == len(list(net.parameters()))
+    assert pickle.loads(pickle.dumps(net))._param_names == net._param_names
+
+
 def test_reference_attributes_exist():
     """common/diffusionpose.py:74, 87-90: attributes ported code may read."""
     m = D3DP(tiny_args(), KL, KR, is_train=False)
