@@ -104,6 +104,9 @@ PROTOTYPES = {
     "d3dp_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "d3dp_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "d3dp_profile_class_name": (C.c_char_p, [C.c_int32]),
+    # test hooks (include/d3dp_hip.h, last section)
+    "d3dp_debug_x2_variants": (C.c_int, []),
+    "d3dp_debug_train_linear": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

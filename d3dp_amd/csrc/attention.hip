@@ -1835,7 +1835,7 @@ int d3dp_launch_attn_spatial_bf16(const void* qkv, void* out, int n_seq, SeqMap 
 }
 
 #if D3DP_ATTN_STAMP
-extern "C" int d3dp_debug_attn_stamps(unsigned long long* dst) {
+extern "C" __attribute__((visibility("default"))) int d3dp_debug_attn_stamps(unsigned long long* dst) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(d3dp_attn_stamps), sizeof(unsigned long long) * 4 * 8 * 16 * 8);
 }
 #endif

@@ -10,6 +10,7 @@
 //   N4  Procrustes-aligned errors (P-MPJPE)      common/loss.py:190-395 (batched 3x3 SVD alignment)
 // All of them are HBM-bound index/elementwise work on tensors that are tiny next to the denoiser's; they exist so the
 // data never leaves the device between the dataset pool, the sampler and the metrics.
+#include "../../include/d3dp_hip.h"
 #include "common.h"
 #include "kernels.h"
 

@@ -355,9 +355,9 @@ int run_block(d3dp_ctx* c, const BlockDev& w, int axis, float* x, void* y1, void
 extern "C" {
 
 int d3dp_abi_version(void) { return D3DP_ABI_VERSION; }
-// test hook (not part of the ABI in include/d3dp_hip.h): 1 if this library carries the experiment kernels of gemm_x2.hip
+// test hook (include/d3dp_hip.h, "test hooks"): 1 if this library carries the experiment kernels of gemm_x2.hip
 int d3dp_debug_x2_variants(void) { return d3dp_x2_variants_built() ? 1 : 0; }
-// test hook (not part of the ABI): the training step's split-fp16 Linear alone, out[M, N] = A[M, K] W[N, K]^T + bias on fp32
+// test hook (include/d3dp_hip.h, "test hooks"): the training step's split-fp16 Linear alone, out[M, N] = A[M, K] W[N, K]^T + bias on fp32
 // device operands -- absmax, operand passes and gemm_f16x2_dyn_kernel as the step launches them.  tail: 0 = the rows behind the
 // last whole 256-row tile as one more row of tiles, 1 = as 16 x 64 blocks at the end of the kernel.  amax_out: optional
 // pre-zeroed device slot (amax_pos: see kernels.h).  Allocates its operand buffers and synchronises the stream.
@@ -426,6 +426,18 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->train_tail_blocks = !(tt && !strcmp(tt, "split"));
   const char* ta = getenv("D3DP_TRAIN_ATTN");
   c->train_attn_x2 = (ta && !strcmp(ta, "f32")) ? 0 : (ta && !strcmp(ta, "x2t")) ? 1 : 2;
+  // D3DP_TRAIN_WGRAD=each / D3DP_TRAIN_TAIL=split / D3DP_TRAIN_GELU=pass were round 5's same-box A/B switches: they make the
+  // configs[4] shapes take the launch forms the library keeps for the shapes its merged / fused forms do not cover (widths below
+  // 256, contractions that are not a multiple of 16 k-steps).  Measured and superseded: like the experiment
+  // kernels below they are honoured by the `make variants` library only and REFUSED here -- never ignored.  (What stays: the
+  // cross-check implementations D3DP_TRAIN_IMPL=f32, D3DP_TRAIN_ATTN=f32|x2t, D3DP_TRAIN_ATTN_BWD=valu, D3DP_EXACT_IMPL, D3DP_NO_FOLD,
+  // and the profiling switch D3DP_TRAIN_OVERLAP=0|1: one stream, so that no kernel's duration contains a wait for CUs.)
+  if ((!c->train_gelu_in_prep || !c->train_wgrad_merged || !c->train_tail_blocks) && !d3dp_x2_variants_built()) {
+    delete c;
+    return fail(D3DP_ENOTSUP, "D3DP_TRAIN_WGRAD=each / D3DP_TRAIN_TAIL=split / D3DP_TRAIN_GELU=pass select superseded launch forms of the "
+                              "training step that only the variants build honours (make -C d3dp_amd/csrc variants; "
+                              "D3DP_LIB=d3dp_amd/lib/variants/libd3dp_variants.so)");
+  }
   {
     // Measurement switches of experiments that were measured and not adopted: the row-class skewed schedule
     // (D3DP_X2_SKEW=1|2|4), the ping-pong (D3DP_X2_PP=1) and wide (D3DP_X2_WIDE=1) forms of the EXACT Linear, norm2 folded into

@@ -33,6 +33,14 @@ extern "C" {
 
 #define D3DP_ABI_VERSION 3
 
+/* The library is built with -fvisibility=hidden: the functions declared in this header -- and nothing else -- are its dynamic
+ * symbols (tests/test_abi.py compares `nm -D` with this file). */
+#if defined(__GNUC__) || defined(__clang__)
+#define D3DP_API __attribute__((visibility("default")))
+#else
+#define D3DP_API
+#endif
+
 enum {
   D3DP_OK = 0,
   D3DP_EINVAL = -1,      /* bad argument / unsupported shape */
@@ -105,23 +113,23 @@ typedef struct d3dp_weights {
 
 typedef struct d3dp_ctx d3dp_ctx;
 
-int d3dp_abi_version(void);
-const char* d3dp_last_error(void);
+D3DP_API int d3dp_abi_version(void);
+D3DP_API const char* d3dp_last_error(void);
 
 /* Lifetime.  Replaces: MixSTE2.__init__ (mixste.py:142-210) + .cuda() (main.py:243).
  * Shapes: 1 <= frames <= 1024 (the split-fp16 / bf16 MFMA attention kernels hold a sequence of up to 256 frames; longer
  * clips -- `-f 351`, common/arguments.py:58 -- run both attentions on a chunked fp32 row kernel; d3dp_train_* needs <= 256),
  * joints <= 32, channels in {64, 128, 256, 512}, head dim in {8, 16, 32, 64}, hidden % 64 == 0 (D3DP_ENOTSUP otherwise). */
-int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out);
-int d3dp_destroy(d3dp_ctx* ctx);
+D3DP_API int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out);
+D3DP_API int d3dp_destroy(d3dp_ctx* ctx);
 /* Replaces: load_state_dict (main.py:257).  Converts/packs weights for cfg.mode (synchronises `stream`).
  * Non-finite weights (a diverged checkpoint) are not an error: like the reference, the library loads them and the outputs
  * are non-finite where the reference's are (d3dp_status reports it); an EXACT context then runs its split-bf16
  * implementation (d3dp_exact_scales: implementation 1), which has fp32's exponent range. */
-int d3dp_set_weights(d3dp_ctx* ctx, const d3dp_weights* w, void* stream);
+D3DP_API int d3dp_set_weights(d3dp_ctx* ctx, const d3dp_weights* w, void* stream);
 /* D3DP_MODE_TRAIN only: use the caller's fp32 device buffers in place (no packed copy, no launch, no synchronisation), so
  * an optimizer step needs no re-push.  The buffers must stay allocated while the context uses them. */
-int d3dp_set_weights_borrowed(d3dp_ctx* ctx, const d3dp_weights* w);
+D3DP_API int d3dp_set_weights_borrowed(d3dp_ctx* ctx, const d3dp_weights* w);
 
 /* EXACT mode's split-fp16 operands (x 2^s = hi + lo, two fp16) hold |x| 2^s < 65504: with the default s = 4 that is
  * |x| < D3DP_SPLIT_RANGE, beyond which hi would be inf and the Linear NaN where the fp32 reference stays finite.  The
@@ -145,23 +153,23 @@ int d3dp_set_weights_borrowed(d3dp_ctx* ctx, const d3dp_weights* w);
  * the proj Linear hands fc1 the un-normalised residual stream; that epilogue checks every value it splits, exactly, at run
  * time, and reports through d3dp_status.) */
 #define D3DP_SPLIT_RANGE 4094.0f
-int d3dp_exact_range_bound(const d3dp_ctx* ctx, float* bound);
-int d3dp_exact_scales(const d3dp_ctx* ctx, float* s_kv, float* s_hidden, int32_t* implementation);
-int d3dp_status(d3dp_ctx* ctx, int32_t* nonfinite);
+D3DP_API int d3dp_exact_range_bound(const d3dp_ctx* ctx, float* bound);
+D3DP_API int d3dp_exact_scales(const d3dp_ctx* ctx, float* s_kv, float* s_hidden, int32_t* implementation);
+D3DP_API int d3dp_status(d3dp_ctx* ctx, int32_t* nonfinite);
 
 /* Scratch needed by d3dp_denoise for a (B, H) call. */
-int d3dp_workspace_bytes(const d3dp_ctx* ctx, int32_t B, int32_t H, size_t* bytes);
+D3DP_API int d3dp_workspace_bytes(const d3dp_ctx* ctx, int32_t B, int32_t H, size_t* bytes);
 
 /* One denoiser evaluation.  Replaces: MixSTE2.forward(x_2d, x_3d, t), eval branch (mixste.py:278-298) and,
  * with H = 1, the train branch's forward (mixste.py:215-225). */
-int d3dp_denoise(d3dp_ctx* ctx, const float* x2d, const float* x_t, const int64_t* t, float* out, int32_t B,
+D3DP_API int d3dp_denoise(d3dp_ctx* ctx, const float* x2d, const float* x_t, const int64_t* t, float* out, int32_t B,
                  int32_t H, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Flip-TTA pre-step.  Replaces diffusionpose.py:148-153.
  *   xt2[0:B]  = clamp(img, +-1.1 scale) / scale
  *   xt2[B:2B] = x negated, joints permuted (perm[j] = source joint of joint j; device int32[J])
  * img (B,H,F,J,3) -> xt2 (2B,H,F,J,3). */
-int d3dp_ddim_pre(const float* img, float* xt2, const int32_t* perm, float scale, int32_t B, int32_t H, int32_t F,
+D3DP_API int d3dp_ddim_pre(const float* img, float* xt2, const int32_t* perm, float scale, int32_t B, int32_t H, int32_t F,
                   int32_t J, void* stream);
 
 /* Flip-TTA post-step + DDIM update.  Replaces diffusionpose.py:158-169 and :244-254.
@@ -170,14 +178,14 @@ int d3dp_ddim_pre(const float* img, float* xt2, const int32_t* perm, float scale
  *   pn      = float((sqrt_recip * img - x_start) / sqrt_recipm1)  (fp64, predict_noise_from_start :129-133)
  *   img_next= x_start*c_xstart + c_noise*pn + sigma*noise         (fp32, unless `last`)
  * `noise` may be NULL only when `last` != 0.  img_next may alias img. */
-int d3dp_ddim_post(const float* pred2, const float* img, const float* noise, const int32_t* perm, float scale,
+D3DP_API int d3dp_ddim_post(const float* pred2, const float* img, const float* noise, const int32_t* perm, float scale,
                    double sqrt_recip, double sqrt_recipm1, float c_xstart, float c_noise, float sigma, int32_t last,
                    float* x_start, size_t xs_bstride, float* img_next, int32_t B, int32_t H, int32_t F, int32_t J,
                    void* stream);
 
 /* Train-time forward diffusion.  Replaces prepare_diffusion_concat/q_sample (diffusionpose.py:260-267, 290-306):
  *   out[b] = float(clamp(a[b]*(x0[b]*scale) + s[b]*noise[b], +-1.1 scale) / scale); a, s are device fp64 (B). */
-int d3dp_q_sample(const float* x0, const float* noise, const double* sqrt_ac, const double* sqrt_1mac, float scale,
+D3DP_API int d3dp_q_sample(const float* x0, const float* noise, const double* sqrt_ac, const double* sqrt_1mac, float scale,
                   float* out, int32_t B, int32_t per_b, void* stream);
 
 /* JPMA: joint-wise reprojection-based multi-hypothesis aggregation (the consumer of the sampler / all-gather output).
@@ -187,7 +195,7 @@ int d3dp_q_sample(const float* x0, const float* noise, const double* sqrt_ac, co
  *   agg (B,K,F,J,3)  <- the hypothesis whose reprojection is closest to gt2d (first minimum, like torch.min)
  *   sel (B,K,F,J) int32 or NULL; err_sel / err_min (B,K,F,J) or NULL: |selected - gt3d| and min_h |pred_h - gt3d|
  *   (their means over (B,F,J) are the reference's J_Agg and J_Best errors per step). */
-int d3dp_jpma(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d, float* agg,
+D3DP_API int d3dp_jpma(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d, float* agg,
               int32_t* sel, float* err_sel, float* err_min, int32_t B, int32_t K, int32_t H, int32_t F, int32_t J,
               int32_t zero_root, void* stream);
 /* d3dp_jpma straight on an all-gather result: `gathered` = (R, B, K, H_local, F, J, 3), rank-major, exactly what
@@ -195,7 +203,7 @@ int d3dp_jpma(const float* pred, const float* traj, const float* cam, const floa
  * Same outputs and the same selection, bit for bit, as d3dp_jpma on the (B, K, R H_local, F, J, 3) tensor that a
  * permute + copy of `gathered` would produce (158.6 MB per rank and step at configs[3] that are never moved).
  * Replaces: main.py:700-718 after the hypothesis exchange of SURVEY.md 8 E1. */
-int d3dp_jpma_gathered(const float* gathered, const float* traj, const float* cam, const float* gt2d, const float* gt3d,
+D3DP_API int d3dp_jpma_gathered(const float* gathered, const float* traj, const float* cam, const float* gt2d, const float* gt3d,
                        float* agg, int32_t* sel, float* err_sel, float* err_min, int32_t R, int32_t B, int32_t K,
                        int32_t H_local, int32_t F, int32_t J, int32_t zero_root, void* stream);
 /* d3dp_jpma with the 3DHP evaluation's options and pose outputs (main_3dhp.py:777-835): root_joint = index of the joint
@@ -203,7 +211,7 @@ int d3dp_jpma_gathered(const float* gathered, const float* traj, const float* ca
  * project_to_2d_linear (f * clamp(X/Z) + c) instead of the distortion model; jbest (B,K,F,J,3) = per joint the
  * hypothesis closest to gt3d (J-Best pose), mean (B,K,F,J,3) = average over hypotheses (P-Agg pose).  Any output may be
  * NULL. */
-int d3dp_jpma_ex(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d, float* agg,
+D3DP_API int d3dp_jpma_ex(const float* pred, const float* traj, const float* cam, const float* gt2d, const float* gt3d, float* agg,
                  int32_t* sel, float* err_sel, float* err_min, float* jbest, float* mean, int32_t B, int32_t K, int32_t H,
                  int32_t F, int32_t J, int32_t root_joint, int32_t linear_projection, void* stream);
 
@@ -216,10 +224,10 @@ int d3dp_jpma_ex(const float* pred, const float* traj, const float* cam, const f
  * d3dp_train_backward launches a block's weight-gradient product on a second, library-owned stream, forked from and joined
  * back to `stream` with events before it returns (the host is never synchronised; env D3DP_TRAIN_OVERLAP=0: one stream).
  * No gradient is accumulated with float atomics: the same inputs give the same bits. */
-int d3dp_train_workspace_bytes(const d3dp_ctx* ctx, int32_t B, size_t* bytes);
-int d3dp_train_forward(d3dp_ctx* ctx, const float* x2d, const float* x3d, const int64_t* t, const float* masks, float* out,
+D3DP_API int d3dp_train_workspace_bytes(const d3dp_ctx* ctx, int32_t B, size_t* bytes);
+D3DP_API int d3dp_train_forward(d3dp_ctx* ctx, const float* x2d, const float* x3d, const int64_t* t, const float* masks, float* out,
                        int32_t B, void* workspace, size_t workspace_bytes, void* stream);
-int d3dp_train_backward(d3dp_ctx* ctx, const float* x2d, const float* x3d, const int64_t* t, const float* masks,
+D3DP_API int d3dp_train_backward(d3dp_ctx* ctx, const float* x2d, const float* x3d, const int64_t* t, const float* masks,
                         const float* grad_out, const d3dp_weights* grads, int32_t B, void* workspace,
                         size_t workspace_bytes, void* stream);
 
@@ -228,36 +236,36 @@ int d3dp_train_backward(d3dp_ctx* ctx, const float* x2d, const float* x3d, const
  * partial clip = the LAST F frames, n < F replicate-padded on the right (reference main.py:267-299,
  * in_the_wild/utils.py:199-240).  dst_flip (optional): the flipped input main.py:646-648 builds (x negated, joints
  * permuted by perm[J], perm[j] = source joint). */
-int d3dp_clip_count(int32_t n, int32_t F);
-int d3dp_clip_gather(const float* src, float* dst, float* dst_flip, const int32_t* perm, int32_t n, int32_t F, int32_t J,
+D3DP_API int d3dp_clip_count(int32_t n, int32_t F);
+D3DP_API int d3dp_clip_gather(const float* src, float* dst, float* dst_flip, const int32_t* perm, int32_t n, int32_t F, int32_t J,
                      int32_t D, void* stream);
 /* de-chunking: pred (n_clips,K,H,F,J,D) -> out (K,H,n,J,D)  (in_the_wild/videopose_diffusion.py:150-164, including
  * its n < F behaviour: the last n frames of the padded clip). */
-int d3dp_clip_scatter(const float* pred, float* out, int32_t n, int32_t K, int32_t H, int32_t F, int32_t J, int32_t D,
+D3DP_API int d3dp_clip_scatter(const float* pred, float* out, int32_t n, int32_t K, int32_t H, int32_t F, int32_t J, int32_t D,
                       int32_t last_wins, void* stream);   /* last_wins: main_3dhp.py:327-330 (final clip owns the last F frames) */
 /* E1 reduced exchange: d3dp_jpma_winners writes this rank's per-joint winner win (B,K,F,J,5) =
  * (2D error, x, y, z, bits of int32 global hypothesis index h_offset + h); after an all-gather over R ranks
  * (rank-major) d3dp_jpma_combine picks the smallest 2D error per joint, lowest rank on ties (= lowest global h, the
  * element torch.min returns in loss.py:67).  n = B*K*F*J. */
-int d3dp_jpma_winners(const float* pred, const float* traj, const float* cam, const float* gt2d, float* win,
+D3DP_API int d3dp_jpma_winners(const float* pred, const float* traj, const float* cam, const float* gt2d, float* win,
                       int32_t h_offset, int32_t B, int32_t K, int32_t H, int32_t F, int32_t J, int32_t zero_root,
                       void* stream);
-int d3dp_jpma_combine(const float* win, int32_t R, size_t n, float* agg, int32_t* sel, void* stream);
+D3DP_API int d3dp_jpma_combine(const float* win, int32_t R, size_t n, float* agg, int32_t* sel, void* stream);
 /* N3 training batch assembly from device-resident pools (common/generators.py:12-171 ChunkedGenerator_Seq):
  * pool2d (N,J,2), pool3d (N,J,3) or NULL; table (nb,4) int32 = (first pool frame of the sequence, sequence length,
  * chunk start frame (may be negative / run past the end: edge frames repeat), flip); perm2d/perm3d (J) = left/right
  * swap for flipped items (x negated); zero_root: joint 0 of out3d written as 0 (main.py:365). */
-int d3dp_batch_gather(const float* pool2d, const float* pool3d, const int32_t* table, const int32_t* perm2d,
+D3DP_API int d3dp_batch_gather(const float* pool2d, const float* pool3d, const int32_t* table, const int32_t* perm2d,
                       const int32_t* perm3d, float* out2d, float* out3d, int32_t nb, int32_t F, int32_t J,
                       int32_t zero_root, void* stream);
 /* AdamW (main.py:311: torch.optim.AdamW(lr, weight_decay=0.1)) over all parameter tensors in one launch.
  * chunks: device array of d3dp_adam_chunk (one block each); step = 1-based step count of this update. */
 typedef struct d3dp_adam_chunk { float* p; const float* g; float* m; float* v; int32_t n; int32_t pad; } d3dp_adam_chunk;
-int d3dp_adamw_step(const void* chunks, int32_t n_chunks, double lr, double beta1, double beta2, double eps,
+D3DP_API int d3dp_adamw_step(const void* chunks, int32_t n_chunks, double lr, double beta1, double beta2, double eps,
                     double weight_decay, int64_t step, void* stream);
 /* N4 Procrustes-aligned per-joint errors (common/loss.py:190-395 p_mpjpe*): pred (B,KH,F,J,3), target (B,F,J,3) ->
  * err (B,KH,F,J) and (optional) the aligned poses. */
-int d3dp_procrustes(const float* pred, const float* target, float* err, float* aligned, int32_t B, int32_t KH, int32_t F,
+D3DP_API int d3dp_procrustes(const float* pred, const float* target, float* err, float* aligned, int32_t B, int32_t KH, int32_t F,
                     int32_t J, void* stream);
 
 /* ---- single operators (unit parity tests; same kernels the denoiser launches) ---------------------------- */
@@ -265,7 +273,7 @@ int d3dp_procrustes(const float* pred, const float* target, float* err, float* a
  * mode EXACT: everything fp32 (fp32 MFMA; the EXACT denoiser itself runs mode 3 below).  mode FAST: A, W bf16 (uint16
  * storage), fp32 accumulate, epi 0 or 1 only, out bf16 unless (epi & 16) (fp32): the persistent streaming kernel the
  * denoiser uses. */
-int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, const float* bias, void* out, int32_t M,
+D3DP_API int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, const float* bias, void* out, int32_t M,
                    int32_t N, int32_t K, void* stream);
 /* Multi-head attention over qkv[T,3C] -> out[T,C]; axis 0 = spatial (sequences of J joints), 1 = temporal
  * (sequences of F frames); tokens ordered (seq_batch, f, n).  impl 0 = fp32-VALU row kernel (any activation type),
@@ -273,13 +281,13 @@ int d3dp_op_linear(int32_t mode, int32_t epi, const void* A, const void* W, cons
  * (temporal axis), 2 = the EXACT-mode kernels: split-fp16 operands on the fp16 matrix cores (both axes; head dim 64).  Inside
  * the denoiser those read the packed rows of its qkv Linear (d3dp_op_linear_x2, epi 4); this entry point takes plain fp32
  * rows and repacks them into a stream-ordered temporary (hipMallocAsync) first. */
-int d3dp_op_attention(int32_t act_bf16, int32_t impl, int32_t axis, const void* qkv, void* out, int32_t n_bh,
+D3DP_API int d3dp_op_attention(int32_t act_bf16, int32_t impl, int32_t axis, const void* qkv, void* out, int32_t n_bh,
                       int32_t F, int32_t J, int32_t C, int32_t heads, void* stream);
-int d3dp_op_layernorm(int32_t out_bf16, const float* x, const float* w, const float* b, float eps, void* out,
+D3DP_API int d3dp_op_layernorm(int32_t out_bf16, const float* x, const float* w, const float* b, float eps, void* out,
                       int32_t T, int32_t C, void* stream);
 /* mode 2 of d3dp_op_linear: split-bf16.  A and W are three bf16 planes each (x = x0 + x1 + x2, made by
  * d3dp_op_split3: dst[0..n) | dst[n..2n) | dst[2n..3n)); epi 0 -> fp32 out, epi 1 -> GELU then three bf16 planes out. */
-int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream);
+D3DP_API int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream);
 /* The EXACT-mode Linear on split-fp16 operands.  A2 [M][K] and W2 [N][K] hold TWO fp16 per element, y = src * scale =
  * hi + lo with hi = fp16(y), lo = fp16(y - hi), in the line-interleaved layout "h2i": a matrix row is K/32 blocks of 64 fp16
  * (128 bytes), block kb = [hi of columns 32 kb .. 32 kb + 31 | lo of the same 32 columns] -- one 32-deep k-step of one row,
@@ -303,21 +311,34 @@ int d3dp_op_split3(const float* src, void* dst, size_t n, void* stream);
  * D3DP_X2_PP, D3DP_X2_WIDE, D3DP_SEQ_PAD, D3DP_FOLD_LN read by d3dp_create, fail with D3DP_ENOTSUP -- they are never ignored.
  * Cross-check switches the product library does honour (read in d3dp_create): D3DP_EXACT_IMPL=bf16x3|f32, D3DP_NO_FOLD=1
  * (other implementations of EXACT mode's Linears / residual adds, same tolerance), D3DP_TRAIN_IMPL=f32. */
-int d3dp_op_split2(const float* src, void* dst, size_t n, float scale, void* stream);
-int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* bias, float w_scale, void* out, int32_t M,
+D3DP_API int d3dp_op_split2(const float* src, void* dst, size_t n, float scale, void* stream);
+D3DP_API int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, const float* bias, float w_scale, void* out, int32_t M,
                       int32_t N, int32_t K, void* stream);
 /* fp32 <-> bf16 conversion helper (round-to-nearest-even), n elements */
-int d3dp_op_to_bf16(const float* src, void* dst, size_t n, void* stream);
+D3DP_API int d3dp_op_to_bf16(const float* src, void* dst, size_t n, void* stream);
 
 /* ---- per-kernel timing (HIP events on the launch stream) -------------------------------------------------
  * While enabled, every kernel launched by d3dp_denoise is bracketed by hipEventRecord on `stream`.
  * d3dp_profile_read synchronises the recorded events and returns, per kernel class, the launch count and the
  * summed duration in milliseconds.  Classes are listed by d3dp_profile_class_name. */
 #define D3DP_PROFILE_CLASSES 12
-int d3dp_profile_enable(d3dp_ctx* ctx, int32_t on);
-int d3dp_profile_read(d3dp_ctx* ctx, int64_t* counts /*host[D3DP_PROFILE_CLASSES]*/,
+D3DP_API int d3dp_profile_enable(d3dp_ctx* ctx, int32_t on);
+D3DP_API int d3dp_profile_read(d3dp_ctx* ctx, int64_t* counts /*host[D3DP_PROFILE_CLASSES]*/,
                       double* total_ms /*host[D3DP_PROFILE_CLASSES]*/);
-const char* d3dp_profile_class_name(int32_t cls);
+D3DP_API const char* d3dp_profile_class_name(int32_t cls);
+
+/* ---- test hooks ------------------------------------------------------------------------------------------
+ * Exported for tests/ only; no reference call site stands behind them and hosts must not bind them.
+ * d3dp_debug_x2_variants: 1 if this library was built with the measured-negative experiment kernels of gemm_x2.hip
+ *   (`make variants`: lib/variants/libd3dp_variants.so), 0 for the product library.
+ * d3dp_debug_train_linear: the training step's split-fp16 Linear alone, out[M, N] = A[M, K] W[N, K]^T + bias on fp32 device
+ *   operands -- absmax, operand split and gemm_f16x2_dyn_kernel exactly as d3dp_train_forward launches them.  tail: 0 = the rows
+ *   behind the last whole 256-row tile as one more row of tiles, 1 = as 16 x 64 blocks inside the same launch; amax_out:
+ *   optional pre-zeroed device word receiving the output's absmax (amax_pos = 1: its largest positive value).  Allocates its
+ *   operand buffers and synchronises `stream`. */
+D3DP_API int d3dp_debug_x2_variants(void);
+D3DP_API int d3dp_debug_train_linear(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N,
+                                     int32_t K, int32_t tail, unsigned* amax_out, int32_t amax_pos, void* stream);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,21 @@ def test_every_declared_symbol_is_exported(lib):
     assert names[0] == "gemm_qkv" and len(set(names)) == _lib.PROFILE_CLASSES
 
 
+def test_exports_are_exactly_the_header(lib):
+    """the library's dynamic symbols are the functions include/d3dp_hip.h declares (the C ABI plus its
+    documented "test hooks" section) and nothing else -- no C++-mangled internals (`-fvisibility=hidden`, csrc/exports.map).
+    hipcc's own per-translation-unit markers (`__hip_cuid_*`) are the only other names."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.strip() and not l.split()[-1].startswith("__hip_cuid_"))
+    assert exported == header_functions()
+    assert not any(n.startswith("_Z") for n in exported)
+    src = open(os.path.join(REPO, "include", "d3dp_hip.h")).read()
+    hooks = src[src.index("---- test hooks"):]
+    assert sorted(set(re.findall(r"\b(d3dp_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", hooks, flags=re.S)))) == \
+        ["d3dp_debug_train_linear", "d3dp_debug_x2_variants"]
+
+
 def make_model(frames=243, cs=512, dep=8, H=20, K=10, is_train=False):
     args = SimpleNamespace(number_of_frames=frames, test_time_augmentation=True, timestep=1000, scale=1.0, cs=cs, dep=dep)
     return D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=is_train, num_proposals=H, sampling_timesteps=K)
@@ -120,7 +135,7 @@ def test_header_is_plain_c_and_links():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = os.path.join(root, "include", "d3dp_hip.h")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
-    names = sorted(set(re.findall(r"^(?:int|const char\*)\s+(d3dp_[a-z0-9_]+)\s*\(", open(hdr).read(), flags=re.M)))
+    names = sorted(set(re.findall(r"^D3DP_API (?:int|const char\*)\s+(d3dp_[a-z0-9_]+)\s*\(", open(hdr).read(), flags=re.M)))
     assert len(names) >= 30 and set(names) == set(_lib.PROTOTYPES), set(names) ^ set(_lib.PROTOTYPES)
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "link.c")

@@ -1202,14 +1202,12 @@ def test_training_step_fp32_linears_cross_check(monkeypatch, cs):
     print(f"training step, fp32-MFMA Linears vs split-fp16 Linears: worst relative gradient difference {worst:.2e}")
 
 
-@pytest.mark.gpu
-def test_training_step_scheduling_switches_agree(monkeypatch):
-    """Round 5's scheduling changes of the training step against the forms they replaced (switches read when the context is
-    created): one launch for a block's four weight gradients / one each (D3DP_TRAIN_WGRAD=each), a batch's last
-    T mod 256 rows as 16 x 64 blocks / as a round of tiles or a split-K launch (D3DP_TRAIN_TAIL=split), d h_pre inside the
-    operand pass / by a pass of its own (D3DP_TRAIN_GELU=pass), two / one / no operand sets on the second stream
-    (D3DP_TRAIN_OVERLAP=1 | 0).  Same arithmetic up to the grouping of fp32 partial sums and one operand scale: loss and every
-    gradient agree to fp32 noise.  T = 2 x 243 x 17 = 32 x 256 + 70 rows: the fc1 products take the remainder-block path."""
+_TRAIN_SWITCHES = ("D3DP_TRAIN_WGRAD", "D3DP_TRAIN_TAIL", "D3DP_TRAIN_GELU", "D3DP_TRAIN_OVERLAP")
+
+
+def _training_step_under(monkeypatch, cases):
+    """One configs[4]-shaped step (T = 2 x 243 x 17 = 32 x 256 + 70 rows: the fc1 products take the remainder-block path) per
+    entry of `cases` (name -> environment read when the context is created): {name: (loss, {parameter: gradient})}."""
     Fr, B, cs, dep = 243, 2, 512, 2
     x2d = torch.from_numpy(synthetic_inputs_2d(931, B, Fr)).cuda()
     gt = torch.from_numpy(synthetic_noise(932, (B, Fr, 17, 3))) * 0.3
@@ -1222,13 +1220,9 @@ def test_training_step_scheduling_switches_agree(monkeypatch):
     for i in range(dep):                                   # recorded DropPath masks: every run scales the same samples
         for kind, n in (("STEblocks", B * Fr), ("TTEblocks", B * 17)):
             drop[f"{kind}.{i}"] = tuple((torch.rand(n, generator=g) < 0.85).float() / 0.85 for _ in range(2))
-    switches = ("D3DP_TRAIN_WGRAD", "D3DP_TRAIN_TAIL", "D3DP_TRAIN_GELU", "D3DP_TRAIN_OVERLAP")
     res = {}
-    for name, env in (("default", {}), ("wgrad_each", {"D3DP_TRAIN_WGRAD": "each"}), ("tail_split", {"D3DP_TRAIN_TAIL": "split"}),
-                      ("gelu_pass", {"D3DP_TRAIN_GELU": "pass"}), ("one_set", {"D3DP_TRAIN_OVERLAP": "1"}),
-                      ("one_stream", {"D3DP_TRAIN_OVERLAP": "0"}),
-                      ("round4", {"D3DP_TRAIN_WGRAD": "each", "D3DP_TRAIN_TAIL": "split", "D3DP_TRAIN_GELU": "pass", "D3DP_TRAIN_OVERLAP": "1"})):
-        for k in switches:
+    for name, env in cases:
+        for k in _TRAIN_SWITCHES:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1241,6 +1235,44 @@ def test_training_step_scheduling_switches_agree(monkeypatch):
         loss.backward(loss.clone().detach())
         torch.cuda.synchronize()
         res[name] = (loss.item(), {k: p.grad.double().cpu() for k, p in m.pose_estimator.named_parameters()})
+    return res
+
+
+def test_training_step_stream_switches_change_no_bit(monkeypatch):
+    """D3DP_TRAIN_OVERLAP=1 | 0 (one operand set on the second stream / everything on the caller's stream: the profiling switch the
+    one-stream kernel tables under profiles/ are taken with) change the schedule and no arithmetic: every gradient bit-equal."""
+    res = _training_step_under(monkeypatch, (("default", {}), ("one_set", {"D3DP_TRAIN_OVERLAP": "1"}), ("one_stream", {"D3DP_TRAIN_OVERLAP": "0"})))
+    ref = res["default"]
+    for name in ("one_set", "one_stream"):
+        assert res[name][0] == ref[0] and all(torch.equal(res[name][1][k], ref[1][k]) for k in ref[1]), name
+
+
+def test_product_library_refuses_the_superseded_training_launch_forms(monkeypatch):
+    """round 5's A/B switches select launch forms that were measured and superseded; the product library
+    REFUSES them (D3DP_ENOTSUP) instead of ignoring them -- only the `make variants` build honours them."""
+    if _lib.load().d3dp_debug_x2_variants() == 1:
+        pytest.skip("this is the variants build: it honours the switches (test_training_step_scheduling_switches_agree)")
+    for k, v in (("D3DP_TRAIN_WGRAD", "each"), ("D3DP_TRAIN_TAIL", "split"), ("D3DP_TRAIN_GELU", "pass")):
+        for kk in _TRAIN_SWITCHES:
+            monkeypatch.delenv(kk, raising=False)
+        monkeypatch.setenv(k, v)
+        args = SimpleNamespace(number_of_frames=27, test_time_augmentation=True, timestep=1000, scale=1.0, cs=64, dep=1)
+        m = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=True).cuda()
+        with pytest.raises(_lib.D3DPHipError, match="superseded launch forms"):
+            m.pose_estimator._context(torch.device("cuda", 0))
+
+
+@pytest.mark.variants
+def test_training_step_scheduling_switches_agree(monkeypatch):
+    """(variants build) Round 5's scheduling changes of the training step against the forms they replaced: one launch for a
+    block's four weight gradients / one each (D3DP_TRAIN_WGRAD=each), a batch's last T mod 256 rows as 16 x 64 blocks / as a
+    round of tiles or a split-K launch (D3DP_TRAIN_TAIL=split), d h_pre inside the operand pass / by a pass of its own
+    (D3DP_TRAIN_GELU=pass).  Same arithmetic up to the grouping of fp32 partial sums and one operand scale: loss and every
+    gradient agree to fp32 noise."""
+    res = _training_step_under(monkeypatch, (
+        ("default", {}), ("wgrad_each", {"D3DP_TRAIN_WGRAD": "each"}), ("tail_split", {"D3DP_TRAIN_TAIL": "split"}),
+        ("gelu_pass", {"D3DP_TRAIN_GELU": "pass"}),
+        ("round4", {"D3DP_TRAIN_WGRAD": "each", "D3DP_TRAIN_TAIL": "split", "D3DP_TRAIN_GELU": "pass", "D3DP_TRAIN_OVERLAP": "1"})))
     ref = res["default"]
     for name, (loss, grads) in res.items():
         if name == "default":
@@ -1249,9 +1281,6 @@ def test_training_step_scheduling_switches_agree(monkeypatch):
         worst = max((grads[k] - ref[1][k]).norm().item() / max(ref[1][k].norm().item(), 1e-30) for k in grads)
         print(f"training step, {name} vs default: loss difference {abs(loss - ref[0]):.1e}, worst relative gradient difference {worst:.2e}")
         assert worst < 2e-5, (name, worst)
-    # the stream / operand-set switches change no arithmetic at all
-    for name in ("one_set", "one_stream"):
-        assert all(torch.equal(res[name][1][k], ref[1][k]) for k in ref[1]), name
 
 
 def test_bench_launches_its_own_ranks_when_two_gpus_are_visible():
@@ -1501,8 +1530,7 @@ def test_non_finite_weights_load_and_propagate():
 def _train_linear(A, W, b, tail, amax_pos=0):
     import ctypes as C
     lib = _lib.load()
-    fn = lib.d3dp_debug_train_linear                       # test hook of capi.hip (not in include/d3dp_hip.h)
-    fn.restype, fn.argtypes = C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 4 + [C.c_void_p, C.c_int32, C.c_void_p]
+    fn = lib.d3dp_debug_train_linear                       # test hook (include/d3dp_hip.h, "test hooks")
     M, K = A.shape
     N = W.shape[0]
     out = torch.full((M, N), float("nan"), device="cuda")
