@@ -208,7 +208,79 @@ def jpma_inputs(x2d, frames, dev):
     return traj.float().contiguous(), cam, x2d
 
 
-def timed_steps(model, x2d, x2f, steps, warmup, gen, gather, dev="cuda"):
+class GpuTelemetry:
+    """Shader clock and package power of THIS rank's GPU, sampled by a background thread while the timed steps run (started
+    after the warm-up, stopped before any other leg): VERDICT r5 item 3 -- box-to-box differences of the headline (50.3 ... 50.9
+    hypothesis-clips/s with unchanged kernels) must be attributable to the box.  Source: the amdgpu hwmon files of the card whose
+    PCI address is the HIP device's (freq1_input = current sclk in Hz, power1_input / power1_average in microwatts, power1_cap),
+    read every `period` seconds; no subprocess, no device call, nothing on the GPU's queues."""
+
+    def __init__(self, device_index=0, period=0.02):
+        self.period, self.samples, self._stop, self._thread = period, [], None, None
+        self.dir, self.source = self._find(device_index)
+        self.cap_w = self._read("power1_cap", 1e-6)
+
+    @staticmethod
+    def _find(device_index):
+        import glob
+        cands = [d for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*") if os.path.exists(os.path.join(d, "freq1_input"))]
+        if not cands:
+            return None, "no amdgpu hwmon directory is readable"
+        want = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        except Exception:
+            pass
+        for d in cands:
+            pci = os.path.basename(os.path.realpath(os.path.join(d, "..", "..")))      # .../0000:75:00.0
+            if want and pci.lower().startswith(want):
+                return d, f"{d} (PCI {pci} = the HIP device)"
+        if len(cands) == 1:
+            return cands[0], f"{cands[0]} (the only card with sensors)"
+        return None, f"{len(cands)} cards with sensors, none at the HIP device's PCI address {want}"
+
+    def _read(self, name, scale):
+        if not self.dir:
+            return None
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().strip()) * scale
+        except Exception:
+            return None
+
+    def start(self):
+        import threading
+        if not self.dir:
+            return
+        self._stop = threading.Event()
+        pw = "power1_input" if os.path.exists(os.path.join(self.dir, "power1_input")) else "power1_average"
+
+        def run():
+            while not self._stop.is_set():
+                self.samples.append((self._read("freq1_input", 1e-6), self._read(pw, 1e-6)))
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread:
+            self._stop.set()
+            self._thread.join()
+            self._thread = None
+
+    def report(self):
+        clk = [c for c, _ in self.samples if c]
+        pw = [p for _, p in self.samples if p]
+        mean = lambda v: round(sum(v) / len(v), 1) if v else None
+        return {"clock_mhz_mean": mean(clk), "clock_mhz_min": min(clk) if clk else None, "clock_mhz_max": max(clk) if clk else None,
+                "power_w_mean": mean(pw), "power_w_max": max(pw) if pw else None, "power_cap_w": self.cap_w,
+                "samples": len(self.samples), "period_s": self.period, "source": self.source,
+                "what": "sclk (hwmon freq1_input) and package power (hwmon power1_input) of this rank's GPU over the timed steps only"}
+
+
+def timed_steps(model, x2d, x2f, steps, warmup, gen, gather, dev="cuda", telemetry=None):
     """`gather` (N > 1): the step ends with the exchange and its consumer -- all-gather of every rank's hypotheses, JPMA on
     the result (dist.jpma_allgather) -- and returns (local predictions, aggregated poses, selected hypothesis)."""
     import torch
@@ -225,6 +297,8 @@ def timed_steps(model, x2d, x2f, steps, warmup, gen, gather, dev="cuda"):
     if gather:
         dist.barrier()
     device_sync(dev)
+    if telemetry:
+        telemetry.start()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = one()
@@ -232,6 +306,8 @@ def timed_steps(model, x2d, x2f, steps, warmup, gen, gather, dev="cuda"):
     if gather:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if telemetry:
+        telemetry.stop()
     if gather:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -346,6 +422,22 @@ def roofline_from_profile(prof, numerics, B, H, K):
 PEAK_HBM_TBS = 8.0             # HBM3E, MI355X_MICROARCH.md
 
 
+def bytes_entry(nbytes, ms, n):
+    """A row-wise kernel class against the HBM roofline: ALGORITHMIC bytes / HIP-event time.  When that rate exceeds the HBM
+    peak the pass did not come from HBM: at small pass sizes (FAST mode's 62 k-row passes: 32-127 MB per tensor) producer and
+    consumer meet in the 256 MiB Infinity Cache.  The HBM roofline then does not bound the kernel and no fraction of it is printed
+    (a `frac` above 1 says the model is wrong, not the kernel); the guide gives no Infinity-Cache bandwidth to
+    price it against, so the entry carries the rate and the reason."""
+    ach = nbytes / (ms * 1e-3) / 1e12
+    e = {"bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_TBS, "unit": "TB/s", "frac": round(ach / PEAK_HBM_TBS, 4),
+         "ms_per_step": round(ms, 2), "launches": n, "avg_launch_us": round(ms / n * 1e3, 1)}
+    if ach > PEAK_HBM_TBS:
+        e.update({"bound": "cache", "peak": None, "frac": None,
+                  "note": f"{nbytes / n / 1e6:.0f} MB of algorithmic bytes per launch move at {ach:.1f} TB/s > the {PEAK_HBM_TBS:.0f} TB/s HBM peak: "
+                          "the operands of this pass are Infinity-Cache resident (256 MiB), the HBM roofline does not apply"})
+    return e
+
+
 def roofline_by_kernel(prof, numerics, B, H, K):
     """Every kernel class of the step against the roofline that bounds it (proj, fc1 and the attention
     kernels must not hide behind the dominant qkv Linear).  GEMM classes and the temporal attention: ALGORITHMIC FLOP / HIP-event
@@ -374,13 +466,119 @@ def roofline_by_kernel(prof, numerics, B, H, K):
                       "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "ms_per_step": round(ms, 2), "launches": n,
                       "avg_launch_us": round(ms / n * 1e3, 1)}
         elif k in byts:
-            ach = byts[k] / (ms * 1e-3) / 1e12
-            out[k] = {"bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_TBS, "unit": "TB/s",
-                      "frac": round(ach / PEAK_HBM_TBS, 4), "ms_per_step": round(ms, 2), "launches": n,
-                      "avg_launch_us": round(ms / n * 1e3, 1)}
+            out[k] = bytes_entry(byts[k], ms, n)
         else:
             out[k] = {"bound": "latency", "ms_per_step": round(ms, 3), "launches": n}
     return out
+
+
+def train_roofline_by_kernel(prof, B, steps=1):
+    """The configs[4] training step, class by class, from the library's own per-launch HIP events (classes
+    12-23 of d3dp_profile_read; the weight-gradient class on the library's second stream).  `prof` sums `steps` steps.
+    ALGORITHMIC work per step (T = B F J token rows, 16 blocks, C = 512, hidden = 2 C, 8 heads of 64):
+      train_linear   forward + dgrad of the four Linears: 2 x (3 + 1 + 2 + 2) C^2 x 2 FLOP per token and block
+      train_wgrad    the four weight gradients: (3 + 1 + 2 + 2) C^2 x 2
+      attention      forward 4 n C, pass Q (S, dP, dQ) 6 n C, pass KV (dK, dV; its recomputed S and dP are overhead) 4 n C per token,
+                     n = 17 (spatial) / 243 (temporal), 8 blocks per axis
+      operand passes fp32 rows in, split rows out (8 B per element; the fc1 gradient's pass also reads the saved pre-activation):
+                     forward widths C, C, C, 2 C; backward C, C, 3 C and 12 B x 2 C
+      LayerNorm fwd  block middle (2 rows in, 1 out) + block end (2 in, 2 out): 28 C B per token and block (+ the embedding pass)
+      LayerNorm bwd  norm2 (3 rows in, 1 out) + norm1 / shared norm (4 in, 1 out): 36 C B per token and block
+    Classes on the MFMA roofline use the dense fp16 peak (every product is three fp16-MFMA passes: x 3 in matrix work)."""
+    T = B * F_ * J_
+    nb = 2 * DEPTH
+    lin = 8 * C_ * C_ * 2 * T * nb
+    att = lambda n, k: k * n * C_ * T * DEPTH
+    flop = {"train_linear": 2 * lin, "train_wgrad": lin,
+            "train_attn_fwd_spatial": att(J_, 4), "train_attn_fwd_temporal": att(F_, 4),
+            "train_attn_bwd_q_spatial": att(J_, 6), "train_attn_bwd_q_temporal": att(F_, 6),
+            "train_attn_bwd_kv_spatial": att(J_, 4), "train_attn_bwd_kv_temporal": att(F_, 4)}
+    byts = {"train_operand_pass": (8 * 5 * C_ + 8 * 5 * C_ + 12 * 2 * C_) * T * nb,
+            "train_ln_fwd": 28 * C_ * T * nb + 8 * C_ * T, "train_ln_bwd": 36 * C_ * T * nb}
+    out = {}
+    # what an event pair adds to the launch it brackets (class event_pair_overhead: empty pairs on the busy stream), subtracted per launch
+    ne, mse = prof.get("event_pair_overhead", (0, 0.0))
+    over_ms = mse / ne if ne else 0.0
+    for k, (n, ms) in prof.items():
+        if not k.startswith("train_") or ms <= 0 or n <= 0:
+            continue
+        ms, n = max(ms - n * over_ms, 0.0) / steps, n // steps
+        if k in flop:
+            ach = flop[k] / (ms * 1e-3) / 1e12
+            out[k] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                      "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "matrix_pipe_work_frac": round(ach * EXACT_PASSES / PEAK_MFMA_TFLOPS, 4),
+                      "ms_per_step": round(ms, 3), "launches": n, "avg_launch_us": round(ms / n * 1e3, 1),
+                      "algorithmic_gflop_per_step": round(flop[k] / 1e9, 1)}
+        elif k in byts:
+            out[k] = bytes_entry(byts[k], ms, n)
+            out[k]["algorithmic_gb_per_step"] = round(byts[k] / 1e9, 2)
+        else:
+            out[k] = {"bound": "latency", "ms_per_step": round(ms, 3), "launches": n}
+    return out
+
+
+def train_step_leg(steps=10, warmup=2, profile=True, telemetry=True):
+    """BASELINE configs[4]: one training step (q_sample + MixSTE2 forward / backward, MPJPE loss seeded as main.py:393, DropPath on,
+    every gradient; F=243 H=1 B=4) -- `steps` steps after `warmup`, wall clock around a device synchronisation; then, untimed, the
+    per-class profile of 3 more steps."""
+    import torch
+    from d3dp_amd import D3DP
+    from d3dp_amd.weights import H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, make_state_dict, synthetic_inputs_2d, synthetic_noise
+    B = 4
+    args = SimpleNamespace(number_of_frames=F_, test_time_augmentation=True, timestep=1000, scale=1.0, cs=C_, dep=DEPTH)
+    sd = make_state_dict(7, C_, DEPTH, F_)
+    mt = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=True)
+    mt.load_state_dict(sd, strict=False)
+    mt = mt.cuda().train()
+    x2 = torch.from_numpy(synthetic_inputs_2d(901, B, F_)).cuda()
+    gt = torch.from_numpy(synthetic_noise(902, (B, F_, J_, 3))).cuda() * 0.3
+    gt[:, :, 0] = 0
+
+    def step():
+        mt.zero_grad(set_to_none=True)
+        pred = mt(x2, gt)                                  # prepare_targets (q_sample) + MixSTE2 train branch, DropPath on
+        loss = torch.mean(torch.norm(pred - gt, dim=-1))   # loss.py:6-13
+        loss.backward(loss.clone().detach())               # main.py:393
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    tele = GpuTelemetry(torch.cuda.current_device()) if telemetry else None
+    if tele:
+        tele.start()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dtt = (time.perf_counter() - t0) / steps
+    if tele:
+        tele.stop()
+    tfl = 3 * B * flops_per_denoiser_call() / 1e12            # forward + 2x backward (SURVEY 8 D4)
+    tr = {"workload": "BASELINE configs[4]: q_sample + MixSTE2 fwd/bwd + MPJPE loss, F=243 H=1 B=4, DropPath on, every gradient",
+          "ms_per_step": dtt * 1e3, "steps": steps, "warmup": warmup, "algorithmic_tflop_per_step": tfl, "tflops": tfl / dtt,
+          "frac_of_mfma_peak": tfl / dtt / PEAK_MFMA_TFLOPS, "arithmetic": mt.pose_estimator.train_arithmetic()}
+    if tele:
+        r = tele.report()
+        tr.update({"clock_mhz_mean": r["clock_mhz_mean"], "power_w_mean": r["power_w_mean"], "power_cap_w": r["power_cap_w"]})
+    if profile:
+        pe, ps = mt.pose_estimator, 3
+        pe.profile_enable(True)
+        for _ in range(ps):
+            step()
+        prof = pe.profile_read()
+        pe.profile_enable(False)
+        tr["roofline_by_kernel"] = train_roofline_by_kernel(prof, B, ps)
+        tot = sum(v["ms_per_step"] for v in tr["roofline_by_kernel"].values())
+        tr["kernel_ms_per_step_sum"] = round(tot, 3)
+        ne, mse = prof.get("event_pair_overhead", (0, 0.0))
+        tr["event_pair_overhead_us"] = round(mse / ne * 1e3, 2) if ne else None
+        tr["roofline_note"] = ("per-launch HIP events of the library (d3dp_profile_read, classes 12-23) over 3 extra steps, untimed; the events "
+                               "serialise nothing; the time an EMPTY event pair takes on the busy stream (`event_pair_overhead_us`) is subtracted "
+                               "per launch; while the profile is on the library keeps the weight-gradient products on the caller's stream (un-profiled they "
+                               "run on a second stream beside the dgrad products), so the classes add up to a ONE-stream step: slightly "
+                               "above `ms_per_step`")
+    return tr, mt, sd, x2, gt
 
 
 def lib_sha256():
@@ -399,7 +597,7 @@ def attach_traffic(roof, numerics, chunk_seqs, batch=None):
     They are printed only when this run uses that very build AND launches the kernel over the same number of rows (within
     5 %): counters of another build or another pass size are not this run's traffic."""
     sha, tj, seen = lib_sha256(), None, []
-    for name in ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json"):   # newest first; keyed by the library's hash
+    for name in ("r06_gemm_traffic.json", "r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json"):   # newest first; keyed by the library's hash
         tpath = os.path.join(REPO, "profiles", name)
         if os.path.exists(tpath):
             cand = json.load(open(tpath)).get(numerics, {}).get(roof["kernel"])
@@ -424,7 +622,7 @@ def attach_traffic(roof, numerics, chunk_seqs, batch=None):
                             f"bytes/launch {tj['algorithmic_bytes_per_launch']} (read amplification "
                             f"{tj.get('read_amplification', float('nan')):.2f}x: the weight matrix is re-fetched by every XCD "
                             f"every tile round); hardware MFMA busy {tj.get('mfma_util_hw', float('nan')):.3f} of kernel cycles")
-    for sname in ("r05_step_pmc.json", "r04_step_pmc.json"):
+    for sname in ("r06_step_pmc.json", "r05_step_pmc.json", "r04_step_pmc.json"):
         spath = os.path.join(REPO, "profiles", sname)
         if not os.path.exists(spath):
             continue
@@ -467,37 +665,27 @@ def other_configs(numerics, gen, with_cpu=True):
                          "whole_path_frac_of_mfma_peak": fl * 5 / dt / 1e12 / PEAK_MFMA_TFLOPS}
     del m
     torch.cuda.empty_cache()
+    # ---- a clip longer than 256 frames (reference common/arguments.py:58 `-f`): the same sampler at F = 351
+    Fl = 351
+    xl_np = synthetic_inputs_2d(1235, B, Fl)
+    xl, xlf = torch.from_numpy(xl_np).cuda(), torch.from_numpy(flip_2d(xl_np)).cuda()
+    ml = build_model(H, K, numerics, 0, frames=Fl)
+    dtl, _ = timed_steps(ml, xl, xlf, 3, 1, gen, gather=False)
+    fll = 2 * K * flops_per_denoiser_call(frames=Fl) * B * H
+    out["f351_sampler"] = {"workload": f"ddim_sample_flip F={Fl} B={B} H={H} K={K} flip-TTA, numerics={numerics} (configs[1] at a clip "
+                                       f"length above the 256 frames the MFMA attention kernels hold)",
+                           "value": B * H * 3 / dtl, "unit": "hypothesis-clips/s (K=5 units, F=351)", "ms_per_step": dtl / 3 * 1e3,
+                           "steps": 3, "warmup": 1, "frame_pose_hypotheses_per_sec": B * H * 3 / dtl * Fl,
+                           "whole_path_tflops": fll * 3 / dtl / 1e12,
+                           "whole_path_frac_of_mfma_peak": fll * 3 / dtl / 1e12 / PEAK_MFMA_TFLOPS,
+                           "vs_f243_per_flop": (fll * 3 / dtl) / (fl * 5 / dt)}
+    pl = profile_step(ml, xl, xlf, gen)
+    out["f351_sampler"]["kernel_ms_per_step"] = {k: round(ms, 3) for k, (_, ms) in pl.items() if ms > 0}
+    del ml
+    torch.cuda.empty_cache()
     # ---- configs[4]: the training step
-    args = SimpleNamespace(number_of_frames=F_, test_time_augmentation=True, timestep=1000, scale=1.0, cs=C_, dep=DEPTH)
-    sd = make_state_dict(7, C_, DEPTH, F_)
-    mt = D3DP(args, H36M_JOINTS_LEFT, H36M_JOINTS_RIGHT, is_train=True)
-    mt.load_state_dict(sd, strict=False)
-    mt = mt.cuda().train()
-    x2 = torch.from_numpy(synthetic_inputs_2d(901, B, F_)).cuda()
-    gt = torch.from_numpy(synthetic_noise(902, (B, F_, J_, 3))).cuda() * 0.3
-    gt[:, :, 0] = 0
-
-    def step():
-        mt.zero_grad(set_to_none=True)
-        pred = mt(x2, gt)                                  # prepare_targets (q_sample) + MixSTE2 train branch, DropPath on
-        loss = torch.mean(torch.norm(pred - gt, dim=-1))   # loss.py:6-13
-        loss.backward(loss.clone().detach())               # main.py:393
-        return loss
-
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    n = 10
-    t0 = time.perf_counter()
-    for _ in range(n):
-        step()
-    torch.cuda.synchronize()
-    dtt = (time.perf_counter() - t0) / n
-    tfl = 3 * B * flops_per_denoiser_call() / 1e12            # forward + 2x backward
-    tr = {"workload": "BASELINE configs[4]: q_sample + MixSTE2 fwd/bwd + MPJPE loss, F=243 H=1 B=4, DropPath on, every gradient",
-          "ms_per_step": dtt * 1e3, "steps": n, "warmup": 2, "algorithmic_tflop_per_step": tfl, "tflops": tfl / dtt,
-          "frac_of_mfma_peak": tfl / dtt / PEAK_MFMA_TFLOPS, "arithmetic": mt.pose_estimator.train_arithmetic()
-          if hasattr(mt.pose_estimator, "train_arithmetic") else "fp32 MFMA"}
+    tr, mt, sd, x2, gt = train_step_leg()
+    tfl = tr["algorithmic_tflop_per_step"]
     del mt
     torch.cuda.empty_cache()
     if with_cpu:
@@ -603,6 +791,9 @@ def main():
                     help="CPU baseline from the bounded K=1 sample only (about 25 s) instead of the live, un-extrapolated BASELINE "
                          "configs[1] run (about three minutes of host CPU), which is the default")
     ap.add_argument("--cpu-full", action="store_true", help="(default now; kept for older command lines)")
+    ap.add_argument("--train-only", action="store_true",
+                    help="time ONLY the BASELINE configs[4] training step (--steps / --warmup apply) and print {'c5_train_step': ...}: "
+                         "the command the rocprofv3 passes under profiles/r06_c5_* wrap")
     ap.add_argument("--dist-dry-run", type=int, default=0, metavar="N",
                     help="no GPU needed: drive the N-rank control flow of this file (self-launch, WORLD_SIZE check, shard "
                          "check, timed loop with the all-gather, MAX-reduce, multi_gpu block) over gloo with a CPU "
@@ -620,6 +811,10 @@ def main():
     import torch
     from d3dp_amd.dist import init_from_env, rank_generator
     from d3dp_amd.weights import flip_2d, synthetic_inputs_2d
+    if a.train_only:
+        tr = train_step_leg(steps=max(a.steps, 1), warmup=max(a.warmup, 1), profile=not a.no_profile)[0]
+        print(json.dumps({"c5_train_step": tr}))
+        return
     if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:      # before any rendezvous: a mismatched job must not hang
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the job has WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
     rank, world, local = init_from_env("gloo" if dry else None)
@@ -640,7 +835,8 @@ def main():
     gen = rank_generator(1, rank, dev)
     sharding_ok = shard_check(rank, world, a.numerics, dev, make) if world > 1 else None
     model = DryRunSampler(H, K, frames) if dry else build_model(H, K, a.numerics, a.chunk_seqs)
-    dt, out = timed_steps(model, x2d, x2f, a.steps, a.warmup, gen, gather=world > 1, dev=dev)
+    tele = GpuTelemetry(local) if (rank == 0 and not dry) else None
+    dt, out = timed_steps(model, x2d, x2f, a.steps, a.warmup, gen, gather=world > 1, dev=dev, telemetry=tele)
     if world > 1:
         local_preds, agg, sel = out
         assert agg.shape == (B, K, frames, J_, 3) and bool(torch.isfinite(agg).all()) and int(sel.max()) < H * world
@@ -669,6 +865,11 @@ def main():
                    "whole_path_frac_of_mfma_peak": value * flop_per_unit / 1e12 / (peak * world),
                    "mfma_peak_used_tflops": peak},
     }
+    if tele is not None:
+        tr = tele.report()
+        # the three keys VERDICT r5 item 3 names, at the top level; the rest of the samples' summary beside them
+        res.update({"clock_mhz_mean": tr["clock_mhz_mean"], "power_w_mean": tr["power_w_mean"], "power_cap_w": tr["power_cap_w"],
+                    "telemetry": tr})
     if world > 1:
         import torch.distributed as dist
         flag = torch.tensor([1 if sharding_ok else 0], device=dev)

@@ -17,14 +17,14 @@ LIB_PATH = os.environ.get("D3DP_LIB") or os.path.join(_HERE, "lib", "libd3dp_hip
 MODE_EXACT, MODE_FAST, MODE_TRAIN = 0, 1, 2
 MODE_SPLIT3 = 2   # d3dp_op_linear only: split-bf16 operands
 EPI_BIAS, EPI_GELU, EPI_RESID, EPI_QKV_PACK = 0, 1, 2, 4     # (| D << 8: the skewed schedule of epi 1 / 4, include/d3dp_hip.h)
-PROFILE_CLASSES = 12
+PROFILE_CLASSES = 25
 
 
 class AdamChunk(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int32),
                 ("pad", C.c_int32)]
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Cfg(C.Structure):

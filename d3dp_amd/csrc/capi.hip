@@ -62,10 +62,19 @@ int d3dp_check_launch(const char* what) {
 
 namespace {
 
-enum ProfClass { P_QKV = 0, P_PROJ, P_FC1, P_FC2, P_ATTN_S, P_ATTN_T, P_LN, P_LN2, P_EMBED, P_HEAD, P_TIME, P_OTHER };
+enum ProfClass { P_QKV = 0, P_PROJ, P_FC1, P_FC2, P_ATTN_S, P_ATTN_T, P_LN, P_LN2, P_EMBED, P_HEAD, P_TIME, P_OTHER,
+                 // the training step (d3dp_train_forward / d3dp_train_backward)
+                 T_LINEAR, T_WGRAD, T_ATTN_FWD_S, T_ATTN_FWD_T, T_ATTN_BQ_S, T_ATTN_BQ_T, T_ATTN_BKV_S, T_ATTN_BKV_T, T_OPERAND,
+                 T_LN_FWD, T_LN_BWD, T_OTHER,
+                 P_EMPTY };                            // event pairs with nothing between them: what a scope adds to a launch's time
+static_assert(P_EMPTY + 1 == D3DP_PROFILE_CLASSES, "include/d3dp_hip.h: D3DP_PROFILE_CLASSES");
 const char* kClassNames[D3DP_PROFILE_CLASSES] = {"gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "attn_spatial",
                                                  "attn_temporal", "layernorm", "norm_pair", "embed_ln", "head",
-                                                 "time_mlp", "other"};
+                                                 "time_mlp", "other",
+                                                 "train_linear", "train_wgrad", "train_attn_fwd_spatial", "train_attn_fwd_temporal",
+                                                 "train_attn_bwd_q_spatial", "train_attn_bwd_q_temporal", "train_attn_bwd_kv_spatial",
+                                                 "train_attn_bwd_kv_temporal", "train_operand_pass", "train_ln_fwd", "train_ln_bwd",
+                                                 "train_other", "event_pair_overhead"};
 
 struct BlockDev {
   const float *n1w, *n1b, *n2w, *n2b, *qkv_b, *proj_b, *fc1_b, *fc2_b;
@@ -244,7 +253,8 @@ struct d3dp_ctx {
       if (pool.size() >= 32768) { if (flush_events() != 0) return -1; }
       else {
         Ev e{};
-        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return -1;
+        // (no system-scope fence at the event: the bracket must not add an L2 write-back of the kernel's output to the time it measures)
+        if (hipEventCreateWithFlags(&e.a, hipEventDisableSystemFence) != hipSuccess || hipEventCreateWithFlags(&e.b, hipEventDisableSystemFence) != hipSuccess) return -1;
         pool.push_back(e);
       }
     }
@@ -261,8 +271,8 @@ namespace {
 
 struct Scope {
   d3dp_ctx* c; int slot; hipStream_t st;
-  Scope(d3dp_ctx* c_, int cls, hipStream_t st_) : c(c_), slot(c_->begin(cls, st_)), st(st_) {}
-  ~Scope() { c->end(slot, st); }
+  Scope(d3dp_ctx* c_, int cls, hipStream_t st_) : c(c_), slot(c_ ? c_->begin(cls, st_) : -1), st(st_) {}
+  ~Scope() { if (c) c->end(slot, st); }
 };
 
 // out = epi(A W^T + bias).  out_f32: fp32 output even in FAST mode (the Linear outputs that feed a residual add).
@@ -1144,6 +1154,7 @@ struct X2Train {
   float* ws;
   const TrainLayout& L;
   int n_cu;
+  d3dp_ctx* pc = nullptr;                              // per-kernel profile (d3dp_profile_enable): classes T_LINEAR / T_WGRAD / T_OPERAND
   hipStream_t st_w = nullptr;                          // the weight-gradient products' stream (null: `st`)
   bool tail_blocks = true;                             // d3dp_ctx::train_tail_blocks
   // the dY operand (row form / transposed form) and the weight-gradient product's partial tiles live in one of two sets of
@@ -1181,6 +1192,7 @@ struct X2Train {
   int flush_wgrads() {
     if (!n_def) return 0;
     hipStream_t sw = st_w ? st_w : st;
+    Scope ps(pc, T_WGRAD, sw);
     int r = d3dp_launch_linear_f16x2_tn_many(def, n_def, mTp, mZ, sw);
     if (r) return r;
     D3dpSumTable tb{};
@@ -1248,6 +1260,7 @@ struct X2Train {
   // partial sums are added in a fixed order, else the extra round.
   int gemm(const float* A2, const float* W2, const float* bias, const float* ua, const float* uw, float* out, int T, int N,
            int K, unsigned* out_amax = nullptr, int amax_pos = 0) {
+    Scope ps(pc, T_LINEAR, st);
     const int tn = (N + 127) / 128, q = T / 256, rem = T - q * 256;
     const int rounds_all = ((q + (rem ? 1 : 0)) * tn + n_cu - 1) / n_cu, rounds_full = (q * tn + n_cu - 1) / n_cu;
     const int nk = K / 32;
@@ -1281,10 +1294,11 @@ struct X2Train {
               const float* ln_b = nullptr, float ln_eps = 0.f) {
     const int sa = 2 * l, sw = 2 * l + 1;
     if (l < 0 || sw >= kBwdSlot0) return -1;
-    if (!a_amax_ready && !a_prepared) d3dp_launch_absmax(A, (size_t)T * K, amax() + sa, st);
     const float* a2 = ws + o_a;
     if (a_prepared) a2 = ws + L.x_cols + xoff(l);
     else {
+      Scope ps(pc, T_OPERAND, st);
+      if (!a_amax_ready) d3dp_launch_absmax(A, (size_t)T * K, amax() + sa, st);
       // the operand of this product and, in the same pass, what the wgrad of this Linear will want of it: the backward pass
       // then neither recomputes this activation (LayerNorm / GELU outputs) nor reads it again.  Where the TN wgrad kernel applies
       // that is the SAME row form (kept, zero rows behind T), else a second, transposed form.
@@ -1304,6 +1318,7 @@ struct X2Train {
     const float* w2 = ws + L.op_w;
     if (batched) w2 = ws + L.w_rows + woff(l);
     else {
+      Scope ps(pc, T_OPERAND, st);
       d3dp_launch_absmax(W, (size_t)N * K, amax() + sw, st);
       rows(W, N, K, ws + L.op_w, sw);
     }
@@ -1316,15 +1331,19 @@ struct X2Train {
   int gelu_operand(int l, const float* hpre, int blk, int T, int N, int K) {
     const int Tp = pad_rows(T, N, K);
     if ((size_t)Tp > L.Tp_max) return -1;
+    Scope ps(pc, T_OPERAND, st);
     return d3dp_launch_gelu_rowprep(hpre, ws + L.x_cols + xoff(l), T, Tp, K, amax() + kPmaxSlot0 + blk, amax() + 2 * l, uns() + 2 * l, st);
   }
   // dX[T, K] = dY[T, N] W[N, K]   (sdy: the absmax slot of dY, shared with wgrad; l: the forward Linear whose W this is)
   int dgrad(int l, const float* dY, int sdy, const float* W, float* dX, int T, int N, int K, unsigned* out_amax = nullptr) {
     const int sw = 2 * l + 1;
-    if (!dy_ready) rows(dY, T, N, ws + o_a, sdy);
+    {
+      Scope ps(pc, T_OPERAND, st);
+      if (!dy_ready) rows(dY, T, N, ws + o_a, sdy);
+      if (!batched) cols(W, N, K, N, ws + L.op_w, sw);   // W^T: [K][2 N]  (N % 32 == 0: the model's widths)
+    }
     const float* wt = ws + L.op_w;
     if (batched) wt = ws + L.w_cols + woff(l);         // (prepared by the forward pass of this step)
-    else cols(W, N, K, N, ws + L.op_w, sw);            // W^T: [K][2 N]  (N % 32 == 0: the model's widths)
     return gemm(ws + o_a, wt, nullptr, uns() + sdy, uns() + sw, dX, T, K, N, out_amax);
   }
   // split count / padded token count of the wgrad product dW[N, K] = dY^T X
@@ -1355,6 +1374,7 @@ struct X2Train {
       set_used += L.Tp_max * (size_t)N;
     }
     dy_ready = true;
+    Scope ps(pc, T_OPERAND, st);
     if (d3dp_tn_applies(N, K))       // the row form alone (zero rows behind T): dgrad's operand AND the TN wgrad's
       return d3dp_launch_rowprep(dY, ws + o_a, bias_part, bias_rows, T, Tp, N, amax() + sdy, uns() + sdy, st, mask, axis, F, J,
                                  gelu_pre);
@@ -1379,6 +1399,7 @@ struct X2Train {
     }
     int r;
     hipStream_t sw = st_w ? st_w : st;
+    Scope ps(pc, T_WGRAD, sw);
     if (d3dp_tn_applies(N, K)) {                        // both operands in their row forms [Tp][2 .]: nothing was transposed
       if (!dy_ready) return -1;
       r = d3dp_launch_linear_f16x2_tn(ws + o_a, ws + L.x_cols + xoff(l), uns() + sdy, uns() + sx, ws + o_part, N, K, Tp, Z, sw);
@@ -1417,34 +1438,39 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
   const int T = (int)L.T, C = g.channels, F = g.frames, J = g.joints, Hd = g.hidden;
   float *xn = ws + L.xn, *y = ws + L.y, *hid = ws + L.hid;
   X2Train x2{st, ws, L, c->n_cu};
+  x2.pc = c->prof ? c : nullptr;
+  d3dp_ctx* const pc = x2.pc;                            // (TP: one launch inside a profile scope of its class)
+#define TP(cls, call) { Scope ps_(pc, cls, st); LAUNCH_TRY(call); }
   x2.use_set(0);
   x2.tail_blocks = c->train_tail_blocks;
   x2.merged_setup(T, c->train_wgrad_merged);
   const bool use_x2 = c->train_x2 && C % 32 == 0 && Hd % 32 == 0;
   if (use_x2) {
+    Scope ps_(pc, T_OTHER, st);
     LAUNCH_TRY(x2.begin(true));
     LAUNCH_TRY(x2.prepare_weights(c));
   }
   auto lin = [&](int l, const float* A, const float* W, const float* bias, float* out, int M, int N, int K, bool a_amax_ready = false,
                  unsigned* out_amax = nullptr, int amax_pos = 0, bool a_prepared = false, const float* ln_w = nullptr,
                  const float* ln_b = nullptr, float ln_eps = 0.f) {
-    return use_x2 ? x2.forward(l, A, W, bias, out, M, N, K, a_amax_ready, out_amax, amax_pos, a_prepared, ln_w, ln_b, ln_eps)
-                  : lin32(A, W, bias, out, M, N, K, st);
+    if (use_x2) return x2.forward(l, A, W, bias, out, M, N, K, a_amax_ready, out_amax, amax_pos, a_prepared, ln_w, ln_b, ln_eps);
+    Scope ps_(pc, T_LINEAR, st);
+    return lin32(A, W, bias, out, M, N, K, st);
   };
   // the qkv / fc1 operands straight from the INPUT of the LayerNorm in front of them (no fp32 normalised activation is written)
   const bool ln_fused = use_x2 && x2.ln_operand_applies(3 * C, C) && x2.ln_operand_applies(Hd, C);
   // attention on split-fp16 operands (train_attn.hip): needs the split Linears' device-side scales, head dim 64, <= 256 frames
   const bool attn_x2 = use_x2 && c->train_attn_x2 > 0 && C / g.heads == 64 && F <= 256;
   const bool attn_x2_s = attn_x2 && c->train_attn_x2 > 1;      // the spatial axis too
-  LAUNCH_TRY(d3dp_train_time_mlp(t, c->freq, c->t1w, c->t1b, c->t3w, c->t3b, ws + L.dtemb, ws + L.temb, B, C, st));   // (dtemb: free until the backward pass; needs B x 2 C)
+  TP(T_OTHER, d3dp_train_time_mlp(t, c->freq, c->t1w, c->t1b, c->t3w, c->t3b, ws + L.dtemb, ws + L.temb, B, C, st));   // (dtemb: free until the backward pass; needs B x 2 C)
   float* slab0 = ws + L.saved0;
-  LAUNCH_TRY(d3dp_launch_embed_ln(0, x2d, x3d, ws + L.temb, c->ew, c->eb, c->spos, c->ste[0].n1w, c->ste[0].n1b,
-                                  g.eps_block, slab0 + L.o_xin, xn, 0, B, 1, F, J, C, st));
+  TP(T_LN_FWD, d3dp_launch_embed_ln(0, x2d, x3d, ws + L.temb, c->ew, c->eb, c->spos, c->ste[0].n1w, c->ste[0].n1b,
+                                    g.eps_block, slab0 + L.o_xin, xn, 0, B, 1, F, J, C, st));
   // Every Linear's activation operand arrives with its absmax already in slot 2 l, left there by the kernel that produced it
   // (round 4 ran 64 absmax launches per step); the two exceptions are the first block's input, which the inference embedding
   // kernel writes, and the temporal attention's output (the fp32-MFMA kernel is shared with inference).
   auto slot = [&](int l) -> unsigned* { return use_x2 ? x2.amax() + 2 * l : nullptr; };
-  if (use_x2) d3dp_launch_absmax(xn, (size_t)T * C, slot(0), st);
+  if (use_x2) { Scope ps_(pc, T_OTHER, st); d3dp_launch_absmax(xn, (size_t)T * C, slot(0), st); }
   for (int blk = 0; blk < 2 * g.depth; ++blk) {
     const int kind = blk & 1, d = blk >> 1;
     const BlockDev& w = kind ? c->tte[d] : c->ste[d];
@@ -1455,21 +1481,24 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
                                  w.n1w, w.n1b, g.eps_block));
     else LAUNCH_TRY(lin(4 * blk, xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C, true, qkv_amax));
     bool att_ready = true;
-    if (kind == 0 && ax2)
-      LAUNCH_TRY(d3dp_train_attn_x2_fwd(S + L.o_qkv, S + L.o_att, ws + L.stats_x2 + (size_t)blk * L.stats_x2_stride, B * F,
-                                        spatial_map(F, J), C, g.heads, qkv_amax, slot(4 * blk + 1), st));
-    else if (kind == 0)
-      LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * F, spatial_map(F, J), C, g.heads, st, slot(4 * blk + 1)));
-    else if (ax2)
-      LAUNCH_TRY(d3dp_train_attn_x2_fwd(S + L.o_qkv, S + L.o_att, ws + L.stats_x2 + (size_t)blk * L.stats_x2_stride, B * J,
-                                        temporal_map(F, J), C, g.heads, qkv_amax, slot(4 * blk + 1), st));
-    else if (use_x2 && C / g.heads == 64 && F <= 256) {  // temporal axis on the fp32 matrix cores (bitwise an fp32 fmaf chain per
-      LAUNCH_TRY(d3dp_launch_attn_temporal_f32(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st));   // product)
-      att_ready = false;
-    } else LAUNCH_TRY(d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st, slot(4 * blk + 1)));
+    auto attention = [&]() -> int {                      // (the launcher's own return code)
+      if (kind == 0 && ax2)
+        return d3dp_train_attn_x2_fwd(S + L.o_qkv, S + L.o_att, ws + L.stats_x2 + (size_t)blk * L.stats_x2_stride, B * F,
+                                      spatial_map(F, J), C, g.heads, qkv_amax, slot(4 * blk + 1), st);
+      if (kind == 0) return d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * F, spatial_map(F, J), C, g.heads, st, slot(4 * blk + 1));
+      if (ax2)
+        return d3dp_train_attn_x2_fwd(S + L.o_qkv, S + L.o_att, ws + L.stats_x2 + (size_t)blk * L.stats_x2_stride, B * J,
+                                      temporal_map(F, J), C, g.heads, qkv_amax, slot(4 * blk + 1), st);
+      if (use_x2 && C / g.heads == 64 && F <= 256) {     // temporal axis on the fp32 matrix cores (bitwise an fp32 fmaf chain per product)
+        att_ready = false;
+        return d3dp_launch_attn_temporal_f32(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st);
+      }
+      return d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st, slot(4 * blk + 1));
+    };
+    TP(kind ? T_ATTN_FWD_T : T_ATTN_FWD_S, attention());
     LAUNCH_TRY(lin(4 * blk + 1, S + L.o_att, (const float*)w.proj_w, w.proj_b, y, T, C, C, att_ready));
-    LAUNCH_TRY(d3dp_train_add_mask_ln(S + L.o_xin, y, mask_ptr(masks, g, B, blk, 0), kind, F, J, w.n2w, w.n2b, g.eps_block,
-                                      S + L.o_xmid, ln_fused ? nullptr : xn, slot(4 * blk + 2), T, C, st));
+    TP(T_LN_FWD, d3dp_train_add_mask_ln(S + L.o_xin, y, mask_ptr(masks, g, B, blk, 0), kind, F, J, w.n2w, w.n2b, g.eps_block,
+                                        S + L.o_xmid, ln_fused ? nullptr : xn, slot(4 * blk + 2), T, C, st));
     const float* fc1_in = ln_fused ? S + L.o_xmid : xn;
     const float *f1w = ln_fused ? w.n2w : nullptr, *f1b = ln_fused ? w.n2b : nullptr;
     if (use_x2 && x2.gelu_operand_applies(C, Hd)) {
@@ -1482,7 +1511,7 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     } else {
       LAUNCH_TRY(lin(4 * blk + 2, fc1_in, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, true, nullptr, 0, false, f1w, f1b,
                      g.eps_block));
-      LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, slot(4 * blk + 3), st));
+      TP(T_OPERAND, d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, slot(4 * blk + 3), st));
       LAUNCH_TRY(lin(4 * blk + 3, hid, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd, true));
     }
     // the block's end in one pass: residual add, the shared norm (+ Temporal_pos_embed after the first spatial block,
@@ -1492,12 +1521,13 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     float* x_next = last ? ws + L.x_final : S + L.saved_stride + L.o_xin;
     const float *nw = c->hnw, *nb = c->hnb;
     if (!last) { const BlockDev& wn = kind ? c->ste[d + 1] : c->tte[d]; nw = wn.n1w; nb = wn.n1b; }
-    LAUNCH_TRY(d3dp_train_add_mask_ln2(S + L.o_xmid, y, mask_ptr(masks, g, B, blk, 1), kind, F, J, kind ? c->tnw : c->snw,
-                                       kind ? c->tnb : c->snb, g.eps_block, (kind == 0 && d == 0) ? c->tpos : nullptr, nw, nb,
-                                       last ? g.eps_head : g.eps_block, S + L.o_xout, x_next,
-                                       last ? ws + L.z : (ln_fused ? nullptr : xn), last ? nullptr : slot(4 * (blk + 1)), T, C, st));
+    TP(T_LN_FWD, d3dp_train_add_mask_ln2(S + L.o_xmid, y, mask_ptr(masks, g, B, blk, 1), kind, F, J, kind ? c->tnw : c->snw,
+                                         kind ? c->tnb : c->snb, g.eps_block, (kind == 0 && d == 0) ? c->tpos : nullptr, nw, nb,
+                                         last ? g.eps_head : g.eps_block, S + L.o_xout, x_next,
+                                         last ? ws + L.z : (ln_fused ? nullptr : xn), last ? nullptr : slot(4 * (blk + 1)), T, C, st));
   }
-  LAUNCH_TRY(d3dp_train_head_linear(ws + L.z, c->hw, c->hb, out, T, C, st));
+  TP(T_OTHER, d3dp_train_head_linear(ws + L.z, c->hw, c->hb, out, T, C, st));
+#undef TP
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
 }
@@ -1531,22 +1561,27 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
   HIP_TRY(zero(grads->time1_w, 2 * CC)); HIP_TRY(zero(grads->time1_b, 2 * C));
   HIP_TRY(zero(grads->time3_w, 2 * CC)); HIP_TRY(zero(grads->time3_b, C));
   HIP_TRY(zero(ws + L.zero_bias, 4 * (size_t)C));
-  if (ztab.count) LAUNCH_TRY(d3dp_train_zero_many(ztab, st));
+  d3dp_ctx* const pc = c->prof ? c : nullptr;
+#define TP(cls, call) { Scope ps_(pc, cls, st); LAUNCH_TRY(call); }
+  if (ztab.count) TP(T_OTHER, d3dp_train_zero_many(ztab, st));
   const float* zb = ws + L.zero_bias;
   float *xn = ws + L.xn, *hid = ws + L.hid, *dA = ws + L.dA, *dB = ws + L.dB, *dC = ws + L.dC, *dqkv = ws + L.dqkv,
         *dh = ws + L.dh, *At = ws + L.At, *Xt = ws + L.Xt, *Wt = ws + L.Wt;
 
   X2Train x2{st, ws, L, c->n_cu};
+  x2.pc = pc;
   x2.use_set(0);
   x2.tail_blocks = c->train_tail_blocks;
   x2.merged_setup(T, c->train_wgrad_merged);
   const bool use_x2 = c->train_x2 && C % 32 == 0 && Hd % 32 == 0;
   if (use_x2) {
-    LAUNCH_TRY(x2.begin(false));
+    TP(T_OTHER, x2.begin(false));
     x2.batched = 8 * g.depth <= D3DP_WPREP_MAX;          // (the forward pass of this step left the weight operands in place)
   }
   // second stream for the weight-gradient products (see d3dp_ctx::aux)
-  const bool overlap = use_x2 && c->train_overlap;
+  // (under the per-kernel profile everything runs on the caller's stream: a class's time must not contain a wait for CUs that a
+  //  product on the second stream holds -- same arithmetic, test_training_step_stream_switches_change_no_bit)
+  const bool overlap = use_x2 && c->train_overlap && !c->prof;
   if (overlap && !c->aux) {
     HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -1637,10 +1672,14 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     float* bp = red.take((size_t)D3DP_DYPREP_ROWS * N);
     int rows = 0;
     if (!bp || mk || gelu_pre) return -1;
-    if ((r = d3dp_train_colsum(dY, bp, &rows, D3DP_DYPREP_ROWS, T, N, st))) return r;
-    red.add(bp, dbias, N, rows, N);
-    if ((r = d3dp_train_transpose_pad(dY, At, T, N, Tp, st))) return r;
-    if ((r = d3dp_train_transpose_pad(X, Xt, T, K, Tp, st))) return r;
+    {
+      Scope ps_(pc, T_OPERAND, st);
+      if ((r = d3dp_train_colsum(dY, bp, &rows, D3DP_DYPREP_ROWS, T, N, st))) return r;
+      red.add(bp, dbias, N, rows, N);
+      if ((r = d3dp_train_transpose_pad(dY, At, T, N, Tp, st))) return r;
+      if ((r = d3dp_train_transpose_pad(X, Xt, T, K, Tp, st))) return r;
+    }
+    Scope ps_(pc, T_WGRAD, st);
     if (hipMemsetAsync(dW, 0, (size_t)N * K * 4, st) != hipSuccess) return -3;
     return d3dp_launch_linear_f32_splitk(At, Xt, dW, N, K, Tp, st);       // contraction over tokens: split-K
   };
@@ -1648,7 +1687,8 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
   auto dgrad = [&](int l, const float* dY, int N, const float* W, int K, float* dX, unsigned* out_amax = nullptr) -> int {
     if (use_x2) return sdy < 0 ? -1 : x2.dgrad(l, dY, sdy, W, dX, T, N, K, out_amax);  // (always right behind the wgrad of the same dY)
     int r;
-    if ((r = d3dp_train_transpose_pad(W, Wt, N, K, N, st))) return r;
+    { Scope ps_(pc, T_OPERAND, st); if ((r = d3dp_train_transpose_pad(W, Wt, N, K, N, st))) return r; }
+    Scope ps_(pc, T_LINEAR, st);
     return lin32(dY, Wt, zb, dX, T, K, N, st);
   };
   // a slot for the absmax the producer of the next dY leaves (split-fp16 path only)
@@ -1667,7 +1707,7 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     float* hp = red.take((size_t)512 * (3 * C + 4));
     int rows = 0;
     if (!hp) return fail(D3DP_ESTATE, "d3dp_train_backward: partial-sum region too small");
-    LAUNCH_TRY(d3dp_train_head_bwd(grad_out, ws + L.z, c->hw, dC, hp, &rows, T, C, st));   // (z: left by the forward pass)
+    TP(T_OTHER, d3dp_train_head_bwd(grad_out, ws + L.z, c->hw, dC, hp, &rows, T, C, st));   // (z: left by the forward pass)
     red.add(hp, G(grads->head_w), 3 * (size_t)C, rows, 3 * (size_t)C + 4);
     red.add(hp + 3 * C, G(grads->head_b), 3, rows, 3 * (size_t)C + 4);
   }
@@ -1682,7 +1722,7 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     const float* S = ws + L.saved0 + (size_t)lb * L.saved_stride;
     const float* mk = mask_ptr(masks, g, B, lb, 1);
     D3DP_FRESH(ps, pa)
-    LAUNCH_TRY(d3dp_train_ln_bwd(dC, ws + L.x_final, c->hnw, g.eps_head, nullptr, nullptr, S + L.o_xout, lk ? c->tnw : c->snw,
+    TP(T_LN_BWD, d3dp_train_ln_bwd(dC, ws + L.x_final, c->hnw, g.eps_head, nullptr, nullptr, S + L.o_xout, lk ? c->tnw : c->snw,
                                  g.eps_block, dB, mk, lk, F, J, (mk && !mip2) ? dC : nullptr, pa, part_hn,
                                  (lk ? part_tn : part_sn) + (size_t)(lb >> 1) * lnrows * 2 * C, T, C, st));
     dy = (mk && !mip2) ? dC : dB;
@@ -1696,7 +1736,7 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     float* S = ws + L.saved0 + (size_t)blk * L.saved_stride;
     // here: dB = d x_out(blk), dy = its DropPath-scaled form, absmax in slot ps_next
     // ---- MLP branch ----
-    if (!use_x2) LAUNCH_TRY(d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, nullptr, st));   // (x2: wgrad reads the forward pass' operand)
+    if (!use_x2) TP(T_OPERAND, d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, nullptr, st));   // (x2: wgrad reads the forward pass' operand)
     LAUNCH_TRY(wgrad(4 * blk + 3, dy, C, hid, Hd, G(gw.fc2_w), G(gw.fc2_b), ps_next, dy_mask, kind));
     {
       // d hidden = dy W_fc2; d h_pre = d hidden x gelu'(h_pre).  Split-fp16 path: the product is formed by the operand pass of
@@ -1704,8 +1744,8 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
       const bool gip = use_x2 && c->train_gelu_in_prep && x2.gelu_in_prep_applies(Hd, C);
       D3DP_FRESH(ps, pa)
       LAUNCH_TRY(dgrad(4 * blk + 3, dy, C, (const float*)w.fc2_w, Hd, dh, gip ? pa : nullptr));                         // d hidden
-      if (!gip) LAUNCH_TRY(d3dp_train_gelu_bwd(dh, S + L.o_hpre, dh, (size_t)T * Hd, pa, st));             // d h_pre
-      if (!use_x2) LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xmid, w.n2w, w.n2b, g.eps_block, nullptr, F, J, xn, T, C, st));   // xn2
+      if (!gip) TP(T_OPERAND, d3dp_train_gelu_bwd(dh, S + L.o_hpre, dh, (size_t)T * Hd, pa, st));             // d h_pre
+      if (!use_x2) TP(T_LN_FWD, d3dp_train_ln_pos(S + L.o_xmid, w.n2w, w.n2b, g.eps_block, nullptr, F, J, xn, T, C, st));   // xn2
       LAUNCH_TRY(wgrad(4 * blk + 2, dh, Hd, xn, C, G(gw.fc1_w), G(gw.fc1_b), ps, nullptr, 0, gip ? S + L.o_hpre : nullptr));
       LAUNCH_TRY(dgrad(4 * blk + 2, dh, Hd, (const float*)w.fc1_w, C, dC));                                             // d xn2
     }
@@ -1715,7 +1755,7 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
       float* pn = ln_part(gw.norm2_w, gw.norm2_b, 1);
       D3DP_FRESH(ps, pa)
       if (!pn) return fail(D3DP_ESTATE, "d3dp_train_backward: partial-sum region too small");
-      LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xmid, w.n2w, g.eps_block, dB, nullptr, nullptr, nullptr, 0.f, dA, mk, kind, F, J,
+      TP(T_LN_BWD, d3dp_train_ln_bwd(dC, S + L.o_xmid, w.n2w, g.eps_block, dB, nullptr, nullptr, nullptr, 0.f, dA, mk, kind, F, J,
                                    (mk && !mip1) ? dC : nullptr, pa, pn, nullptr, T, C, st));
       dy = (mk && !mip1) ? dC : dA;
       // ---- attention branch ----
@@ -1727,16 +1767,20 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
       D3DP_FRESH(pdo, pado)
       D3DP_FRESH(pq, paq)
       LAUNCH_TRY(dgrad(4 * blk + 1, dy, C, (const float*)w.proj_w, C, dB, pado));                                       // d att
-      LAUNCH_TRY(d3dp_train_attn_x2_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats_x2 + (size_t)blk * L.stats_x2_stride,
-                                        kind ? B * J : B * F, kind ? temporal_map(F, J) : spatial_map(F, J), C, g.heads,
-                                        x2.amax() + X2Train::kQkvSlot0 + blk, pado, paq, st));
+      // (the per-kernel profile times the two passes apart; otherwise one call launches both)
+      for (int part = pc ? 1 : 0; part <= (pc ? 2 : 0); ++part)
+        TP(part == 2 ? (kind ? T_ATTN_BKV_T : T_ATTN_BKV_S) : (kind ? T_ATTN_BQ_T : T_ATTN_BQ_S),
+           d3dp_train_attn_x2_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats_x2 + (size_t)blk * L.stats_x2_stride,
+                                  kind ? B * J : B * F, kind ? temporal_map(F, J) : spatial_map(F, J), C, g.heads,
+                                  x2.amax() + X2Train::kQkvSlot0 + blk, pado, paq, st, part));
       ps_dqkv = pq;
     } else {
       LAUNCH_TRY(dgrad(4 * blk + 1, dy, C, (const float*)w.proj_w, C, dB));                                             // d att
-      if (kind == 0) LAUNCH_TRY(d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * F, spatial_map(F, J), C, g.heads, st));
-      else LAUNCH_TRY(d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * J, temporal_map(F, J), C, g.heads, st));
+      // (fp32 kernels: both passes behind one launcher -- timed together under the pass-Q class)
+      if (kind == 0) TP(T_ATTN_BQ_S, d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * F, spatial_map(F, J), C, g.heads, st))
+      else TP(T_ATTN_BQ_T, d3dp_train_attn_bwd(S + L.o_qkv, S + L.o_att, dB, dqkv, ws + L.stats, B * J, temporal_map(F, J), C, g.heads, st));
     }
-    if (!use_x2) LAUNCH_TRY(d3dp_train_ln_pos(S + L.o_xin, w.n1w, w.n1b, g.eps_block, nullptr, F, J, xn, T, C, st));    // xn1
+    if (!use_x2) TP(T_LN_FWD, d3dp_train_ln_pos(S + L.o_xin, w.n1w, w.n1b, g.eps_block, nullptr, F, J, xn, T, C, st));    // xn1
     LAUNCH_TRY(wgrad(4 * blk, dqkv, 3 * C, xn, C, G(gw.qkv_w), G(gw.qkv_b), ps_dqkv));
     LAUNCH_TRY(dgrad(4 * blk, dqkv, 3 * C, (const float*)w.qkv_w, C, dC));                                          // d xn1
     float* pn1 = ln_part(gw.norm1_w, gw.norm1_b, 1);
@@ -1750,15 +1794,15 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
       float* g_out = pb == 0 ? ws + L.y : nullptr;       // d of Temporal_pos_embed's sum (added behind block 0's shared norm); y: a forward
                                                          // temporary -- NOT z, which a second backward over the same forward reads again
       D3DP_FRESH(ps, pa)
-      LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xin, w.n1w, g.eps_block, dA, g_out, Sp + L.o_xout, pk ? c->tnw : c->snw, g.eps_block,
+      TP(T_LN_BWD, d3dp_train_ln_bwd(dC, S + L.o_xin, w.n1w, g.eps_block, dA, g_out, Sp + L.o_xout, pk ? c->tnw : c->snw, g.eps_block,
                                    dB, mk, pk, F, J, (mk && !mip2) ? dC : nullptr, pa, pn1,
                                    (pk ? part_tn : part_sn) + (size_t)(pb >> 1) * lnrows * 2 * C, T, C, st));
-      if (g_out) LAUNCH_TRY(d3dp_train_groupsum(g_out, G(grads->temporal_pos), T, C, 1, F, J, 1, st));
+      if (g_out) TP(T_OTHER, d3dp_train_groupsum(g_out, G(grads->temporal_pos), T, C, 1, F, J, 1, st));
       dy = (mk && !mip2) ? dC : dB;
       dy_mask = mip2 ? mk : nullptr;
       ps_next = ps;
     } else {
-      LAUNCH_TRY(d3dp_train_ln_bwd(dC, S + L.o_xin, w.n1w, g.eps_block, dA, nullptr, nullptr, nullptr, 0.f, dB, nullptr, 0, F, J,
+      TP(T_LN_BWD, d3dp_train_ln_bwd(dC, S + L.o_xin, w.n1w, g.eps_block, dA, nullptr, nullptr, nullptr, 0.f, dB, nullptr, 0, F, J,
                                    nullptr, nullptr, pn1, nullptr, T, C, st));
     }
   }
@@ -1766,6 +1810,7 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
   LAUNCH_TRY(join());                                    // every weight gradient is on the caller's stream's timeline again
   // ---- embedding, position and time embeddings (dB = d of the embedded tokens) ------------------------------------
   {
+    Scope ps_(pc, T_OTHER, st);
     float* ep = red.take((size_t)D3DP_EMBED_BWD_ROWS * 5 * C);
     float* bp = red.take((size_t)512 * C);
     float* sp = red.take((size_t)kGroupSlices * J * C);
@@ -1783,8 +1828,12 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     red.flush();                                          // (dtemb feeds the time MLP's backward below)
   }
   if (red.rc) return fail(D3DP_EHIP, "d3dp_train_backward: the gradient reduction failed");
-  LAUNCH_TRY(d3dp_train_time_mlp_bwd(t, c->freq, c->t1w, c->t1b, c->t3w, ws + L.dtemb, G(grads->time1_w),
-                                     G(grads->time1_b), G(grads->time3_w), G(grads->time3_b), B, C, st));
+  TP(T_OTHER, d3dp_train_time_mlp_bwd(t, c->freq, c->t1w, c->t1b, c->t3w, ws + L.dtemb, G(grads->time1_w),
+                                      G(grads->time1_b), G(grads->time3_w), G(grads->time3_b), B, C, st));
+#undef TP
+  // (profile only) eight empty scopes on the still-busy stream: the time an event pair adds to every launch it brackets --
+  // event-to-event durations of 15 - 80 us kernels are not kernel durations without it (bench.py subtracts the average)
+  for (int i = 0; pc && i < 8; ++i) { Scope ps_(pc, P_EMPTY, st); }
   HIP_TRY(hipGetLastError());
   return D3DP_OK;
 }

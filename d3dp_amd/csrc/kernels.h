@@ -265,7 +265,7 @@ int d3dp_train_attn_x2_fwd(const float* qkv, float* out, void* stats, int n_seq,
                            const unsigned* amax_qkv, unsigned* amax_out, hipStream_t st);
 int d3dp_train_attn_x2_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, void* stats, int n_seq, SeqMap map,
                            int C, int heads, const unsigned* amax_qkv, const unsigned* amax_do, unsigned* amax_out,
-                           hipStream_t st);
+                           hipStream_t st, int part = 0);
 int d3dp_train_embed_bwd(const float* dx, const float* x2d, const float* x3d, float* part, int T, int C, hipStream_t st);
 int d3dp_train_head_linear(const float* z, const float* w, const float* b, float* out, int T, int C, hipStream_t st);
 int d3dp_train_head_bwd(const float* g, const float* z, const float* w, float* dz, float* part, int* rows, int T, int C,

@@ -507,11 +507,13 @@ int ta_launch(int which, const float* qkv, const float* o, const float* dout, fl
   TAStat* s = reinterpret_cast<TAStat*>(stats);
   if (which == 0)
     hipLaunchKernelGGL((tattn_fwd_kernel<NKT, NW>), grid, blk, lds, st, qkv, out, s, map, C, heads, groups, n_work, amax_qkv, amax_out);
-  else {
-    hipLaunchKernelGGL((tattn_bwd_q_kernel<NKT, NW>), grid, blk, lds, st, qkv, o, dout, dqkv, s, map, C, heads, groups, n_work,
-                       amax_qkv, amax_do, amax_out);
-    hipLaunchKernelGGL((tattn_bwd_kv_kernel<NKT, NW>), grid, blk, lds, st, qkv, dout, dqkv, (const TAStat*)s, map, C, heads, groups,
-                       n_work, amax_qkv, amax_do, amax_out);
+  else {                                               // which: 1 = both passes, 2 = pass Q alone, 3 = pass KV alone (needs pass Q's D_i)
+    if (which != 3)
+      hipLaunchKernelGGL((tattn_bwd_q_kernel<NKT, NW>), grid, blk, lds, st, qkv, o, dout, dqkv, s, map, C, heads, groups, n_work,
+                         amax_qkv, amax_do, amax_out);
+    if (which != 2)
+      hipLaunchKernelGGL((tattn_bwd_kv_kernel<NKT, NW>), grid, blk, lds, st, qkv, dout, dqkv, (const TAStat*)s, map, C, heads, groups,
+                         n_work, amax_qkv, amax_do, amax_out);
   }
   return 0;
 }
@@ -542,9 +544,11 @@ int d3dp_train_attn_x2_fwd(const float* qkv, float* out, void* stats, int n_seq,
 }
 // dqkv [T, 3C] = the gradient of (q | k | v) given dout [T, C]; o: the forward output; amax_do: absmax slot of dout;
 // amax_out (optional): absmax slot of dqkv (both passes add to it)
+// (part: 0 = both passes, 1 = pass Q alone (dq, D_i), 2 = pass KV alone (dk, dv; after pass Q): the library's per-kernel
+//  profile times them apart)
 int d3dp_train_attn_x2_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, void* stats, int n_seq, SeqMap map,
                            int C, int heads, const unsigned* amax_qkv, const unsigned* amax_do, unsigned* amax_out,
-                           hipStream_t st) {
-  if (!qkv || !o || !dout || !dqkv || !amax_do) return -1;
-  return ta_dispatch(1, qkv, o, dout, nullptr, dqkv, stats, n_seq, map, C, heads, amax_qkv, amax_do, amax_out, st);
+                           hipStream_t st, int part) {
+  if (!qkv || !o || !dout || !dqkv || !amax_do || part < 0 || part > 2) return -1;
+  return ta_dispatch(1 + part, qkv, o, dout, nullptr, dqkv, stats, n_seq, map, C, heads, amax_qkv, amax_do, amax_out, st);
 }

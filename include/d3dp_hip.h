@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D3DP_ABI_VERSION 3
+#define D3DP_ABI_VERSION 4
 
 /* The library is built with -fvisibility=hidden: the functions declared in this header -- and nothing else -- are its dynamic
  * symbols (tests/test_abi.py compares `nm -D` with this file). */
@@ -318,10 +318,16 @@ D3DP_API int d3dp_op_linear_x2(int32_t epi, const void* A2, const void* W2, cons
 D3DP_API int d3dp_op_to_bf16(const float* src, void* dst, size_t n, void* stream);
 
 /* ---- per-kernel timing (HIP events on the launch stream) -------------------------------------------------
- * While enabled, every kernel launched by d3dp_denoise is bracketed by hipEventRecord on `stream`.
+ * While enabled, every kernel launched by d3dp_denoise, d3dp_train_forward and d3dp_train_backward is bracketed by
+ * hipEventRecord on the caller's stream (while enabled the training step keeps its weight-gradient products on that stream too
+ * instead of its second one: no class's time contains a wait for compute units another stream holds; same results bit for bit).
  * d3dp_profile_read synchronises the recorded events and returns, per kernel class, the launch count and the
- * summed duration in milliseconds.  Classes are listed by d3dp_profile_class_name. */
-#define D3DP_PROFILE_CLASSES 12
+ * summed duration in milliseconds.  Classes are listed by d3dp_profile_class_name: 0-11 the denoiser's (d3dp_denoise),
+ * 12-23 the training step's (ABI v4): train_linear (forward and dgrad products), train_wgrad (a block's merged weight-gradient
+ * product + the sum of its partial tiles), train_attn_{fwd,bwd_q,bwd_kv}_{spatial,temporal}, train_operand_pass (fp32 rows -> split
+ * operands), train_ln_fwd, train_ln_bwd, train_other; 24 event_pair_overhead: event pairs with nothing between them, recorded at
+ * the end of d3dp_train_backward -- the time a bracket adds to the launch it times. */
+#define D3DP_PROFILE_CLASSES 25
 D3DP_API int d3dp_profile_enable(d3dp_ctx* ctx, int32_t on);
 D3DP_API int d3dp_profile_read(d3dp_ctx* ctx, int64_t* counts /*host[D3DP_PROFILE_CLASSES]*/,
                       double* total_ms /*host[D3DP_PROFILE_CLASSES]*/);
