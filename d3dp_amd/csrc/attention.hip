@@ -17,6 +17,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "ta_common.h"
 
 #ifndef D3DP_ATTN_PAIR
 #define D3DP_ATTN_PAIR 1     // temporal split-fp16 kernel: both query tiles of a wave share one pass over the K image
@@ -1241,6 +1242,124 @@ __global__ __launch_bounds__(512) void attn_temporal_x2_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Temporal axis of clips LONGER than 256 frames (reference common/arguments.py:58 `-f`; round 6).  The
+// persistent kernel above holds the K and V images of a whole sequence in LDS (256 keys = 128 KiB) and forms a query's softmax
+// over the complete score row; beyond 256 frames round 5 sent both attentions to the chunked fp32 VALU row kernel -- measured at
+// F = 351: 53 % of the sampler's time, ten times the cost per FLOP of the 243-frame path.  Here: the flash form on the same
+// split-fp16 operands and packed qkv rows.  A work unit = one (sequence, head) problem x one group of eight 16-query tiles (one
+// per wave); the keys pass through LDS in chunks of 128 (K and V hi / lo images in the one-swizzle layout of ta_common.h: 64 KiB,
+// two workgroups per CU) under an online softmax in base-2 units -- running row maximum, denominator and O^T per query in
+// registers, rescaled whenever a key pair raises the maximum -- exactly the forward kernel of the training step
+// (train_attn.hip tattn_fwd_kernel) with the key range cut into chunks and its operands taken from the packed rows: K and V are
+// ALREADY split (the qkv Linear's epilogue), so staging is sixteen-byte copies, no arithmetic.  Any length up to the library's
+// 1024 frames; results differ from the two-pass kernel only in the rounding of the rescaled partial sums (fp32-class either way).
+template <int OUTS>
+__global__ __launch_bounds__(512) void attn_temporal_x2_long_kernel(const float* __restrict__ qkv, void* __restrict__ out_v,
+                                                                    SeqMap map, int C, int heads, int groups, int n_work,
+                                                                    X2Scales sc) {
+  constexpr int NW = 8, NKC = 128, NKT = NKC / 16, PLANE = NKC * 128;
+  __shared__ __attribute__((aligned(16))) char kimg[2 * PLANE];
+  __shared__ __attribute__((aligned(16))) char vimg[2 * PLANE];
+  const int n = map.n_tok;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const size_t ldb = (size_t)12 * C, rsb = (size_t)map.tok_stride * ldb;   // bytes per packed token row / between two tokens of a sequence
+  using u32x4 = unsigned __attribute__((ext_vector_type(4)));
+  // rows k0 .. k0 + NKC - 1 of one packed operand (byte offset `off` inside a row: hi plane; lo plane 2 C bytes further) -> its
+  // hi / lo images; keys >= n: zero rows (their scores are masked, their probabilities 0: V must be finite there)
+  auto stage = [&](const char* row0, int off, int k0, char* img) {
+#pragma unroll
+    for (int i0 = 0; i0 < NKC * 8; i0 += 2 * 512) {
+      u32x4 h[2], l[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = i0 + u * 512 + tid, row = idx >> 3, slot = idx & 7;
+        h[u] = (u32x4){0u, 0u, 0u, 0u}; l[u] = h[u];
+        if (k0 + row < n) {
+          const char* p = row0 + (size_t)(k0 + row) * rsb + off + slot * 16;
+          h[u] = *reinterpret_cast<const u32x4*>(p);
+          l[u] = *reinterpret_cast<const u32x4*>(p + 2 * C);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = i0 + u * 512 + tid, row = idx >> 3, slot = idx & 7;
+        const int o = row * 128 + ((slot ^ ta_sw(row)) << 4);
+        *reinterpret_cast<u32x4*>(img + o) = h[u];
+        *reinterpret_cast<u32x4*>(img + PLANE + o) = l[u];
+      }
+    }
+  };
+  const TAFrag fk = ta_frag(kimg, lane), fv = ta_frag(vimg, lane);
+  for (int unit = blockIdx.x; unit < n_work; unit += gridDim.x) {
+    const int prob = unit / groups, group = unit - prob * groups;
+    const int seq = prob / heads, head = prob - seq * heads;
+    const int tok0 = seq_base(map, seq);
+    const char* row0 = reinterpret_cast<const char*>(qkv) + (size_t)tok0 * ldb;
+    const int qt = group * NW + wave;
+    const bool active = qt * 16 < n;                     // (wave-uniform)
+    const int q = qt * 16 + fi;
+    f16x8 qh[2], ql[2];
+    if (active)
+      ta_load_row_op(reinterpret_cast<const float*>(row0 + (size_t)min(q, n - 1) * rsb) + head * 64, fg, sc.q, qh, ql);
+    float mrun = -INFINITY, lrun = 0.f;                  // running row maximum (base-2 logit units), 1024 x running denominator
+    f32x4 o[4];
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < n; k0 += NKC) {
+      __syncthreads();                                   // every wave is done with the previous chunk's (or unit's) images
+      stage(row0, 4 * C + head * 128, k0, kimg);
+      stage(row0, 8 * C + head * 128, k0, vimg);
+      __syncthreads();
+      if (!active) continue;
+#pragma unroll
+      for (int t = 0; t < NKT; t += 2) {
+        if (k0 + 16 * t >= n) break;                     // (uniform: the rest of the chunk lies behind the sequence)
+        f32x4 a, b;
+        ta_rows_pair<PLANE>(fk, t, qh, ql, a, b);        // S^T [key][query], raw: x sc.cexp = logits in base-2 units
+        float sv[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sv[r] = a[r] * sc.cexp; sv[4 + r] = b[r] * sc.cexp; }
+        if (k0 + 16 * (t + 2) > n) {                     // (uniform: only the sequence's last pair holds keys >= n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (k0 + 16 * t + 4 * fg + r >= n) sv[r] = -INFINITY;
+            if (k0 + 16 * (t + 1) + 4 * fg + r >= n) sv[4 + r] = -INFINITY;
+          }
+        }
+        float mx = sv[0];
+#pragma unroll
+        for (int e = 1; e < 8; ++e) mx = fmaxf(mx, sv[e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);              // (finite from the first pair on: key 0 exists)
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+        mrun = mnew;
+        float psum = 0.f;
+        f16x8 ph, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float y = __builtin_amdgcn_exp2f(sv[e] - mnew + 10.0f);   // p x 1024
+          psum += y;
+          const f16 hh = (f16)y;
+          ph[e] = hh;
+          pl[e] = (f16)fmaf(y, 1.0f, -(float)hh);
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        lrun = fmaf(lrun, alpha, psum);
+#pragma unroll
+        for (int dn = 0; dn < 4; ++dn) o[dn] *= alpha;
+        ta_tr_chunk<PLANE>(fv, t >> 1, ph, pl, o);       // O^T[d][query] += V^T P^T
+      }
+    }
+    // o = (v scale) x 1024 x sum_j p_j v_j against the running maximum; lrun = 1024 x sum_j p_j
+    if (active && q < n)
+      store_o_x2<OUTS>(o, sc.onorm / lrun, out_v, (size_t)(tok0 + q * map.tok_stride), C, head * 64 + fg * 4, sc.oplane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // -DD3DP_ATTN_W16=1 (measurement build; not part of the default library): the temporal split-fp16 kernel as SIXTEEN waves
 // of at most 128 registers, one 16-query tile each, the score row in two halves of 128 keys with an online softmax --
 // the form VERDICT r3 item 3 named beside progressive DMA.  Four waves per SIMD instead of two cover each other's LDS and
@@ -1814,7 +1933,16 @@ int d3dp_launch_attn_x2(int act, int axis, const void* qkv, void* out, int n_seq
     else hipLaunchKernelGGL((attn_spatial_x2_kernel<0>), dim3((n_prob + 3) / 4), dim3(256), 0, st, (const float*)qkv, out, n_prob, map, C, heads, plane, sc);
     return 0;
   }
-  if (n > 256) return -2;
+  if (n > 256) {                                       // long clips: keys in chunks of 128 under an online softmax (see the kernel)
+    const int groups = ((n + 15) / 16 + 7) / 8, n_work = n_seq * heads * groups;
+    static PerDeviceOnce once;
+    const int cus = once.get([&](int dev) { return d3dp_cu_count(dev); });
+    if (cus < 0) return -3;
+    const dim3 grid(n_work < 2 * cus ? n_work : 2 * cus), blk(512);
+    if (act == 3) hipLaunchKernelGGL((attn_temporal_x2_long_kernel<2>), grid, blk, 0, st, (const float*)qkv, out, map, C, heads, groups, n_work, sc);
+    else hipLaunchKernelGGL((attn_temporal_x2_long_kernel<0>), grid, blk, 0, st, (const float*)qkv, out, map, C, heads, groups, n_work, sc);
+    return 0;
+  }
 #define X2_CASE(NKT_)                                                                                         \
   return act == 3 ? launch_temporal_x2<NKT_, 2>(qkv, out, n_seq, map, C, heads, plane, sc, st)                \
                   : launch_temporal_x2<NKT_, 0>(qkv, out, n_seq, map, C, heads, plane, sc, st);

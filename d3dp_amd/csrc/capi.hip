@@ -135,10 +135,13 @@ struct d3dp_ctx {
   bool train() const { return cfg.mode == D3DP_MODE_TRAIN; }
   bool exact() const { return !fast() && !train(); }
   bool x2() const { return exact() && exact_impl == 0; }
-  // split-fp16 attention kernels: head dim 64 and a temporal sequence that fits their LDS images (<= 256 frames: every BASELINE
-  // configuration).  Longer clips (`-f 351`, reference common/arguments.py:58, mixste.py:172) keep the split-fp16 Linears and
-  // take the chunked fp32 row kernel for both attentions (attention.hip attn_rows_kernel): slower, same tolerance.
-  bool x2_attn() const { return x2() && cfg.channels / cfg.heads == 64 && cfg.frames <= 256; }
+  // split-fp16 attention kernels: head dim 64.  Up to 256 frames (every BASELINE configuration) the temporal kernel holds a whole
+  // sequence's K / V images in LDS; longer clips (`-f 351`, reference common/arguments.py:58, mixste.py:172) take the flash form of the
+  // same arithmetic (attention.hip attn_temporal_x2_long_kernel: keys in chunks of 128 under an online softmax; round 5 ran both
+  // attentions of such clips on the chunked fp32 VALU row kernel, ten times the cost per FLOP).  D3DP_LONG_ATTN=rows keeps that
+  // kernel as a cross-check (read in d3dp_create).
+  bool long_rows = false;
+  bool x2_attn() const { return x2() && cfg.channels / cfg.heads == 64 && (cfg.frames <= 256 || !long_rows); }
   // proj / fc2 add into the residual stream in their epilogue (x += ...), so the row kernels read x alone
   bool fold_resid() const { return x2() && fold; }
   bool fold = true;
@@ -402,7 +405,7 @@ const char* d3dp_profile_class_name(int32_t cls) {
 int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   if (!cfg || !out) return fail(D3DP_EINVAL, "d3dp_create: null argument");
   const d3dp_cfg& g = *cfg;
-  // (frames > 256: no MFMA attention kernel holds the sequence; both attentions then run the chunked fp32 row kernel)
+  // (frames > 256: EXACT mode's temporal attention takes the chunked-key flash kernel; FAST / TRAIN contexts the fp32 row kernel)
   if (g.frames < 1 || g.frames > 1024) return fail(D3DP_ENOTSUP, "frames=%d not in [1,1024]", g.frames);
   if (g.joints < 1 || g.joints > 32) return fail(D3DP_ENOTSUP, "joints=%d not in [1,32]", g.joints);
   if (g.channels != 64 && g.channels != 128 && g.channels != 256 && g.channels != 512)
@@ -421,6 +424,8 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->cfg = g;
   const char* xf = getenv("D3DP_EXACT_IMPL");
   c->exact_impl = c->exact_impl_req = (xf && !strcmp(xf, "bf16x3")) ? 1 : (xf && !strcmp(xf, "f32")) ? 2 : 0;
+  const char* lr = getenv("D3DP_LONG_ATTN");             // cross-check: clips > 256 frames on the fp32 row attention kernel
+  c->long_rows = lr && !strcmp(lr, "rows");
   const char* nf = getenv("D3DP_NO_FOLD");               // cross-check: residual adds (and norm2) in the row kernels
   c->fold = !(nf && nf[0] == '1');
   const char* ti = getenv("D3DP_TRAIN_IMPL");
