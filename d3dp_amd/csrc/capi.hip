@@ -178,6 +178,7 @@ struct d3dp_ctx {
   bool train_overlap = true;
   int train_overlap_sets = 2;    // D3DP_TRAIN_OVERLAP=1: one operand set (every operand pass waits for the product before it)
   bool train_gelu_in_prep = true;// D3DP_TRAIN_GELU=pass: d h_pre by a pass of its own (gelu_bwd_kernel) instead of inside the fc1 gradients' operand pass
+  bool train_ln_direct = true;  // D3DP_TRAIN_LN_OPERAND=pass: the qkv / fc1 operands by an operand pass behind the LayerNorm (round 5) instead of by its producer
   bool train_wgrad_merged = true;// D3DP_TRAIN_WGRAD=each: a launch (and 32 MB of partial tiles) per weight gradient instead of one per block
   bool train_tail_blocks = true; // D3DP_TRAIN_TAIL=split: the round-4 handling of a batch's last T mod 256 rows (an extra round of tiles,
                                  // or a split-K launch of their own) instead of the 16 x 64 blocks at the end of the product's kernel
@@ -437,6 +438,8 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->train_gelu_in_prep = !(tg && !strcmp(tg, "pass"));
   const char* tw = getenv("D3DP_TRAIN_WGRAD");
   c->train_wgrad_merged = !(tw && !strcmp(tw, "each"));
+  const char* tl = getenv("D3DP_TRAIN_LN_OPERAND");       // =pass: round 5's operand pass behind every LayerNorm (variants build only)
+  c->train_ln_direct = !(tl && !strcmp(tl, "pass"));
   const char* tt = getenv("D3DP_TRAIN_TAIL");
   c->train_tail_blocks = !(tt && !strcmp(tt, "split"));
   const char* ta = getenv("D3DP_TRAIN_ATTN");
@@ -447,9 +450,9 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   // kernels below they are honoured by the `make variants` library only and REFUSED here -- never ignored.  (What stays: the
   // cross-check implementations D3DP_TRAIN_IMPL=f32, D3DP_TRAIN_ATTN=f32|x2t, D3DP_TRAIN_ATTN_BWD=valu, D3DP_EXACT_IMPL, D3DP_NO_FOLD,
   // and the profiling switch D3DP_TRAIN_OVERLAP=0|1: one stream, so that no kernel's duration contains a wait for CUs.)
-  if ((!c->train_gelu_in_prep || !c->train_wgrad_merged || !c->train_tail_blocks) && !d3dp_x2_variants_built()) {
+  if ((!c->train_gelu_in_prep || !c->train_wgrad_merged || !c->train_tail_blocks || !c->train_ln_direct) && !d3dp_x2_variants_built()) {
     delete c;
-    return fail(D3DP_ENOTSUP, "D3DP_TRAIN_WGRAD=each / D3DP_TRAIN_TAIL=split / D3DP_TRAIN_GELU=pass select superseded launch forms of the "
+    return fail(D3DP_ENOTSUP, "D3DP_TRAIN_WGRAD=each / D3DP_TRAIN_TAIL=split / D3DP_TRAIN_GELU=pass / D3DP_TRAIN_LN_OPERAND=pass select superseded launch forms of the "
                               "training step that only the variants build honours (make -C d3dp_amd/csrc variants; "
                               "D3DP_LIB=d3dp_amd/lib/variants/libd3dp_variants.so)");
   }
@@ -1464,6 +1467,10 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
   };
   // the qkv / fc1 operands straight from the INPUT of the LayerNorm in front of them (no fp32 normalised activation is written)
   const bool ln_fused = use_x2 && x2.ln_operand_applies(3 * C, C) && x2.ln_operand_applies(Hd, C);
+  // ... and (round 6) written BY the kernel that produces that input, at the scale the LayerNorm's own weights bound (train.hip
+  // ln_operand_scale): the operand pass in front of qkv / fc1 disappears (block 0's qkv operand: the embedding kernel is shared
+  // with inference and keeps the pass)
+  const bool ln_direct = ln_fused && c->train_ln_direct && C % 256 == 0;
   // attention on split-fp16 operands (train_attn.hip): needs the split Linears' device-side scales, head dim 64, <= 256 frames
   const bool attn_x2 = use_x2 && c->train_attn_x2 > 0 && C / g.heads == 64 && F <= 256;
   const bool attn_x2_s = attn_x2 && c->train_attn_x2 > 1;      // the spatial axis too
@@ -1482,8 +1489,9 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     float* S = ws + L.saved0 + (size_t)blk * L.saved_stride;
     const bool ax2 = kind == 1 ? attn_x2 : attn_x2_s;
     unsigned* qkv_amax = ax2 ? x2.amax() + X2Train::kQkvSlot0 + blk : nullptr;
-    if (ln_fused) LAUNCH_TRY(lin(4 * blk, S + L.o_xin, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C, true, qkv_amax, 0, false,
-                                 w.n1w, w.n1b, g.eps_block));
+    if (ln_direct && blk > 0) LAUNCH_TRY(lin(4 * blk, nullptr, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C, true, qkv_amax, 0, true));
+    else if (ln_fused) LAUNCH_TRY(lin(4 * blk, S + L.o_xin, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C, true, qkv_amax, 0, false,
+                                      w.n1w, w.n1b, g.eps_block));
     else LAUNCH_TRY(lin(4 * blk, xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C, true, qkv_amax));
     bool att_ready = true;
     auto attention = [&]() -> int {                      // (the launcher's own return code)
@@ -1502,19 +1510,26 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     };
     TP(kind ? T_ATTN_FWD_T : T_ATTN_FWD_S, attention());
     LAUNCH_TRY(lin(4 * blk + 1, S + L.o_att, (const float*)w.proj_w, w.proj_b, y, T, C, C, att_ready));
-    TP(T_LN_FWD, d3dp_train_add_mask_ln(S + L.o_xin, y, mask_ptr(masks, g, B, blk, 0), kind, F, J, w.n2w, w.n2b, g.eps_block,
-                                        S + L.o_xmid, ln_fused ? nullptr : xn, slot(4 * blk + 2), T, C, st));
+    if (ln_direct)
+      TP(T_LN_FWD, d3dp_train_add_mask_ln(S + L.o_xin, y, mask_ptr(masks, g, B, blk, 0), kind, F, J, w.n2w, w.n2b, g.eps_block,
+                                          S + L.o_xmid, nullptr, slot(4 * blk + 2), T, C, st, ws + L.x_cols + x2.xoff(4 * blk + 2),
+                                          x2.pad_rows(T, Hd, C), x2.uns() + 2 * (4 * blk + 2)))
+    else
+      TP(T_LN_FWD, d3dp_train_add_mask_ln(S + L.o_xin, y, mask_ptr(masks, g, B, blk, 0), kind, F, J, w.n2w, w.n2b, g.eps_block,
+                                          S + L.o_xmid, ln_fused ? nullptr : xn, slot(4 * blk + 2), T, C, st));
     const float* fc1_in = ln_fused ? S + L.o_xmid : xn;
     const float *f1w = ln_fused ? w.n2w : nullptr, *f1b = ln_fused ? w.n2b : nullptr;
     if (use_x2 && x2.gelu_operand_applies(C, Hd)) {
       // the fc2 operand = split(GELU(fc1 output)) in one pass, its scale from the largest positive fc1 output (the fc1
       // epilogue leaves it): no fp32 hidden tensor, no separate operand pass
-      LAUNCH_TRY(lin(4 * blk + 2, fc1_in, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, true,
-                     x2.amax() + X2Train::kPmaxSlot0 + blk, 1, false, f1w, f1b, g.eps_block));
+      if (ln_direct) LAUNCH_TRY(lin(4 * blk + 2, nullptr, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, true,
+                                    x2.amax() + X2Train::kPmaxSlot0 + blk, 1, true));
+      else LAUNCH_TRY(lin(4 * blk + 2, fc1_in, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, true,
+                          x2.amax() + X2Train::kPmaxSlot0 + blk, 1, false, f1w, f1b, g.eps_block));
       LAUNCH_TRY(x2.gelu_operand(4 * blk + 3, S + L.o_hpre, blk, T, C, Hd));
       LAUNCH_TRY(lin(4 * blk + 3, nullptr, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd, true, nullptr, 0, true));
     } else {
-      LAUNCH_TRY(lin(4 * blk + 2, fc1_in, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, true, nullptr, 0, false, f1w, f1b,
+      LAUNCH_TRY(lin(4 * blk + 2, fc1_in, (const float*)w.fc1_w, w.fc1_b, S + L.o_hpre, T, Hd, C, true, nullptr, 0, ln_direct, f1w, f1b,
                      g.eps_block));
       TP(T_OPERAND, d3dp_train_gelu_fwd(S + L.o_hpre, hid, (size_t)T * Hd, slot(4 * blk + 3), st));
       LAUNCH_TRY(lin(4 * blk + 3, hid, (const float*)w.fc2_w, w.fc2_b, y, T, C, Hd, true));
@@ -1529,7 +1544,10 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
     TP(T_LN_FWD, d3dp_train_add_mask_ln2(S + L.o_xmid, y, mask_ptr(masks, g, B, blk, 1), kind, F, J, kind ? c->tnw : c->snw,
                                          kind ? c->tnb : c->snb, g.eps_block, (kind == 0 && d == 0) ? c->tpos : nullptr, nw, nb,
                                          last ? g.eps_head : g.eps_block, S + L.o_xout, x_next,
-                                         last ? ws + L.z : (ln_fused ? nullptr : xn), last ? nullptr : slot(4 * (blk + 1)), T, C, st));
+                                         last ? ws + L.z : (ln_fused ? nullptr : xn), last ? nullptr : slot(4 * (blk + 1)), T, C, st,
+                                         (ln_direct && !last) ? ws + L.x_cols + x2.xoff(4 * (blk + 1)) : nullptr,
+                                         (ln_direct && !last) ? x2.pad_rows(T, 3 * C, C) : 0,
+                                         (ln_direct && !last) ? x2.uns() + 2 * 4 * (blk + 1) : nullptr));
   }
   TP(T_OTHER, d3dp_train_head_linear(ws + L.z, c->hw, c->hb, out, T, C, st));
 #undef TP

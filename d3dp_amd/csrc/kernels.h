@@ -217,12 +217,14 @@ extern "C" int d3dp_clip_count(int32_t n, int32_t F);
 //  workgroup -- so that the split-fp16 Linear that consumes the result needs no absmax pass of its own)
 // x_out = x_in + mask[sample] y ; xn = LN(x_out)  (xn may be null: only amax, the absmax of LN(x_out), is produced)
 int d3dp_train_add_mask_ln(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* w,
-                           const float* b, float eps, float* x_out, float* xn, unsigned* amax, int T, int C, hipStream_t st);
+                           const float* b, float eps, float* x_out, float* xn, unsigned* amax, int T, int C, hipStream_t st,
+                           void* op = nullptr, int Tp = 0, float* op_unscale = nullptr);
 // x_out = x_in + mask[sample] y ; x_next = LN_a(x_out) (+ pos[f]) ; xn = LN_b(x_next)  (wb null: no second norm; xn null with
 // wb given: LN_b's output is not stored, only its absmax)
 int d3dp_train_add_mask_ln2(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* wa,
                             const float* ba, float eps_a, const float* pos, const float* wb, const float* bb, float eps_b,
-                            float* x_out, float* x_next, float* xn, unsigned* amax, int T, int C, hipStream_t st);
+                            float* x_out, float* x_next, float* xn, unsigned* amax, int T, int C, hipStream_t st, void* op = nullptr,
+                            int Tp = 0, float* op_unscale = nullptr);
 int d3dp_train_ln_pos(const float* x, const float* w, const float* b, float eps, const float* pos, int F, int J, float* y,
                       int T, int C, hipStream_t st);
 // LayerNorm backward, one (xa == null) or two chained LayerNorms (y = LN_b(xb), xb = LN_a(xa) (+ pos)) in one pass:

@@ -79,35 +79,88 @@ __device__ __forceinline__ void block_amax_commit(float m, unsigned* amax) {
     atomicMax(amax, __float_as_uint(fmaxf(fmaxf(part_amax[0], part_amax[1]), fmaxf(part_amax[2], part_amax[3]))));
 }
 
+// A LayerNorm's output straight into the split-fp16 operand rows of the Linear behind it (round 6): no fp32 normalised tensor, no
+// operand pass (round 5: the producer left the output's ABSMAX, rowprep_ln_kernel read the LayerNorm's input again and wrote the
+// rows).  The operand scale must be known before the first element is written, and here it is, from the weights alone:
+// sum x^2 <= C and sum x^ = 0 give |x^_i| <= sqrt(C - 1), so |LN(x)_i| <= sqrt(C - 1) max|gamma| + max|beta|.  The bound is a few binades
+// above the true absmax (seed weights: 2^2 .. 2^3); a split operand keeps 22 bits of every element within 2^8 of its scale's range
+// and an absolute error of 2^-40 of that range below, so nothing measurable is lost (test_training_step_* tolerances unchanged).
+// ln_operand_scale: every wave of the launch derives the same power of two from the gamma / beta values its lanes hold.
+template <int NV>
+__device__ __forceinline__ float ln_operand_scale(const float (&wl)[NV], const float (&bl)[NV], int C, float& bound) {
+  float gw = 0.f, gb = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { gw = fmaxf(gw, fabsf(wl[i])); gb = fmaxf(gb, fabsf(bl[i])); }
+  gw = wave_max(gw); gb = wave_max(gb);
+  bound = fmaf(sqrtf((float)(C - 1)), gw, gb);
+  if (!(bound > 0.f) || !(bound < INFINITY)) return 1.0f;
+  int e;
+  frexpf(bound, &e);                                   // (as gemm_x2.hip dyn_scale: the largest magnitude lands below 2^14)
+  return ldexpf(1.0f, 14 - e);
+}
+// a lane's NV values of row `op_row` (TRow<C>::V4 layout: float4 groups at columns (g 64 + lane) 4) -> h2i split rows [.][2 C]
+template <int C, int NV>
+__device__ __forceinline__ void store_operand_row(f16* op_row, int lane, const float (&v)[NV], float sc) {
+#pragma unroll
+  for (int g = 0; g < NV / 4; ++g) {
+    f16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f16 h, l; split2h_scaled(v[g * 4 + e] * sc, h, l); hi[e] = h; lo[e] = l; }
+    f16* d = op_row + h2i_col((g * 64 + lane) * 4);
+    *reinterpret_cast<f16x4*>(d) = hi;
+    *reinterpret_cast<f16x4*>(d + kH2iLo) = lo;
+  }
+}
+
 // ---- x_out = x_in + m[sample] * y ; xn = LN(x_out)  (+ absmax of xn: the fc1 operand) ------------------------------
+// (op != null, C % 256 == 0: LN(x_out) as split operand rows [Tp][2 C] at the scale of ln_operand_scale, rows T .. Tp - 1 zero;
+//  op_unscale[0] = 1 / scale, amax[0] = the bound)
 template <int C>
 __global__ __launch_bounds__(256) void add_mask_ln_kernel(const float* __restrict__ x_in, const float* __restrict__ y,
                                                           const float* __restrict__ mask, int axis, int F, int J,
                                                           const float* __restrict__ w, const float* __restrict__ b,
                                                           float eps, float* __restrict__ x_out, float* __restrict__ xn,
-                                                          unsigned* __restrict__ amax, int T) {
+                                                          unsigned* __restrict__ amax, int T, f16* __restrict__ op, int Tp,
+                                                          float* __restrict__ op_unscale) {
   using R = TRow<C>;
   constexpr int NV = R::NV;
   const int lane = threadIdx.x & 63;
   float wl[NV], bl[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) { wl[i] = w[R::col(i, lane)]; bl[i] = b[R::col(i, lane)]; }
-  float am = 0.f;
-  for (int tok = blockIdx.x * 4 + (threadIdx.x >> 6); tok < T; tok += gridDim.x * 4) {
-    const float m = mask ? mask[sample_of(tok, axis, F, J)] : 1.0f;
-    float v[NV], yy[NV];
-    R::load(x_in + (size_t)tok * C, lane, v);
-    R::load(y + (size_t)tok * C, lane, yy);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = v[i] + m * yy[i];
-    R::store(x_out + (size_t)tok * C, lane, v);
-    float mean, rstd;
-    R::stats(v, eps, mean, rstd);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) { v[i] = fmaf((v[i] - mean) * rstd, wl[i], bl[i]); am = fmaxf(am, fabsf(v[i])); }
-    if (xn) R::store(xn + (size_t)tok * C, lane, v);     // (null: only its absmax is wanted -- the operand pass recomputes it)
+  float am = 0.f, sc = 1.f;
+  if constexpr (R::V4) {
+    if (op) {
+      float bound;
+      sc = ln_operand_scale<NV>(wl, bl, C, bound);
+      if (blockIdx.x == 0 && threadIdx.x == 0) { op_unscale[0] = 1.0f / sc; if (amax) amax[0] = __float_as_uint(bound); }
+    }
   }
-  block_amax_commit(am, amax);
+  const int rows = (R::V4 && op) ? max(T, Tp) : T;
+  for (int tok = blockIdx.x * 4 + (threadIdx.x >> 6); tok < rows; tok += gridDim.x * 4) {
+    float v[NV];
+    if (tok < T) {
+      const float m = mask ? mask[sample_of(tok, axis, F, J)] : 1.0f;
+      float yy[NV];
+      R::load(x_in + (size_t)tok * C, lane, v);
+      R::load(y + (size_t)tok * C, lane, yy);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = v[i] + m * yy[i];
+      R::store(x_out + (size_t)tok * C, lane, v);
+      float mean, rstd;
+      R::stats(v, eps, mean, rstd);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { v[i] = fmaf((v[i] - mean) * rstd, wl[i], bl[i]); am = fmaxf(am, fabsf(v[i])); }
+      if (xn) R::store(xn + (size_t)tok * C, lane, v);   // (null: only its absmax / its operand rows are wanted)
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = 0.f;           // (the TN weight-gradient product wants zero rows behind T)
+    }
+    if constexpr (R::V4) {
+      if (op) store_operand_row<C, NV>(op + (size_t)tok * 2 * C, lane, v, sc);
+    }
+  }
+  if (!(R::V4 && op)) block_amax_commit(am, amax);
 }
 
 // ---- the end of a block in ONE pass over its rows (mixste.py:113-115 second line, then :243/:250 or :257/:273):
@@ -121,7 +174,8 @@ __global__ __launch_bounds__(256) void add_mask_ln2_kernel(const float* __restri
                                                            const float* __restrict__ pos, const float* __restrict__ wb,
                                                            const float* __restrict__ bb, float eps_b, float* __restrict__ x_out,
                                                            float* __restrict__ x_next, float* __restrict__ xn,
-                                                           unsigned* __restrict__ amax, int T) {
+                                                           unsigned* __restrict__ amax, int T, f16* __restrict__ op, int Tp,
+                                                           float* __restrict__ op_unscale) {
   using R = TRow<C>;
   constexpr int NV = R::NV;
   const int lane = threadIdx.x & 63;
@@ -132,7 +186,24 @@ __global__ __launch_bounds__(256) void add_mask_ln2_kernel(const float* __restri
     wal[i] = wa[c]; bal[i] = ba[c];
     wbl[i] = wb ? wb[c] : 0.f; bbl[i] = wb ? bb[c] : 0.f;
   }
-  float am = 0.f;
+  float am = 0.f, sc = 1.f;
+  const bool to_op = R::V4 && op && wb;                  // (LN_b's output as the next Linear's operand rows: see add_mask_ln_kernel)
+  if constexpr (R::V4) {
+    if (to_op) {
+      float bound;
+      sc = ln_operand_scale<NV>(wbl, bbl, C, bound);
+      if (blockIdx.x == 0 && threadIdx.x == 0) { op_unscale[0] = 1.0f / sc; if (amax) amax[0] = __float_as_uint(bound); }
+    }
+  }
+  if constexpr (R::V4) {
+    if (to_op)                                           // zero rows behind T (few: one workgroup pass)
+      for (int tok = T + blockIdx.x * 4 + (threadIdx.x >> 6); tok < Tp; tok += gridDim.x * 4) {
+        float z[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) z[i] = 0.f;
+        store_operand_row<C, NV>(op + (size_t)tok * 2 * C, lane, z, 1.0f);
+      }
+  }
   for (int tok = blockIdx.x * 4 + (threadIdx.x >> 6); tok < T; tok += gridDim.x * 4) {
     const float m = mask ? mask[sample_of(tok, axis, F, J)] : 1.0f;
     float v[NV], yy[NV];
@@ -158,9 +229,12 @@ __global__ __launch_bounds__(256) void add_mask_ln2_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < NV; ++i) { v[i] = fmaf((v[i] - mean) * rstd, wbl[i], bbl[i]); am = fmaxf(am, fabsf(v[i])); }
       if (xn) R::store(xn + (size_t)tok * C, lane, v);
+      if constexpr (R::V4) {
+        if (to_op) store_operand_row<C, NV>(op + (size_t)tok * 2 * C, lane, v, sc);
+      }
     }
   }
-  block_amax_commit(am, amax);
+  if (!to_op) block_amax_commit(am, amax);
 }
 
 // ---- y = LN(x) (+ pos[f]) -- the fp32 cross-check path's recomputation of a Linear input in the backward pass -----------
@@ -807,18 +881,20 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(const int64_t* __rest
 
 static int row_blocks(int T) { return (T + 3) / 4 < kRowBlocks ? (T + 3) / 4 : kRowBlocks; }
 int d3dp_train_add_mask_ln(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* w,
-                           const float* b, float eps, float* x_out, float* xn, unsigned* amax, int T, int C, hipStream_t st) {
-  if (!w || !b || (!xn && !amax)) return -1;
+                           const float* b, float eps, float* x_out, float* xn, unsigned* amax, int T, int C, hipStream_t st,
+                           void* op, int Tp, float* op_unscale) {
+  if (!w || !b || (!xn && !amax && !op) || (op && (C % 256 != 0 || Tp < T || !op_unscale))) return -1;
   TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((add_mask_ln_kernel<CC>), dim3(row_blocks(T)), dim3(256), 0, st, x_in, y, mask, axis,
-                                         F, J, w, b, eps, x_out, xn, amax, T))
+                                         F, J, w, b, eps, x_out, xn, amax, T, (f16*)op, Tp, op_unscale))
   return 0;
 }
 int d3dp_train_add_mask_ln2(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* wa,
                             const float* ba, float eps_a, const float* pos, const float* wb, const float* bb, float eps_b,
-                            float* x_out, float* x_next, float* xn, unsigned* amax, int T, int C, hipStream_t st) {
-  if (!wa || !ba || !x_out || !x_next || (xn && !wb) || (wb && !bb)) return -1;
+                            float* x_out, float* x_next, float* xn, unsigned* amax, int T, int C, hipStream_t st, void* op, int Tp,
+                            float* op_unscale) {
+  if (!wa || !ba || !x_out || !x_next || (xn && !wb) || (wb && !bb) || (op && (C % 256 != 0 || Tp < T || !op_unscale || !wb))) return -1;
   TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((add_mask_ln2_kernel<CC>), dim3(row_blocks(T)), dim3(256), 0, st, x_in, y, mask, axis,
-                                         F, J, wa, ba, eps_a, pos, wb, bb, eps_b, x_out, x_next, xn, amax, T))
+                                         F, J, wa, ba, eps_a, pos, wb, bb, eps_b, x_out, x_next, xn, amax, T, (f16*)op, Tp, op_unscale))
   return 0;
 }
 int d3dp_train_ln_pos(const float* x, const float* w, const float* b, float eps, const float* pos, int F, int J, float* y,

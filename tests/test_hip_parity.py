@@ -1214,7 +1214,7 @@ def test_training_step_fp32_linears_cross_check(monkeypatch, cs):
     print(f"training step, fp32-MFMA Linears vs split-fp16 Linears: worst relative gradient difference {worst:.2e}")
 
 
-_TRAIN_SWITCHES = ("D3DP_TRAIN_WGRAD", "D3DP_TRAIN_TAIL", "D3DP_TRAIN_GELU", "D3DP_TRAIN_OVERLAP")
+_TRAIN_SWITCHES = ("D3DP_TRAIN_WGRAD", "D3DP_TRAIN_TAIL", "D3DP_TRAIN_GELU", "D3DP_TRAIN_OVERLAP", "D3DP_TRAIN_LN_OPERAND")
 
 
 def _training_step_under(monkeypatch, cases):
@@ -1264,7 +1264,7 @@ def test_product_library_refuses_the_superseded_training_launch_forms(monkeypatc
     REFUSES them (D3DP_ENOTSUP) instead of ignoring them -- only the `make variants` build honours them."""
     if _lib.load().d3dp_debug_x2_variants() == 1:
         pytest.skip("this is the variants build: it honours the switches (test_training_step_scheduling_switches_agree)")
-    for k, v in (("D3DP_TRAIN_WGRAD", "each"), ("D3DP_TRAIN_TAIL", "split"), ("D3DP_TRAIN_GELU", "pass")):
+    for k, v in (("D3DP_TRAIN_WGRAD", "each"), ("D3DP_TRAIN_TAIL", "split"), ("D3DP_TRAIN_GELU", "pass"), ("D3DP_TRAIN_LN_OPERAND", "pass")):
         for kk in _TRAIN_SWITCHES:
             monkeypatch.delenv(kk, raising=False)
         monkeypatch.setenv(k, v)
@@ -1283,7 +1283,7 @@ def test_training_step_scheduling_switches_agree(monkeypatch):
     gradient agree to fp32 noise."""
     res = _training_step_under(monkeypatch, (
         ("default", {}), ("wgrad_each", {"D3DP_TRAIN_WGRAD": "each"}), ("tail_split", {"D3DP_TRAIN_TAIL": "split"}),
-        ("gelu_pass", {"D3DP_TRAIN_GELU": "pass"}),
+        ("gelu_pass", {"D3DP_TRAIN_GELU": "pass"}), ("ln_operand_pass", {"D3DP_TRAIN_LN_OPERAND": "pass"}),
         ("round4", {"D3DP_TRAIN_WGRAD": "each", "D3DP_TRAIN_TAIL": "split", "D3DP_TRAIN_GELU": "pass", "D3DP_TRAIN_OVERLAP": "1"})))
     ref = res["default"]
     for name, (loss, grads) in res.items():
