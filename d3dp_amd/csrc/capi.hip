@@ -1494,14 +1494,19 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
                                       w.n1w, w.n1b, g.eps_block));
     else LAUNCH_TRY(lin(4 * blk, xn, (const float*)w.qkv_w, w.qkv_b, S + L.o_qkv, T, 3 * C, C, true, qkv_amax));
     bool att_ready = true;
+    // the split-fp16 attention also writes the proj Linear's operand rows (scale: the qkv absmax bounds every output), round 6
+    const bool att_direct = ax2 && ln_direct && d3dp_tn_applies(C, C);
+    void* att_op = att_direct ? ws + L.x_cols + x2.xoff(4 * blk + 1) : nullptr;
+    const int att_tp = att_direct ? x2.pad_rows(T, C, C) : 0;
+    float* att_un = att_direct ? x2.uns() + 2 * (4 * blk + 1) : nullptr;
     auto attention = [&]() -> int {                      // (the launcher's own return code)
       if (kind == 0 && ax2)
         return d3dp_train_attn_x2_fwd(S + L.o_qkv, S + L.o_att, ws + L.stats_x2 + (size_t)blk * L.stats_x2_stride, B * F,
-                                      spatial_map(F, J), C, g.heads, qkv_amax, slot(4 * blk + 1), st);
+                                      spatial_map(F, J), C, g.heads, qkv_amax, slot(4 * blk + 1), st, att_op, T, att_tp, att_un);
       if (kind == 0) return d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * F, spatial_map(F, J), C, g.heads, st, slot(4 * blk + 1));
       if (ax2)
         return d3dp_train_attn_x2_fwd(S + L.o_qkv, S + L.o_att, ws + L.stats_x2 + (size_t)blk * L.stats_x2_stride, B * J,
-                                      temporal_map(F, J), C, g.heads, qkv_amax, slot(4 * blk + 1), st);
+                                      temporal_map(F, J), C, g.heads, qkv_amax, slot(4 * blk + 1), st, att_op, T, att_tp, att_un);
       if (use_x2 && C / g.heads == 64 && F <= 256) {     // temporal axis on the fp32 matrix cores (bitwise an fp32 fmaf chain per product)
         att_ready = false;
         return d3dp_launch_attn_temporal_f32(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st);
@@ -1509,7 +1514,7 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
       return d3dp_launch_attn_rows(0, S + L.o_qkv, S + L.o_att, B * J, temporal_map(F, J), C, g.heads, st, slot(4 * blk + 1));
     };
     TP(kind ? T_ATTN_FWD_T : T_ATTN_FWD_S, attention());
-    LAUNCH_TRY(lin(4 * blk + 1, S + L.o_att, (const float*)w.proj_w, w.proj_b, y, T, C, C, att_ready));
+    LAUNCH_TRY(lin(4 * blk + 1, S + L.o_att, (const float*)w.proj_w, w.proj_b, y, T, C, C, att_ready, nullptr, 0, att_direct));
     if (ln_direct)
       TP(T_LN_FWD, d3dp_train_add_mask_ln(S + L.o_xin, y, mask_ptr(masks, g, B, blk, 0), kind, F, J, w.n2w, w.n2b, g.eps_block,
                                           S + L.o_xmid, nullptr, slot(4 * blk + 2), T, C, st, ws + L.x_cols + x2.xoff(4 * blk + 2),

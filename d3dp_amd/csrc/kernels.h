@@ -264,7 +264,8 @@ constexpr int D3DP_EMBED_BWD_ROWS = 64;
 // (optional): absmax slot of the result.
 size_t d3dp_train_attn_x2_stats_bytes(int n_seq, int n_tok, int heads);
 int d3dp_train_attn_x2_fwd(const float* qkv, float* out, void* stats, int n_seq, SeqMap map, int C, int heads,
-                           const unsigned* amax_qkv, unsigned* amax_out, hipStream_t st);
+                           const unsigned* amax_qkv, unsigned* amax_out, hipStream_t st, void* op = nullptr, int T = 0, int Tp = 0,
+                           float* op_unscale = nullptr);
 int d3dp_train_attn_x2_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, void* stats, int n_seq, SeqMap map,
                            int C, int heads, const unsigned* amax_qkv, const unsigned* amax_do, unsigned* amax_out,
                            hipStream_t st, int part = 0);

@@ -49,7 +49,8 @@ template <int NKT, int NW>
 __global__ __launch_bounds__(NW * 64) void tattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                            TAStat* __restrict__ stats, SeqMap map, int C, int heads, int groups,
                                                            int n_work, const unsigned* __restrict__ amax_qkv,
-                                                           unsigned* __restrict__ amax_out) {
+                                                           unsigned* __restrict__ amax_out, f16* __restrict__ op, int T, int Tp,
+                                                           float* __restrict__ op_unscale) {
   constexpr int NK = 16 * NKT, PLANE = NK * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
@@ -60,6 +61,16 @@ __global__ __launch_bounds__(NW * 64) void tattn_fwd_kernel(const float* __restr
   const size_t ld = (size_t)3 * C, rs = (size_t)map.tok_stride * ld;
   const float sq = ta_scale(amax_qkv);
   float am = 0.f;
+  // op (round 6): the output ALSO as the split operand rows [Tp][2 C] of the proj Linear behind it (h2i; rows T .. Tp - 1 zero), at
+  // the scale of q / k / v -- every output is a convex combination of v rows, so |o| <= max |v| <= the qkv absmax: the bound is
+  // known before the first element is written and the operand pass between attention and proj disappears.  op_unscale[0] = 1 /
+  // scale, amax_out[0] = the bound.
+  if (op) {
+    if (blockIdx.x == 0 && tid == 0) { op_unscale[0] = 1.0f / sq; if (amax_out) amax_out[0] = amax_qkv[0]; }
+    const size_t n8 = (size_t)(Tp - T) * C / 4;        // 16-byte pieces of the pad rows (2 C fp16 each)
+    uint4* z = reinterpret_cast<uint4*>(op + (size_t)T * 2 * C);
+    for (size_t i = (size_t)blockIdx.x * (NW * 64) + tid; i < n8; i += (size_t)gridDim.x * (NW * 64)) z[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
   for (int unit = blockIdx.x; unit < n_work; unit += gridDim.x) {
   const int prob = unit / groups, group = unit % groups;
   const int seq = prob / heads, head = prob % heads;
@@ -130,12 +141,22 @@ __global__ __launch_bounds__(NW * 64) void tattn_fwd_kernel(const float* __restr
         const float4 r4 = make_float4(o[dn][0] * inv, o[dn][1] * inv, o[dn][2] * inv, o[dn][3] * inv);
         am = fmaxf(am, fmaxf(fmaxf(fabsf(r4.x), fabsf(r4.y)), fmaxf(fabsf(r4.z), fabsf(r4.w))));
         *reinterpret_cast<float4*>(dst + dn * 16) = r4;
+        if (op) {
+          // (the true-scale value first, the exact power of two inside the split: both halves must round the SAME number)
+          const float y[4] = {ta_opaque(r4.x * sq), ta_opaque(r4.y * sq), ta_opaque(r4.z * sq), ta_opaque(r4.w * sq)};
+          f16x4 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const f16 hh = (f16)y[e]; hi[e] = hh; lo[e] = (f16)(y[e] - (float)hh); }
+          f16* d = op + tok * 2 * C + h2i_col(head * 64 + dn * 16 + fg * 4);
+          *reinterpret_cast<f16x4*>(d) = hi;
+          *reinterpret_cast<f16x4*>(d + kH2iLo) = lo;
+        }
       }
       if (fg == 0) stats[(size_t)prob * n + q].L = mrun + __builtin_amdgcn_logf(lrun) - 10.0f;   // log2(sum exp2(s))
     }
   }
   }
-  if (amax_out) ta_block_amax<NW>(am, amax_out, part);
+  if (amax_out && !op) ta_block_amax<NW>(am, amax_out, part);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -344,10 +365,11 @@ __global__ __launch_bounds__(NW * 64) void tattn_bwd_kv_kernel(const float* __re
   if (amax_out) ta_block_amax<NW>(am, amax_out, part);
 }
 
+struct TAOperand { f16* op; int T, Tp; float* unscale; };   // forward only: the output also as the next Linear's operand rows
 template <int NKT>
 int ta_launch(int which, const float* qkv, const float* o, const float* dout, float* out, float* dqkv, void* stats, int n_seq,
               SeqMap map, int C, int heads, const unsigned* amax_qkv, const unsigned* amax_do, unsigned* amax_out,
-              hipStream_t st) {
+              hipStream_t st, TAOperand po = {nullptr, 0, 0, nullptr}) {
   constexpr int NK = 16 * NKT, NW = NKT <= 2 ? 2 : (NKT <= 4 ? 4 : 8);
   const size_t lds = (size_t)4 * NK * 128 + NK * 8 + 64;
   static PerDeviceOnce once;
@@ -361,7 +383,8 @@ int ta_launch(int which, const float* qkv, const float* o, const float* dout, fl
   const dim3 grid(n_work < 2048 ? n_work : 2048), blk(NW * 64);   // (<= 2048 absmax atomics per launch)
   TAStat* s = reinterpret_cast<TAStat*>(stats);
   if (which == 0)
-    hipLaunchKernelGGL((tattn_fwd_kernel<NKT, NW>), grid, blk, lds, st, qkv, out, s, map, C, heads, groups, n_work, amax_qkv, amax_out);
+    hipLaunchKernelGGL((tattn_fwd_kernel<NKT, NW>), grid, blk, lds, st, qkv, out, s, map, C, heads, groups, n_work, amax_qkv, amax_out,
+                       po.op, po.T, po.Tp, po.unscale);
   else {                                               // which: 1 = both passes, 2 = pass Q alone, 3 = pass KV alone (needs pass Q's D_i)
     if (which != 3)
       hipLaunchKernelGGL((tattn_bwd_q_kernel<NKT, NW>), grid, blk, lds, st, qkv, o, dout, dqkv, s, map, C, heads, groups, n_work,
@@ -375,10 +398,11 @@ int ta_launch(int which, const float* qkv, const float* o, const float* dout, fl
 
 int ta_dispatch(int which, const float* qkv, const float* o, const float* dout, float* out, float* dqkv, void* stats, int n_seq,
                 SeqMap map, int C, int heads, const unsigned* amax_qkv, const unsigned* amax_do, unsigned* amax_out,
-                hipStream_t st) {
+                hipStream_t st, TAOperand po = {nullptr, 0, 0, nullptr}) {
   const int n = map.n_tok;
   if (C / heads != 64 || C % 4 != 0 || n < 1 || n > 256 || !amax_qkv || !stats) return -2;
-#define TA_CASE(NKT_) return ta_launch<NKT_>(which, qkv, o, dout, out, dqkv, stats, n_seq, map, C, heads, amax_qkv, amax_do, amax_out, st);
+  if (po.op && (po.Tp < po.T || !po.unscale || C % 32 != 0)) return -1;
+#define TA_CASE(NKT_) return ta_launch<NKT_>(which, qkv, o, dout, out, dqkv, stats, n_seq, map, C, heads, amax_qkv, amax_do, amax_out, st, po);
   if (n <= 32) { TA_CASE(2) }
   if (n <= 64) { TA_CASE(4) }
   if (n <= 128) { TA_CASE(8) }
@@ -392,10 +416,14 @@ size_t d3dp_train_attn_x2_stats_bytes(int n_seq, int n_tok, int heads) { return 
 
 // out [T, C] = softmax(q k^T / 8) v per (sequence, head); stats: n_seq x heads x n_tok (L, D) pairs for the backward pass;
 // amax_qkv: absmax slot of the whole qkv tensor (the qkv Linear's epilogue); amax_out (optional): absmax slot of `out`
+// op (optional): the output also as split operand rows [Tp][2 C] (rows T .. Tp - 1 zero; T = all token rows of the batch) at the
+// scale of q / k / v, op_unscale[0] = 1 / scale, amax_out[0] = the bound (the qkv absmax) -- see tattn_fwd_kernel
 int d3dp_train_attn_x2_fwd(const float* qkv, float* out, void* stats, int n_seq, SeqMap map, int C, int heads,
-                           const unsigned* amax_qkv, unsigned* amax_out, hipStream_t st) {
+                           const unsigned* amax_qkv, unsigned* amax_out, hipStream_t st, void* op, int T, int Tp,
+                           float* op_unscale) {
   if (!qkv || !out) return -1;
-  return ta_dispatch(0, qkv, nullptr, nullptr, out, nullptr, stats, n_seq, map, C, heads, amax_qkv, nullptr, amax_out, st);
+  return ta_dispatch(0, qkv, nullptr, nullptr, out, nullptr, stats, n_seq, map, C, heads, amax_qkv, nullptr, amax_out, st,
+                     TAOperand{(f16*)op, T, Tp, op_unscale});
 }
 // dqkv [T, 3C] = the gradient of (q | k | v) given dout [T, C]; o: the forward output; amax_do: absmax slot of dout;
 // amax_out (optional): absmax slot of dqkv (both passes add to it)
