@@ -294,10 +294,24 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const float* dy, const flo
   }
   const bool want_m = dxm != nullptr || amax != nullptr;
   float am = 0.f;
-  for (int tok = blockIdx.x * 4 + wv; tok < T; tok += gridDim.x * 4) {
-    float v[NV], d[NV];
-    R::load(xb + (size_t)tok * C, lane, v);
-    R::load(dy + (size_t)tok * C, lane, d);
+  // Every input row of a token -- xb, dy, the residual gradient, the second LayerNorm's input -- is requested up front, and the NEXT
+  // token's rows while this one's are reduced (round 6): as loads issued where the formula first needs them (round 5) a row cost
+  // three exposed memory latencies between its wave reductions, 41 - 43 us per launch against 24 - 30 us of HBM time.
+  const int stride = gridDim.x * 4;
+  auto load_row = [&](int tok, float (&vb)[NV], float (&dd)[NV], float (&dr)[NV], float (&va)[NV]) {
+    R::load(xb + (size_t)tok * C, lane, vb);
+    R::load(dy + (size_t)tok * C, lane, dd);
+    if (dres) R::load(dres + (size_t)tok * C, lane, dr);
+    if constexpr (TWO) R::load(xa + (size_t)tok * C, lane, va);
+  };
+  float v[NV], d[NV], dr[NV], va[NV], nv[NV], nd[NV], ndr[NV], nva[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { dr[i] = 0.f; va[i] = 0.f; ndr[i] = 0.f; nva[i] = 0.f; }
+  int tok = blockIdx.x * 4 + wv;
+  if (tok < T) load_row(tok, v, d, dr, va);
+  for (; tok < T; tok += stride) {
+    const bool more = tok + stride < T;
+    if (more) load_row(tok + stride, nv, nd, ndr, nva);
     float mean, rstd;
     R::stats(v, eps_b, mean, rstd);
     float s1 = 0.f, s2 = 0.f;
@@ -315,28 +329,26 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const float* dy, const flo
 #pragma unroll
     for (int i = 0; i < NV; ++i) d[i] = rstd * (d[i] - s1 - v[i] * s2);
     if (dres) {
-      R::load(dres + (size_t)tok * C, lane, v);
 #pragma unroll
-      for (int i = 0; i < NV; ++i) d[i] += v[i];
+      for (int i = 0; i < NV; ++i) d[i] += dr[i];
     }
     if constexpr (TWO) {
       if (g_out) R::store(g_out + (size_t)tok * C, lane, d);
-      R::load(xa + (size_t)tok * C, lane, v);
-      R::stats(v, eps_a, mean, rstd);
+      R::stats(va, eps_a, mean, rstd);
       s1 = 0.f; s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
-        v[i] = (v[i] - mean) * rstd;
-        aga[i] = fmaf(d[i], v[i], aga[i]);
+        va[i] = (va[i] - mean) * rstd;
+        aga[i] = fmaf(d[i], va[i], aga[i]);
         aba[i] += d[i];
         d[i] *= wal[i];
         s1 += d[i];
-        s2 = fmaf(d[i], v[i], s2);
+        s2 = fmaf(d[i], va[i], s2);
       }
       s1 = wave_sum(s1) * (1.0f / C);
       s2 = wave_sum(s2) * (1.0f / C);
 #pragma unroll
-      for (int i = 0; i < NV; ++i) d[i] = rstd * (d[i] - s1 - v[i] * s2);
+      for (int i = 0; i < NV; ++i) d[i] = rstd * (d[i] - s1 - va[i] * s2);
     }
     R::store(dx + (size_t)tok * C, lane, d);
     if (want_m) {
@@ -344,6 +356,10 @@ __global__ __launch_bounds__(256) void ln_bwd2_kernel(const float* dy, const flo
 #pragma unroll
       for (int i = 0; i < NV; ++i) { d[i] *= k; am = fmaxf(am, fabsf(d[i])); }
       if (dxm) R::store(dxm + (size_t)tok * C, lane, d);
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { v[i] = nv[i]; d[i] = nd[i]; dr[i] = ndr[i]; va[i] = nva[i]; }
     }
   }
   // this workgroup's [dgamma | dbeta] rows: the four waves' sums in the order 0, 1, 2, 3
