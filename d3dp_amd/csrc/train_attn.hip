@@ -45,13 +45,15 @@ __device__ __forceinline__ void ta_block_amax(float am, unsigned* amax, float* p
 
 // ------------------------------------------------------------------------------------------------------------------------
 // forward
-template <int NKT, int NW>
-__global__ __launch_bounds__(NW * 64) void tattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+// (NKC: key tiles per LDS chunk.  Round 6: the images hold 128 keys at a time -- the online softmax runs over key pairs anyway --
+//  so a 243-frame problem needs 64 KiB instead of 128 and TWO workgroups share a CU: four waves per SIMD instead of two)
+template <int NKT, int NW, int NKC>
+__global__ __launch_bounds__(NW * 64, 4) void tattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                            TAStat* __restrict__ stats, SeqMap map, int C, int heads, int groups,
                                                            int n_work, const unsigned* __restrict__ amax_qkv,
                                                            unsigned* __restrict__ amax_out, f16* __restrict__ op, int T, int Tp,
                                                            float* __restrict__ op_unscale) {
-  constexpr int NK = 16 * NKT, PLANE = NK * 128;
+  constexpr int NK = 16 * NKC, PLANE = NK * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
   char* vimg = smem + 2 * PLANE;
@@ -76,35 +78,39 @@ __global__ __launch_bounds__(NW * 64) void tattn_fwd_kernel(const float* __restr
   const int seq = prob / heads, head = prob % heads;
   const int base = ta_seq_base(map, seq);
   const float* p0 = qkv + (size_t)base * ld + (size_t)head * 64;
-  if (unit != (int)blockIdx.x) __syncthreads();        // every wave is done with the previous unit's images
-  ta_stage<NK, NW * 64>(p0 + C, rs, n, sq, kimg, tid);
-  ta_stage<NK, NW * 64>(p0 + 2 * C, rs, n, sq, vimg, tid);
-  __syncthreads();
   const int qt = group * NW + wave;
-  if (qt * 16 < n) {
-    const int fi = lane & 15, fg = lane >> 4;
-    const int q = qt * 16 + fi;
-    const size_t tok = (size_t)(base + min(q, n - 1) * map.tok_stride);
-    f16x8 qh[2], ql[2];
-    ta_load_row_op(qkv + tok * ld + head * 64, fg, sq, qh, ql);
-    const TAFrag fk = ta_frag(kimg, lane), fv = ta_frag(vimg, lane);
-    const float cexp = 0.125f * kLog2e / (sq * sq);   // raw accumulator -> logit in base-2 units
-    float mrun = -INFINITY, lrun = 0.f;                // running row maximum (base-2 logit units) and denominator
-    f32x4 o[4];
+  const bool active = qt * 16 < n;                     // (wave-uniform)
+  const int fi = lane & 15, fg = lane >> 4;
+  const int q = qt * 16 + fi;
+  const size_t tok = (size_t)(base + min(q, n - 1) * map.tok_stride);
+  f16x8 qh[2], ql[2];
+  if (active) ta_load_row_op(qkv + tok * ld + head * 64, fg, sq, qh, ql);
+  const TAFrag fk = ta_frag(kimg, lane), fv = ta_frag(vimg, lane);
+  const float cexp = 0.125f * kLog2e / (sq * sq);     // raw accumulator -> logit in base-2 units
+  float mrun = -INFINITY, lrun = 0.f;                  // running row maximum (base-2 logit units) and denominator
+  f32x4 o[4];
 #pragma unroll
-    for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int dn = 0; dn < 4; ++dn) o[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int kc = 0; kc < NKT && 16 * kc < n; kc += NKC) {
+  if (unit != (int)blockIdx.x || kc != 0) __syncthreads();   // every wave is done with the previous chunk's / unit's images
+  ta_stage<NK, NW * 64>(p0 + C + (size_t)kc * 16 * rs, rs, n - 16 * kc, sq, kimg, tid);
+  ta_stage<NK, NW * 64>(p0 + 2 * C + (size_t)kc * 16 * rs, rs, n - 16 * kc, sq, vimg, tid);
+  __syncthreads();
+  if (active) {
 #pragma unroll
-    for (int t = 0; t < NKT; t += 2) {
+    for (int t = 0; t < NKC; t += 2) {
+      if (16 * (kc + t) >= n) break;                   // (uniform: the rest of the chunk lies behind the sequence)
       f32x4 a, b;
       ta_rows_pair<PLANE>(fk, t, qh, ql, a, b);
       float s[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s[r] = a[r] * cexp; s[4 + r] = b[r] * cexp; }
-      if (16 * (t + 2) > n) {                          // (uniform: only the last pair(s) hold keys >= n)
+      if (16 * (kc + t + 2) > n) {                     // (uniform: only the last pair(s) hold keys >= n)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (16 * t + 4 * fg + r >= n) s[r] = -INFINITY;
-          if (16 * (t + 1) + 4 * fg + r >= n) s[4 + r] = -INFINITY;
+          if (16 * (kc + t) + 4 * fg + r >= n) s[r] = -INFINITY;
+          if (16 * (kc + t + 1) + 4 * fg + r >= n) s[4 + r] = -INFINITY;
         }
       }
       float mx = s[0];
@@ -132,6 +138,9 @@ __global__ __launch_bounds__(NW * 64) void tattn_fwd_kernel(const float* __restr
       for (int dn = 0; dn < 4; ++dn) o[dn] *= alpha;
       ta_tr_chunk<PLANE>(fv, t >> 1, ph, pl, o);
     }
+  }
+  }
+  if (active) {
     // o = (v scale) x 1024 x sum_j p_j v_j against the running maximum; lrun = 1024 x sum_j p_j
     const float inv = 1.0f / (sq * lrun);
     if (q < n) {
@@ -371,10 +380,11 @@ int ta_launch(int which, const float* qkv, const float* o, const float* dout, fl
               SeqMap map, int C, int heads, const unsigned* amax_qkv, const unsigned* amax_do, unsigned* amax_out,
               hipStream_t st, TAOperand po = {nullptr, 0, 0, nullptr}) {
   constexpr int NK = 16 * NKT, NW = NKT <= 2 ? 2 : (NKT <= 4 ? 4 : 8);
-  const size_t lds = (size_t)4 * NK * 128 + NK * 8 + 64;
+  constexpr int NKC = NKT > 8 ? 8 : NKT;               // forward: key tiles per LDS chunk
+  const size_t lds = (size_t)4 * NK * 128 + NK * 8 + 64, lds_fwd = (size_t)4 * NKC * 16 * 128 + 64;
   static PerDeviceOnce once;
   if (once.get([&](int) {
-        return d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_fwd_kernel<NKT, NW>), 160 * 1024) < 0 ? -3
+        return d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_fwd_kernel<NKT, NW, NKC>), 160 * 1024) < 0 ? -3
                : d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_bwd_q_kernel<NKT, NW>), 160 * 1024) < 0 ? -3
                : d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_bwd_kv_kernel<NKT, NW>), 160 * 1024);
       }) < 0) return -3;
@@ -383,7 +393,7 @@ int ta_launch(int which, const float* qkv, const float* o, const float* dout, fl
   const dim3 grid(n_work < 2048 ? n_work : 2048), blk(NW * 64);   // (<= 2048 absmax atomics per launch)
   TAStat* s = reinterpret_cast<TAStat*>(stats);
   if (which == 0)
-    hipLaunchKernelGGL((tattn_fwd_kernel<NKT, NW>), grid, blk, lds, st, qkv, out, s, map, C, heads, groups, n_work, amax_qkv, amax_out,
+    hipLaunchKernelGGL((tattn_fwd_kernel<NKT, NW, NKC>), grid, blk, lds_fwd, st, qkv, out, s, map, C, heads, groups, n_work, amax_qkv, amax_out,
                        po.op, po.T, po.Tp, po.unscale);
   else {                                               // which: 1 = both passes, 2 = pass Q alone, 3 = pass KV alone (needs pass Q's D_i)
     if (which != 3)
