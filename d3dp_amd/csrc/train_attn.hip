@@ -170,13 +170,13 @@ __global__ __launch_bounds__(NW * 64, 4) void tattn_fwd_kernel(const float* __re
 
 // ------------------------------------------------------------------------------------------------------------------------
 // backward, pass Q: dQ (and D_i into the statistics)
-template <int NKT, int NW>
-__global__ __launch_bounds__(NW * 64) void tattn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+template <int NKT, int NW, int NKC, int WPE>
+__global__ __launch_bounds__(NW * 64, WPE) void tattn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                              const float* __restrict__ dout, float* __restrict__ dqkv,
                                                              TAStat* __restrict__ stats, SeqMap map, int C, int heads, int groups,
                                                              int n_work, const unsigned* __restrict__ amax_qkv,
                                                              const unsigned* __restrict__ amax_do, unsigned* __restrict__ amax_out) {
-  constexpr int NK = 16 * NKT, PLANE = NK * 128;
+  constexpr int NK = 16 * NKC, PLANE = NK * 128;      // (the images hold NKC key tiles at a time: see tattn_fwd_kernel)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kimg = smem;
   char* vimg = smem + 2 * PLANE;
@@ -191,19 +191,16 @@ __global__ __launch_bounds__(NW * 64) void tattn_bwd_q_kernel(const float* __res
   const int seq = prob / heads, head = prob % heads;
   const int base = ta_seq_base(map, seq);
   const float* p0 = qkv + (size_t)base * ld + (size_t)head * 64;
-  if (unit != (int)blockIdx.x) __syncthreads();
-  ta_stage<NK, NW * 64>(p0 + C, rs, n, sq, kimg, tid);
-  ta_stage<NK, NW * 64>(p0 + 2 * C, rs, n, sq, vimg, tid);
-  __syncthreads();
   const int qt = group * NW + wave;
-  if (qt * 16 < n) {
-    const int fi = lane & 15, fg = lane >> 4;
-    const int q = qt * 16 + fi;
-    const size_t tok = (size_t)(base + min(q, n - 1) * map.tok_stride);
-    f16x8 qh[2], ql[2], gh[2], gl[2];
+  const bool active = qt * 16 < n;                     // (wave-uniform)
+  const int fi = lane & 15, fg = lane >> 4;
+  const int q = qt * 16 + fi;
+  const size_t tok = (size_t)(base + min(q, n - 1) * map.tok_stride);
+  f16x8 qh[2], ql[2], gh[2], gl[2];
+  float D = 0.f, L = 0.f;
+  if (active) {
     ta_load_row_op(qkv + tok * ld + head * 64, fg, sq, qh, ql);
     ta_load_row_op(dout + tok * C + head * 64, fg, sg, gh, gl);
-    float D = 0.f;
     {
       const float* gs = dout + tok * C + head * 64;
       const float* os = o + tok * C + head * 64;
@@ -218,16 +215,25 @@ __global__ __launch_bounds__(NW * 64) void tattn_bwd_q_kernel(const float* __res
       D += __shfl_xor(D, 16, 64);
       D += __shfl_xor(D, 32, 64);
     }
-    const float L = stats[(size_t)prob * n + min(q, n - 1)].L;
-    const TAFrag fk = ta_frag(kimg, lane), fv = ta_frag(vimg, lane);
-    const float cexp = 0.125f * kLog2e / (sq * sq);
-    const float cdp = 1.0f / (sq * sg);                // raw dP accumulator -> true scale
-    int eb = 20;                                       // running biased exponent of the row's largest |dS| (floor 2^-107)
-    f32x4 dq[4];
+    L = stats[(size_t)prob * n + min(q, n - 1)].L;
+  }
+  const TAFrag fk = ta_frag(kimg, lane), fv = ta_frag(vimg, lane);
+  const float cexp = 0.125f * kLog2e / (sq * sq);
+  const float cdp = 1.0f / (sq * sg);                  // raw dP accumulator -> true scale
+  int eb = 20;                                         // running biased exponent of the row's largest |dS| (floor 2^-107)
+  f32x4 dq[4];
 #pragma unroll
-    for (int dn = 0; dn < 4; ++dn) dq[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int dn = 0; dn < 4; ++dn) dq[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int kc = 0; kc < NKT && 16 * kc < n; kc += NKC) {
+  if (unit != (int)blockIdx.x || kc != 0) __syncthreads();
+  ta_stage<NK, NW * 64>(p0 + C + (size_t)kc * 16 * rs, rs, n - 16 * kc, sq, kimg, tid);
+  ta_stage<NK, NW * 64>(p0 + 2 * C + (size_t)kc * 16 * rs, rs, n - 16 * kc, sq, vimg, tid);
+  __syncthreads();
+  if (active) {
 #pragma unroll
-    for (int t = 0; t < NKT; t += 2) {
+    for (int t = 0; t < NKC; t += 2) {
+      if (16 * (kc + t) >= n) break;                   // (uniform)
       f32x4 a, b, c, d;
       ta_rows_pair<PLANE>(fk, t, qh, ql, a, b);        // S^T  [key][query]
       ta_rows_pair<PLANE>(fv, t, gh, gl, c, d);        // dP^T [key][query]
@@ -238,11 +244,11 @@ __global__ __launch_bounds__(NW * 64) void tattn_bwd_q_kernel(const float* __res
         ds[r] = pa * (fmaf(c[r], cdp, -D)) * 0.125f;
         ds[4 + r] = pb * (fmaf(d[r], cdp, -D)) * 0.125f;
       }
-      if (16 * (t + 2) > n) {                          // (uniform: only the last pair(s) hold keys >= n)
+      if (16 * (kc + t + 2) > n) {                     // (uniform: only the last pair(s) hold keys >= n)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (16 * t + 4 * fg + r >= n) ds[r] = 0.f;
-          if (16 * (t + 1) + 4 * fg + r >= n) ds[4 + r] = 0.f;
+          if (16 * (kc + t) + 4 * fg + r >= n) ds[r] = 0.f;
+          if (16 * (kc + t + 1) + 4 * fg + r >= n) ds[4 + r] = 0.f;
         }
       }
       const int en = max(eb, ta_exp_of_max(ds));
@@ -257,6 +263,9 @@ __global__ __launch_bounds__(NW * 64) void tattn_bwd_q_kernel(const float* __res
       ta_split_run(ds, eb, sh, sl);
       ta_tr_chunk<PLANE>(fk, t >> 1, sh, sl, dq);      // dQ^T[d][query] += K^T dS^T
     }
+  }
+  }
+  if (active) {
     if (q < n) {
       const float un = 1.0f / sq;
       float* dst = dqkv + tok * ld + head * 64 + fg * 4;
@@ -276,13 +285,13 @@ __global__ __launch_bounds__(NW * 64) void tattn_bwd_q_kernel(const float* __res
 
 // ------------------------------------------------------------------------------------------------------------------------
 // backward, pass KV: dK, dV
-template <int NKT, int NW>
-__global__ __launch_bounds__(NW * 64) void tattn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+template <int NKT, int NW, int NKC, int WPE>
+__global__ __launch_bounds__(NW * 64, WPE) void tattn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                               float* __restrict__ dqkv, const TAStat* __restrict__ stats,
                                                               SeqMap map, int C, int heads, int groups, int n_work,
                                                               const unsigned* __restrict__ amax_qkv,
                                                               const unsigned* __restrict__ amax_do, unsigned* __restrict__ amax_out) {
-  constexpr int NK = 16 * NKT, PLANE = NK * 128;
+  constexpr int NK = 16 * NKC, PLANE = NK * 128;      // (the images hold NKC QUERY tiles at a time)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* qimg = smem;
   char* gimg = smem + 2 * PLANE;
@@ -297,34 +306,41 @@ __global__ __launch_bounds__(NW * 64) void tattn_bwd_kv_kernel(const float* __re
   const int prob = unit / groups, group = unit % groups;
   const int seq = prob / heads, head = prob % heads;
   const int base = ta_seq_base(map, seq);
-  if (unit != (int)blockIdx.x) __syncthreads();
-  ta_stage<NK, NW * 64>(qkv + (size_t)base * ld + (size_t)head * 64, rs, n, sq, qimg, tid);
-  ta_stage<NK, NW * 64>(dout + (size_t)base * C + (size_t)head * 64, (size_t)map.tok_stride * C, n, sg, gimg, tid);
+  const int kt = group * NW + wave;
+  const bool active = kt * 16 < n;                     // (wave-uniform)
+  const int fi = lane & 15, fg = lane >> 4;
+  const int key = kt * 16 + fi;
+  const bool live = key < n;
+  const size_t tok = (size_t)(base + min(key, n - 1) * map.tok_stride);
+  f16x8 kh[2], kl[2], vh[2], vl[2];
+  if (active) {
+    ta_load_row_op(qkv + tok * ld + C + head * 64, fg, sq, kh, kl);
+    ta_load_row_op(qkv + tok * ld + 2 * C + head * 64, fg, sq, vh, vl);
+  }
+  const TAFrag fq = ta_frag(qimg, lane), fgr = ta_frag(gimg, lane);
+  const float cexp = 0.125f * kLog2e / (sq * sq);
+  const float cdp = 1.0f / (sq * sg);
+  int eb = 20;
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int dn = 0; dn < 4; ++dn) { dk[dn] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dn] = dk[dn]; }
+#pragma unroll 1
+  for (int qc = 0; qc < NKT && 16 * qc < n; qc += NKC) {
+  if (unit != (int)blockIdx.x || qc != 0) __syncthreads();
+  ta_stage<NK, NW * 64>(qkv + (size_t)base * ld + (size_t)head * 64 + (size_t)qc * 16 * rs, rs, n - 16 * qc, sq, qimg, tid);
+  ta_stage<NK, NW * 64>(dout + (size_t)base * C + (size_t)head * 64 + (size_t)qc * 16 * map.tok_stride * C, (size_t)map.tok_stride * C,
+                        n - 16 * qc, sg, gimg, tid);
   for (int i = tid; i < NK; i += NW * 64) {
     // rows >= n: their Q and dO image rows are zero, so any FINITE p and dS contribute nothing: L = +large keeps p = 0
     float2 v = make_float2(1.0e30f, 0.f);
-    if (i < n) { const TAStat s = stats[(size_t)prob * n + i]; v = make_float2(s.L, s.D); }
+    if (16 * qc + i < n) { const TAStat s = stats[(size_t)prob * n + 16 * qc + i]; v = make_float2(s.L, s.D); }
     st[i] = v;
   }
   __syncthreads();
-  const int kt = group * NW + wave;
-  if (kt * 16 < n) {
-    const int fi = lane & 15, fg = lane >> 4;
-    const int key = kt * 16 + fi;
-    const bool live = key < n;
-    const size_t tok = (size_t)(base + min(key, n - 1) * map.tok_stride);
-    f16x8 kh[2], kl[2], vh[2], vl[2];
-    ta_load_row_op(qkv + tok * ld + C + head * 64, fg, sq, kh, kl);
-    ta_load_row_op(qkv + tok * ld + 2 * C + head * 64, fg, sq, vh, vl);
-    const TAFrag fq = ta_frag(qimg, lane), fgr = ta_frag(gimg, lane);
-    const float cexp = 0.125f * kLog2e / (sq * sq);
-    const float cdp = 1.0f / (sq * sg);
-    int eb = 20;
-    f32x4 dk[4], dv[4];
+  if (active) {
 #pragma unroll
-    for (int dn = 0; dn < 4; ++dn) { dk[dn] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dn] = dk[dn]; }
-#pragma unroll
-    for (int t = 0; t < NKT; t += 2) {
+    for (int t = 0; t < NKC; t += 2) {
+      if (16 * (qc + t) >= n) break;                   // (uniform)
       f32x4 a, b, c, d;
       ta_rows_pair<PLANE>(fq, t, kh, kl, a, b);        // S  [query][key]
       ta_rows_pair<PLANE>(fgr, t, vh, vl, c, d);       // dP [query][key]
@@ -355,6 +371,9 @@ __global__ __launch_bounds__(NW * 64) void tattn_bwd_kv_kernel(const float* __re
       ta_split_run(ds, eb, sh, sl);
       ta_tr_chunk<PLANE>(fq, t >> 1, sh, sl, dk);      // dK^T[d][key] += Q^T dS
     }
+  }
+  }
+  if (active) {
     if (live) {
       const float uk = 1.0f / sq, uv = 1.0f / (sg * 1024.0f);
       float* dst = dqkv + tok * ld + C + head * 64 + fg * 4;
@@ -381,12 +400,15 @@ int ta_launch(int which, const float* qkv, const float* o, const float* dout, fl
               hipStream_t st, TAOperand po = {nullptr, 0, 0, nullptr}) {
   constexpr int NK = 16 * NKT, NW = NKT <= 2 ? 2 : (NKT <= 4 ? 4 : 8);
   constexpr int NKC = NKT > 8 ? 8 : NKT;               // forward: key tiles per LDS chunk
-  const size_t lds = (size_t)4 * NK * 128 + NK * 8 + 64, lds_fwd = (size_t)4 * NKC * 16 * 128 + 64;
+  // pass Q: chunked the same way, registers held to 128 (18 dwords of scratch per lane) for two workgroups per CU: 96 -> 92 us per
+  // temporal launch.  pass KV (215 registers; at 128 it spills 41 dwords: 100 -> 122 us; chunked at its own register count: 102) keeps
+  // whole sequences of Q / dO in LDS and one workgroup per CU.
+  const size_t lds = (size_t)4 * NKC * 16 * 128 + 64, lds_kv = (size_t)4 * NK * 128 + NK * 8 + 64, lds_fwd = lds;
   static PerDeviceOnce once;
   if (once.get([&](int) {
         return d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_fwd_kernel<NKT, NW, NKC>), 160 * 1024) < 0 ? -3
-               : d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_bwd_q_kernel<NKT, NW>), 160 * 1024) < 0 ? -3
-               : d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_bwd_kv_kernel<NKT, NW>), 160 * 1024);
+               : d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_bwd_q_kernel<NKT, NW, NKC, 4>), 160 * 1024) < 0 ? -3
+               : d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_bwd_kv_kernel<NKT, NW, NKT, 2>), 160 * 1024);
       }) < 0) return -3;
   const int tiles = (map.n_tok + 15) / 16, groups = (tiles + NW - 1) / NW;
   const int n_work = n_seq * heads * groups;
@@ -397,10 +419,10 @@ int ta_launch(int which, const float* qkv, const float* o, const float* dout, fl
                        po.op, po.T, po.Tp, po.unscale);
   else {                                               // which: 1 = both passes, 2 = pass Q alone, 3 = pass KV alone (needs pass Q's D_i)
     if (which != 3)
-      hipLaunchKernelGGL((tattn_bwd_q_kernel<NKT, NW>), grid, blk, lds, st, qkv, o, dout, dqkv, s, map, C, heads, groups, n_work,
+      hipLaunchKernelGGL((tattn_bwd_q_kernel<NKT, NW, NKC, 4>), grid, blk, lds, st, qkv, o, dout, dqkv, s, map, C, heads, groups, n_work,
                          amax_qkv, amax_do, amax_out);
     if (which != 2)
-      hipLaunchKernelGGL((tattn_bwd_kv_kernel<NKT, NW>), grid, blk, lds, st, qkv, dout, dqkv, (const TAStat*)s, map, C, heads, groups,
+      hipLaunchKernelGGL((tattn_bwd_kv_kernel<NKT, NW, NKT, 2>), grid, blk, lds_kv, st, qkv, dout, dqkv, (const TAStat*)s, map, C, heads, groups,
                          n_work, amax_qkv, amax_do, amax_out);
   }
   return 0;
