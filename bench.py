@@ -499,10 +499,13 @@ def train_roofline_by_kernel(prof, B, steps=1):
     # what an event pair adds to the launch it brackets (class event_pair_overhead: empty pairs on the busy stream), subtracted per launch
     ne, mse = prof.get("event_pair_overhead", (0, 0.0))
     over_ms = mse / ne if ne else 0.0
-    for k, (n, ms) in prof.items():
-        if not k.startswith("train_") or ms <= 0 or n <= 0:
+    corrected = {k: (n // steps, max(ms - n * over_ms, 0.0) / steps) for k, (n, ms) in prof.items() if k.startswith("train_") and n > 0}
+    if corrected.get("train_attn_bwd_kv_spatial", (0, 0.0))[1] < 1e-3:   # sequences of <= 32 tokens: both passes are ONE kernel, timed as pass Q
+        flop["train_attn_bwd_q_spatial"] += flop.pop("train_attn_bwd_kv_spatial")
+        corrected.pop("train_attn_bwd_kv_spatial", None)
+    for k, (n, ms) in corrected.items():
+        if ms <= 0:
             continue
-        ms, n = max(ms - n * over_ms, 0.0) / steps, n // steps
         if k in flop:
             ach = flop[k] / (ms * 1e-3) / 1e12
             out[k] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",

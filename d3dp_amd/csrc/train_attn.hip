@@ -393,6 +393,161 @@ __global__ __launch_bounds__(NW * 64, WPE) void tattn_bwd_kv_kernel(const float*
   if (amax_out) ta_block_amax<NW>(am, amax_out, part);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// backward of sequences of at most 32 tokens (the spatial axis: 17 joints) in ONE kernel (round 6).  As two launches -- pass Q
+// with K / V images, then pass KV with Q / dO images -- a block's spatial backward read q, k, v and dO twice each and o once:
+// 406 MB per launch pair, 112 us.  A sequence this short fits a workgroup whole: all four operands are staged once as images (32
+// KiB), each wave takes one 16-row tile through pass Q as a query tile and through pass KV as a key tile -- its register operands
+// are row-fragment reads of the very images the other wave's products contract over -- and D_i = dO_i . O_i goes from pass Q to
+// pass KV through LDS instead of the statistics buffer.  Same products, same splits, same accumulation order as the two
+// kernels: bit-identical gradients (test_attention_backward_on_matrix_cores_matches_the_valu_kernels covers n = 9, 17 through it).
+__global__ __launch_bounds__(128) void tattn_bwd_small_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                              const float* __restrict__ dout, float* __restrict__ dqkv,
+                                                              const TAStat* __restrict__ stats, SeqMap map, int C, int heads,
+                                                              int n_work, const unsigned* __restrict__ amax_qkv,
+                                                              const unsigned* __restrict__ amax_do, unsigned* __restrict__ amax_out) {
+  constexpr int NK = 32, PLANE = NK * 128, NW = 2;
+  __shared__ __attribute__((aligned(16))) char smem[8 * PLANE];
+  __shared__ float2 st[NK];                              // (L, D) of the sequence's queries
+  __shared__ float part[NW];
+  char* qimg = smem;
+  char* kimg = smem + 2 * PLANE;
+  char* vimg = smem + 4 * PLANE;
+  char* gimg = smem + 6 * PLANE;
+  const int n = map.n_tok;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const size_t ld = (size_t)3 * C, rs = (size_t)map.tok_stride * ld;
+  const float sq = ta_scale(amax_qkv), sg = ta_scale(amax_do);
+  const float cexp = 0.125f * kLog2e / (sq * sq);
+  const float cdp = 1.0f / (sq * sg);                    // raw dP accumulator -> true scale
+  const TAFrag fq = ta_frag(qimg, lane), fk = ta_frag(kimg, lane), fv = ta_frag(vimg, lane), fgr = ta_frag(gimg, lane);
+  auto row_op = [&](const TAFrag& f, int t, f16x8 (&h)[2], f16x8 (&l)[2]) {   // tile t's rows as a split register operand
+    h[0] = *reinterpret_cast<const f16x8*>(f.r0 + t * 2048);
+    h[1] = *reinterpret_cast<const f16x8*>(f.r1 + t * 2048);
+    l[0] = *reinterpret_cast<const f16x8*>(f.r0 + t * 2048 + PLANE);
+    l[1] = *reinterpret_cast<const f16x8*>(f.r1 + t * 2048 + PLANE);
+  };
+  float am = 0.f;
+  for (int unit = blockIdx.x; unit < n_work; unit += gridDim.x) {
+    const int seq = unit / heads, head = unit - seq * heads;
+    const int base = ta_seq_base(map, seq);
+    const float* p0 = qkv + (size_t)base * ld + (size_t)head * 64;
+    const float* g0 = dout + (size_t)base * C + (size_t)head * 64;
+    if (unit != (int)blockIdx.x) __syncthreads();        // every wave is done with the previous unit's images
+    ta_stage<NK, NW * 64>(p0, rs, n, sq, qimg, tid);
+    ta_stage<NK, NW * 64>(p0 + C, rs, n, sq, kimg, tid);
+    ta_stage<NK, NW * 64>(p0 + 2 * C, rs, n, sq, vimg, tid);
+    ta_stage<NK, NW * 64>(g0, (size_t)map.tok_stride * C, n, sg, gimg, tid);
+    const int row = wave * 16 + fi;                      // this lane's query (pass Q) and key (pass KV)
+    const bool live = row < n;
+    const size_t tok = (size_t)(base + min(row, n - 1) * map.tok_stride);
+    {
+      // D_i = dO_i . O_i in the channel order of tattn_bwd_q_kernel; rows >= n: L = +large keeps p = 0 in pass KV
+      float D = 0.f;
+      const float* gs = dout + tok * C + head * 64;
+      const float* os = o + tok * C + head * 64;
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int c4 = 0; c4 < 2; ++c4) {
+          const float4 g = *reinterpret_cast<const float4*>(gs + half * 32 + fg * 8 + c4 * 4);
+          const float4 ov = *reinterpret_cast<const float4*>(os + half * 32 + fg * 8 + c4 * 4);
+          D = fmaf(g.x, ov.x, D); D = fmaf(g.y, ov.y, D); D = fmaf(g.z, ov.z, D); D = fmaf(g.w, ov.w, D);
+        }
+      D += __shfl_xor(D, 16, 64);
+      D += __shfl_xor(D, 32, 64);
+      if (fg == 0) st[row] = live ? make_float2(stats[(size_t)unit * n + row].L, D) : make_float2(1.0e30f, 0.f);
+    }
+    __syncthreads();
+    if (wave * 16 < n) {
+      // ---- pass Q: this wave's tile as QUERIES against the key pair (0, 1)
+      {
+        f16x8 qh[2], ql[2], gh[2], gl[2];
+        row_op(fq, wave, qh, ql);
+        row_op(fgr, wave, gh, gl);
+        const float2 ld_ = st[row];
+        f32x4 a, b, c, d;
+        ta_rows_pair<PLANE>(fk, 0, qh, ql, a, b);        // S^T  [key][query]
+        ta_rows_pair<PLANE>(fv, 0, gh, gl, c, d);        // dP^T [key][query]
+        float ds[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pa = __builtin_amdgcn_exp2f(fmaf(a[r], cexp, -ld_.x)), pb = __builtin_amdgcn_exp2f(fmaf(b[r], cexp, -ld_.x));
+          ds[r] = pa * (fmaf(c[r], cdp, -ld_.y)) * 0.125f;
+          ds[4 + r] = pb * (fmaf(d[r], cdp, -ld_.y)) * 0.125f;
+          if (4 * fg + r >= n) ds[r] = 0.f;
+          if (16 + 4 * fg + r >= n) ds[4 + r] = 0.f;
+        }
+        const int eb = max(20, ta_exp_of_max(ds));
+        f16x8 sh, sl;
+        ta_split_run(ds, eb, sh, sl);
+        f32x4 dq[4];
+#pragma unroll
+        for (int dn = 0; dn < 4; ++dn) dq[dn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ta_tr_chunk<PLANE>(fk, 0, sh, sl, dq);           // dQ^T[d][query] = K^T dS^T
+        if (live) {
+          const float un = 1.0f / sq;
+          float* dst = dqkv + tok * ld + head * 64 + fg * 4;
+#pragma unroll
+          for (int dn = 0; dn < 4; ++dn) {
+            const float4 r4 = make_float4(ldexpf(dq[dn][0], eb - 140) * un, ldexpf(dq[dn][1], eb - 140) * un,
+                                          ldexpf(dq[dn][2], eb - 140) * un, ldexpf(dq[dn][3], eb - 140) * un);
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(r4.x), fabsf(r4.y)), fmaxf(fabsf(r4.z), fabsf(r4.w))));
+            *reinterpret_cast<float4*>(dst + dn * 16) = r4;
+          }
+        }
+      }
+      // ---- pass KV: the same tile as KEYS against the query pair (0, 1)
+      {
+        f16x8 kh[2], kl[2], vh[2], vl[2];
+        row_op(fk, wave, kh, kl);
+        row_op(fv, wave, vh, vl);
+        f32x4 a, b, c, d;
+        ta_rows_pair<PLANE>(fq, 0, kh, kl, a, b);        // S  [query][key]
+        ta_rows_pair<PLANE>(fgr, 0, vh, vl, c, d);       // dP [query][key]
+        float ds[8];
+        f16x8 ph, pl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float2 sa = st[4 * fg + r], sb = st[16 + 4 * fg + r];
+          float pa = __builtin_amdgcn_exp2f(fmaf(a[r], cexp, -sa.x)), pb = __builtin_amdgcn_exp2f(fmaf(b[r], cexp, -sb.x));
+          if (!live) { pa = 0.f; pb = 0.f; }
+          ds[r] = pa * (fmaf(c[r], cdp, -sa.y)) * 0.125f;
+          ds[4 + r] = pb * (fmaf(d[r], cdp, -sb.y)) * 0.125f;
+          const float ya = ta_opaque(pa * 1024.0f), yb = ta_opaque(pb * 1024.0f);
+          const f16 ha = (f16)ya, hb = (f16)yb;
+          ph[r] = ha; pl[r] = (f16)(ya - (float)ha);
+          ph[4 + r] = hb; pl[4 + r] = (f16)(yb - (float)hb);
+        }
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int dn = 0; dn < 4; ++dn) { dk[dn] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dn] = dk[dn]; }
+        ta_tr_chunk<PLANE>(fgr, 0, ph, pl, dv);          // dV^T[d][key] = dO^T P
+        const int eb = max(20, ta_exp_of_max(ds));
+        f16x8 sh, sl;
+        ta_split_run(ds, eb, sh, sl);
+        ta_tr_chunk<PLANE>(fq, 0, sh, sl, dk);           // dK^T[d][key] = Q^T dS
+        if (live) {
+          const float uk = 1.0f / sq, uv = 1.0f / (sg * 1024.0f);
+          float* dst = dqkv + tok * ld + C + head * 64 + fg * 4;
+#pragma unroll
+          for (int dn = 0; dn < 4; ++dn) {
+            const float4 k4 = make_float4(ldexpf(dk[dn][0], eb - 140) * uk, ldexpf(dk[dn][1], eb - 140) * uk,
+                                          ldexpf(dk[dn][2], eb - 140) * uk, ldexpf(dk[dn][3], eb - 140) * uk);
+            const float4 v4 = make_float4(dv[dn][0] * uv, dv[dn][1] * uv, dv[dn][2] * uv, dv[dn][3] * uv);
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(k4.x), fabsf(k4.y)), fmaxf(fabsf(k4.z), fabsf(k4.w))));
+            am = fmaxf(am, fmaxf(fmaxf(fabsf(v4.x), fabsf(v4.y)), fmaxf(fabsf(v4.z), fabsf(v4.w))));
+            *reinterpret_cast<float4*>(dst + dn * 16) = k4;
+            *reinterpret_cast<float4*>(dst + C + dn * 16) = v4;
+          }
+        }
+      }
+    }
+  }
+  if (amax_out) ta_block_amax<NW>(am, amax_out, part);
+}
+
 struct TAOperand { f16* op; int T, Tp; float* unscale; };   // forward only: the output also as the next Linear's operand rows
 template <int NKT>
 int ta_launch(int which, const float* qkv, const float* o, const float* dout, float* out, float* dqkv, void* stats, int n_seq,
@@ -417,7 +572,15 @@ int ta_launch(int which, const float* qkv, const float* o, const float* dout, fl
   if (which == 0)
     hipLaunchKernelGGL((tattn_fwd_kernel<NKT, NW, NKC>), grid, blk, lds_fwd, st, qkv, out, s, map, C, heads, groups, n_work, amax_qkv, amax_out,
                        po.op, po.T, po.Tp, po.unscale);
-  else {                                               // which: 1 = both passes, 2 = pass Q alone, 3 = pass KV alone (needs pass Q's D_i)
+  else if (NKT == 2) {
+    // sequences of at most 32 tokens: both passes in ONE kernel (tattn_bwd_small_kernel); under the per-kernel profile it is timed as
+    // pass Q and the pass-KV call is empty
+    if (which != 3) {
+      const dim3 g2(n_seq * heads < 4096 ? n_seq * heads : 4096);
+      hipLaunchKernelGGL(tattn_bwd_small_kernel, g2, dim3(128), 0, st, qkv, o, dout, dqkv, (const TAStat*)s, map, C, heads, n_seq * heads,
+                         amax_qkv, amax_do, amax_out);
+    }
+  } else {                                             // which: 1 = both passes, 2 = pass Q alone, 3 = pass KV alone (needs pass Q's D_i)
     if (which != 3)
       hipLaunchKernelGGL((tattn_bwd_q_kernel<NKT, NW, NKC, 4>), grid, blk, lds, st, qkv, o, dout, dqkv, s, map, C, heads, groups, n_work,
                          amax_qkv, amax_do, amax_out);
