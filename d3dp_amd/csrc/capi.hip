@@ -1438,7 +1438,11 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
   if (!c->train()) return fail(D3DP_ESTATE, "d3dp_train_forward needs a D3DP_MODE_TRAIN context");
   if (!c->weights_set) return fail(D3DP_ESTATE, "weights not set");
   const d3dp_cfg& g = c->cfg;
-  if (g.frames > 256) return fail(D3DP_ENOTSUP, "the training step's attention backward holds a sequence in LDS: frames=%d > 256 (inference runs any clip length)", g.frames);
+  // clips longer than 256 frames (reference common/arguments.py:58, main.py:325 train at any `-f`): the split-fp16 attention kernels
+  // pass their keys / queries through LDS in chunks (train_attn.hip, round 6); the fp32 cross-check kernels hold whole sequences
+  if (g.frames > 256 && !(c->train_x2 && c->train_attn_x2 == 2 && g.channels / g.heads == 64 && g.channels % 32 == 0 && g.hidden % 32 == 0))
+    return fail(D3DP_ENOTSUP, "frames=%d > 256: the training step runs such clips on its split-fp16 attention kernels only (head dim 64, "
+                              "no D3DP_TRAIN_IMPL=f32 / D3DP_TRAIN_ATTN=f32|x2t cross-check)", g.frames);
   const TrainLayout L = train_layout(g, B);
   if (workspace_bytes < L.total_floats * 4) return fail(D3DP_ESTATE, "train workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -1472,7 +1476,7 @@ int d3dp_train_forward(d3dp_ctx* c, const float* x2d, const float* x3d, const in
   // with inference and keeps the pass)
   const bool ln_direct = ln_fused && c->train_ln_direct && C % 256 == 0;
   // attention on split-fp16 operands (train_attn.hip): needs the split Linears' device-side scales, head dim 64, <= 256 frames
-  const bool attn_x2 = use_x2 && c->train_attn_x2 > 0 && C / g.heads == 64 && F <= 256;
+  const bool attn_x2 = use_x2 && c->train_attn_x2 > 0 && C / g.heads == 64 && F <= 1024;
   const bool attn_x2_s = attn_x2 && c->train_attn_x2 > 1;      // the spatial axis too
   TP(T_OTHER, d3dp_train_time_mlp(t, c->freq, c->t1w, c->t1b, c->t3w, c->t3b, ws + L.dtemb, ws + L.temb, B, C, st));   // (dtemb: free until the backward pass; needs B x 2 C)
   float* slab0 = ws + L.saved0;
@@ -1628,7 +1632,7 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
     return hipStreamWaitEvent(st, c->ev_done[s], 0) == hipSuccess ? 0 : -3;
   };
   auto join = [&]() -> int { int r = wait_set(0); return r ? r : wait_set(1); };
-  const bool attn_x2 = use_x2 && c->train_attn_x2 > 0 && C / g.heads == 64 && F <= 256;   // (as the forward pass of this step)
+  const bool attn_x2 = use_x2 && c->train_attn_x2 > 0 && C / g.heads == 64 && F <= 1024;  // (as the forward pass of this step)
   const bool attn_x2_s = attn_x2 && c->train_attn_x2 > 1;
   Reducer red{ws + L.red, L.red_floats, 0, st};
   red.items.reserve(24 * (size_t)g.depth + 32);

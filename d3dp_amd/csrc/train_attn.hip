@@ -558,12 +558,16 @@ int ta_launch(int which, const float* qkv, const float* o, const float* dout, fl
   // pass Q: chunked the same way, registers held to 128 (18 dwords of scratch per lane) for two workgroups per CU: 96 -> 92 us per
   // temporal launch.  pass KV (215 registers; at 128 it spills 41 dwords: 100 -> 122 us; chunked at its own register count: 102) keeps
   // whole sequences of Q / dO in LDS and one workgroup per CU.
-  const size_t lds = (size_t)4 * NKC * 16 * 128 + 64, lds_kv = (size_t)4 * NK * 128 + NK * 8 + 64, lds_fwd = lds;
+  // Sequences longer than 256 tokens (training at `-f 351`, reference common/arguments.py:58): every kernel is chunked, so nothing
+  // holds a whole sequence -- pass KV then takes its queries in chunks of 128 too (at its own register count: one workgroup per CU).
+  constexpr int NKC_KV = NKT > 16 ? 8 : NKT;
+  const size_t lds = (size_t)4 * NKC * 16 * 128 + 64, lds_kv = (size_t)4 * NKC_KV * 16 * 128 + NKC_KV * 16 * 8 + 64, lds_fwd = lds;
+  (void)NK;
   static PerDeviceOnce once;
   if (once.get([&](int) {
         return d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_fwd_kernel<NKT, NW, NKC>), 160 * 1024) < 0 ? -3
                : d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_bwd_q_kernel<NKT, NW, NKC, 4>), 160 * 1024) < 0 ? -3
-               : d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_bwd_kv_kernel<NKT, NW, NKT, 2>), 160 * 1024);
+               : d3dp_lds_opt_in(reinterpret_cast<const void*>(tattn_bwd_kv_kernel<NKT, NW, NKC_KV, 2>), 160 * 1024);
       }) < 0) return -3;
   const int tiles = (map.n_tok + 15) / 16, groups = (tiles + NW - 1) / NW;
   const int n_work = n_seq * heads * groups;
@@ -585,7 +589,7 @@ int ta_launch(int which, const float* qkv, const float* o, const float* dout, fl
       hipLaunchKernelGGL((tattn_bwd_q_kernel<NKT, NW, NKC, 4>), grid, blk, lds, st, qkv, o, dout, dqkv, s, map, C, heads, groups, n_work,
                          amax_qkv, amax_do, amax_out);
     if (which != 2)
-      hipLaunchKernelGGL((tattn_bwd_kv_kernel<NKT, NW, NKT, 2>), grid, blk, lds_kv, st, qkv, dout, dqkv, (const TAStat*)s, map, C, heads, groups,
+      hipLaunchKernelGGL((tattn_bwd_kv_kernel<NKT, NW, NKC_KV, 2>), grid, blk, lds_kv, st, qkv, dout, dqkv, (const TAStat*)s, map, C, heads, groups,
                          n_work, amax_qkv, amax_do, amax_out);
   }
   return 0;
@@ -595,13 +599,15 @@ int ta_dispatch(int which, const float* qkv, const float* o, const float* dout, 
                 SeqMap map, int C, int heads, const unsigned* amax_qkv, const unsigned* amax_do, unsigned* amax_out,
                 hipStream_t st, TAOperand po = {nullptr, 0, 0, nullptr}) {
   const int n = map.n_tok;
-  if (C / heads != 64 || C % 4 != 0 || n < 1 || n > 256 || !amax_qkv || !stats) return -2;
+  if (C / heads != 64 || C % 4 != 0 || n < 1 || n > 1024 || !amax_qkv || !stats) return -2;
   if (po.op && (po.Tp < po.T || !po.unscale || C % 32 != 0)) return -1;
 #define TA_CASE(NKT_) return ta_launch<NKT_>(which, qkv, o, dout, out, dqkv, stats, n_seq, map, C, heads, amax_qkv, amax_do, amax_out, st, po);
   if (n <= 32) { TA_CASE(2) }
   if (n <= 64) { TA_CASE(4) }
   if (n <= 128) { TA_CASE(8) }
-  TA_CASE(16)
+  if (n <= 256) { TA_CASE(16) }
+  if (n <= 512) { TA_CASE(32) }
+  TA_CASE(64)
 #undef TA_CASE
 }
 

@@ -492,7 +492,7 @@ class MixSTE2(nn.Module):
     def train_arithmetic(self) -> str:
         """What the training step's Linears run on (bench.py reports it next to the step time)."""
         ta = os.environ.get("D3DP_TRAIN_ATTN", "")
-        x2_ok = self.embed_dim // self.num_heads == 64 and self.num_frame <= 256
+        x2_ok = self.embed_dim // self.num_heads == 64 and self.num_frame <= 1024
         if ta == "f32" or not x2_ok:
             attn = "fp32 attention (fp32 MFMA: temporal forward, backward of both axes; spatial forward on the VALU)"
         elif ta == "x2t":

@@ -223,7 +223,10 @@ D3DP_API int d3dp_jpma_ex(const float* pred, const float* traj, const float* cam
  * same inputs/masks/workspace.  grads: device fp32 buffers shaped like the weights (zeroed, then filled, here).
  * d3dp_train_backward launches a block's weight-gradient product on a second, library-owned stream, forked from and joined
  * back to `stream` with events before it returns (the host is never synchronised; env D3DP_TRAIN_OVERLAP=0: one stream).
- * No gradient is accumulated with float atomics: the same inputs give the same bits. */
+ * No gradient is accumulated with float atomics: the same inputs give the same bits.
+ * Clip length: any F <= 1024 like inference (reference common/arguments.py:58); beyond 256 frames the step needs head dim 64 and
+ * its split-fp16 attention kernels (keys / queries through LDS in chunks) -- the fp32 cross-check implementations
+ * (D3DP_TRAIN_IMPL=f32, D3DP_TRAIN_ATTN=f32|x2t) hold whole sequences and answer D3DP_ENOTSUP there. */
 D3DP_API int d3dp_train_workspace_bytes(const d3dp_ctx* ctx, int32_t B, size_t* bytes);
 D3DP_API int d3dp_train_forward(d3dp_ctx* ctx, const float* x2d, const float* x3d, const int64_t* t, const float* masks, float* out,
                        int32_t B, void* workspace, size_t workspace_bytes, void* stream);
