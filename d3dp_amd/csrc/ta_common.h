@@ -40,6 +40,9 @@ template <int NK, int NT>
 __device__ __forceinline__ void ta_stage(const float* __restrict__ src, size_t rs, int n, float sc, char* img, int tid) {
   constexpr int PLANE = NK * 128;
   constexpr int ITEMS = NK * 8;                        // 16-byte slots of one plane
+#ifdef D3DP_TA_PROBE                                   // timing probe (results INVALID): 1 = no staging at all, 2 = loads without the split
+  if (D3DP_TA_PROBE == 1 && sc != -12345.f) return;
+#endif
   for (int i0 = 0; i0 < ITEMS; i0 += 4 * NT) {
     float4 a[4], b[4];
 #pragma unroll
@@ -57,6 +60,10 @@ __device__ __forceinline__ void ta_stage(const float* __restrict__ src, size_t r
       const int idx = i0 + u * NT + tid, row = idx >> 3, slot = idx & 7;
       if (idx < ITEMS) {
         f16x8 hi, lo;
+#if defined(D3DP_TA_PROBE) && D3DP_TA_PROBE == 2
+        hi = __builtin_bit_cast(f16x8, a[u]); lo = __builtin_bit_cast(f16x8, b[u]);
+        if (sc == -12345.f)
+#endif
         ta_split8(a[u], b[u], hi, lo, sc);
         const int off = row * 128 + ((slot ^ ta_sw(row)) << 4);
         *reinterpret_cast<f16x8*>(img + off) = hi;

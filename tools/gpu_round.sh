@@ -1,6 +1,6 @@
 #!/bin/bash
 # One parametrised driver for everything this repo runs on the GPU box (replaces the per-call scratch scripts of rounds 2-3):
-#   tools/gpu_round.sh STAGE [STAGE ...]      results under gpurun_out/$TAG/ (TAG defaults to "r05")
+#   tools/gpu_round.sh STAGE [STAGE ...]      results under gpurun_out/$TAG/ (TAG defaults to "r06")
 # stages
 #   guard        the new kernels once, small, under a short timeout (a hang here must not take the rest of the call with it);
 #                on failure the remaining stages run with D3DP_X2_SKEW=0
@@ -13,8 +13,10 @@
 #   pmc_step     the same counters over every kernel class of one step (one filtered pass per class and counter group)
 #   gemm         tools/gemm_bench.py micro-benchmark of the four Linear shapes (GEMM_ARGS)
 #   train        tools/train_bench.py
+#   c5stats      rocprofv3 --kernel-trace --stats of bench.py's OWN configs[4] step (bench.py --train-only), two streams and one
+#   c5pmc        FETCH_SIZE / WRITE_SIZE / MFMA-busy over every kernel of that step (3 steps per pass: 1 warm-up + 2 timed)
 set -u
-TAG=${TAG:-r05}; R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O
+TAG=${TAG:-r06}; R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
 QUICK="--no-cpu-baseline --no-other-leg --no-parity --no-configs"
 json_line() { python -c "
@@ -87,6 +89,19 @@ for stage in "$@"; do
       timeout 300 python tools/gemm_bench.py --x2 ${GEMM_ARGS:---m 128960 --iters 10} > $O/gemm_bench.log 2>&1; cat $O/gemm_bench.log ;;
     train)
       timeout 300 python tools/train_bench.py ${TRAIN_ARGS:-10} > $O/train_bench.log 2>&1; tail -3 $O/train_bench.log ;;
+    c5stats)
+      for mode in two one; do
+        ( cd /tmp && [ $mode = one ] && export D3DP_TRAIN_OVERLAP=0; timeout 400 rocprofv3 --kernel-trace --stats -d $O/c5st_$mode -- python $R/bench.py --train-only --steps 10 --warmup 2 --no-profile > $O/c5_prof_$mode.json 2>/dev/null )
+        db=$(find $O/c5st_$mode -name "*.db" | head -1); [ -n "$db" ] && python tools/rocprof_summary.py $db $O/c5_kernel_stats_$mode.md > /dev/null; rm -rf $O/c5st_$mode
+      done; head -24 $O/c5_kernel_stats_one.md | cut -c1-150 ;;
+    c5pmc)
+      csvs=""
+      for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+        t=$(echo $c | cut -d' ' -f1); d=$O/c5pmc_$t
+        ( cd /tmp && D3DP_TRAIN_OVERLAP=0 timeout 300 rocprofv3 --pmc $c --output-format csv -d $d -- python $R/bench.py --train-only --steps 2 --warmup 1 --no-profile > $d.log 2>&1 )
+        f=$(find $d -name "*counter_collection.csv" 2>/dev/null | head -1); [ -n "$f" ] && csvs="$csvs $f" || echo "no counters: $t (see $d.log)"
+      done
+      python tools/pmc_step_summary.py $O/c5_pmc.md $csvs > /dev/null; head -20 $O/c5_pmc.md | cut -c1-150; find $O -name "*.csv" -size +20M -delete ;;
     *) echo "unknown stage $stage" ;;
   esac
 done

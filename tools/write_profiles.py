@@ -11,7 +11,7 @@ import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1]
-RN = sys.argv[2] if len(sys.argv) > 2 else "r05"
+RN = sys.argv[2] if len(sys.argv) > 2 else "r06"
 F = os.path.join(R, "gpurun_out", TAG)
 P = os.path.join(R, "profiles")
 F_, J_, C_ = 243, 17, 512
@@ -114,6 +114,38 @@ if os.path.exists(tk):
            f"# step time in the profiled run: {tl[-1] if tl else 'n/a'}; in bench.py's configs block (no optimizer step): "
            f"{c5.get('ms_per_step', float('nan')):.2f} ms.", ""]
     open(os.path.join(P, RN + "_train_step_kernel_stats.md"), "w").write("\n".join(hdr) + open(tk).read())
+# ---- round 6: the configs[4] step as bench.py itself runs it: rocprofv3 --stats on two streams and on one, and
+# the whole step's counters
+c5 = d.get("configs", {}).get("c5_train_step", {})
+for mode, what in (("two", "the weight-gradient products on the library's second stream, as un-profiled: the two GEMM kernels' and ln_bwd2<true>'s durations are CONCURRENT and contain waits for compute units"),
+                   ("one", "D3DP_TRAIN_OVERLAP=0: everything on the caller's stream, so that no duration contains a wait -- the durations add up to the step")):
+    src = os.path.join(F, f"c5_kernel_stats_{mode}.md")
+    if os.path.exists(src):
+        pj = os.path.join(F, f"c5_prof_{mode}.json")
+        ms = json.load(open(pj))["c5_train_step"]["ms_per_step"] if os.path.exists(pj) and os.path.getsize(pj) else float("nan")
+        hdr = [f"# rocprofv3 --kernel-trace --stats -- python bench.py --train-only --steps 10 --warmup 2 --no-profile   (tools/gpu_round.sh c5stats; 12 steps",
+               f"# of BASELINE configs[4]: q_sample + MixSTE2 forward / backward + MPJPE loss, B=4 F=243, no optimizer step -- bench.py's own c5 leg).",
+               f"# {what}.", f"# step time in this profiled run: {ms:.2f} ms; in the un-profiled bench line of the same build: {c5.get('ms_per_step', float('nan')):.2f} ms.", ""]
+        open(os.path.join(P, f"{RN}_c5_kernel_stats_{'one_stream' if mode == 'one' else 'two_streams'}.md"), "w").write("\n".join(hdr) + open(src).read())
+src = os.path.join(F, "c5_pmc.md")
+if os.path.exists(src):
+    rows = [l for l in open(src) if l.startswith("| `")]
+    head = [h.strip() for h in open(src).readline().strip().strip("|").split("|")]
+    tot = {h: 0.0 for h in head[2:]}
+    for l in rows:
+        cells = [x.strip() for x in l.strip().strip("|").split("|")]
+        for h, v in zip(head[2:], cells[2:]):
+            tot[h] += float(v)
+    nsteps = 3
+    hbm = (tot.get("FETCH_SIZE", 0) * 1024 * 2 + tot.get("WRITE_SIZE", 0) * 1024) / nsteps
+    busy = (tot["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (tot["GRBM_GUI_ACTIVE"] / 8) if tot.get("GRBM_GUI_ACTIVE") else None
+    hdr = ["# rocprofv3 --pmc <counter set> -- python bench.py --train-only --steps 2 --warmup 1 --no-profile, D3DP_TRAIN_OVERLAP=0 (tools/gpu_round.sh c5pmc):",
+           f"# every kernel of {nsteps} configs[4] steps (incl. torch's own small kernels), one pass per counter set; sums over the {nsteps} steps.",
+           f"# per step: HBM-side bytes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md) {hbm / 1e9:.2f} GB; hardware matrix-pipe busy (sum of",
+           f"# SQ_VALU_MFMA_BUSY_CYCLES / 1024 over sum of GRBM_GUI_ACTIVE / 8) {busy if busy is None else round(busy, 4)}.", ""]
+    open(os.path.join(P, RN + "_c5_pmc.md"), "w").write("\n".join(hdr) + open(src).read())
+    json.dump({"lib_sha256": sha, "hbm_gb_per_step": hbm / 1e9, "mfma_busy_hw": busy, "steps_counted": nsteps,
+               "source": f"profiles/{RN}_c5_pmc.md"}, open(os.path.join(P, RN + "_c5_pmc.json"), "w"), indent=1)
 for src, dst in (("parity.log", "_parity.log"), ("variants.log", "_variants_tests.log"), ("tests_full.log", "_gpu_tests_full.log")):
     if os.path.exists(os.path.join(F, src)):
         shutil.copy(os.path.join(F, src), os.path.join(P, RN + dst))
