@@ -73,6 +73,51 @@ __device__ __forceinline__ void ta_stage(const float* __restrict__ src, size_t r
   }
 }
 
+// The same for NS matrices at once: every matrix's loads of a pass are in flight before the first conversion -- ONE exposed memory round
+// trip per chunk instead of one per operand (round 6: with the operands staged one after the other the loads' latency, not the
+// split arithmetic, was 20 - 40 % of the training attention kernels: D3DP_TA_PROBE builds).  rows [0, n) valid for all of them.
+template <int NK, int NT, int NS>
+__device__ __forceinline__ void ta_stage_many(const float* const (&src)[NS], const size_t (&rs)[NS], const float (&sc)[NS],
+                                              char* const (&img)[NS], int n, int tid) {
+  constexpr int PLANE = NK * 128;
+  constexpr int ITEMS = NK * 8;
+#ifdef D3DP_TA_PROBE
+  if (D3DP_TA_PROBE == 1 && sc[0] != -12345.f) return;
+#endif
+  for (int i0 = 0; i0 < ITEMS; i0 += 4 * NT) {
+    float4 a[NS][4], b[NS][4];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0 + u * NT + tid, row = idx >> 3, slot = idx & 7;
+        a[s][u] = make_float4(0.f, 0.f, 0.f, 0.f); b[s][u] = a[s][u];
+        if (idx < ITEMS && row < n) {
+          const float* p = src[s] + (size_t)row * rs[s] + slot * 8;
+          a[s][u] = *reinterpret_cast<const float4*>(p);
+          b[s][u] = *reinterpret_cast<const float4*>(p + 4);
+        }
+      }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0 + u * NT + tid, row = idx >> 3, slot = idx & 7;
+        if (idx < ITEMS) {
+          f16x8 hi, lo;
+#if defined(D3DP_TA_PROBE) && D3DP_TA_PROBE == 2
+          hi = __builtin_bit_cast(f16x8, a[s][u]); lo = __builtin_bit_cast(f16x8, b[s][u]);
+          if (sc[0] == -12345.f)
+#endif
+          ta_split8(a[s][u], b[s][u], hi, lo, sc[s]);
+          const int off = row * 128 + ((slot ^ ta_sw(row)) << 4);
+          *reinterpret_cast<f16x8*>(img[s] + off) = hi;
+          *reinterpret_cast<f16x8*>(img[s] + PLANE + off) = lo;
+        }
+      }
+  }
+}
+
 // per-lane fragment addresses inside an image (hi plane; the lo plane is PLANE bytes further)
 //   r0 / r1 : ROW fragment -- image row (16 t + lane & 15), channels 8 fg .. + 7 (r0) and 32 + 8 fg .. + 7 (r1); tile t at + t 2048
 //   t[dn]   : TRANSPOSED fragment -- channel dn 16 + (lane & 15), image rows 32 c + 4 fg + {0..3} (first read) and + 16 (second,

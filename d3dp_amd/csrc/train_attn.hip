@@ -94,8 +94,13 @@ __global__ __launch_bounds__(NW * 64, 4) void tattn_fwd_kernel(const float* __re
 #pragma unroll 1
   for (int kc = 0; kc < NKT && 16 * kc < n; kc += NKC) {
   if (unit != (int)blockIdx.x || kc != 0) __syncthreads();   // every wave is done with the previous chunk's / unit's images
-  ta_stage<NK, NW * 64>(p0 + C + (size_t)kc * 16 * rs, rs, n - 16 * kc, sq, kimg, tid);
-  ta_stage<NK, NW * 64>(p0 + 2 * C + (size_t)kc * 16 * rs, rs, n - 16 * kc, sq, vimg, tid);
+  {
+    const float* const src2[2] = {p0 + C + (size_t)kc * 16 * rs, p0 + 2 * C + (size_t)kc * 16 * rs};
+    const size_t rs2[2] = {rs, rs};
+    const float sc2[2] = {sq, sq};
+    char* const img2[2] = {kimg, vimg};
+    ta_stage_many<NK, NW * 64, 2>(src2, rs2, sc2, img2, n - 16 * kc, tid);
+  }
   __syncthreads();
   if (active) {
 #pragma unroll
@@ -227,8 +232,13 @@ __global__ __launch_bounds__(NW * 64, WPE) void tattn_bwd_q_kernel(const float* 
 #pragma unroll 1
   for (int kc = 0; kc < NKT && 16 * kc < n; kc += NKC) {
   if (unit != (int)blockIdx.x || kc != 0) __syncthreads();
-  ta_stage<NK, NW * 64>(p0 + C + (size_t)kc * 16 * rs, rs, n - 16 * kc, sq, kimg, tid);
-  ta_stage<NK, NW * 64>(p0 + 2 * C + (size_t)kc * 16 * rs, rs, n - 16 * kc, sq, vimg, tid);
+  {
+    const float* const src2[2] = {p0 + C + (size_t)kc * 16 * rs, p0 + 2 * C + (size_t)kc * 16 * rs};
+    const size_t rs2[2] = {rs, rs};
+    const float sc2[2] = {sq, sq};
+    char* const img2[2] = {kimg, vimg};
+    ta_stage_many<NK, NW * 64, 2>(src2, rs2, sc2, img2, n - 16 * kc, tid);
+  }
   __syncthreads();
   if (active) {
 #pragma unroll
@@ -327,6 +337,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void tattn_bwd_kv_kernel(const float*
 #pragma unroll 1
   for (int qc = 0; qc < NKT && 16 * qc < n; qc += NKC) {
   if (unit != (int)blockIdx.x || qc != 0) __syncthreads();
+  // (one operand after the other here: both at once -- ta_stage_many, as in the forward pass and pass Q -- costs this 200-register
+  //  kernel more than the second round trip: 98 -> 105 us)
   ta_stage<NK, NW * 64>(qkv + (size_t)base * ld + (size_t)head * 64 + (size_t)qc * 16 * rs, rs, n - 16 * qc, sq, qimg, tid);
   ta_stage<NK, NW * 64>(dout + (size_t)base * C + (size_t)head * 64 + (size_t)qc * 16 * map.tok_stride * C, (size_t)map.tok_stride * C,
                         n - 16 * qc, sg, gimg, tid);
@@ -435,10 +447,13 @@ __global__ __launch_bounds__(128) void tattn_bwd_small_kernel(const float* __res
     const float* p0 = qkv + (size_t)base * ld + (size_t)head * 64;
     const float* g0 = dout + (size_t)base * C + (size_t)head * 64;
     if (unit != (int)blockIdx.x) __syncthreads();        // every wave is done with the previous unit's images
-    ta_stage<NK, NW * 64>(p0, rs, n, sq, qimg, tid);
-    ta_stage<NK, NW * 64>(p0 + C, rs, n, sq, kimg, tid);
-    ta_stage<NK, NW * 64>(p0 + 2 * C, rs, n, sq, vimg, tid);
-    ta_stage<NK, NW * 64>(g0, (size_t)map.tok_stride * C, n, sg, gimg, tid);
+    {
+      const float* const src4[4] = {p0, p0 + C, p0 + 2 * C, g0};
+      const size_t rs4[4] = {rs, rs, rs, (size_t)map.tok_stride * C};
+      const float sc4[4] = {sq, sq, sq, sg};
+      char* const img4[4] = {qimg, kimg, vimg, gimg};
+      ta_stage_many<NK, NW * 64, 4>(src4, rs4, sc4, img4, n, tid);
+    }
     const int row = wave * 16 + fi;                      // this lane's query (pass Q) and key (pass KV)
     const bool live = row < n;
     const size_t tok = (size_t)(base + min(row, n - 1) * map.tok_stride);
