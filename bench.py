@@ -581,6 +581,16 @@ def train_step_leg(steps=10, warmup=2, profile=True, telemetry=True):
                                "per launch; while the profile is on the library keeps the weight-gradient products on the caller's stream (un-profiled they "
                                "run on a second stream beside the dgrad products), so the classes add up to a ONE-stream step: slightly "
                                "above `ms_per_step`")
+    # the whole step's counters (separate rocprofv3 --pmc passes of THIS command, tools/gpu_round.sh c5pmc), printed only for the build
+    # they were taken on
+    cp = os.path.join(REPO, "profiles", "r06_c5_pmc.json")
+    if os.path.exists(cp):
+        cj = json.load(open(cp))
+        if cj.get("lib_sha256") == lib_sha256():
+            tr["hbm_gb_per_step"] = round(cj["hbm_gb_per_step"], 2)
+            tr["mfma_busy_hw"] = round(cj["mfma_busy_hw"], 4)
+            tr["counters_note"] = ("HBM-side bytes (FETCH_SIZE x 2 + WRITE_SIZE) and hardware matrix-pipe busy fraction over every kernel of the step, one "
+                                   "rocprofv3 --pmc pass per counter set of `bench.py --train-only` on this build (profiles/r06_c5_pmc.md)")
     return tr, mt, sd, x2, gt
 
 
