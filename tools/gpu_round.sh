@@ -74,7 +74,10 @@ for stage in "$@"; do
         B="$R/bench.py --steps 1 --warmup 0 --no-profile --numerics $mode $QUICK"
         csvs=""
         i=0
-        for rx in "f16x2_kernelILi0ELi1E" "f16x2_kernelILi2ELi0E" "f16x2_kernelILi1ELi0E" "attn_temporal_x2" "attn_spatial_x2" "ln2_kernel" "ln_kernel<" "embed_ln" "head_kernel"; do
+        RX=("f16x2_kernelILi0ELi1E" "f16x2_kernelILi2ELi0E" "f16x2_kernelILi1ELi0E" "attn_temporal_x2" "attn_spatial_x2" "ln2_kernel" "ln_kernel<" "embed_ln" "head_kernel")
+        # (FAST mode's kernels carry other names: the four instantiations of the streaming bf16 Linear -- qkv, fc1 + GELU, fc2, proj --, the bf16 attentions)
+        [ $mode = fast ] && RX=("stream_kernelILi0EDF16bLi8ELi4ELi1E" "stream_kernelILi1EDF16bLi8ELi4ELi0E" "stream_kernelILi0EDF16bLi16ELi4ELi0E" "stream_kernelILi0EDF16bLi8ELi4ELi0E" "attn_temporal2_bf16" "attn_spatial_bf16" "ln2_kernel" "ln_kernelILi512" "embed_ln" "head_kernel")
+        for rx in "${RX[@]}"; do
           i=$((i + 1))
           for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
             t=$(echo $c | cut -d' ' -f1); d=$O/step_${mode}_${i}_$t
