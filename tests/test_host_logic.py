@@ -179,6 +179,66 @@ def test_bench_roofline_is_algorithmic_flop_over_the_guides_dense_peak():
     assert roof["traffic"] == t3["hbm_bytes_per_launch"] and 1.3 < roof["traffic"] / t3["algorithmic_bytes_per_launch"] < 1.7
 
 
+def test_bench_telemetry_reads_the_hwmon_of_the_hip_device(tmp_path, monkeypatch):
+    """bench.py samples sclk and package power of the timed steps from the amdgpu hwmon directory of the card at the
+    HIP device's PCI address (no subprocess, nothing on the GPU's queues).  Here on a fake sysfs tree: two cards with sensors, the second
+    is the device; units (Hz, microwatts) and the mean / min / max arithmetic."""
+    import glob as _glob
+    import bench
+    cards = {}
+    for i, pci in enumerate(("0000:05:00.0", "0000:75:00.0")):
+        dev = tmp_path / "devices" / pci
+        hw = dev / "hwmon" / f"hwmon{i}"
+        hw.mkdir(parents=True)
+        (hw / "freq1_input").write_text(str((1500 + 300 * i) * 1000000))
+        (hw / "power1_input").write_text(str((900 + 499 * i) * 1000000))
+        (hw / "power1_cap").write_text("1400000000")
+        link = tmp_path / "drm" / f"card{i}"
+        link.mkdir(parents=True)
+        (link / "device").symlink_to(dev)
+        cards[i] = str(link / "device" / "hwmon" / f"hwmon{i}")
+    monkeypatch.setattr(_glob, "glob", lambda pat: sorted(cards.values()))
+    props = SimpleNamespace(pci_domain_id=0, pci_bus_id=0x75, pci_device_id=0)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: props)
+    t = bench.GpuTelemetry(0, period=0.005)
+    assert t.dir == cards[1] and "0000:75:00.0" in t.source and t.cap_w == 1400.0
+    t.start()
+    import time
+    time.sleep(0.05)
+    t.stop()
+    r = t.report()
+    assert r["samples"] >= 3 and r["clock_mhz_mean"] == 1800.0 and r["clock_mhz_min"] == r["clock_mhz_max"] == 1800.0
+    assert r["power_w_mean"] == 1399.0 and r["power_cap_w"] == 1400.0
+    # no sensors readable: the keys are None, nothing raises
+    monkeypatch.setattr(_glob, "glob", lambda pat: [])
+    r0 = bench.GpuTelemetry(0).report()
+    assert r0["clock_mhz_mean"] is None and r0["power_w_mean"] is None and r0["samples"] == 0
+
+
+def test_bench_training_roofline_is_algorithmic_work_over_corrected_event_time():
+    """configs.c5_train_step.roofline_by_kernel: per class ALGORITHMIC FLOP (bytes) over the library's event time minus the empty
+    event pair's time per launch; both attention passes of short sequences run as ONE kernel and its class carries both passes' work;
+    no fraction above 1 is ever printed (a row kernel faster than HBM is reported as cache-resident)."""
+    import bench
+    B, T = 4, 4 * 243 * 17
+    lin = 8 * 512 * 512 * 2 * T * 16
+    prof = {"gemm_qkv": (10, 5.0),                                   # (the denoiser's classes are not the training step's)
+            "train_linear": (128 * 3, 3 * (6.4 + 128 * 0.004)), "train_wgrad": (16 * 3, 3 * (2.7 + 16 * 0.004)),
+            "train_attn_bwd_q_spatial": (8 * 3, 3 * (0.64 + 8 * 0.004)), "train_attn_bwd_kv_spatial": (8 * 3, 3 * 8 * 0.004),
+            "train_attn_bwd_q_temporal": (8 * 3, 3 * (0.7 + 8 * 0.004)), "train_operand_pass": (145 * 3, 3 * (0.001 + 145 * 0.004)),
+            "event_pair_overhead": (24, 24 * 0.004)}
+    r = bench.train_roofline_by_kernel(prof, B, 3)
+    assert "gemm_qkv" not in r and "event_pair_overhead" not in r and "train_attn_bwd_kv_spatial" not in r
+    assert r["train_linear"]["launches"] == 128 and r["train_linear"]["ms_per_step"] == pytest.approx(6.4, abs=1e-3)
+    assert r["train_linear"]["achieved"] == pytest.approx(2 * lin / 6.4e-3 / 1e12, rel=1e-3)
+    assert r["train_wgrad"]["frac"] == pytest.approx(lin / 2.7e-3 / 1e12 / 2500.0, abs=2e-4)
+    assert r["train_attn_bwd_q_spatial"]["algorithmic_gflop_per_step"] == pytest.approx(10 * 17 * 512 * T * 8 / 1e9, rel=1e-3)
+    assert r["train_attn_bwd_q_temporal"]["algorithmic_gflop_per_step"] == pytest.approx(6 * 243 * 512 * T * 8 / 1e9, rel=1e-3)
+    op = r["train_operand_pass"]                                     # 14 GB in 1 us: not an HBM rate
+    assert op["bound"] == "cache" and op["frac"] is None and op["peak"] is None
+    assert all(v.get("frac") is None or v["frac"] <= 1.0 for v in r.values())
+
+
 def test_rational_erf_of_the_exact_fc1_epilogue_is_fp32_class():
     """common.h gelu_erf_rational (one rational x P(x^2)/Q(x^2) instead of libm's erff), restated in numpy with the same
     coefficients and fma order: against fp64 its GELU is as accurate as torch's own fp32 GELU on N(0,1) inputs."""
