@@ -594,6 +594,30 @@ def train_step_leg(steps=10, warmup=2, profile=True, telemetry=True):
     return tr, mt, sd, x2, gt
 
 
+def fast_mode_on_fp16_operands(B, H, K, steps, warmup):
+    """VERDICT r4 item 7 / r5 item 7 (optional; no parity claim): FAST mode with IEEE fp16 instead of bf16 as its 2-byte operand type --
+    the same kernels, the type swapped at build time (`make -C d3dp_amd/csrc fastf16`: lib/variants/libd3dp_fastf16.so, common.h
+    D3DP_FAST_F16) -- timed on the same workload in a CHILD process that loads that library (D3DP_LIB), with its distance to the fp32
+    oracle on the small parity problem beside the bf16 figure.  None when the variant library was not built."""
+    import subprocess
+    lib = os.path.join(REPO, "d3dp_amd", "lib", "variants", "libd3dp_fastf16.so")
+    if not os.path.exists(lib):
+        return None
+    env = dict(os.environ, D3DP_LIB=lib)
+    cmd = [sys.executable, os.path.abspath(__file__), "--numerics", "fast", "--steps", str(steps), "--warmup", str(warmup), "--batch", str(B),
+           "--hyps", str(H), "--ksteps", str(K), "--no-cpu-baseline", "--no-other-leg", "--no-configs", "--no-profile"]
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600).stdout
+        d = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    except Exception as e:                                  # (a secondary leg must not take the bench line with it)
+        return {"error": f"{type(e).__name__}: {e}"}
+    return {"value": d["value"], "unit": "hypothesis-clips/s", "ms_per_step": d["ms_per_step"], "steps": steps, "warmup": warmup,
+            "mpjpe_mm_vs_fp32_oracle": d.get("parity", {}).get("fast_mpjpe_mm"), "parity_workload": d.get("parity", {}).get("workload"),
+            "library": "d3dp_amd/lib/variants/libd3dp_fastf16.so (child process)",
+            "what": "FAST mode's kernels with fp16 (11 significand bits) instead of bf16 (8) as the 2-byte operand type, unscaled: every "
+                    "value FAST mode stores in 2 bytes lies inside fp16's range for this model; same MFMA rate"}
+
+
 def lib_sha256():
     from d3dp_amd import _lib
     h = hashlib.sha256()
@@ -929,6 +953,11 @@ def main():
                 leg["kernel_ms_per_step"] = {k: round(ms, 3) for k, (_, ms) in po.items() if ms > 0}
             res[other + "_mode"] = leg
             del mo
+            mo = None
+            torch.cuda.empty_cache()
+            f16 = fast_mode_on_fp16_operands(B, H, K, st, wu) if other == "fast" else None
+            if f16 is not None:
+                res["fast_mode"]["fp16_operands"] = f16
         if not a.no_parity:
             res["parity"] = quick_parity()
         if not a.no_configs:

@@ -280,7 +280,8 @@ template <int C0>
 __device__ __forceinline__ bf16x8 load_vt_frag(const char* vb) {
   const v4bf16 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) v4bf16*)(vb + C0 * 4096));
   const v4bf16 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) v4bf16*)(vb + C0 * 4096 + 2048));
-  return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  typedef __bf16 raw8 __attribute__((ext_vector_type(8)));     // (16-bit payloads: whatever `bf16` is in this build, common.h D3DP_FAST_F16)
+  return __builtin_bit_cast(bf16x8, (raw8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
 }
 
 template <int NKT, int C0>
@@ -288,7 +289,7 @@ __device__ __forceinline__ void pv_chunks(const FragBases& fb, const bf16x8 (&pf
   if constexpr (C0 < NKT / 2) {
 #pragma unroll
     for (int dn = 0; dn < 4; ++dn)
-      o[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(load_vt_frag<C0>(fb.v[dn]), pf[C0], o[dn], 0, 0, 0);
+      o[dn] = D3DP_MFMA_16x16x32_BF16(load_vt_frag<C0>(fb.v[dn]), pf[C0], o[dn]);
     if (C0 & 1) __builtin_amdgcn_sched_barrier(0);
     pv_chunks<NKT, C0 + 1>(fb, pf, o);
   }
@@ -307,8 +308,8 @@ __device__ __forceinline__ void attn_tile(const FragBases& fb, bf16x8 q0, bf16x8
     const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(fb.k0 + t * 2048);
     const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(fb.k1 + t * 2048);
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q0, a, 0, 0, 0);
-    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q1, a, 0, 0, 0);
+    a = D3DP_MFMA_16x16x32_BF16(k0, q0, a);
+    a = D3DP_MFMA_16x16x32_BF16(k1, q1, a);
     s[t] = a;
     if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the ds_read hoisting window (VGPR pressure)
   }

@@ -3,9 +3,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// -DD3DP_FAST_F16=1 (`make fastf16`: lib/variants/libd3dp_fastf16.so, NOT the product library): FAST mode's 2-byte operand type is
+// IEEE fp16 instead of bf16 -- 11 significand bits instead of 8 at the same MFMA rate (reported beside
+// the bf16 figure, no parity claim).  Every value FAST mode stores in 2 bytes lies inside fp16's range for this model (LayerNorm
+// outputs <= 23, |w| < 1, probabilities, GELU outputs; the residual stream stays fp32), so the type is swapped and nothing is scaled.
+#ifndef D3DP_FAST_F16
+#define D3DP_FAST_F16 0
+#endif
+#if D3DP_FAST_F16
+typedef _Float16 bf16;
+typedef _Float16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));
+#define D3DP_MFMA_16x16x32_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#else
 typedef __bf16 bf16;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define D3DP_MFMA_16x16x32_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -287,12 +287,12 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_kernel(const bf16* __restrict
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         f32x4 c = acc[mi][ni];
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][0], af[2], c, 0, 0, 0);   // smallest terms first
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][1], af[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][2], af[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][0], af[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][1], af[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][0], af[0], c, 0, 0, 0);
+        c = D3DP_MFMA_16x16x32_BF16(wf[ni][0], af[2], c);   // smallest terms first
+        c = D3DP_MFMA_16x16x32_BF16(wf[ni][1], af[1], c);
+        c = D3DP_MFMA_16x16x32_BF16(wf[ni][2], af[0], c);
+        c = D3DP_MFMA_16x16x32_BF16(wf[ni][0], af[1], c);
+        c = D3DP_MFMA_16x16x32_BF16(wf[ni][1], af[0], c);
+        c = D3DP_MFMA_16x16x32_BF16(wf[ni][0], af[0], c);
         acc[mi][ni] = c;
       }
     }
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(MI == 4 ? 768 : 512) void gemm_bf16_stream_kernel(c
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], wf[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = D3DP_MFMA_16x16x32_BF16(af[mi], wf[ni], acc[mi][ni]);
     }
   };
   __builtin_amdgcn_s_setprio(1);

@@ -13,7 +13,7 @@ def short(name):
         name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
-    return re.sub(r"\(.*", "", name)[:60]
+    return re.sub(r"\(.*", "", name)[:96]      # (long enough to keep the template arguments that tell the FAST Linears apart)
 
 
 def main(out, *passes):
