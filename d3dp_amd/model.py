@@ -509,7 +509,7 @@ class MixSTE2(nn.Module):
               else "the four weight gradients of a block as one TN launch")
         return ("split-fp16 Linears (three fp16-MFMA passes, fp32 accumulate, device-side operand scales; forward and dgrad on "
                 "256 x 128 tiles with the batch's last T mod 256 rows as 16 x 64 blocks, " + wg + ", partial tiles summed in a "
-                "fixed order), " + attn)
+                "fixed order; LayerNorm and attention outputs written by their producers as the next Linear's operand rows), " + attn)
 
     # -- profiling passthrough --------------------------------------------------------------------
     def profile_enable(self, on: bool = True):
