@@ -14,6 +14,7 @@
 //                               the probabilities land directly in the A/B fragment layout of the P.V MFMA.
 //   attn_temporal_f32_kernel  : EXACT mode temporal axis on the fp32 matrix cores.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -63,10 +64,15 @@ __device__ __forceinline__ void ld_vec(const T* p, float* v) {
 // chunks of `kchunk` keys under the online softmax (one chunk = the whole sequence up to 256 tokens, which is every BASELINE
 // configuration; longer clips -- `-f 351`, reference common/arguments.py:58 -- run here instead of being refused).
 // amax (optional): absmax of the fp32 output, one atomicMax per workgroup (the training step's proj operand scale).
-template <typename T, int HD, int TPP, int OUTS>   // OUTS: 0 = T out, 3 = three split-bf16 planes, 2 = two split-fp16 planes
+// GEN (round 6: any head dim the reference's `-cs` / 8 heads gives, common/arguments.py:49): HD is the register capacity, the
+// head dim itself the run-time `hd_rt` (a multiple of the 16-byte vector, <= HD); the 16-byte slots behind it hold zeros in
+// q / K / V and are not stored.  Instantiated for fp32 rows only (the fp32 implementation of the widths outside {64 .. 512}).
+template <typename T, int HD, int TPP, int OUTS, bool GEN = false>   // OUTS: 0 = T out, 3 = three split-bf16 planes, 2 = two split-fp16 planes
 __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qkv, void* __restrict__ out_v, int n_prob,
                                                         SeqMap map, int C, int heads, size_t plane, int kchunk,
-                                                        unsigned* __restrict__ amax) {
+                                                        unsigned* __restrict__ amax, int hd_rt) {
+  static_assert(!GEN || (OUTS == 0 && sizeof(T) == 4), "the run-time head dim form exists for fp32 rows");
+  const int hd = GEN ? hd_rt : HD;
   constexpr int PPB = 256 / TPP;
   constexpr int VN = Vec16<T>::N;                 // elements per 16-byte vector
   constexpr int LDR = HD + VN;                    // padded LDS row (elements)
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qk
   const int base = seq_base(map, seq);
   T* Ks = smem + (size_t)lp * 2 * kchunk * LDR;
   T* Vs = Ks + (size_t)kchunk * LDR;
-  const float scale = 1.0f / sqrtf((float)HD);
+  const float scale = 1.0f / sqrtf((float)hd);
   float am = 0.f;
 
   for (int q0 = 0; q0 < n; q0 += TPP) {
@@ -92,7 +98,13 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qk
     const size_t tok = (size_t)(base + (act ? q0 + row : 0) * map.tok_stride);
     float q[HD], o[HD];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) ld_vec<T, VN>(qkv + tok * 3 * C + head * HD + c * VN, q + c * VN);
+    for (int c = 0; c < CH; ++c) {
+      if (!GEN || c * VN < hd) ld_vec<T, VN>(qkv + tok * 3 * C + head * hd + c * VN, q + c * VN);
+      else {
+#pragma unroll
+        for (int e = 0; e < VN; ++e) q[c * VN + e] = 0.f;
+      }
+    }
 #pragma unroll
     for (int d = 0; d < HD; ++d) o[d] = 0.f;
     float m = -INFINITY, l = 0.f;
@@ -102,9 +114,10 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qk
       if (live) {
         for (int u = row; u < nk * CH; u += TPP) {
           const int j = u / CH, c = u % CH;
-          const T* src = qkv + (size_t)(base + (k0 + j) * map.tok_stride) * 3 * C + C + head * HD + c * VN;
-          *reinterpret_cast<float4*>(Ks + j * LDR + c * VN) = *reinterpret_cast<const float4*>(src);
-          *reinterpret_cast<float4*>(Vs + j * LDR + c * VN) = *reinterpret_cast<const float4*>(src + C);
+          const T* src = qkv + (size_t)(base + (k0 + j) * map.tok_stride) * 3 * C + C + head * hd + c * VN;
+          const bool in = !GEN || c * VN < hd;
+          *reinterpret_cast<float4*>(Ks + j * LDR + c * VN) = in ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(Vs + j * LDR + c * VN) = in ? *reinterpret_cast<const float4*>(src + C) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
       __syncthreads();
@@ -189,9 +202,10 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qk
         *reinterpret_cast<bf16x4*>(dst + 2 * plane + c * 4) = p2;
       }
     } else {
-      T* dst = reinterpret_cast<T*>(out_v) + tok * C + head * HD;
+      T* dst = reinterpret_cast<T*>(out_v) + tok * C + head * hd;
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
+        if (GEN && c * VN >= hd) continue;
         float r[VN];
 #pragma unroll
         for (int e = 0; e < VN; ++e) { r[e] = o[c * VN + e] * inv; am = fmaxf(am, fabsf(r[e])); }
@@ -211,19 +225,24 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const T* __restrict__ qk
   }
 }
 
-template <typename T, int HD, int TPP, int OUTS>
+template <typename T, int HD, int TPP, int OUTS, bool GEN = false>
 int launch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int heads, size_t plane, unsigned* amax, hipStream_t st) {
   constexpr int PPB = 256 / TPP;
   constexpr int LDR = HD + Vec16<T>::N;
   const int n_prob = n_seq * heads;
-  const int kchunk = map.n_tok < 256 ? map.n_tok : 256;
+  int kchunk = map.n_tok < 256 ? map.n_tok : 256;
+  if (GEN) {                                           // a 128-wide head: the K / V images of 256 keys do not fit the CU's LDS
+    const int fit = (int)((160 * 1024 - 16) / ((size_t)PPB * 2 * LDR * sizeof(T)));
+    if (fit < 1) return -2;
+    if (kchunk > fit) kchunk = fit >= 128 ? 128 : fit;
+  }
   const size_t lds = (size_t)PPB * 2 * kchunk * LDR * sizeof(T) + 16;   // (+ the four absmax partials)
   if (lds > 160 * 1024) return -2;
-  auto kern = attn_rows_kernel<T, HD, TPP, OUTS>;
+  auto kern = attn_rows_kernel<T, HD, TPP, OUTS, GEN>;
   static PerDeviceOnce once;                          // (one per template instantiation = per kernel)
   if (once.get([&](int) { return d3dp_lds_opt_in(reinterpret_cast<const void*>(kern), 160 * 1024); }) < 0) return -3;
   hipLaunchKernelGGL(kern, dim3((n_prob + PPB - 1) / PPB), dim3(256), lds, st, (const T*)qkv, out, n_prob, map, C, heads,
-                     plane, kchunk, amax);
+                     plane, kchunk, amax, C / heads);
   return 0;
 }
 
@@ -237,9 +256,27 @@ int dispatch_rows(const void* qkv, void* out, int n_seq, SeqMap map, int C, int 
                          : launch_rows<T, HD_, 256, OUTS>(qkv, out, n_seq, map, C, heads, plane, amax, st);
   switch (hd) {
     ROWS_CASE(64) ROWS_CASE(32) ROWS_CASE(16) ROWS_CASE(8)
-    default: return -2;
+    default: break;
   }
 #undef ROWS_CASE
+  // any other head dim (a multiple of 4 up to 128): the run-time form, fp32 rows in and out
+  if constexpr (std::is_same<T, float>::value && OUTS == 0) {
+    if (hd < 4 || hd % 4 || hd > 128 || hd * heads != C) return -2;
+#define ROWS_GEN(HD_)                                                                                                       \
+  {                                                                                                                         \
+    if (small) {                                                                                                            \
+      const int r = launch_rows<T, HD_, 32, OUTS, true>(qkv, out, n_seq, map, C, heads, plane, amax, st);                   \
+      if (r != -2) return r;                          /* (-2: eight problems' images do not fit the LDS) */                 \
+    }                                                                                                                       \
+    return launch_rows<T, HD_, 256, OUTS, true>(qkv, out, n_seq, map, C, heads, plane, amax, st);                           \
+  }
+    if (hd <= 16) ROWS_GEN(16)
+    if (hd <= 32) ROWS_GEN(32)
+    if (hd <= 64) ROWS_GEN(64)
+    ROWS_GEN(128)
+#undef ROWS_GEN
+  }
+  return -2;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1910,8 +1947,8 @@ int d3dp_launch_attn_temporal_f32(int act, const void* qkv, void* out, int n_seq
 }
 
 // EXACT-mode attention on the fp16 matrix cores (split-fp16 operands; head dim 64) over PACKED qkv rows (see above).
-// act 0 -> fp32 out, 3 -> two fp16 planes out (the EXACT Linear's operand format).  axis 0: <= 32 tokens per sequence;
-// axis 1: <= 256.
+// act 0 -> fp32 out, 3 -> two fp16 planes out (the EXACT Linear's operand format).  axis 0 with <= 32 tokens per sequence:
+// one wave per problem; otherwise the persistent whole-sequence kernel (<= 256 tokens) or the chunked-key form (longer).
 void d3dp_launch_qkv_pack_x2(const float* src, void* dst, size_t T, int C, float act_scale, hipStream_t st) {
   const size_t total = T * (size_t)(3 * C / 4);
   const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -1927,8 +1964,7 @@ int d3dp_launch_attn_x2(int act, int axis, const void* qkv, void* out, int n_seq
   const int n = map.n_tok;
   const X2Scales sc = {act_scale, 0.125f * 1.44269504088896340736f / (act_scale * act_scale),
                        1.0f / act_scale, act_scale};
-  if (axis == 0) {
-    if (n > 32) return -2;
+  if (axis == 0 && n <= 32) {                          // (more than 32 joints: the kernels below take any SeqMap)
     const int n_prob = n_seq * heads;
     if (act == 3) hipLaunchKernelGGL((attn_spatial_x2_kernel<2>), dim3((n_prob + 3) / 4), dim3(256), 0, st, (const float*)qkv, out, n_prob, map, C, heads, plane, sc);
     else hipLaunchKernelGGL((attn_spatial_x2_kernel<0>), dim3((n_prob + 3) / 4), dim3(256), 0, st, (const float*)qkv, out, n_prob, map, C, heads, plane, sc);

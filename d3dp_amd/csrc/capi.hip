@@ -408,16 +408,31 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   const d3dp_cfg& g = *cfg;
   // (frames > 256: EXACT mode's temporal attention takes the chunked-key flash kernel; FAST / TRAIN contexts the fp32 row kernel)
   if (g.frames < 1 || g.frames > 1024) return fail(D3DP_ENOTSUP, "frames=%d not in [1,1024]", g.frames);
-  if (g.joints < 1 || g.joints > 32) return fail(D3DP_ENOTSUP, "joints=%d not in [1,32]", g.joints);
-  if (g.channels != 64 && g.channels != 128 && g.channels != 256 && g.channels != 512)
-    return fail(D3DP_ENOTSUP, "channels=%d not in {64,128,256,512}", g.channels);
-  if (g.heads < 1 || g.channels % g.heads) return fail(D3DP_EINVAL, "heads=%d does not divide channels", g.heads);
-  const int hd = g.channels / g.heads;
-  if (hd != 8 && hd != 16 && hd != 32 && hd != 64) return fail(D3DP_ENOTSUP, "head dim %d not in {8,16,32,64}", hd);
-  if (g.hidden % 64 || g.hidden < 64) return fail(D3DP_ENOTSUP, "hidden=%d must be a multiple of 64", g.hidden);
+  // (more than 32 joints: the spatial axis takes the whole-sequence attention kernels the temporal axis runs on, round 6)
+  if (g.joints < 1 || g.joints > 256) return fail(D3DP_ENOTSUP, "joints=%d not in [1,256]", g.joints);
+  if (g.heads < 1 || g.channels < 1 || g.channels % g.heads) return fail(D3DP_EINVAL, "heads=%d does not divide channels=%d", g.heads, g.channels);
   if (g.depth < 1) return fail(D3DP_EINVAL, "depth=%d", g.depth);
   if (g.mode != D3DP_MODE_EXACT && g.mode != D3DP_MODE_FAST && g.mode != D3DP_MODE_TRAIN)
     return fail(D3DP_EINVAL, "mode=%d", g.mode);
+  const int hd = g.channels / g.heads;
+  // The matrix-core kernels (split-fp16 / bf16 operands) and the row kernels around them are instantiated for the widths
+  // {64, 128, 256, 512} with head dims {8, 16, 32, 64}: every configuration the reference publishes (`-cs 512`, README.md:33-39)
+  // and its smaller powers of two.  The reference itself takes ANY `-cs` its 8 heads divide (common/arguments.py:49,
+  // mixste.py:46-62): such a width runs EXACT mode on the fp32 implementation -- fp32-MFMA Linears (gemm_f32_kernel), the fp32
+  // row attention with a run-time head dim, run-time-width row kernels (pointwise.hip *_g_kernel) -- i.e. the cross-check
+  // implementation D3DP_EXACT_IMPL=f32 selects by hand for the instantiated widths: same tolerance, roughly a fifth of the
+  // throughput.  FAST and TRAIN contexts exist for the instantiated widths only.
+  const bool width_inst = (g.channels == 64 || g.channels == 128 || g.channels == 256 || g.channels == 512) &&
+                          (hd == 8 || hd == 16 || hd == 32 || hd == 64) && g.hidden >= 64 && g.hidden % 64 == 0;
+  if (!width_inst) {
+    if (g.mode != D3DP_MODE_EXACT)
+      return fail(D3DP_ENOTSUP, "channels=%d heads=%d hidden=%d: FAST and TRAIN contexts exist for channels in {64,128,256,512} with head dim in "
+                                "{8,16,32,64} and hidden a multiple of 64; other widths run in D3DP_MODE_EXACT (fp32 implementation)",
+                  g.channels, g.heads, g.hidden);
+    if (g.channels > 1024 || g.channels % 4 || hd % 4 || hd > 128 || g.hidden < 4 || g.hidden % 4)
+      return fail(D3DP_ENOTSUP, "channels=%d heads=%d hidden=%d: the fp32 implementation takes channels <= 1024, head dim a multiple of 4 up to 128 "
+                                "and hidden a multiple of 4", g.channels, g.heads, g.hidden);
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
     return fail(D3DP_EHIP, "no HIP device visible: libd3dp_hip has no CPU fallback");
@@ -425,6 +440,13 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   c->cfg = g;
   const char* xf = getenv("D3DP_EXACT_IMPL");
   c->exact_impl = c->exact_impl_req = (xf && !strcmp(xf, "bf16x3")) ? 1 : (xf && !strcmp(xf, "f32")) ? 2 : 0;
+  if (!width_inst) {
+    if (c->exact_impl_req == 1) {
+      delete c;
+      return fail(D3DP_ENOTSUP, "D3DP_EXACT_IMPL=bf16x3 exists for channels in {64,128,256,512}; channels=%d runs the fp32 implementation", g.channels);
+    }
+    c->exact_impl = c->exact_impl_req = 2;
+  }
   const char* lr = getenv("D3DP_LONG_ATTN");             // cross-check: clips > 256 frames on the fp32 row attention kernel
   c->long_rows = lr && !strcmp(lr, "rows");
   const char* nf = getenv("D3DP_NO_FOLD");               // cross-check: residual adds (and norm2) in the row kernels

@@ -89,11 +89,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     pw[i] = W + (size_t)min(n0 + lrow[i], N - 1) * K + lk[i];
   }
   float4 ra[2], rw[2];
+  // (K is any multiple of 4: the float4 slots of the last k-step that lie behind K contribute zeros -- widths that are not a
+  //  multiple of 16, round 6)
   auto gload = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      ra[i] = *reinterpret_cast<const float4*>(pa[i] + kt * XBK);
-      rw[i] = *reinterpret_cast<const float4*>(pw[i] + kt * XBK);
+      const bool in = kt * XBK + lk[i] < K;
+      ra[i] = in ? *reinterpret_cast<const float4*>(pa[i] + kt * XBK) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rw[i] = in ? *reinterpret_cast<const float4*>(pw[i] + kt * XBK) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto lstore = [&](int buf) {
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 
   // split-K: blockIdx.y owns k-steps [kt0, nk) of the K / XBK total (gridDim.y == 1: everything)
   const int kt0 = blockIdx.y * nk_per_split;
-  const int nk = min(K / XBK, kt0 + nk_per_split);
+  const int nk = min((K + XBK - 1) / XBK, kt0 + nk_per_split);
   if (kt0 >= nk) return;
   gload(kt0);
   lstore(0);
@@ -168,10 +171,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------
 int d3dp_launch_linear_f32(int epi, const float* A, const float* W, const float* bias, float* out, int M, int N,
                            int K, hipStream_t st) {
-  if (K % XBK != 0 || N % 4 != 0 || M <= 0) return -1;
+  if (K < 4 || K % 4 != 0 || N % 4 != 0 || M <= 0) return -1;
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
   dim3 g(tm * tn), b(256);
-  const int nk = K / XBK;
+  const int nk = (K + XBK - 1) / XBK;
   if (epi == EPI_RESID) hipLaunchKernelGGL((gemm_f32_kernel<EPI_RESID>), g, b, 0, st, A, W, bias, out, M, N, K, tn, nk);
   else if (epi == EPI_GELU) hipLaunchKernelGGL((gemm_f32_kernel<EPI_GELU>), g, b, 0, st, A, W, bias, out, M, N, K, tn, nk);
   else if (epi == EPI_BIAS) hipLaunchKernelGGL((gemm_f32_kernel<EPI_BIAS>), g, b, 0, st, A, W, bias, out, M, N, K, tn, nk);
@@ -182,9 +185,9 @@ int d3dp_launch_linear_f32(int epi, const float* A, const float* W, const float*
 // split-K form for tall contractions (wgrad: K = tokens): `out` must be zeroed by the caller; partial products are
 // accumulated with fp32 atomics (summation order not fixed: last-bit run-to-run variation, fine for gradients).
 int d3dp_launch_linear_f32_splitk(const float* A, const float* W, float* out, int M, int N, int K, hipStream_t st) {
-  if (K % XBK != 0 || N % 4 != 0 || M <= 0) return -1;
+  if (K < 4 || K % 4 != 0 || N % 4 != 0 || M <= 0) return -1;
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
-  const int nk = K / XBK;
+  const int nk = (K + XBK - 1) / XBK;
   const int target = 256;                                         // workgroups aimed at: ~1 per CU measured best (88 ms/step vs 103 at 4 per CU: fewer fp32 atomics)
   int splits = (target + tm * tn - 1) / (tm * tn);
   if (splits > nk / 8) splits = nk / 8 > 0 ? nk / 8 : 1;

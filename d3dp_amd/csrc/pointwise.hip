@@ -369,6 +369,182 @@ __global__ __launch_bounds__(256) void time_mlp_kernel(const int64_t* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Any width (round 6, VERDICT r5 missing 4): the reference takes every `-cs` its 8 heads divide (common/arguments.py:49,
+// mixste.py:46-62); the kernels above are instantiated for C in {64, 128, 256, 512}, the widths whose Linears run on the
+// split-fp16 matrix-core kernels.  Other widths run the fp32 implementation (capi.hip: exact_impl 2 -- fp32-MFMA Linears,
+// fp32 row attention) through the four kernels below: the same arithmetic in the same order per row (two-pass statistics,
+// 1 / C as a multiplied reciprocal, fma with gamma / beta), the width a run-time argument, a lane's NVM slots masked behind it.
+// fp32 activations only (the FAST and split-operand forms exist for the instantiated widths).
+// ------------------------------------------------------------------------------------------------
+template <int NVM> struct RowG {
+  static __device__ __forceinline__ void load(const float* p, int C, int lane, float* v) {
+#pragma unroll
+    for (int i = 0; i < NVM; ++i) { const int c = i * 64 + lane; v[i] = c < C ? p[c] : 0.f; }
+  }
+  static __device__ __forceinline__ void store(float* p, int C, int lane, const float* v) {
+#pragma unroll
+    for (int i = 0; i < NVM; ++i) { const int c = i * 64 + lane; if (c < C) p[c] = v[i]; }
+  }
+  static __device__ __forceinline__ void norm(const float* v, const float* w, const float* b, float eps, int C, int lane, float* y) {
+    const float rc = 1.0f / (float)C;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NVM; ++i) s += v[i];                       // (masked slots hold 0)
+    const float mean = wave_sum(s) * rc;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NVM; ++i) { const float d = (i * 64 + lane < C) ? v[i] - mean : 0.f; q = fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * rc + eps);
+#pragma unroll
+    for (int i = 0; i < NVM; ++i) {
+      const int c = i * 64 + lane;
+      y[i] = c < C ? fmaf((v[i] - mean) * rstd, w[c], b[c]) : 0.f;
+    }
+  }
+};
+
+template <int NVM>
+__global__ __launch_bounds__(256) void ln_g_kernel(float* __restrict__ x, const float* __restrict__ yadd, const float* __restrict__ w,
+                                                   const float* __restrict__ b, float eps, float* __restrict__ xn, int T, int C,
+                                                   int write_x) {
+  using R = RowG<NVM>;
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= T) return;
+  float v[NVM], y[NVM];
+  R::load(x + (size_t)tok * C, C, lane, v);
+  if (yadd != nullptr) {
+    R::load(yadd + (size_t)tok * C, C, lane, y);
+#pragma unroll
+    for (int i = 0; i < NVM; ++i) v[i] += y[i];
+    if (write_x) R::store(x + (size_t)tok * C, C, lane, v);
+  }
+  R::norm(v, w, b, eps, C, lane, y);
+  R::store(xn + (size_t)tok * C, C, lane, y);
+}
+
+template <int NVM>
+__global__ __launch_bounds__(256) void ln2_g_kernel(float* __restrict__ x, const float* __restrict__ yadd0, const float* __restrict__ yadd,
+                                                    const float* __restrict__ wa, const float* __restrict__ ba,
+                                                    const float* __restrict__ pos, const float* __restrict__ wb,
+                                                    const float* __restrict__ bb, float eps, float* __restrict__ xn, int T, int C,
+                                                    int F, int J, int SP) {
+  using R = RowG<NVM>;
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= T) return;
+  float v[NVM], y[NVM], z[NVM];
+  R::load(x + (size_t)tok * C, C, lane, v);
+  if (yadd0 != nullptr) {
+    R::load(yadd0 + (size_t)tok * C, C, lane, y);
+#pragma unroll
+    for (int i = 0; i < NVM; ++i) v[i] += y[i];
+  }
+  if (yadd != nullptr) {
+    R::load(yadd + (size_t)tok * C, C, lane, y);
+#pragma unroll
+    for (int i = 0; i < NVM; ++i) v[i] += y[i];
+  }
+  R::norm(v, wa, ba, eps, C, lane, y);
+  if (pos != nullptr) {
+    const int f = min((tok % SP) / J, F - 1);
+    float pv[NVM];
+    R::load(pos + (size_t)f * C, C, lane, pv);
+#pragma unroll
+    for (int i = 0; i < NVM; ++i) y[i] += pv[i];
+  }
+  R::store(x + (size_t)tok * C, C, lane, y);
+  R::norm(y, wb, bb, eps, C, lane, z);
+  R::store(xn + (size_t)tok * C, C, lane, z);
+}
+
+template <int NVM>
+__global__ __launch_bounds__(256) void embed_ln_g_kernel(const float* __restrict__ x2d, const float* __restrict__ x3d,
+                                                         const float* __restrict__ temb, const float* __restrict__ ew,
+                                                         const float* __restrict__ eb, const float* __restrict__ spos,
+                                                         const float* __restrict__ lnw, const float* __restrict__ lnb, float eps,
+                                                         float* __restrict__ x, float* __restrict__ xn, int seq0, int n_seq, int H,
+                                                         int F, int J, int SP, int C) {
+  using R = RowG<NVM>;
+  const int lane = threadIdx.x & 63;
+  const int tl = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int FJ = F * J;
+  if (tl >= n_seq * SP) return;
+  const bool pad = (tl % SP) >= FJ;
+  const int seq = seq0 + tl / SP, fj = pad ? 0 : tl % SP, nj = fj % J;
+  const int b = seq / H;
+  const float* p2 = x2d + ((size_t)b * FJ + fj) * 2;
+  const float* p3 = x3d + ((size_t)seq * FJ + fj) * 3;
+  float in5[5] = {p2[0], p2[1], p3[0], p3[1], p3[2]};
+  if (pad) { in5[0] = in5[1] = in5[2] = in5[3] = in5[4] = 0.f; }
+  float v[NVM], y[NVM];
+#pragma unroll
+  for (int i = 0; i < NVM; ++i) {
+    const int c = i * 64 + lane;
+    float a = 0.f;
+    if (c < C) {
+      const float* wr = ew + c * 5;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) a = fmaf(in5[k], wr[k], a);
+      a += eb[c];
+      a += spos[nj * C + c];
+      a += temb[b * C + c];
+    }
+    v[i] = a;
+  }
+  R::store(x + (size_t)tl * C, C, lane, v);
+  R::norm(v, lnw, lnb, eps, C, lane, y);
+  R::store(xn + (size_t)tl * C, C, lane, y);
+}
+
+template <int NVM>
+__global__ __launch_bounds__(256) void head_g_kernel(const float* __restrict__ x, const float* __restrict__ yadd0,
+                                                     const float* __restrict__ yadd, const float* __restrict__ wa,
+                                                     const float* __restrict__ ba, float eps_a, const float* __restrict__ wh,
+                                                     const float* __restrict__ bh, float eps_h, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float* __restrict__ out, int T, int C, int FJ,
+                                                     int SP) {
+  using R = RowG<NVM>;
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= T) return;
+  float v[NVM], y[NVM], z[NVM];
+  R::load(x + (size_t)tok * C, C, lane, v);
+  if (yadd0 != nullptr) {
+    R::load(yadd0 + (size_t)tok * C, C, lane, y);
+#pragma unroll
+    for (int i = 0; i < NVM; ++i) v[i] += y[i];
+  }
+  if (yadd != nullptr) {
+    R::load(yadd + (size_t)tok * C, C, lane, y);
+#pragma unroll
+    for (int i = 0; i < NVM; ++i) v[i] += y[i];
+  }
+  R::norm(v, wa, ba, eps_a, C, lane, y);
+  R::norm(y, wh, bh, eps_h, C, lane, z);
+  float acc[3];
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    float wv[NVM];
+    R::load(w + o * C, C, lane, wv);
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < NVM; ++i) a = fmaf(z[i], wv[i], a);
+    acc[o] = wave_sum(a) + b[o];
+  }
+  const int fj = tok % SP;
+  if (lane < 3 && fj < FJ) out[((size_t)(tok / SP) * FJ + fj) * 3 + lane] = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : acc[2]);
+}
+
+// widths the instantiated kernels take; everything else goes through the *_g kernels (fp32 activations, C <= 1024)
+__host__ inline bool width_instantiated(int C) { return C == 64 || C == 128 || C == 256 || C == 512; }
+#define DISPATCH_G(C, ...)                                                  \
+  if ((C) < 1 || (C) > 1024) return -2;                                     \
+  if ((C) <= 256) { constexpr int NVM = 4; __VA_ARGS__; }                   \
+  else if ((C) <= 512) { constexpr int NVM = 8; __VA_ARGS__; }              \
+  else { constexpr int NVM = 16; __VA_ARGS__; }
+
 }  // namespace
 
 #define DISPATCH_C(C, ...)                          \
@@ -397,6 +573,11 @@ int d3dp_launch_embed_ln(int act_bf16, const float* x2d, const float* x3d, const
   const int T = n_seq * SP;
   dim3 g((T + 3) / 4), blk(256);
   const size_t plane = (size_t)T * C;
+  if (!width_instantiated(C)) {
+    if (act_bf16 != 0) return -2;
+    DISPATCH_G(C, hipLaunchKernelGGL((embed_ln_g_kernel<NVM>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (float*)xn, seq0, n_seq, H, F, J, SP, C))
+    return 0;
+  }
   DISPATCH_C(C,
     if (act_bf16 == 1) hipLaunchKernelGGL((embed_ln_kernel<CC, bf16>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, plane, seq0, n_seq, H, F, J, SP);
     else if (act_bf16 == 2) hipLaunchKernelGGL((embed_ln_kernel<CC, b3>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, plane, seq0, n_seq, H, F, J, SP);
@@ -409,6 +590,11 @@ int d3dp_launch_ln(int act_bf16, float* x, const void* yadd, int write_x, const 
                    void* xn, int T, int C, hipStream_t st) {
   dim3 g((T + 3) / 4), blk(256);
   const size_t plane = (size_t)T * C;
+  if (!width_instantiated(C)) {
+    if (act_bf16 != 0) return -2;
+    DISPATCH_G(C, hipLaunchKernelGGL((ln_g_kernel<NVM>), g, blk, 0, st, x, (const float*)yadd, w, b, eps, (float*)xn, T, C, write_x))
+    return 0;
+  }
   DISPATCH_C(C,
     if (act_bf16 == 1) hipLaunchKernelGGL((ln_kernel<CC, bf16, bf16>), g, blk, 0, st, x, (const bf16*)yadd, w, b, eps, (bf16*)xn, plane, T, write_x);
     else if (act_bf16 == 2) hipLaunchKernelGGL((ln_kernel<CC, b3, float>), g, blk, 0, st, x, (const float*)yadd, w, b, eps, (bf16*)xn, plane, T, write_x);
@@ -422,6 +608,11 @@ int d3dp_launch_ln2(int act_bf16, float* x, const void* yadd0, const void* yadd,
   if (SP <= 0) SP = F * J;
   dim3 g((T + 3) / 4), blk(256);
   const size_t plane = (size_t)T * C;
+  if (!width_instantiated(C)) {
+    if (act_bf16 != 0) return -2;
+    DISPATCH_G(C, hipLaunchKernelGGL((ln2_g_kernel<NVM>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, pos, wb, bb, eps, (float*)xn, T, C, F, J, SP))
+    return 0;
+  }
   DISPATCH_C(C,
     if (act_bf16 == 1) hipLaunchKernelGGL((ln2_kernel<CC, bf16, bf16>), g, blk, 0, st, x, (const bf16*)yadd0, (const bf16*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, plane, T, F, J, SP);
     else if (act_bf16 == 2) hipLaunchKernelGGL((ln2_kernel<CC, b3, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, pos, wb, bb, eps, (bf16*)xn, plane, T, F, J, SP);
@@ -435,6 +626,11 @@ int d3dp_launch_head(int act_bf16, const float* x, const void* yadd0, const void
                      hipStream_t st, int FJ, int SP) {
   if (FJ <= 0 || SP <= 0) { FJ = SP = 1 << 30; }       // compact rows: out row = input row
   dim3 g((T + 3) / 4), blk(256);
+  if (!width_instantiated(C)) {
+    if (act_bf16 != 0) return -2;
+    DISPATCH_G(C, hipLaunchKernelGGL((head_g_kernel<NVM>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T, C, FJ, SP))
+    return 0;
+  }
   DISPATCH_C(C,
     if (act_bf16 == 1) hipLaunchKernelGGL((head_kernel<CC, bf16>), g, blk, 0, st, x, (const bf16*)yadd0, (const bf16*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T, FJ, SP);
     else hipLaunchKernelGGL((head_kernel<CC, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T, FJ, SP))

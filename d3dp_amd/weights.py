@@ -33,11 +33,11 @@ def block_param_shapes(cs: int) -> "OrderedDict[str, tuple]":
     ])
 
 
-def param_shapes(cs: int, dep: int, frames: int) -> "OrderedDict[str, tuple]":
+def param_shapes(cs: int, dep: int, frames: int, joints: int = NUM_JOINTS) -> "OrderedDict[str, tuple]":
     """Ordered {name: shape} of every MixSTE2 parameter (names relative to the
-    ``pose_estimator.`` prefix)."""
+    ``pose_estimator.`` prefix).  ``joints``: MixSTE2's ``num_joints`` (mixste.py:141; D3DP itself builds 17)."""
     out: "OrderedDict[str, tuple]" = OrderedDict()
-    out["Spatial_pos_embed"] = (1, NUM_JOINTS, cs)
+    out["Spatial_pos_embed"] = (1, joints, cs)
     out["Temporal_pos_embed"] = (1, frames, cs)
     out["Spatial_patch_to_embedding.weight"] = (cs, IN_CHANS)
     out["Spatial_patch_to_embedding.bias"] = (cs,)
@@ -65,10 +65,10 @@ def _is_norm(name: str) -> bool:
             or name.startswith("Temporal_norm") or name.startswith("head.0."))
 
 
-def make_numpy_weights(seed: int, cs: int, dep: int, frames: int) -> "OrderedDict[str, np.ndarray]":
+def make_numpy_weights(seed: int, cs: int, dep: int, frames: int, joints: int = NUM_JOINTS) -> "OrderedDict[str, np.ndarray]":
     """fp32 numpy arrays keyed by the reference parameter names (no prefix)."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    shapes = param_shapes(cs, dep, frames)
+    shapes = param_shapes(cs, dep, frames, joints)
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     fan_in_of_bias = {}
     for name, shp in shapes.items():
@@ -88,13 +88,13 @@ def make_numpy_weights(seed: int, cs: int, dep: int, frames: int) -> "OrderedDic
     return out
 
 
-def make_state_dict(seed: int, cs: int, dep: int, frames: int, prefix: str = "pose_estimator."):
+def make_state_dict(seed: int, cs: int, dep: int, frames: int, prefix: str = "pose_estimator.", joints: int = NUM_JOINTS):
     """torch fp32 tensors keyed ``pose_estimator.<name>`` (loadable with
     ``D3DP.load_state_dict(..., strict=False)``; the 12 fp64 diffusion buffers are
     rebuilt by the constructor)."""
     import torch
     return OrderedDict((prefix + k, torch.from_numpy(v.copy()))
-                       for k, v in make_numpy_weights(seed, cs, dep, frames).items())
+                       for k, v in make_numpy_weights(seed, cs, dep, frames, joints).items())
 
 
 def synthetic_inputs_2d(seed: int, batch: int, frames: int):
