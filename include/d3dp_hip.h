@@ -117,9 +117,19 @@ D3DP_API int d3dp_abi_version(void);
 D3DP_API const char* d3dp_last_error(void);
 
 /* Lifetime.  Replaces: MixSTE2.__init__ (mixste.py:142-210) + .cuda() (main.py:243).
- * Shapes: 1 <= frames <= 1024 (the split-fp16 / bf16 MFMA attention kernels hold a sequence of up to 256 frames; longer
- * clips -- `-f 351`, common/arguments.py:58 -- run both attentions on a chunked fp32 row kernel; d3dp_train_* needs <= 256),
- * joints <= 32, channels in {64, 128, 256, 512}, head dim in {8, 16, 32, 64}, hidden % 64 == 0 (D3DP_ENOTSUP otherwise). */
+ * Shapes (D3DP_ENOTSUP outside them, with the reason in d3dp_last_error):
+ *   1 <= frames <= 1024   up to 256 frames the MFMA attention kernels hold a whole sequence; longer clips (`-f 351`,
+ *                         common/arguments.py:58) take chunked-key forms of the same kernels (EXACT, TRAIN) or the row kernel (FAST);
+ *   1 <= joints <= 256    MixSTE2's num_joints (mixste.py:141; D3DP builds 17): above 32 the spatial axis runs on the
+ *                         whole-sequence attention kernels of the temporal axis;
+ *   channels in {64, 128, 256, 512} with head dim in {8, 16, 32, 64} and hidden % 64 == 0: every mode, on the matrix-core
+ *                         kernels (split-fp16 / bf16 operands) -- `-cs 512`, the width of every published checkpoint
+ *                         (README.md:33-39), and its smaller powers of two;
+ *   any other width the reference's 8 heads divide (common/arguments.py:49, mixste.py:46-62) with channels <= 1024,
+ *                         head dim % 4 == 0 and <= 128, hidden % 4 == 0: D3DP_MODE_EXACT only, on the fp32 implementation
+ *                         (fp32-MFMA Linears, fp32 row attention, run-time-width row kernels; d3dp_exact_scales reports
+ *                         implementation 2): the same 1e-3 mm tolerance at roughly a fifth of the throughput.  FAST and TRAIN
+ *                         contexts exist for the instantiated widths only. */
 D3DP_API int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out);
 D3DP_API int d3dp_destroy(d3dp_ctx* ctx);
 /* Replaces: load_state_dict (main.py:257).  Converts/packs weights for cfg.mode (synchronises `stream`).

@@ -115,6 +115,36 @@ def test_fails_loudly_without_gpu(lib):
         m.pose_estimator(torch.zeros(1, 9, 17, 2), torch.zeros(1, 1, 9, 17, 3), torch.zeros(1, dtype=torch.long))
 
 
+def test_create_validates_widths_and_joints_before_it_looks_for_a_device(lib):
+    """d3dp_create checks the shape first (no GPU needed to see the verdict): the instantiated widths in every mode, any other
+    width the reference's 8 heads divide (head dim % 4 == 0, <= 1024 channels) in EXACT mode only, up to 256 joints -- and a
+    refusal names its reason (D3DP_ENOTSUP = -2); a shape the library takes gets as far as the device check (-3 here)."""
+    import ctypes as C
+
+    def create(frames, joints, cs, heads, hidden, mode):
+        cfg = _lib.Cfg(frames, joints, cs, 8, heads, hidden, 1e-6, 1e-5, mode, 0)   # (frames, joints, channels, depth, heads, hidden, ...)
+        h = C.c_void_p()
+        return lib.d3dp_create(C.byref(cfg), C.byref(h)), lib.d3dp_last_error().decode()
+
+    for mode in (_lib.MODE_EXACT, _lib.MODE_FAST, _lib.MODE_TRAIN):
+        for cs in (64, 128, 256, 512):
+            assert create(27, 17, cs, 8, 2 * cs, mode)[0] == -3
+        assert create(27, 40, 512, 8, 1024, mode)[0] == -3              # more than 32 joints
+        assert create(27, 256, 512, 8, 1024, mode)[0] == -3
+    for cs in (32, 96, 224, 384, 768, 1024):                            # other widths: EXACT (fp32 implementation) only
+        assert create(27, 17, cs, 8, 2 * cs, _lib.MODE_EXACT)[0] == -3
+        for mode in (_lib.MODE_FAST, _lib.MODE_TRAIN):
+            rc, msg = create(27, 17, cs, 8, 2 * cs, mode)
+            assert rc == -2 and "FAST and TRAIN contexts exist" in msg, msg
+    for args, needle in (((27, 17, 200, 8, 400, _lib.MODE_EXACT), "head dim a multiple of 4"),
+                         ((27, 17, 2048, 8, 4096, _lib.MODE_EXACT), "channels <= 1024"),
+                         ((27, 257, 512, 8, 1024, _lib.MODE_EXACT), "joints=257 not in [1,256]"),
+                         ((1025, 17, 512, 8, 1024, _lib.MODE_EXACT), "frames=1025")):
+        rc, msg = create(*args)
+        assert rc == -2 and needle in msg, msg
+    assert create(27, 17, 512, 7, 1024, _lib.MODE_EXACT)[0] == -1       # heads must divide channels: D3DP_EINVAL
+
+
 def test_product_code_never_imports_the_oracle():
     for root, _, files in os.walk(os.path.join(REPO, "d3dp_amd")):
         for f in files:
