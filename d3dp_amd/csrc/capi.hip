@@ -421,17 +421,25 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   // mixste.py:46-62): such a width runs EXACT mode on the fp32 implementation -- fp32-MFMA Linears (gemm_f32_kernel), the fp32
   // row attention with a run-time head dim, run-time-width row kernels (pointwise.hip *_g_kernel) -- i.e. the cross-check
   // implementation D3DP_EXACT_IMPL=f32 selects by hand for the instantiated widths: same tolerance, roughly a fifth of the
-  // throughput.  FAST and TRAIN contexts exist for the instantiated widths only.
+  // throughput.  A TRAIN context of such a width (the reference trains at any `-cs` too: main.py:325) takes the fp32 path of the
+  // training step -- what D3DP_TRAIN_IMPL=f32 selects for the instantiated widths -- through the run-time-width row kernels of
+  // train_g.hip and the VALU attention backward with a run-time head dim.  FAST contexts exist for the instantiated widths only.
   const bool width_inst = (g.channels == 64 || g.channels == 128 || g.channels == 256 || g.channels == 512) &&
                           (hd == 8 || hd == 16 || hd == 32 || hd == 64) && g.hidden >= 64 && g.hidden % 64 == 0;
   if (!width_inst) {
-    if (g.mode != D3DP_MODE_EXACT)
-      return fail(D3DP_ENOTSUP, "channels=%d heads=%d hidden=%d: FAST and TRAIN contexts exist for channels in {64,128,256,512} with head dim in "
-                                "{8,16,32,64} and hidden a multiple of 64; other widths run in D3DP_MODE_EXACT (fp32 implementation)",
+    if (g.mode == D3DP_MODE_FAST)
+      return fail(D3DP_ENOTSUP, "channels=%d heads=%d hidden=%d: FAST contexts exist for channels in {64,128,256,512} with head dim in "
+                                "{8,16,32,64} and hidden a multiple of 64; other widths run in D3DP_MODE_EXACT / D3DP_MODE_TRAIN (fp32 implementation)",
                   g.channels, g.heads, g.hidden);
     if (g.channels > 1024 || g.channels % 4 || hd % 4 || hd > 128 || g.hidden < 4 || g.hidden % 4)
       return fail(D3DP_ENOTSUP, "channels=%d heads=%d hidden=%d: the fp32 implementation takes channels <= 1024, head dim a multiple of 4 up to 128 "
                                 "and hidden a multiple of 4", g.channels, g.heads, g.hidden);
+    // (the fp32 attention backward holds two whole-sequence images of its capacity head dim + the statistics in the CU's 160 KiB)
+    const int nmax = std::max(g.frames, g.joints), cap = hd <= 16 ? 16 : hd <= 32 ? 32 : hd <= 64 ? 64 : 128;
+    if (g.mode == D3DP_MODE_TRAIN && (nmax > 256 || (size_t)nmax * (8 * (cap + 4) + 12) > 160 * 1024))
+      return fail(D3DP_ENOTSUP, "channels=%d heads=%d frames=%d joints=%d: training at a width outside {64,128,256,512} runs the fp32 attention "
+                                "backward, which holds a whole sequence in LDS (<= 256 tokens; <= 153 at head dims above 64)",
+                  g.channels, g.heads, g.frames, g.joints);
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -452,7 +460,7 @@ int d3dp_create(const d3dp_cfg* cfg, d3dp_ctx** out) {
   const char* nf = getenv("D3DP_NO_FOLD");               // cross-check: residual adds (and norm2) in the row kernels
   c->fold = !(nf && nf[0] == '1');
   const char* ti = getenv("D3DP_TRAIN_IMPL");
-  c->train_x2 = !(ti && !strcmp(ti, "f32"));
+  c->train_x2 = !(ti && !strcmp(ti, "f32")) && width_inst;     // (a width outside the instantiated set: the fp32 path)
   const char* ov = getenv("D3DP_TRAIN_OVERLAP");
   c->train_overlap = !(ov && ov[0] == '0');
   c->train_overlap_sets = (ov && ov[0] == '1') ? 1 : 2;
@@ -1734,8 +1742,9 @@ int d3dp_train_backward(d3dp_ctx* c, const float* x2d, const float* x3d, const i
       if ((r = d3dp_train_transpose_pad(X, Xt, T, K, Tp, st))) return r;
     }
     Scope ps_(pc, T_WGRAD, st);
-    if (hipMemsetAsync(dW, 0, (size_t)N * K * 4, st) != hipSuccess) return -3;
-    return d3dp_launch_linear_f32_splitk(At, Xt, dW, N, K, Tp, st);       // contraction over tokens: split-K
+    // contraction over tokens: split-K, the chunks' partial products added in a fixed order (no float atomics: this path's gradients
+    // are bit-reproducible too)
+    return d3dp_launch_linear_f32_splitk(At, Xt, dW, N, K, Tp, st, ws + L.part, (size_t)(1024 + 64) * 256 * 128);
   };
   // dgrad: dX[T, K] = dY[T, N] W[N, K]   (W transposed to [K, N])
   auto dgrad = [&](int l, const float* dY, int N, const float* W, int K, float* dX, unsigned* out_amax = nullptr) -> int {

@@ -37,11 +37,7 @@ __device__ __forceinline__ void epilogue4(const float* v, const float* __restric
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = gelu_erf(r[i]);
   }
-  if constexpr (EPI == EPI_ATOMIC) {
-    float* o = reinterpret_cast<float*>(out) + row_off + n;     // split-K partial sums (out pre-zeroed by the caller)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) atomicAdd(o + i, r[i]);
-  } else if constexpr (EPI == EPI_RESID) {
+  if constexpr (EPI == EPI_RESID) {
     float* o = reinterpret_cast<float*>(out) + row_off + n;
     float4 x = *reinterpret_cast<float4*>(o);
     x.x += r[0]; x.y += r[1]; x.z += r[2]; x.w += r[3];
@@ -159,7 +155,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         const int n = n0 + wc * 64 + ni * 32 + q * 8 + lh * 4;
         if (n >= N) continue;
         float v[4] = {acc[mi][ni][q * 4 + 0], acc[mi][ni][q * 4 + 1], acc[mi][ni][q * 4 + 2], acc[mi][ni][q * 4 + 3]};
-        epilogue4<EPI, float>(v, (EPI == EPI_ATOMIC && blockIdx.y != 0) ? nullptr : bias, out, (size_t)m * N, n);
+        // EPI_PARTIAL: split-K chunk blockIdx.y leaves ITS product as out[blockIdx.y][M][N]; the caller adds the chunks in order
+        // (round 6: the split-K form added them with fp32 atomics -- the last float atomics of the library)
+        if constexpr (EPI == EPI_PARTIAL) epilogue4<EPI_BIAS, float>(v, nullptr, out + (size_t)blockIdx.y * M * N, (size_t)m * N, n);
+        else epilogue4<EPI, float>(v, bias, out, (size_t)m * N, n);
       }
   }
 }
@@ -182,18 +181,22 @@ int d3dp_launch_linear_f32(int epi, const float* A, const float* W, const float*
   return 0;
 }
 
-// split-K form for tall contractions (wgrad: K = tokens): `out` must be zeroed by the caller; partial products are
-// accumulated with fp32 atomics (summation order not fixed: last-bit run-to-run variation, fine for gradients).
-int d3dp_launch_linear_f32_splitk(const float* A, const float* W, float* out, int M, int N, int K, hipStream_t st) {
-  if (K < 4 || K % 4 != 0 || N % 4 != 0 || M <= 0) return -1;
+// split-K form for tall contractions (wgrad: K = tokens): the k-steps are cut into ~ (CUs / output tiles) chunks, every chunk leaves
+// its partial product in `part` ([chunks][M][N] floats, part_floats of room) and d3dp_launch_sum_partials adds them in chunk order
+// into `out`: a fixed summation order, bit-reproducible (through round 5 the chunks were added with fp32 atomics).
+int d3dp_launch_linear_f32_splitk(const float* A, const float* W, float* out, int M, int N, int K, hipStream_t st, float* part,
+                                  size_t part_floats) {
+  if (K < 4 || K % 4 != 0 || N % 4 != 0 || M <= 0 || !part) return -1;
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
   const int nk = (K + XBK - 1) / XBK;
-  const int target = 256;                                         // workgroups aimed at: ~1 per CU measured best (88 ms/step vs 103 at 4 per CU: fewer fp32 atomics)
+  const int target = 256;                                         // workgroups aimed at: ~1 per CU
   int splits = (target + tm * tn - 1) / (tm * tn);
   if (splits > nk / 8) splits = nk / 8 > 0 ? nk / 8 : 1;
   const int per = (nk + splits - 1) / splits;
-  hipLaunchKernelGGL((gemm_f32_kernel<EPI_ATOMIC>), dim3(tm * tn, (nk + per - 1) / per), dim3(256), 0, st, A, W, nullptr,
-                     out, M, N, K, tn, per);
+  const int chunks = (nk + per - 1) / per;                        // (every chunk owns at least one k-step: every partial is written)
+  if ((size_t)chunks * M * N > part_floats) return -1;
+  hipLaunchKernelGGL((gemm_f32_kernel<EPI_PARTIAL>), dim3(tm * tn, chunks), dim3(256), 0, st, A, W, nullptr, part, M, N, K, tn, per);
+  d3dp_launch_sum_partials(part, out, (size_t)M * N, chunks, st);
   return 0;
 }
 

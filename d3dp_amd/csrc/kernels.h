@@ -36,7 +36,7 @@ inline int d3dp_lds_opt_in(const void* kern, int bytes) {
   return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 1 : -3;
 }
 
-enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_ATOMIC = 3, EPI_QKV_PACK = 4, EPI_RESID_LN = 5, EPI_GELU_LN = 6 };
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_PARTIAL = 3, EPI_QKV_PACK = 4, EPI_RESID_LN = 5, EPI_GELU_LN = 6 };
 
 // ---- gemm.hip ----------------------------------------------------------------------------------
 int d3dp_launch_linear_bf16_stream(int epi, int out_f32, const void* A, const void* W, const float* bias, void* out,
@@ -144,7 +144,8 @@ void d3dp_launch_sum_partials_bias(const float* part, const float* bias, float* 
 void d3dp_launch_absmax(const float* src, size_t n, unsigned* out, hipStream_t st);
 // flag[0] |= 1 if any of x[0..n) is inf / nan
 void d3dp_launch_nonfinite_flag(const float* x, size_t n, unsigned* flag, hipStream_t st);
-int d3dp_launch_linear_f32_splitk(const float* A, const float* W, float* out, int M, int N, int K, hipStream_t st);
+int d3dp_launch_linear_f32_splitk(const float* A, const float* W, float* out, int M, int N, int K, hipStream_t st, float* part,
+                                  size_t part_floats);
 int d3dp_launch_linear_f32(int epi, const float* A, const float* W, const float* bias, float* out, int M, int N,
                            int K, hipStream_t st);
 
@@ -279,3 +280,20 @@ int d3dp_train_time_mlp(const int64_t* t, const float* freq, const float* w1, co
 int d3dp_train_time_mlp_bwd(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2,
                             const float* dtemb, float* dw1, float* db1, float* dw2, float* db2, int B, int C,
                             hipStream_t st);
+
+// train_g.hip: the training step's row kernels at a run-time width (any C <= 1024; the fp32 path of capi.hip for the widths
+// train.hip does not instantiate).  The d3dp_train_* launchers above forward to these when d3dp_width_instantiated(C) is false.
+inline bool d3dp_width_instantiated(int C) { return C == 64 || C == 128 || C == 256 || C == 512; }
+int d3dp_train_g_add_mask_ln(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* w,
+                             const float* b, float eps, float* x_out, float* xn, int T, int C, hipStream_t st);
+int d3dp_train_g_add_mask_ln2(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* wa,
+                              const float* ba, float eps_a, const float* pos, const float* wb, const float* bb, float eps_b,
+                              float* x_out, float* x_next, float* xn, int T, int C, hipStream_t st);
+int d3dp_train_g_ln_pos(const float* x, const float* w, const float* b, float eps, const float* pos, int F, int J, float* y, int T,
+                        int C, hipStream_t st);
+int d3dp_train_g_ln_bwd(const float* dy, const float* xb, const float* wb, float eps_b, const float* dres, float* g_out,
+                        const float* xa, const float* wa, float eps_a, float* dx, const float* mask, int axis, int F, int J,
+                        float* dxm, float* part_b, float* part_a, int T, int C, int blocks, hipStream_t st);
+int d3dp_train_g_head_linear(const float* z, const float* w, const float* b, float* out, int T, int C, hipStream_t st);
+int d3dp_train_g_time_mlp_bwd(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2,
+                              const float* dtemb, float* dw1, float* db1, float* dw2, float* db2, int B, int C, hipStream_t st);

@@ -525,10 +525,14 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const float* __restr
 // Pass 2 (thread per key row; Q, dO in LDS, m/l/D from pass 1): dK_j, dV_j.
 struct AttnStats { float m, l, D; };
 
-template <int HD>
+// GEN (round 6: a head dim outside {8, 16, 32, 64}, i.e. a width train.hip does not instantiate): HD is the register / LDS
+// capacity, the head dim itself the run-time hd_rt (a multiple of 4, <= HD); everything behind it is zero in q, k, v, dO and is
+// not stored.
+template <int HD, bool GEN = false>
 __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                          const float* __restrict__ dout, float* __restrict__ dqkv,
-                                                         AttnStats* __restrict__ stats, SeqMap map, int C, int heads) {
+                                                         AttnStats* __restrict__ stats, SeqMap map, int C, int heads, int hd_rt) {
+  const int hd = GEN ? hd_rt : HD;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* Ks = reinterpret_cast<float*>(smem_raw);
   const int n = map.n_tok;
@@ -538,9 +542,10 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const float* __restrict
   const int base = (seq / map.inner) * map.outer_stride + (seq % map.inner) * map.inner_stride;
   for (int u = threadIdx.x; u < n * (HD / 4); u += blockDim.x) {
     const int j = u / (HD / 4), c = u % (HD / 4);
-    const float* src = qkv + (size_t)(base + j * map.tok_stride) * 3 * C + C + head * HD + c * 4;
-    *reinterpret_cast<float4*>(Ks + j * LDR + c * 4) = *reinterpret_cast<const float4*>(src);
-    *reinterpret_cast<float4*>(Vs + j * LDR + c * 4) = *reinterpret_cast<const float4*>(src + C);
+    const float* src = qkv + (size_t)(base + j * map.tok_stride) * 3 * C + C + head * hd + c * 4;
+    const bool in = !GEN || c * 4 < hd;
+    *reinterpret_cast<float4*>(Ks + j * LDR + c * 4) = in ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(Vs + j * LDR + c * 4) = in ? *reinterpret_cast<const float4*>(src + C) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
   // two threads (adjacent lanes) per query row, each owning half of the head dimension: q, dO, dQ halves stay in
@@ -550,14 +555,15 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const float* __restrict
   const int ii = live ? i : n - 1;
   constexpr int HH = HD / 2;
   const size_t tok = (size_t)(base + ii * map.tok_stride);
-  const float scale = 1.0f / sqrtf((float)HD);
+  const float scale = 1.0f / sqrtf((float)hd);
   float q[HH], dO[HH], dq[HH];
   float D = 0.f;
 #pragma unroll
   for (int d = 0; d < HH; ++d) {
-    q[d] = qkv[tok * 3 * C + head * HD + half * HH + d];
-    dO[d] = dout[tok * C + head * HD + half * HH + d];
-    D = fmaf(dO[d], o[tok * C + head * HD + half * HH + d], D);
+    const bool in = !GEN || half * HH + d < hd;
+    q[d] = in ? qkv[tok * 3 * C + head * hd + half * HH + d] : 0.f;
+    dO[d] = in ? dout[tok * C + head * hd + half * HH + d] : 0.f;
+    D = fmaf(dO[d], in ? o[tok * C + head * hd + half * HH + d] : 0.f, D);
     dq[d] = 0.f;
   }
   D += __shfl_xor(D, 1, 64);
@@ -629,14 +635,16 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(const float* __restrict
   }
   if (!live) return;
 #pragma unroll
-  for (int d = 0; d < HH; ++d) dqkv[tok * 3 * C + head * HD + half * HH + d] = dq[d];
+  for (int d = 0; d < HH; ++d)
+    if (!GEN || half * HH + d < hd) dqkv[tok * 3 * C + head * hd + half * HH + d] = dq[d];
   if (half == 0) stats[(size_t)blockIdx.x * n + i] = AttnStats{m, l, D};
 }
 
-template <int HD>
+template <int HD, bool GEN = false>
 __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                           float* __restrict__ dqkv, const AttnStats* __restrict__ stats,
-                                                          SeqMap map, int C, int heads) {
+                                                          SeqMap map, int C, int heads, int hd_rt) {
+  const int hd = GEN ? hd_rt : HD;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* Qs = reinterpret_cast<float*>(smem_raw);
   const int n = map.n_tok;
@@ -648,10 +656,11 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const float* __restric
   for (int u = threadIdx.x; u < n * (HD / 4); u += blockDim.x) {
     const int i = u / (HD / 4), c = u % (HD / 4);
     const size_t tok = (size_t)(base + i * map.tok_stride);
+    const bool in = !GEN || c * 4 < hd;
     *reinterpret_cast<float4*>(Qs + i * LDR + c * 4) =
-        *reinterpret_cast<const float4*>(qkv + tok * 3 * C + head * HD + c * 4);
+        in ? *reinterpret_cast<const float4*>(qkv + tok * 3 * C + head * hd + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     *reinterpret_cast<float4*>(Os + i * LDR + c * 4) =
-        *reinterpret_cast<const float4*>(dout + tok * C + head * HD + c * 4);
+        in ? *reinterpret_cast<const float4*>(dout + tok * C + head * hd + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int i = threadIdx.x; i < n; i += blockDim.x) st[i] = stats[(size_t)blockIdx.x * n + i];
   __syncthreads();
@@ -662,12 +671,13 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const float* __restric
   const int jj = live ? j : n - 1;
   constexpr int HH = HD / 2;
   const size_t tok = (size_t)(base + jj * map.tok_stride);
-  const float scale = 1.0f / sqrtf((float)HD);
+  const float scale = 1.0f / sqrtf((float)hd);
   float k[HH], v[HH], dk[HH], dv[HH];
 #pragma unroll
   for (int d = 0; d < HH; ++d) {
-    k[d] = qkv[tok * 3 * C + C + head * HD + half * HH + d];
-    v[d] = qkv[tok * 3 * C + 2 * C + head * HD + half * HH + d];
+    const bool in = !GEN || half * HH + d < hd;
+    k[d] = in ? qkv[tok * 3 * C + C + head * hd + half * HH + d] : 0.f;
+    v[d] = in ? qkv[tok * 3 * C + 2 * C + head * hd + half * HH + d] : 0.f;
     dk[d] = 0.f; dv[d] = 0.f;
   }
   const float* Qh = Qs + half * HH;
@@ -716,8 +726,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(const float* __restric
   if (!live) return;
 #pragma unroll
   for (int d = 0; d < HH; ++d) {
-    dqkv[tok * 3 * C + C + head * HD + half * HH + d] = dk[d];
-    dqkv[tok * 3 * C + 2 * C + head * HD + half * HH + d] = dv[d];
+    if (GEN && half * HH + d >= hd) continue;
+    dqkv[tok * 3 * C + C + head * hd + half * HH + d] = dk[d];
+    dqkv[tok * 3 * C + 2 * C + head * hd + half * HH + d] = dv[d];
   }
 }
 
@@ -909,6 +920,8 @@ static int row_blocks(int T) { return (T + 3) / 4 < kRowBlocks ? (T + 3) / 4 : k
 int d3dp_train_add_mask_ln(const float* x_in, const float* y, const float* mask, int axis, int F, int J, const float* w,
                            const float* b, float eps, float* x_out, float* xn, unsigned* amax, int T, int C, hipStream_t st,
                            void* op, int Tp, float* op_unscale) {
+  if (!d3dp_width_instantiated(C))                     // (the fp32 path: no operand rows, no absmax)
+    return (op || amax) ? -2 : d3dp_train_g_add_mask_ln(x_in, y, mask, axis, F, J, w, b, eps, x_out, xn, T, C, st);
   if (!w || !b || (!xn && !amax && !op) || (op && (C % 256 != 0 || Tp < T || !op_unscale))) return -1;
   TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((add_mask_ln_kernel<CC>), dim3(row_blocks(T)), dim3(256), 0, st, x_in, y, mask, axis,
                                          F, J, w, b, eps, x_out, xn, amax, T, (f16*)op, Tp, op_unscale))
@@ -918,6 +931,8 @@ int d3dp_train_add_mask_ln2(const float* x_in, const float* y, const float* mask
                             const float* ba, float eps_a, const float* pos, const float* wb, const float* bb, float eps_b,
                             float* x_out, float* x_next, float* xn, unsigned* amax, int T, int C, hipStream_t st, void* op, int Tp,
                             float* op_unscale) {
+  if (!d3dp_width_instantiated(C))
+    return (op || amax) ? -2 : d3dp_train_g_add_mask_ln2(x_in, y, mask, axis, F, J, wa, ba, eps_a, pos, wb, bb, eps_b, x_out, x_next, xn, T, C, st);
   if (!wa || !ba || !x_out || !x_next || (xn && !wb) || (wb && !bb) || (op && (C % 256 != 0 || Tp < T || !op_unscale || !wb))) return -1;
   TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((add_mask_ln2_kernel<CC>), dim3(row_blocks(T)), dim3(256), 0, st, x_in, y, mask, axis,
                                          F, J, wa, ba, eps_a, pos, wb, bb, eps_b, x_out, x_next, xn, amax, T, (f16*)op, Tp, op_unscale))
@@ -925,6 +940,7 @@ int d3dp_train_add_mask_ln2(const float* x_in, const float* y, const float* mask
 }
 int d3dp_train_ln_pos(const float* x, const float* w, const float* b, float eps, const float* pos, int F, int J, float* y,
                       int T, int C, hipStream_t st) {
+  if (!d3dp_width_instantiated(C)) return d3dp_train_g_ln_pos(x, w, b, eps, pos, F, J, y, T, C, st);
   TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((ln_pos_kernel<CC>), dim3(row_blocks(T)), dim3(256), 0, st, x, w, b, eps, pos, F, J,
                                          y, T))
   return 0;
@@ -936,6 +952,8 @@ int d3dp_train_ln_bwd(const float* dy, const float* xb, const float* wb, float e
                       float* dxm, unsigned* amax, float* part_b, float* part_a, int T, int C, hipStream_t st) {
   if (!dy || !xb || !wb || !dx || !part_b || (xa && (!wa || !part_a))) return -1;
   const int blocks = d3dp_train_ln_bwd_blocks(T);
+  if (!d3dp_width_instantiated(C))
+    return amax ? -2 : d3dp_train_g_ln_bwd(dy, xb, wb, eps_b, dres, g_out, xa, wa, eps_a, dx, mask, axis, F, J, dxm, part_b, part_a, T, C, blocks, st);
   if (xa) {
     TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd2_kernel<CC, true>), dim3(blocks), dim3(256), 0, st, dy, xb, wb, eps_b, dres,
                                            g_out, xa, wa, eps_a, dx, mask, axis, F, J, dxm, amax, part_b, part_a, T))
@@ -1238,11 +1256,11 @@ static int launch_attn_bwd_mfma(const float* qkv, const float* o, const float* d
   return 0;
 }
 
-template <int HD>
+template <int HD, bool GEN = false>
 static int launch_attn_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, void* stats, int n_seq,
                            SeqMap map, int C, int heads, hipStream_t st) {
   const int n = map.n_tok;
-  if constexpr (HD == 64) {
+  if constexpr (HD == 64 && !GEN) {
     // head dim 64 on the fp32 matrix cores; D3DP_TRAIN_ATTN_BWD=valu keeps the kernels below (cross-check)
     const char* e = getenv("D3DP_TRAIN_ATTN_BWD");     // (read per call: the tests switch it between two steps)
     const bool valu = e && e[0] == 'v';
@@ -1258,14 +1276,14 @@ static int launch_attn_bwd(const float* qkv, const float* o, const float* dout, 
   if (lds_kv > 160 * 1024 || n > 256) return -2;
   static PerDeviceOnce once;
   if (once.get([&](int) {
-        return d3dp_lds_opt_in(reinterpret_cast<const void*>(attn_bwd_q_kernel<HD>), 160 * 1024) < 0 ? -3
-               : d3dp_lds_opt_in(reinterpret_cast<const void*>(attn_bwd_kv_kernel<HD>), 160 * 1024);
+        return d3dp_lds_opt_in(reinterpret_cast<const void*>(attn_bwd_q_kernel<HD, GEN>), 160 * 1024) < 0 ? -3
+               : d3dp_lds_opt_in(reinterpret_cast<const void*>(attn_bwd_kv_kernel<HD, GEN>), 160 * 1024);
       }) < 0) return -3;
   const int tkv = 2 * n <= 64 ? 64 : (2 * n <= 256 ? 256 : 512), tq = tkv;       // two threads per row in both passes
-  hipLaunchKernelGGL((attn_bwd_q_kernel<HD>), dim3(n_seq * heads), dim3(tq), lds_q, st, qkv, o, dout, dqkv,
-                     (AttnStats*)stats, map, C, heads);
-  hipLaunchKernelGGL((attn_bwd_kv_kernel<HD>), dim3(n_seq * heads), dim3(tkv), lds_kv, st, qkv, dout, dqkv,
-                     (const AttnStats*)stats, map, C, heads);
+  hipLaunchKernelGGL((attn_bwd_q_kernel<HD, GEN>), dim3(n_seq * heads), dim3(tq), lds_q, st, qkv, o, dout, dqkv,
+                     (AttnStats*)stats, map, C, heads, C / heads);
+  hipLaunchKernelGGL((attn_bwd_kv_kernel<HD, GEN>), dim3(n_seq * heads), dim3(tkv), lds_kv, st, qkv, dout, dqkv,
+                     (const AttnStats*)stats, map, C, heads, C / heads);
   return 0;
 }
 
@@ -1276,8 +1294,15 @@ int d3dp_train_attn_bwd(const float* qkv, const float* o, const float* dout, flo
     case 32: return launch_attn_bwd<32>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
     case 16: return launch_attn_bwd<16>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
     case 8: return launch_attn_bwd<8>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
-    default: return -2;
+    default: break;
   }
+  // any other head dim (a multiple of 4 up to 128): the run-time form on the next capacity
+  const int hd = C / heads;
+  if (hd < 4 || hd % 4 || hd > 128 || hd * heads != C) return -2;
+  if (hd <= 16) return launch_attn_bwd<16, true>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
+  if (hd <= 32) return launch_attn_bwd<32, true>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
+  if (hd <= 64) return launch_attn_bwd<64, true>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
+  return launch_attn_bwd<128, true>(qkv, o, dout, dqkv, stats, n_seq, map, C, heads, st);
 }
 // part: D3DP_EMBED_BWD_ROWS partial tables of 5 C floats
 int d3dp_train_embed_bwd(const float* dx, const float* x2d, const float* x3d, float* part, int T, int C, hipStream_t st) {
@@ -1285,6 +1310,7 @@ int d3dp_train_embed_bwd(const float* dx, const float* x2d, const float* x3d, fl
   return 0;
 }
 int d3dp_train_head_linear(const float* z, const float* w, const float* b, float* out, int T, int C, hipStream_t st) {
+  if (!d3dp_width_instantiated(C)) return d3dp_train_g_head_linear(z, w, b, out, T, C, st);
   TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((head_linear_kernel<CC>), dim3((T + 3) / 4), dim3(256), 0, st, z, w, b, out, T))
   return 0;
 }
@@ -1307,6 +1333,7 @@ int d3dp_train_time_mlp(const int64_t* t, const float* freq, const float* w1, co
 int d3dp_train_time_mlp_bwd(const int64_t* t, const float* freq, const float* w1, const float* b1, const float* w2,
                             const float* dtemb, float* dw1, float* db1, float* dw2, float* db2, int B, int C,
                             hipStream_t st) {
+  if (!d3dp_width_instantiated(C)) return d3dp_train_g_time_mlp_bwd(t, freq, w1, b1, w2, dtemb, dw1, db1, dw2, db2, B, C, st);
   TRAIN_DISPATCH_C(C, hipLaunchKernelGGL((time_mlp_bwd_kernel<CC>), dim3((2 * C + 3) / 4), dim3(256), 0, st, t, freq, w1, b1,
                                          w2, dtemb, dw1, db1, dw2, db2, B))
   return 0;

@@ -117,7 +117,7 @@ def test_fails_loudly_without_gpu(lib):
 
 def test_create_validates_widths_and_joints_before_it_looks_for_a_device(lib):
     """d3dp_create checks the shape first (no GPU needed to see the verdict): the instantiated widths in every mode, any other
-    width the reference's 8 heads divide (head dim % 4 == 0, <= 1024 channels) in EXACT mode only, up to 256 joints -- and a
+    width the reference's 8 heads divide (head dim % 4 == 0, <= 1024 channels) in EXACT and TRAIN mode, up to 256 joints -- and a
     refusal names its reason (D3DP_ENOTSUP = -2); a shape the library takes gets as far as the device check (-3 here)."""
     import ctypes as C
 
@@ -131,11 +131,14 @@ def test_create_validates_widths_and_joints_before_it_looks_for_a_device(lib):
             assert create(27, 17, cs, 8, 2 * cs, mode)[0] == -3
         assert create(27, 40, 512, 8, 1024, mode)[0] == -3              # more than 32 joints
         assert create(27, 256, 512, 8, 1024, mode)[0] == -3
-    for cs in (32, 96, 224, 384, 768, 1024):                            # other widths: EXACT (fp32 implementation) only
+    for cs in (32, 96, 224, 384, 768, 1024):                            # other widths: EXACT and TRAIN (fp32 implementation), not FAST
         assert create(27, 17, cs, 8, 2 * cs, _lib.MODE_EXACT)[0] == -3
-        for mode in (_lib.MODE_FAST, _lib.MODE_TRAIN):
-            rc, msg = create(27, 17, cs, 8, 2 * cs, mode)
-            assert rc == -2 and "FAST and TRAIN contexts exist" in msg, msg
+        assert create(27, 17, cs, 8, 2 * cs, _lib.MODE_TRAIN)[0] == -3
+        rc, msg = create(27, 17, cs, 8, 2 * cs, _lib.MODE_FAST)
+        assert rc == -2 and "FAST contexts exist" in msg, msg
+    rc, msg = create(243, 17, 1024, 8, 2048, _lib.MODE_TRAIN)           # heads of 128: the fp32 attention backward holds <= 153 tokens
+    assert rc == -2 and "holds a whole sequence in LDS" in msg, msg
+    assert create(243, 17, 1024, 8, 2048, _lib.MODE_EXACT)[0] == -3
     for args, needle in (((27, 17, 200, 8, 400, _lib.MODE_EXACT), "head dim a multiple of 4"),
                          ((27, 17, 2048, 8, 4096, _lib.MODE_EXACT), "channels <= 1024"),
                          ((27, 257, 512, 8, 1024, _lib.MODE_EXACT), "joints=257 not in [1,256]"),

@@ -4,7 +4,8 @@ The reference takes any ``-cs`` its 8 heads divide (common/arguments.py:49, mixs
 (mixste.py:141); through round 5 ``d3dp_create`` refused every width outside {64, 128, 256, 512} and more than 32 joints.
 
   * other widths run EXACT mode on the library's fp32 implementation (fp32-MFMA Linears, fp32 row attention with a run-time head
-    dim, run-time-width row kernels): sampler and denoiser against the CPU oracle at the same 1e-3 mm tolerance;
+    dim, run-time-width row kernels): sampler and denoiser against the CPU oracle at the same 1e-3 mm tolerance; and they TRAIN on
+    the fp32 path of the training step (train_g.hip): every gradient against torch autograd through the oracle;
   * more than 32 joints: the spatial axis runs on the whole-sequence attention kernels the temporal axis uses (EXACT, FAST and
     TRAIN contexts): denoiser against the oracle, and every gradient of a training step against torch autograd through it.
 """
@@ -52,19 +53,20 @@ def test_sampler_at_a_width_outside_the_instantiated_set(cs, frames, dep):
 
 
 def test_widths_the_library_cannot_run_are_refused_with_the_reason():
-    """FAST / TRAIN contexts exist for the instantiated widths only; a head dim that is not a multiple of 4 (cs = 200 with 8
-    heads) or a width above 1024 has no kernel: D3DP_ENOTSUP with the reason, never a wrong answer."""
+    """FAST contexts exist for the instantiated widths only; a head dim that is not a multiple of 4 (cs = 200 with 8 heads) or a
+    width above 1024 has no kernel; training at a head dim above 64 holds at most 153 tokens per sequence: D3DP_ENOTSUP with the
+    reason, never a wrong answer."""
     x2d = torch.zeros(1, 9, 17, 2, device="cuda")
-    for cs, numerics, needle in ((384, "fast", "FAST and TRAIN contexts exist"), (200, "exact", "head dim a multiple of 4"),
+    for cs, numerics, needle in ((384, "fast", "FAST contexts exist"), (200, "exact", "head dim a multiple of 4"),
                                  (2048, "exact", "channels <= 1024")):
         m = _sampler_model(9, cs, 1, 1, 1, numerics, 3)
         with pytest.raises(_lib.D3DPHipError) as e:
             m(x2d, None, input_2d_flip=x2d)
         assert needle in str(e.value), str(e.value)
-    t = MixSTE2(num_frame=9, num_joints=17, embed_dim_ratio=384, depth=1, is_train=True, numerics="train").cuda().train()
+    t = MixSTE2(num_frame=243, num_joints=17, embed_dim_ratio=1024, depth=1, is_train=True, numerics="train").cuda().train()
     with pytest.raises(_lib.D3DPHipError) as e:
-        t(x2d, torch.zeros(1, 9, 17, 3, device="cuda"), torch.zeros(1, dtype=torch.long, device="cuda"))
-    assert "FAST and TRAIN contexts exist" in str(e.value)
+        t(torch.zeros(1, 243, 17, 2, device="cuda"), torch.zeros(1, 243, 17, 3, device="cuda"), torch.zeros(1, dtype=torch.long, device="cuda"))
+    assert "holds a whole sequence in LDS" in str(e.value)
 
 
 def _denoiser(frames, joints, cs, dep, numerics, seed, train=False):
@@ -124,3 +126,48 @@ def test_training_step_with_more_than_32_joints(joints, frames):
         worst = max(worst, (name, err), key=lambda v: v[1])
         assert err < 2e-3, (name, err)
     print(f"training step at J = {joints}, F = {frames}: worst relative gradient error {worst[1]:.2e} ({worst[0]})")
+
+
+@pytest.mark.parametrize("cs,joints,frames,dep", [(384, 17, 27, 2), (96, 17, 81, 2), (224, 17, 243, 1), (1024, 17, 27, 1), (160, 21, 9, 2)])
+def test_training_step_at_a_width_outside_the_instantiated_set(cs, joints, frames, dep):
+    """The reference trains at any `-cs` (common/arguments.py:49, main.py:325): a TRAIN context of a width outside
+    {64, 128, 256, 512} runs the fp32 path of the training step through the run-time-width row kernels (train_g.hip) and the VALU
+    attention backward with a run-time head dim.  Prediction, loss and EVERY gradient against torch autograd through the oracle,
+    DropPath masks injected (cs = 384: heads of 48 channels; 96: heads of 12; 224 at the full clip length; 1024: heads of 128;
+    160: heads of 20, with 21 joints)."""
+    B = 2
+    m, sd = _denoiser(frames, joints, cs, dep, "train", 43, train=True)
+    g = torch.Generator().manual_seed(cs + frames)
+    x2d = torch.rand(B, frames, joints, 2, generator=g) * 2 - 1
+    x3d = torch.randn(B, frames, joints, 3, generator=g)
+    gt = torch.randn(B, frames, joints, 3, generator=g) * 0.3
+    t = torch.tensor([17, 803])
+    dpd = {}
+    for i in range(dep):
+        mk = lambda S: (torch.rand(S, 1, 1, generator=g) < 0.8).float() / 0.8
+        dpd[f"STEblocks.{i}"] = (mk(B * frames), mk(B * frames))
+        dpd[f"TTEblocks.{i}"] = (mk(B * joints), mk(B * joints))
+    pred = m(x2d.cuda(), x3d.cuda(), t.cuda(), droppath=dpd)
+    loss = torch.mean(torch.norm(pred - gt.cuda(), dim=-1))
+    loss.backward(loss.clone().detach())
+    torch.cuda.synchronize()
+    po = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pred_o = orc.mixste_forward(po, x2d, x3d, t, dep, droppath=dpd)
+    loss_o = torch.mean(torch.norm(pred_o - gt, dim=-1))
+    loss_o.backward(loss_o.clone().detach())
+    assert orc.mpjpe_mm(pred.detach().cpu(), pred_o.detach()) <= EXACT_TOL_MM
+    assert abs(loss.item() - loss_o.item()) < 2e-6
+    worst = ("", 0.0)
+    for name, p in m.named_parameters():
+        ref = po[name].grad.double()
+        err = (p.grad.cpu().double() - ref).norm().item() / max(ref.norm().item(), 1e-12)
+        worst = max(worst, (name, err), key=lambda v: v[1])
+        assert err < 2e-3, (name, err)
+    print(f"training step at cs = {cs}, J = {joints}, F = {frames}: worst relative gradient error {worst[1]:.2e} ({worst[0]})")
+    # a second step over other inputs on the same context: bit-reproducible like the instantiated widths (no float atomics)
+    g1 = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad(set_to_none=True)
+    pred2 = m(x2d.cuda(), x3d.cuda(), t.cuda(), droppath=dpd)
+    l2 = torch.mean(torch.norm(pred2 - gt.cuda(), dim=-1))
+    l2.backward(l2.clone().detach())
+    assert torch.equal(pred, pred2) and all(torch.equal(a, p.grad) for a, p in zip(g1, m.parameters()))
