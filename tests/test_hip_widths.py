@@ -164,7 +164,7 @@ def test_training_step_at_a_width_outside_the_instantiated_set(cs, joints, frame
         worst = max(worst, (name, err), key=lambda v: v[1])
         assert err < 2e-3, (name, err)
     print(f"training step at cs = {cs}, J = {joints}, F = {frames}: worst relative gradient error {worst[1]:.2e} ({worst[0]})")
-    # a second step over other inputs on the same context: bit-reproducible like the instantiated widths (no float atomics)
+    # the same step again on the same context: bit-reproducible like the instantiated widths (no float atomics on this path either)
     g1 = [p.grad.clone() for p in m.parameters()]
     m.zero_grad(set_to_none=True)
     pred2 = m(x2d.cuda(), x3d.cuda(), t.cuda(), droppath=dpd)
