@@ -33,7 +33,7 @@ for stage in "$@"; do
       fi; tail -5 $O/guard.log ;;
     parity)
       # the parity printout of the final library, kept under profiles/ 
-      timeout 1200 python -m pytest tests -m gpu -q -s -k "g3 or g4 or c2_full or c3_full or scale or config5 or longer_than_256 or bit_reproducible" > $O/parity.log 2>&1; grep -E "mm|passed|failed|error|worst" $O/parity.log | tail -40 ;;
+      timeout 1200 python -m pytest tests -m gpu -q -s -k "g3 or g4 or c2_full or c3_full or scale or config5 or longer_than_256 or bit_reproducible or outside_the_instantiated_set or more_than_32_joints or went_through_training" > $O/parity.log 2>&1; grep -E "mm|passed|failed|error|worst" $O/parity.log | tail -40 ;;
     variants)
       # the tests marked `variants` against the library that carries the experiment kernels
       D3DP_LIB=$R/d3dp_amd/lib/variants/libd3dp_variants.so timeout 900 python -m pytest tests -m "gpu and variants" -q -rs > $O/variants.log 2>&1; tail -6 $O/variants.log ;;
