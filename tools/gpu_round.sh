@@ -66,7 +66,7 @@ for stage in "$@"; do
         done
       done
       for d in $O/pmc_*_*/; do f=$(find $d -name "*counter_collection.csv" | head -1); echo "== $d"; [ -n "$f" ] && python tools/pmc_summary.py $f gemm | grep -v "^$"; done > $O/pmc.log 2>&1
-      find $O -name "*.csv" -size +10M -delete; grep -E "==|FETCH|WRITE|MFMA|GRBM" $O/pmc.log ;;
+      rm -rf $O/pmc_*_*/; grep -E "==|FETCH|WRITE|MFMA|GRBM" $O/pmc.log ;;          # (raw counter dumps: gpurun brings back at most 64 MiB)
     pmc_step)
       # One filtered pass per kernel class and counter group: rocprofv3 7.2 segfaults on this run (batch 16: 60 k dispatches)
       # unfiltered, with an alternation in the regex, or with a regex that matches all three Linear instantiations at once.
@@ -87,7 +87,8 @@ for stage in "$@"; do
         done
         python tools/pmc_step_summary.py $O/step_pmc_$mode.md $csvs > /dev/null
         head -14 $O/step_pmc_$mode.md
-      done; find $O -name "*.csv" -size +20M -delete ;;
+        for d in $O/step_${mode}_*/; do rm -rf $d; done           # (raw counter dumps: gpurun brings back at most 64 MiB; the .log files stay)
+      done ;;
     gemm)
       timeout 300 python tools/gemm_bench.py --x2 ${GEMM_ARGS:---m 128960 --iters 10} > $O/gemm_bench.log 2>&1; cat $O/gemm_bench.log ;;
     train)
@@ -104,7 +105,7 @@ for stage in "$@"; do
         ( cd /tmp && D3DP_TRAIN_OVERLAP=0 timeout 300 rocprofv3 --pmc $c --output-format csv -d $d -- python $R/bench.py --train-only --steps 2 --warmup 1 --no-profile > $d.log 2>&1 )
         f=$(find $d -name "*counter_collection.csv" 2>/dev/null | head -1); [ -n "$f" ] && csvs="$csvs $f" || echo "no counters: $t (see $d.log)"
       done
-      python tools/pmc_step_summary.py $O/c5_pmc.md $csvs > /dev/null; head -20 $O/c5_pmc.md | cut -c1-150; find $O -name "*.csv" -size +20M -delete ;;
+      python tools/pmc_step_summary.py $O/c5_pmc.md $csvs > /dev/null; head -20 $O/c5_pmc.md | cut -c1-150; for d in $O/c5pmc_*/; do rm -rf $d; done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
