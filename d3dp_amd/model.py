@@ -503,6 +503,12 @@ class MixSTE2(nn.Module):
                     "power-of-two scale for dS)")
         if os.environ.get("D3DP_TRAIN_ATTN_BWD", "")[:1] == "v":
             attn += "; D3DP_TRAIN_ATTN_BWD=valu: every fp32 attention backward on the VALU kernels instead"
+        hd = self.embed_dim // self.num_heads
+        inst = self.embed_dim in (64, 128, 256, 512) and hd in (8, 16, 32, 64) and self.hidden >= 64 and self.hidden % 64 == 0
+        if not inst:       # (include/d3dp_hip.h d3dp_create: a width outside the instantiated set trains on the fp32 path)
+            return (f"fp32 path of a width outside {{64, 128, 256, 512}} (cs = {self.embed_dim}): fp32-MFMA Linears (weight gradients split-K, "
+                    "chunks added in a fixed order), fp32 row attention forward, VALU attention backward with a run-time head dim, "
+                    "run-time-width row kernels")
         if os.environ.get("D3DP_TRAIN_IMPL") == "f32":
             return "fp32 MFMA Linears (D3DP_TRAIN_IMPL=f32), fp32 attention"
         wg = ("a launch per weight gradient (D3DP_TRAIN_WGRAD=each)" if os.environ.get("D3DP_TRAIN_WGRAD") == "each"

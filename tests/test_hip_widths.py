@@ -171,3 +171,22 @@ def test_training_step_at_a_width_outside_the_instantiated_set(cs, joints, frame
     l2 = torch.mean(torch.norm(pred2 - gt.cuda(), dim=-1))
     l2.backward(l2.clone().detach())
     assert torch.equal(pred, pred2) and all(torch.equal(a, p.grad) for a, p in zip(g1, m.parameters()))
+
+
+def test_cli_trains_and_evaluates_at_a_width_outside_the_instantiated_set(tmp_path):
+    """`main.py -cs 96` (reference common/arguments.py:49): two epochs of training on synthetic sequences through the fp32 path of the
+    training step, a reference-format checkpoint, and `--evaluate` of it through EXACT mode's fp32 implementation -- the loss falls and
+    both protocol lines are written."""
+    import os
+    from d3dp_amd import cli
+    ck = str(tmp_path)
+    common = ["--synthetic", "-c", ck, "-f", "27", "-cs", "96", "-dep", "2", "--synthetic-frames", "120"]
+    assert cli.main(common + ["-e", "3", "-b", "108", "-s", "27", "-cf", "1", "-lr", "0.0005", "--no-eval"]) == 0
+    log = open(os.path.join(ck, "training_log.txt")).read().splitlines()
+    first = float([l for l in log if l.startswith("[1] ")][0].split("3d_train ")[1].split()[0])
+    third = float([l for l in log if l.startswith("[3] ")][0].split("3d_train ")[1].split()[0])
+    print(f"cli training at cs = 96: epoch-1 loss {first:.2f} mm -> epoch-3 loss {third:.2f} mm")
+    assert third < first and os.path.exists(os.path.join(ck, "epoch_3.bin"))
+    assert cli.main(common + ["--evaluate", "epoch_3.bin", "-num_proposals", "4", "-sampling_timesteps", "2", "-b", "2", "--p2"]) == 0
+    txt = open(os.path.join(ck, "h36m_test_log_H4_K2.txt")).read()
+    assert "step 1 : Protocol #1 Error (MPJPE) J_Agg:" in txt and "step 1 : Protocol #2 Error (MPJPE) P_Best:" in txt
