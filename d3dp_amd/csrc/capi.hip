@@ -291,8 +291,13 @@ int linear(d3dp_ctx* c, int cls, int epi, int out_f32, const void* A, const void
     if (cls == P_QKV && c->x2_attn()) epi = EPI_QKV_PACK;
     // qkv and fc1 (epilogues without loads) run the skewed schedule when the context has it on (seq_pitch() pads for it)
     const int skew_d = c->skew() && (epi == EPI_QKV_PACK || epi == EPI_GELU) ? c->skew_d : 0;
+    // proj walks its tiles from the LAST row of tiles to the first: the norm2 row kernel that follows starts at row 0, on the
+    // rows of x this launch wrote last (still in the Infinity Cache at the bench's pass size).  Same tiles, same arithmetic.
+    // Measured on two boxes: layernorm class 276 -> 254 / 279 -> 253 ms per step, proj -5, step -0.45 %; the same order on
+    // fc2 (norm pair +28 ms), fc1, qkv or the row kernels themselves: neutral or worse (profiles/r06_tile_order_ab.md)
+    const int rev = cls == P_PROJ ? X2_TILES_LAST_TO_FIRST : 0;
     return d3dp_launch_linear_f16x2(epi, A, W, bias, wu / a_scale, o_scale, (float*)out, out2 ? out2 : out, aux, c->d_flag, M, N,
-                                    K, st, skew_d, c->pingpong);
+                                    K, st, skew_d, c->pingpong | rev);
   }
   if (c->x3()) return d3dp_launch_linear_bf16x3(epi, A, W, bias, (float*)out, out, M, N, K, st);
   return d3dp_launch_linear_f32(epi, (const float*)A, (const float*)W, bias, (float*)out, M, N, K, st);
@@ -1126,7 +1131,6 @@ TrainLayout train_layout(const d3dp_cfg& g, int B) {
   L.stats_x2 = take(L.stats_x2_stride * 2 * g.depth);
   {
     const size_t lnb = (size_t)D3DP_LN_BWD_BLOCKS * 2 * L.C;         // one LayerNorm call's [dgamma | dbeta] rows
-    const size_t fmax = std::max<size_t>(3 * L.C, L.Hd);
     L.red_floats = (size_t)(6 * g.depth + 2) * lnb                   // 3 LayerNorm backward calls per block + the head's
                    + (size_t)2 * g.depth * std::max(D3DP_DYPREP_ROWS, D3DP_ROWPREP_ROWS) * (5 * L.C + L.Hd + 256)   // bias gradients: the column sums of every dY
                    + (size_t)512 * (3 * L.C + 4) + (size_t)D3DP_EMBED_BWD_ROWS * 5 * L.C + (size_t)512 * L.C   // head, embedding

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
                                                          const float* __restrict__ bias, float unscale, float oscale,
                                                          float* __restrict__ outf, f16* __restrict__ out2,
                                                          float* __restrict__ aux, unsigned* __restrict__ flag, int M,
-                                                         int N, int K, int tiles_n, int total_tiles) {
+                                                         int N, int K, int tiles_n_arg, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sbias = reinterpret_cast<float*>(smem + XNSTAGE * XSTAGE);
   const int G = gridDim.x;
@@ -168,6 +168,11 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
   const int gtot = n_my * NK;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // tiles_n_arg < 0: the tiles from the LAST row of tiles to the first (X2_TILES_LAST_TO_FIRST: proj, whose consumer -- the
+  // norm2 row kernel -- then starts on the rows written last)
+  const int tiles_n = tiles_n_arg < 0 ? -tiles_n_arg : tiles_n_arg;
+  const int t_flip = tiles_n_arg < 0 ? total_tiles - 1 : 0, t_sign = tiles_n_arg < 0 ? -1 : 1;
+  auto tile_of = [&](int ti_) { return t_flip + t_sign * (L + ti_ * G); };
 
   for (int i = tid; i < (EPI == EPI_GELU_LN ? 2 * N : N); i += (XNCW + 4) * 64) sbias[i] = bias[i];   // (GELU_LN: c2 | c1)
   __syncthreads();
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
     const f16* pw[4];
     auto issue = [&]() {
       if (ks == 0) {                                   // new tile: row pointers once per tile, not per k-step
-        const int t = L + ti * G;
+        const int t = tile_of(ti);
         const int m0 = (t / tiles_n) * XBM, n0 = (t % tiles_n) * XBN;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {                  // A pieces 8 lw .. 8 lw + 7 (8 rows each)
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
         // the tile's 256 (mean, rstd) pairs: 2 KiB = two pieces, by loader wave 0, the OLDEST operations of this k-step
         // (every counted wait below then covers them); buffer ti & 1 -- the epilogue of tile ti - 1 may still be reading
         if (ks == 0 && lw == 0) {
-          const int t = L + ti * G;
+          const int t = tile_of(ti);
           const float* rs = aux + (size_t)(t / tiles_n) * XBM * 2 + lane * 4;     // (aux has 256 rows of slack: no clamp)
           char* dst = smem + XROWSTAT + (ti & 1) * (XBM * 8);
           __builtin_amdgcn_global_load_lds(GPTR(rs), LPTR(dst), 16, 0, 0);
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(768) void gemm_f16x2_kernel(const f16* __restrict__
     // + wc*64 + 4 fi.  Every store address is  uniform base + 32-bit lane offset  (the launcher refuses outputs of 4 GiB or
     // more), advanced row by row: per-row 64-bit address arithmetic was most of the epilogue's VALU work, and it runs
     // with the matrix pipes idle.
-    const int t = L + ti * G;
+    const int t = tile_of(ti);
     const int pm0 = (t / tiles_n) * XBM + wr * 64 + 4 * fg, nb = (t % tiles_n) * XBN + wc * 64 + 4 * fi;
     if (nb < N && (!(D3DP_X2_PROBE & 4) || unscale == -12345.f)) {
       const float4 bz = *reinterpret_cast<const float4*>(sbias + nb);
@@ -2433,6 +2438,8 @@ bool d3dp_x2_skew_applies(int epi, int M, int N, int K, int skew_d, int n_cu) {
 int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const float* bias, float unscale, float oscale,
                              float* outf, void* out2, float* aux, unsigned* flag, int M, int N, int K, hipStream_t st,
                              int skew_d, int pingpong) {
+  const bool reverse = (pingpong & X2_TILES_LAST_TO_FIRST) != 0;   // (the plain kernel only)
+  pingpong &= 0xff;
   if (K % (2 * XBK) != 0 || N % 4 != 0 || N > XBIAS_MAX || M <= 0) return -1;
   if ((size_t)M * N * 4 >= ((size_t)1 << 32)) return -1;   // 32-bit byte offsets in the epilogue
   if (epi != EPI_BIAS && epi != EPI_GELU && epi != EPI_QKV_PACK && epi != EPI_RESID && epi != EPI_RESID_LN &&
@@ -2524,7 +2531,7 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
   const KernT kern = kerns[epi == EPI_GELU ? 2 : epi == EPI_RESID ? 3 : epi == EPI_QKV_PACK ? 1 : 0];
 #endif
   hipLaunchKernelGGL(kern, dim3(grid), dim3((XNCW + 4) * 64), XLDS, st, (const f16*)A2, (const f16*)W2, bias, unscale, oscale, outf,
-                     (f16*)out2, aux, flag, M, N, K, tn, total);
+                     (f16*)out2, aux, flag, M, N, K, reverse ? -tn : tn, total);
   return 0;
 }
 

@@ -57,7 +57,10 @@ int d3dp_launch_linear_f16x2(int epi, const void* A2, const void* W2, const floa
                              float* outf, void* out2, float* aux, unsigned* flag, int M, int N, int K, hipStream_t st,
                              int skew_d = 0, int pingpong = 0);
 // pingpong: the two-team form of the kernel (gemm_f16x2_pp_kernel: one wave of a SIMD reads its fragments while the other
-// multiplies); same results bit for bit (the k order and the arithmetic are unchanged)
+// multiplies); same results bit for bit (the k order and the arithmetic are unchanged).  OR-ed with X2_TILES_LAST_TO_FIRST the
+// plain kernel walks its tiles from the last row of tiles to the first (the rows a following row kernel reads first are then the
+// ones written last); same tiles, same results bit for bit
+constexpr int X2_TILES_LAST_TO_FIRST = 0x100;
 // skew_d (1, 2, 4): the row-class skewed schedule of gemm_x2.hip for EPI_QKV_PACK / EPI_GELU -- a tile's epilogue leaves under the
 // next tile's k-loop, D k-steps per 16-row class; d3dp_x2_skew_applies says whether the launcher will use it for a shape
 bool d3dp_x2_skew_applies(int epi, int M, int N, int K, int skew_d, int n_cu);
