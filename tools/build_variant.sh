@@ -8,8 +8,8 @@ make -s >/dev/null
 mkdir -p ../lib/variants/obj
 O=../lib/variants/obj/${NAME}_${FILE%.hip}.o
 EXTRA=""; case $FILE in gemm*.hip) EXTRA=-fno-slp-vectorize;; jpma.hip) EXTRA=-ffp-contract=off;; esac
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $EXTRA $FLAGS -c $FILE -o $O
-OBJS=""; for f in gemm gemm_x2 attention pointwise sampler jpma caller train train_attn capi; do
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fvisibility-inlines-hidden -Wall -Wno-unused-function $EXTRA $FLAGS -c $FILE -o $O
+OBJS=""; for f in gemm gemm_x2 attention pointwise sampler jpma caller train train_g train_attn capi; do
   if [ "$f.hip" = "$FILE" ]; then OBJS="$OBJS $O"; else OBJS="$OBJS ../lib/obj/$f.o"; fi; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libd3dp_$NAME.so $OBJS
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=exports.map -o ../lib/variants/libd3dp_$NAME.so $OBJS
 echo built d3dp_amd/lib/variants/libd3dp_$NAME.so
