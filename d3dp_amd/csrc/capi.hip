@@ -292,7 +292,7 @@ int linear(d3dp_ctx* c, int cls, int epi, int out_f32, const void* A, const void
     // qkv and fc1 (epilogues without loads) run the skewed schedule when the context has it on (seq_pitch() pads for it)
     const int skew_d = c->skew() && (epi == EPI_QKV_PACK || epi == EPI_GELU) ? c->skew_d : 0;
     // proj walks its tiles from the LAST row of tiles to the first: the norm2 row kernel that follows starts at row 0, on the
-    // rows of x this launch wrote last (still in the Infinity Cache at the bench's pass size).  Same tiles, same arithmetic.
+    // rows of x this launch wrote last (its first 6 us run warm: -9.6 % cycles at -1 % L2 fetches).  Same tiles, same arithmetic.
     // Measured on two boxes: layernorm class 276 -> 254 / 279 -> 253 ms per step, proj -5, step -0.45 %; the same order on
     // fc2 (norm pair +28 ms), fc1, qkv or the row kernels themselves: neutral or worse (profiles/r06_tile_order_ab.md)
     const int rev = cls == P_PROJ ? X2_TILES_LAST_TO_FIRST : 0;
