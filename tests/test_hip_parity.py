@@ -1067,6 +1067,7 @@ def test_sampler_parity_on_weights_that_went_through_training(cs, dep):
     mt.load_state_dict(sd0, strict=False)
     mt = mt.cuda().train()
     opt = HipAdamW(mt.parameters(), lr=2e-3, weight_decay=0.1)
+    torch.manual_seed(78)                                    # (the training branch draws its timesteps, noise and DropPath masks from the global generators)
     g = torch.Generator().manual_seed(77)
     x2 = (torch.rand(8, Fr, 17, 2, generator=g) * 2 - 1).cuda()
     gt = (torch.randn(8, Fr, 17, 3, generator=g) * 0.4).cuda()
