@@ -846,6 +846,12 @@ def main():
     ap.add_argument("--train-only", action="store_true",
                     help="time ONLY the BASELINE configs[4] training step (--steps / --warmup apply) and print {'c5_train_step': ...}: "
                          "the command the rocprofv3 passes under profiles/r06_c5_* wrap")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the N-rank code path at ANY world size, including 1: RCCL rendezvous + probe all-reduce, shard check, "
+                         "all-gather + JPMA inside the timed region, the multi_gpu block (d3dp_amd.dist.FORCE_COLLECTIVES).  On a box "
+                         "with ONE GPU this is the only way the RCCL side of --gpus N executes on hardware: at world size 1 the "
+                         "all-gather is RCCL's one-rank copy -- it proves the transport stack and its ordering against the library's "
+                         "stream, not xGMI bandwidth; the secondary legs are skipped")
     ap.add_argument("--dist-dry-run", type=int, default=0, metavar="N",
                     help="no GPU needed: drive the N-rank control flow of this file (self-launch, WORLD_SIZE check, shard "
                          "check, timed loop with the all-gather, MAX-reduce, multi_gpu block) over gloo with a CPU "
@@ -869,7 +875,8 @@ def main():
         return
     if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:      # before any rendezvous: a mismatched job must not hang
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the job has WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
-    rank, world, local = init_from_env("gloo" if dry else None)
+    rank, world, local = init_from_env("gloo" if dry else None, force=a.force_exchange)
+    multi = world > 1 or a.force_exchange                   # the N-rank code path (all-gather + JPMA inside the timed region)
     dev = "cpu" if dry else "cuda"
     if not dry:
         torch.cuda.set_device(local)
@@ -885,11 +892,11 @@ def main():
     x2d = torch.from_numpy(x2d_np).to(dev)
     x2f = torch.from_numpy(flip_2d(x2d_np)).to(dev)
     gen = rank_generator(1, rank, dev)
-    sharding_ok = shard_check(rank, world, a.numerics, dev, make) if world > 1 else None
+    sharding_ok = shard_check(rank, world, a.numerics, dev, make) if multi else None
     model = DryRunSampler(H, K, frames) if dry else build_model(H, K, a.numerics, a.chunk_seqs)
     tele = GpuTelemetry(local) if (rank == 0 and not dry) else None
-    dt, out = timed_steps(model, x2d, x2f, a.steps, a.warmup, gen, gather=world > 1, dev=dev, telemetry=tele)
-    if world > 1:
+    dt, out = timed_steps(model, x2d, x2f, a.steps, a.warmup, gen, gather=multi, dev=dev, telemetry=tele)
+    if multi:
         local_preds, agg, sel = out
         assert agg.shape == (B, K, frames, J_, 3) and bool(torch.isfinite(agg).all()) and int(sel.max()) < H * world
     else:
@@ -922,7 +929,7 @@ def main():
         # the three keys VERDICT r5 item 3 names, at the top level; the rest of the samples' summary beside them
         res.update({"clock_mhz_mean": tr["clock_mhz_mean"], "power_w_mean": tr["power_w_mean"], "power_cap_w": tr["power_cap_w"],
                     "telemetry": tr})
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         flag = torch.tensor([1 if sharding_ok else 0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -931,6 +938,9 @@ def main():
                                  "shard_check": "F=27 B=2 H_local=2 K=2: N ranks on sliced global noise == 1 rank with H=2N, torch.equal"})
         assert bool(flag.item()), "N-rank sampling does not reproduce the 1-rank run"
         assert res["multi_gpu"]["both_select_the_same_poses"], "the winners exchange and all-gather -> JPMA disagree"
+        if a.force_exchange:
+            res["multi_gpu"]["forced"] = (f"--force-exchange: the N-rank code path at world size {world}; at world size 1 every collective is "
+                                          f"RCCL's one-rank form (a device copy) -- the stack executed, xGMI did not")
 
     if rank == 0 and not a.no_profile:
         # per-kernel HIP-event timing (on the launch stream = torch's current stream) over ONE extra untimed step
@@ -947,7 +957,7 @@ def main():
                     "dtype": "none: CPU stand-in sampler over gloo, control flow only",
                     "config": {"workload": f"DRY RUN of the {world}-rank control flow (B={B} H={H}/rank K={K} F={frames}); "
                                            f"measures nothing", "parallelism": f"hshard{world}"}})
-    if rank == 0 and world == 1 and not dry:
+    if rank == 0 and not multi and not dry:
         if not a.no_other_leg:
             other = "fast" if a.numerics == "exact" else "exact"
             model = None
@@ -983,7 +993,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(full=not a.no_cpu_full)
     if rank == 0:
         print(json.dumps(res))
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

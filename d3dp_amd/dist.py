@@ -25,9 +25,24 @@ RCCL_ENV = ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "NCCL_SOCKET_IFNAME", "N
             "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "MASTER_ADDR", "MASTER_PORT", "RANK", "LOCAL_RANK", "WORLD_SIZE")
 
 
-def init_from_env(backend: Optional[str] = None, timeout_s: float = 180.0) -> tuple:
+# A process group of ONE rank normally takes none of the collectives below (there is nothing to exchange).  With this flag set
+# (bench.py --force-exchange, init_from_env(force=True)) they are issued all the same: on a box with one GPU that is the only way
+# the RCCL side of the N-rank path -- rendezvous, communicator, all_gather_into_tensor into the rank-major buffer, the library's
+# kernels ordered behind it on torch's stream -- executes on hardware at all.  It proves the stack, not xGMI bandwidth.
+FORCE_COLLECTIVES = False
+
+
+def _exchanges(group=None) -> bool:
+    """Whether the collectives of this module are issued: an initialised process group of more than one rank (or forced)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
+
+
+def init_from_env(backend: Optional[str] = None, timeout_s: float = 180.0, force: bool = False) -> tuple:
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (set by torch.distributed.run).
-    Returns (rank, world_size, local_rank).  No-op for a single process.
+    Returns (rank, world_size, local_rank).  No-op for a single process unless ``force`` (then a one-rank group is built and
+    FORCE_COLLECTIVES set: see above).
 
     The rendezvous and the first collective are bounded by ``timeout_s`` and a failure names the environment RCCL reads:
     on this ROCm stack cross-process device memory needs dmabuf IPC (``HSA_ENABLE_IPC_MODE_LEGACY=0``, exported when this
@@ -37,7 +52,10 @@ def init_from_env(backend: Optional[str] = None, timeout_s: float = 180.0) -> tu
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if force:
+        global FORCE_COLLECTIVES
+        FORCE_COLLECTIVES = True
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -93,7 +111,7 @@ def all_gather_raw(preds_local: torch.Tensor, group=None) -> torch.Tensor:
     (RCCL) leaves, rank-major, not a byte moved afterwards.  Hypothesis h = r H_local + hl.  The consumers below read this
     layout in place (d3dp_jpma_gathered); `gathered_view` presents it with the reference's axis order as a view."""
     src = preds_local.contiguous()
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _exchanges(group):
         return src[None]
     world = dist.get_world_size(group)
     gathered = torch.empty((world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
@@ -112,7 +130,7 @@ def all_gather_hypotheses(preds_local: torch.Tensor, group=None) -> torch.Tensor
     reference's caller would hold (main.py:698).  One all-gather plus ONE COPY (a flat hypothesis axis cannot be a view of
     the rank-major result): 158.6 MB per rank at configs[3] -- use `jpma_allgather`, which consumes the all-gather result
     in place, when JPMA is what follows.  A no-op without an initialised process group."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _exchanges(group):
         return preds_local
     g = all_gather_raw(preds_local, group)
     R, B, K, Hl = g.shape[:4]
@@ -169,11 +187,12 @@ def jpma_sharded(preds_local: torch.Tensor, traj: torch.Tensor, cam: torch.Tenso
     hypothesis index (B,K,F,J)) as JPMA over the all-gathered (B,K,H_total,F,J,3) tensor, with
     H_local/ (5/3) = 12x less traffic at H_local = 20."""
     from .jpma import jpma_combine, jpma_winners
-    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    rank = dist.get_rank(group) if world > 1 else 0
+    exchanges = _exchanges(group)
+    world = dist.get_world_size(group) if exchanges else 1
+    rank = dist.get_rank(group) if exchanges else 0
     Hl = preds_local.shape[2]
     win = jpma_winners(preds_local, traj, cam, gt_2d, h_offset=rank * Hl, zero_root=zero_root)
-    if world == 1:
+    if not exchanges:
         return jpma_combine(win[None])
     gathered = torch.empty((world * win.shape[0],) + tuple(win.shape[1:]), dtype=win.dtype, device=win.device)
     dist.all_gather_into_tensor(gathered, win.contiguous(), group=group)

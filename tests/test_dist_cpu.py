@@ -116,3 +116,41 @@ def test_bench_dist_dry_run_8_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--dist-dry-run", "4"], capture_output=True,
                         text=True, timeout=120, env=env2, cwd=repo)
     assert r2.returncode != 0 and "WORLD_SIZE=2" in (r2.stderr + r2.stdout)
+
+
+def _forced_worker(rank, port, out):
+    """One rank, collectives forced (d3dp_amd.dist.FORCE_COLLECTIVES): every exchange of the module is issued on a group of one."""
+    import d3dp_amd.dist as dd
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    try:
+        assert dd.init_from_env("gloo", force=True) == (0, 1, 0) and dist.is_initialized() and dd.FORCE_COLLECTIVES
+        B, K, Hl, Fr = 2, 2, 3, 5
+        g = torch.Generator().manual_seed(5)
+        local = torch.randn(B, K, Hl, Fr, 17, 3, generator=g)
+        traj = torch.randn(B, Fr, 1, 3, generator=g) * 0.1 + torch.tensor([0.0, 0.0, 4.0])
+        cam = torch.tensor([1.1, 1.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+        gt2 = torch.randn(B, Fr, 17, 2, generator=g) * 0.2
+        raw = all_gather_raw(local)
+        ok = raw.shape == (1,) + tuple(local.shape) and torch.equal(raw[0], local) and raw.data_ptr() != local.data_ptr()
+        ok = ok and torch.equal(all_gather_hypotheses(local), local)
+        agg_r, sel_r = jpma_sharded(local, traj, cam, gt2)            # (winners all-gathered over the one-rank group)
+        agg_g, sel_g = jpma_allgather(local, traj, cam, gt2)
+        ok = ok and torch.equal(agg_g, agg_r) and torch.equal(sel_g, sel_r)
+        out[0] = bool(ok)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_forced_collectives_on_a_group_of_one_rank():
+    """bench.py --force-exchange (the only way the RCCL side of the N-rank path executes on a one-GPU box): with
+    FORCE_COLLECTIVES set a group of ONE rank still issues the all-gathers -- here over gloo -- and both exchange forms select
+    the same poses; without the flag a group-less process takes none (test_all_gather_is_identity_without_process_group)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_forced_worker, args=(port, out), nprocs=1, join=True)
+    assert dict(out) == {0: True}

@@ -1391,6 +1391,36 @@ def test_bench_launches_its_own_ranks_when_two_gpus_are_visible():
     assert d["config"]["hypotheses_total"] == 4
 
 
+def test_rccl_side_of_the_n_rank_path_executes_on_one_gpu():
+    """`python bench.py --force-exchange` on ONE GPU: the N-rank code path of bench.py / d3dp_amd.dist at world size 1 over the
+    nccl (= RCCL) backend -- rendezvous, communicator and probe all-reduce (`init_from_env`), the shard check through
+    `all_gather_hypotheses`, every timed step ending in `all_gather_into_tensor` into the rank-major buffer with
+    `d3dp_jpma_gathered` launched behind it on torch's stream, the winners exchange beside it.  At world size 1 RCCL's
+    collectives are one-rank copies: what this pins is that the transport stack initialises on the box and that its results
+    reach the library's kernels in order -- the part of BASELINE configs[3] that no gloo test touches.  (Two ranks on one GPU
+    are refused by RCCL: profiles/r06_rccl_same_gpu_probe.json.)"""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    s = __import__("socket").socket()
+    s.bind(("127.0.0.1", 0))
+    env["MASTER_PORT"] = str(s.getsockname()[1])
+    s.close()
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--force-exchange", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--hyps", "3", "--ksteps", "2", "--no-profile"], capture_output=True, text=True, env=env, timeout=900)
+    if r.returncode != 0 and "could not join the nccl process group" in r.stderr:
+        pytest.skip("RCCL does not initialise on this box: " + r.stderr.strip().splitlines()[-1][:300])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    mg = d["multi_gpu"]
+    assert d["n_gpus"] == 1 and mg["world_size"] == 1 and mg["backend"] == "nccl (RCCL)" and "forced" in mg
+    assert mg["sharded_equals_single_rank"] is True and mg["both_select_the_same_poses"] is True
+    assert mg["all_gather_bytes_per_rank"] == 2 * 2 * 3 * 243 * 17 * 3 * 4 and mg["all_gather_ms"] > 0
+    assert d["value"] > 0 and d["config"]["hypotheses_total"] == 3 and "fast_mode" not in d and "cpu_baseline" not in d
+
+
 def _dp_case(B):
     frames, H, K = 27, 2, 2
     m = make_model(frames, 64, 2, H, K, "exact", seed=5)
