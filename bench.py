@@ -17,6 +17,8 @@ and the fused JPMA kernel aggregates them where RCCL left them (north_star: "all
 aggregation", reference main.py:700-718).  Inputs are resident in HBM before the timed region starts.  Prints ONE JSON
 line on rank 0; besides the headline it carries `configs` (BASELINE configs[1] and the configs[4] training step, timed in
 the same run) and, at N > 1, `multi_gpu` (all-gather -> JPMA and the 12x smaller winners exchange side by side).
+`--force-exchange` runs that N-rank code path at world size 1 over RCCL (the only way it executes on a one-GPU box; the stack,
+not xGMI); `--dist-dry-run N` drives its control flow over gloo without a GPU.
 """
 from __future__ import annotations
 
