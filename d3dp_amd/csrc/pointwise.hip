@@ -174,6 +174,19 @@ template <int C> struct Row {
 #pragma unroll
     for (int i = 0; i < NV; ++i) y[i] = fmaf((v[i] - mean) * rstd, wv[i], bv[i]);
   }
+  // the same arithmetic on weights the caller already holds in registers (kernels that keep them across several tokens)
+  static __device__ __forceinline__ void norm_r(const float* v, const float* wv, const float* bv, float eps, float* y) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += v[i];
+    const float mean = wave_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) y[i] = fmaf((v[i] - mean) * rstd, wv[i], bv[i]);
+  }
 };
 
 // Residual adds (mixste.py:113-115) ride on the row-wise kernels.  ln_kernel normalises x + yadd; it writes the sum
@@ -256,6 +269,12 @@ __global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const Y
   ActOut<C, XN>::st(xn, plane, (size_t)tok * C, lane, z);
 }
 
+// Tokens per wave of embed_ln_kernel / head_kernel: the weights of a lane's columns (embedding: 5 + 1 values per column; the
+// LayerNorm pairs; the head's three rows) are loaded ONCE per wave and kept in registers over this many tokens -- as one
+// token per wave these kernels issued 64 / 16 weight loads per lane and token for 2 - 4 data accesses and ran at 0.40 / 0.38 of
+// the HBM roofline.  A workgroup covers 4 kRowTokens consecutive token rows (its four waves step through them side by side).
+constexpr int kRowTokens = 8;
+
 template <int C, typename XN>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__ x2d, const float* __restrict__ x3d,
                                                        const float* __restrict__ temb, const float* __restrict__ ew,
@@ -266,35 +285,48 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
                                                        int n_seq, int H, int F, int J, int SP) {
   using R = Row<C>;
   const int lane = threadIdx.x & 63;
-  const int tl = blockIdx.x * 4 + (threadIdx.x >> 6);          // chunk-local row: sequence tl / SP, token tl % SP
-  const int FJ = F * J;
-  if (tl >= n_seq * SP) return;
-  // SP >= F J rows per sequence (capi.hip: a multiple of 64 when the skewed Linear schedule is in use): the pad rows get
-  // the embedding of an all-zero input at joint 0 -- finite filler that flows through the row-wise kernels and the Linears
-  // and is never read by an attention kernel nor written to the output
-  const bool pad = (tl % SP) >= FJ;
-  const int seq = seq0 + tl / SP, fj = pad ? 0 : tl % SP, nj = fj % J;
-  const int b = seq / H;
-  const float* p2 = x2d + ((size_t)b * FJ + fj) * 2;
-  const float* p3 = x3d + ((size_t)seq * FJ + fj) * 3;
-  float in5[5] = {p2[0], p2[1], p3[0], p3[1], p3[2]};          // channel order [u, v, x, y, z], mixste.py:228
-  if (pad) { in5[0] = in5[1] = in5[2] = in5[3] = in5[4] = 0.f; }
-  float v[R::NV], y[R::NV];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int FJ = F * J, T = n_seq * SP;
+  float w5[R::NV][5], ebv[R::NV], lw[R::NV], lb[R::NV];
 #pragma unroll
   for (int i = 0; i < R::NV; ++i) {
-    const int c = R::elem(lane, i);
-    const float* wr = ew + c * 5;
-    float a = 0.f;
+    const float* wr = ew + R::elem(lane, i) * 5;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) a = fmaf(in5[k], wr[k], a);
-    a += eb[c];
-    a += spos[nj * C + c];
-    a += temb[b * C + c];
-    v[i] = a;
+    for (int k = 0; k < 5; ++k) w5[i][k] = wr[k];
   }
-  if (NT_STREAMS) R::store_nt(x + (size_t)tl * C, lane, v); else R::store(x + (size_t)tl * C, lane, v);
-  R::norm(v, lnw, lnb, eps, lane, y);
-  ActOut<C, XN>::st(xn, plane, (size_t)tl * C, lane, y);
+  R::load(eb, lane, ebv);
+  R::load(lnw, lane, lw);
+  R::load(lnb, lane, lb);
+  for (int it = 0; it < kRowTokens; ++it) {
+    const int tl = (blockIdx.x * kRowTokens + it) * 4 + wave;    // chunk-local row: sequence tl / SP, token tl % SP
+    if (tl >= T) break;
+    // SP >= F J rows per sequence (capi.hip: a multiple of 64 when the skewed Linear schedule is in use): the pad rows get
+    // the embedding of an all-zero input at joint 0 -- finite filler that flows through the row-wise kernels and the Linears
+    // and is never read by an attention kernel nor written to the output
+    const bool pad = (tl % SP) >= FJ;
+    const int seq = seq0 + tl / SP, fj = pad ? 0 : tl % SP, nj = fj % J;
+    const int b = seq / H;
+    const float* p2 = x2d + ((size_t)b * FJ + fj) * 2;
+    const float* p3 = x3d + ((size_t)seq * FJ + fj) * 3;
+    float in5[5] = {p2[0], p2[1], p3[0], p3[1], p3[2]};          // channel order [u, v, x, y, z], mixste.py:228
+    if (pad) { in5[0] = in5[1] = in5[2] = in5[3] = in5[4] = 0.f; }
+    float v[R::NV], y[R::NV], sp[R::NV], tb[R::NV];
+    R::load(spos + (size_t)nj * C, lane, sp);
+    R::load(temb + (size_t)b * C, lane, tb);
+#pragma unroll
+    for (int i = 0; i < R::NV; ++i) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) a = fmaf(in5[k], w5[i][k], a);
+      a += ebv[i];
+      a += sp[i];
+      a += tb[i];
+      v[i] = a;
+    }
+    if (NT_STREAMS) R::store_nt(x + (size_t)tl * C, lane, v); else R::store(x + (size_t)tl * C, lane, v);
+    R::norm_r(v, lw, lb, eps, y);
+    ActOut<C, XN>::st(xn, plane, (size_t)tl * C, lane, y);
+  }
 }
 
 template <int C, typename YT>
@@ -306,35 +338,44 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ x, 
                                                    float* __restrict__ out, int T, int FJ, int SP) {
   using R = Row<C>;
   const int lane = threadIdx.x & 63;
-  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tok >= T) return;
-  float v[R::NV], y[R::NV], z[R::NV];
-  if (NT_STREAMS) R::load_nt(x + (size_t)tok * C, lane, v); else R::load(x + (size_t)tok * C, lane, v);
-  if (yadd0 != nullptr) {
-    if (NT_STREAMS && NT_Y) R::load_nt(yadd0 + (size_t)tok * C, lane, y); else R::load(yadd0 + (size_t)tok * C, lane, y);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float wav[R::NV], bav[R::NV], whv[R::NV], bhv[R::NV], wv[3][R::NV];      // (kRowTokens: above embed_ln_kernel)
+  R::load(wa, lane, wav);
+  R::load(ba, lane, bav);
+  R::load(wh, lane, whv);
+  R::load(bh, lane, bhv);
 #pragma unroll
-    for (int i = 0; i < R::NV; ++i) v[i] += y[i];
+  for (int o = 0; o < 3; ++o) R::load(w + o * C, lane, wv[o]);
+  const float b0 = b[0], b1 = b[1], b2 = b[2];
+  for (int it = 0; it < kRowTokens; ++it) {
+    const int tok = (blockIdx.x * kRowTokens + it) * 4 + wave;
+    if (tok >= T) break;
+    float v[R::NV], y[R::NV], z[R::NV];
+    if (NT_STREAMS) R::load_nt(x + (size_t)tok * C, lane, v); else R::load(x + (size_t)tok * C, lane, v);
+    if (yadd0 != nullptr) {
+      if (NT_STREAMS && NT_Y) R::load_nt(yadd0 + (size_t)tok * C, lane, y); else R::load(yadd0 + (size_t)tok * C, lane, y);
+#pragma unroll
+      for (int i = 0; i < R::NV; ++i) v[i] += y[i];
+    }
+    if (yadd != nullptr) {
+      if (NT_STREAMS && NT_Y) R::load_nt(yadd + (size_t)tok * C, lane, y); else R::load(yadd + (size_t)tok * C, lane, y);
+#pragma unroll
+      for (int i = 0; i < R::NV; ++i) v[i] += y[i];
+    }
+    R::norm_r(v, wav, bav, eps_a, y);
+    R::norm_r(y, whv, bhv, eps_h, z);
+    float acc[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < R::NV; ++i) a = fmaf(z[i], wv[o][i], a);
+      acc[o] = wave_sum(a) + (o == 0 ? b0 : o == 1 ? b1 : b2);
+    }
+    // rows are (sequence, token) at pitch SP >= FJ; the output is compact
+    const int fj = tok % SP;
+    if (lane < 3 && fj < FJ) out[((size_t)(tok / SP) * FJ + fj) * 3 + lane] = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : acc[2]);
   }
-  if (yadd != nullptr) {
-    if (NT_STREAMS && NT_Y) R::load_nt(yadd + (size_t)tok * C, lane, y); else R::load(yadd + (size_t)tok * C, lane, y);
-#pragma unroll
-    for (int i = 0; i < R::NV; ++i) v[i] += y[i];
-  }
-  R::norm(v, wa, ba, eps_a, lane, y);
-  R::norm(y, wh, bh, eps_h, lane, z);
-  float acc[3];
-#pragma unroll
-  for (int o = 0; o < 3; ++o) {
-    float wv[R::NV];
-    R::load(w + o * C, lane, wv);
-    float a = 0.f;
-#pragma unroll
-    for (int i = 0; i < R::NV; ++i) a = fmaf(z[i], wv[i], a);
-    acc[o] = wave_sum(a) + b[o];
-  }
-  // rows are (sequence, token) at pitch SP >= FJ; the output is compact
-  const int fj = tok % SP;
-  if (lane < 3 && fj < FJ) out[((size_t)(tok / SP) * FJ + fj) * 3 + lane] = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : acc[2]);
 }
 
 // one workgroup per batch element; sin/cos table `freq` is supplied by the host (computed with the
@@ -578,11 +619,12 @@ int d3dp_launch_embed_ln(int act_bf16, const float* x2d, const float* x3d, const
     DISPATCH_G(C, hipLaunchKernelGGL((embed_ln_g_kernel<NVM>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (float*)xn, seq0, n_seq, H, F, J, SP, C))
     return 0;
   }
+  const dim3 gk((T + 4 * kRowTokens - 1) / (4 * kRowTokens));     // kRowTokens tokens per wave
   DISPATCH_C(C,
-    if (act_bf16 == 1) hipLaunchKernelGGL((embed_ln_kernel<CC, bf16>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, plane, seq0, n_seq, H, F, J, SP);
-    else if (act_bf16 == 2) hipLaunchKernelGGL((embed_ln_kernel<CC, b3>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, plane, seq0, n_seq, H, F, J, SP);
-    else if (act_bf16 == 3) hipLaunchKernelGGL((embed_ln_kernel<CC, h2>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (f16*)xn, plane, seq0, n_seq, H, F, J, SP);
-    else hipLaunchKernelGGL((embed_ln_kernel<CC, float>), g, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (float*)xn, plane, seq0, n_seq, H, F, J, SP))
+    if (act_bf16 == 1) hipLaunchKernelGGL((embed_ln_kernel<CC, bf16>), gk, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, plane, seq0, n_seq, H, F, J, SP);
+    else if (act_bf16 == 2) hipLaunchKernelGGL((embed_ln_kernel<CC, b3>), gk, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (bf16*)xn, plane, seq0, n_seq, H, F, J, SP);
+    else if (act_bf16 == 3) hipLaunchKernelGGL((embed_ln_kernel<CC, h2>), gk, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (f16*)xn, plane, seq0, n_seq, H, F, J, SP);
+    else hipLaunchKernelGGL((embed_ln_kernel<CC, float>), gk, blk, 0, st, x2d, x3d, temb, ew, eb, spos, lnw, lnb, eps, x, (float*)xn, plane, seq0, n_seq, H, F, J, SP))
   return 0;
 }
 
@@ -631,8 +673,9 @@ int d3dp_launch_head(int act_bf16, const float* x, const void* yadd0, const void
     DISPATCH_G(C, hipLaunchKernelGGL((head_g_kernel<NVM>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T, C, FJ, SP))
     return 0;
   }
+  const dim3 gk((T + 4 * kRowTokens - 1) / (4 * kRowTokens));     // kRowTokens tokens per wave
   DISPATCH_C(C,
-    if (act_bf16 == 1) hipLaunchKernelGGL((head_kernel<CC, bf16>), g, blk, 0, st, x, (const bf16*)yadd0, (const bf16*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T, FJ, SP);
-    else hipLaunchKernelGGL((head_kernel<CC, float>), g, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T, FJ, SP))
+    if (act_bf16 == 1) hipLaunchKernelGGL((head_kernel<CC, bf16>), gk, blk, 0, st, x, (const bf16*)yadd0, (const bf16*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T, FJ, SP);
+    else hipLaunchKernelGGL((head_kernel<CC, float>), gk, blk, 0, st, x, (const float*)yadd0, (const float*)yadd, wa, ba, eps_a, wh, bh, eps_h, w, b, out, T, FJ, SP))
   return 0;
 }
