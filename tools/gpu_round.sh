@@ -5,6 +5,8 @@
 #   guard        the new kernels once, small, under a short timeout (a hang here must not take the rest of the call with it);
 #                on failure the remaining stages run with D3DP_X2_SKEW=0
 #   tests        pytest -m gpu (PYTEST_ARGS to narrow)
+#   parity       pytest -s of the fixture / full-size / training / width tests: the per-test distances, kept as profiles/<RN>_parity.log
+#   variants     the tests marked `variants` against lib/variants/libd3dp_variants.so (the experiment kernels)
 #   smoke        __graft_entry__.smoke()
 #   ab           short bench runs, one per entry of AB (";"-separated "name:ENV=V ENV=V ..." entries; LIB=path selects a variant build)
 #   bench        the driver-style bench line (STEPS / WARMUP)
